@@ -1,0 +1,85 @@
+/*
+ * rsaf.h — C ABI of librsaf.so (gfx950 / MI355X).
+ *
+ * The reference (ayushpradhan-dev/robust-speech-analysis-framework) is pure Python and has no
+ * FFI/plugin registry; its hot path is reached through four Python callables and one nn.Module
+ * (SURVEY.md §8b).  This header is the boundary a maintainer binds (ctypes) to
+ * replace the third-party back-ends those callables drive.  Each entry point cites the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls enqueue work and
+ *     return without synchronising unless stated otherwise;
+ *   - return value: RSAF_OK (0) or an RSAF_ERR_* code; rsaf_last_error() gives the message of the
+ *     calling thread's last failure; no exception crosses the boundary;
+ *   - the caller owns every buffer; workspaces are sized with the matching *_workspace_bytes call;
+ *   - plain C types only (no torch types).
+ */
+#ifndef RSAF_H
+#define RSAF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSAF_OK 0
+#define RSAF_ERR_ARG 1      /* bad argument / unsupported shape */
+#define RSAF_ERR_HIP 2      /* a HIP runtime call failed */
+#define RSAF_ERR_WORKSPACE 3 /* workspace too small */
+
+#define RSAF_ABI_VERSION 1
+
+typedef void* rsaf_stream_t;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int rsaf_abi_version(void);
+const char* rsaf_last_error(void);
+/* Upload the per-device constant tables (Hamming window, FFT twiddles, mel bank, DCT, ...).
+ * Synchronous; called lazily by the first rsaf_smile_* call on a device otherwise. */
+int rsaf_init_device(int device);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py roofline object).
+ * begin: start collecting; end: synchronise the recorded events and copy up to `cap` records.
+ * A record accumulates all launches of one kernel family. */
+typedef struct {
+    char name[48];
+    int64_t launches;
+    double ms;        /* summed event time */
+    double flops;     /* algorithmic FLOPs summed over launches (0 for byte-bound kernels) */
+    double bytes;     /* algorithmic bytes summed over launches */
+} rsaf_prof_record;
+int rsaf_prof_begin(void);
+int rsaf_prof_end(rsaf_prof_record* records_host, int cap, int* n_records_host);
+
+/* ---- openSMILE-style chain ---------------------------------------------------------------------
+ * Replaces the per-file SMILExtract subprocess of src/opensmile_extractor.py:62-75 driven by
+ * Androids.conf:73-368 (cFramer .. cFunctionals).  Layout: all clips of a batch are concatenated
+ * in `wav` (float32 in [-1,1), 16 kHz mono); clip c occupies samples [clip_off[c], clip_off[c+1]).
+ * Frames: n_frames(n) = n < 400 ? 0 : (n-400)/160 + 1 (Androids.conf:73-78), frame_off is their
+ * exclusive prefix sum.  LLDs are written contour-major: lld[i * total_frames + frame_off[c] + t],
+ * i in [0, RSAF_SMILE_NLLD).                                                                    */
+#define RSAF_SMILE_FRAME 400
+#define RSAF_SMILE_HOP 160
+#define RSAF_SMILE_NLLD 38
+#define RSAF_SMILE_NFEAT 912
+int64_t rsaf_smile_n_frames(int64_t n_samples);
+/* Androids.conf:73-139,258-280 (framer, pre-emphasis, Hamming, FFT magnitude, mel/MFCC, RMS
+ * energy, ZCR, intensity/loudness, 16 spectral descriptors).  Rows of LLDs whose kernels are not
+ * built yet (F0final, voicingFinalUnclipped, jitterLocal, jitterDDP, shimmerLocal, logHNR) are
+ * filled with NaN. */
+int rsaf_smile_lld_batch(const float* wav, const int64_t* clip_off, const int64_t* frame_off,
+                         int n_clips, int64_t max_clip_frames, int64_t total_frames, float* lld,
+                         rsaf_stream_t stream);
+/* Androids.conf:284-368 (sma3, delta regression W=2, 12 functionals over the whole clip).
+ * out: [n_clips, RSAF_SMILE_NFEAT] float32 in cCsvSink column order. */
+int rsaf_smile_functionals(const float* lld, const int64_t* frame_off, int n_clips,
+                           int64_t total_frames, float* out, rsaf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSAF_H */

@@ -1,0 +1,112 @@
+"""ctypes binding of librsaf.so (the C ABI in include/rsaf.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "librsaf.so")
+
+RSAF_OK = 0
+
+
+class RsafError(RuntimeError):
+    pass
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+
+# symbol -> (restype, argtypes); must list every function declared in include/rsaf.h
+SIGNATURES = {
+    "rsaf_abi_version": (_I, []),
+    "rsaf_last_error": (C.c_char_p, []),
+    "rsaf_init_device": (_I, [_I]),
+    "rsaf_prof_begin": (_I, []),
+    "rsaf_prof_end": (_I, [C.POINTER(ProfRecord), _I, C.POINTER(_I)]),
+    "rsaf_smile_n_frames": (_L, [_L]),
+    "rsaf_smile_lld_batch": (_I, [_P, _P, _P, _I, _L, _L, _P, _P]),
+    "rsaf_smile_functionals": (_I, [_P, _P, _I, _L, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librsaf.so (once).  Raises RsafError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RsafError(
+            f"{LIB_PATH} not found: build it with "
+            "`python -m robust_speech_analysis_framework_amd.build` (needs hipcc, gfx950). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != RSAF_OK:
+        msg = load().rsaf_last_error()
+        raise RsafError(f"{what or 'librsaf'} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr(stream=None):
+    """hipStream_t of a torch stream (default: torch's current stream) as void*."""
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (must be contiguous)."""
+    if not t.is_contiguous():
+        raise RsafError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def c_void_p_off(t, elems: int):
+    """Device pointer of element ``elems`` of a contiguous torch tensor."""
+    if not t.is_contiguous():
+        raise RsafError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr() + int(elems) * t.element_size())
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RsafError("no HIP device visible: the MI355X path has no CPU fallback")
+
+
+def prof_begin():
+    check(load().rsaf_prof_begin(), "rsaf_prof_begin")
+
+
+def prof_end():
+    lib = load()
+    cap = 64
+    recs = (ProfRecord * cap)()
+    n = C.c_int(0)
+    check(lib.rsaf_prof_end(recs, cap, C.byref(n)), "rsaf_prof_end")
+    out = {}
+    for i in range(min(n.value, cap)):
+        r = recs[i]
+        out[r.name.decode()] = {"launches": int(r.launches), "ms": float(r.ms),
+                                "flops": float(r.flops), "bytes": float(r.bytes)}
+    return out

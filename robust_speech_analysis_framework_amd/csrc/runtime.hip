@@ -1,0 +1,110 @@
+// librsaf.so runtime: error string, ABI version, per-kernel event profiling.
+#include <mutex>
+#include <vector>
+
+#include "rsaf_common.h"
+
+namespace rsaf {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+struct ProfEntry {
+    std::string name;
+    int64_t launches = 0;
+    double flops = 0, bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfEntry> g_prof;
+
+ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes)
+    : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return;
+    for (size_t i = 0; i < g_prof.size(); ++i)
+        if (g_prof[i].name == name) slot = (int)i;
+    if (slot < 0) {
+        g_prof.emplace_back();
+        g_prof.back().name = name;
+        slot = (int)g_prof.size() - 1;
+    }
+    ProfEntry& e = g_prof[slot];
+    e.launches += 1;
+    e.flops += flops;
+    e.bytes += bytes;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        slot = -1;
+        return;
+    }
+    e.events.emplace_back(a, b);
+    (void)hipEventRecord(a, stream);
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot >= (int)g_prof.size() || g_prof[slot].events.empty()) return;
+    (void)hipEventRecord(g_prof[slot].events.back().second, stream);
+}
+
+}  // namespace rsaf
+
+using namespace rsaf;
+
+extern "C" {
+
+int rsaf_abi_version(void) { return RSAF_ABI_VERSION; }
+
+const char* rsaf_last_error(void) { return g_last_error.c_str(); }
+
+int rsaf_prof_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& e : g_prof)
+        for (auto& p : e.events) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    g_prof.clear();
+    g_prof_on = true;
+    return RSAF_OK;
+}
+
+int rsaf_prof_end(rsaf_prof_record* records_host, int cap, int* n_records_host) {
+    RSAF_CHECK_ARG(n_records_host != nullptr, "n_records_host is NULL");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    int n = 0;
+    for (auto& e : g_prof) {
+        double ms = 0;
+        for (auto& p : e.events) {
+            RSAF_CHECK_HIP(hipEventSynchronize(p.second));
+            float t = 0;
+            RSAF_CHECK_HIP(hipEventElapsedTime(&t, p.first, p.second));
+            ms += t;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        e.events.clear();
+        if (records_host && n < cap) {
+            rsaf_prof_record& r = records_host[n];
+            std::memset(&r, 0, sizeof(r));
+            std::strncpy(r.name, e.name.c_str(), sizeof(r.name) - 1);
+            r.launches = e.launches;
+            r.ms = ms;
+            r.flops = e.flops;
+            r.bytes = e.bytes;
+        }
+        ++n;
+    }
+    g_prof.clear();
+    *n_records_host = n;
+    return RSAF_OK;
+}
+
+}  // extern "C"

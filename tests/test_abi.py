@@ -1,0 +1,46 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/rsaf.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rsaf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsaf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    syms = _declared_symbols()
+    assert "rsaf_smile_lld_batch" in syms and "rsaf_smile_functionals" in syms
+
+
+def test_library_exports_every_declared_symbol(rsaf_lib):
+    for s in _declared_symbols():
+        assert hasattr(rsaf_lib, s), f"librsaf.so does not export {s}"
+
+
+def test_python_binding_covers_header(rsaf_lib):
+    from robust_speech_analysis_framework_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared_symbols()
+
+
+def test_abi_version_and_host_only_calls(rsaf_lib):
+    assert rsaf_lib.rsaf_abi_version() == 1
+    # integer-exact frame-count contract (Androids.conf:73-78): no GPU needed
+    for n, want in [(0, 0), (399, 0), (400, 1), (559, 1), (560, 2), (80000, 498), (480000, 2998)]:
+        assert rsaf_lib.rsaf_smile_n_frames(n) == want
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    from robust_speech_analysis_framework_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.load()
+    except _lib.RsafError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must fail loudly without the HIP library")
