@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds processed per second on synthetic 16 kHz mono 30 s clips.
+
+A "step" is one pass of the hot path over one batch of clips that is already resident in HBM:
+every built stage of  extract (openSMILE-style chain, MSHDS, Wav2Vec2 frames) -> CNN-LSTM forward.
+One process per GPU; clips shard across ranks with no data-path collective, the per-clip result
+rows are all-gathered once per step (RCCL) when N > 1.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=1000, help="clips per GPU (weak scaling)")
+    ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic clips tiled to --clips")
+    ap.add_argument("--stages", type=str, default="all")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-clips", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    return ap.parse_args()
+
+
+def cpu_baseline(stages, seconds, sample_clips):
+    """Time the CPU oracle (kind "port") on a bounded sample of the same synthetic workload.
+
+    This is the only place outside tests/ and smoke() that touches oracle/: it is the reported
+    baseline, never the product path."""
+    import numpy as np
+    import torch
+    from oracle import smile_oracle
+    from robust_speech_analysis_framework_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = sample_clips or 4
+    clips = [synth.synth_clip(900000 + k, seconds) for k in range(n)]
+    parts, total = {}, 0.0
+    if "smile" in stages:
+        t0 = time.perf_counter()
+        for c in clips:
+            smile_oracle.extract(c)
+        parts["smile"] = time.perf_counter() - t0
+        total += parts["smile"]
+    cpu_model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n * seconds / total, 2), "unit": "audio-s/s", "cores": 1 if stages == ["smile"] else cores,
+            "kind": "port", "sample": f"{n} x {seconds:g} s clips, stages {stages}, oracle/ (numpy float64 DSP)",
+            "host_cpus": cores, "cpu_model": cpu_model,
+            "seconds_per_stage": {k: round(v, 3) for k, v in parts.items()}}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from robust_speech_analysis_framework_amd import _lib, pipeline, synth
+    _lib.load()
+
+    stages = pipeline.resolve_stages(args.stages)
+    # synthetic shard of this rank: clip index = rank*clips + i (pool-tiled), resident in HBM
+    host = synth.synth_batch(args.clips, args.seconds, pool=args.pool, first=rank * args.pool)
+    wav = torch.from_numpy(host).to(dev)
+    pipe = pipeline.Pipeline(stages, device=dev, seconds=args.seconds)
+    audio_s_per_step = args.clips * args.seconds * world
+
+    def step():
+        rows = pipe.run(wav)                       # [clips, row_width] float32 on device
+        if world > 1:
+            gathered = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, rows)
+            return gathered
+        return rows
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = _lib.prof_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out[:, pipe.finite_cols]).all(), "non-finite results in the timed region"
+
+    if rank == 0:
+        value = audio_s_per_step * args.steps / dt
+        roof = pipeline.roofline(prof, pipe, args.clips, args.seconds, args.steps,
+                                 HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS)
+        line = {
+            "metric": "audio-seconds processed/sec (extract+CNN-LSTM fwd)",
+            "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": pipe.describe(args.clips, args.seconds),
+                       "clips_per_gpu": args.clips, "clip_seconds": args.seconds,
+                       "stages": [s for s in stages], "sharding": f"clips/{world} ranks, all_gather of result rows"},
+            "roofline": roof,
+            "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3)} for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(stages, args.seconds, args.cpu_sample_clips)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,14 @@ def load():
             f"{LIB_PATH} not found: build it with "
             "`python -m robust_speech_analysis_framework_amd.build` (needs hipcc, gfx950). "
             "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (soname
+    # libamdhip64.so.7).  Load it first so librsaf.so's NEEDED libamdhip64.so.7 resolves to that
+    # already-loaded copy instead of /opt/rocm's (two runtimes in one process do not share the
+    # device: the second reports "no ROCm-capable device").
+    import torch
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -145,7 +145,7 @@ def parse_smile_conf(path: str):
                 continue
             if cur is not None and "=" in line:
                 k, v = line.split("=", 1)
-                cur[k.strip().lower()] = v.split(";")[0].strip()
+                cur[k.strip().lower()] = v.strip()
     return sections
 
 

@@ -9,6 +9,10 @@ from oracle import smile_oracle as so
 # parity metric of SURVEY.md §8d: per LLD row / feature column, max|gpu-cpu| / max|cpu|
 TOL = 1e-4
 ROLLOFF_ROWS = (24, 25, 26, 27)
+# spectralFlatness = exp(mean(log P)) / mean(P): the log of the weakest bins (pre-emphasised
+# low-frequency bins ~1e-11 in power) is dominated by float32 FFT rounding (~6e-8 * |X|max per
+# bin), so this one row is compared at 1e-3 (openSMILE itself is float32, FLOAT_DMEM).
+ROW_TOL = {37: 1e-3}
 
 
 def _clips(seconds_list, first=0):
@@ -38,7 +42,7 @@ def _check_lld(gpu, ref):
             assert (err > 1e-3).mean() <= 2e-3, (so.LLD_NAMES[i], (err > 1e-3).mean())
             assert err.max() <= so.DF + 1e-3
         else:
-            assert err.max() / scale <= TOL, (so.LLD_NAMES[i], err.max() / scale)
+            assert err.max() / scale <= ROW_TOL.get(i, TOL), (so.LLD_NAMES[i], err.max() / scale)
 
 
 def test_lld_parity_ragged_batch(rsaf_lib):
@@ -85,8 +89,23 @@ def test_functionals_exact_on_identical_input(rsaf_lib):
     off = 0
     refs = []
     for nf in p.frames:
-        # oracle sma/delta run in float64 on float32 inputs; mirror the kernel's float32 sma/delta
-        refs.append(so.functionals(L[:, off:off + nf]))
+        # the kernel forms sma3/delta in float32 (openSMILE is FLOAT_DMEM); mirror that so the only
+        # difference left is the float64 accumulation order of the statistics themselves
+        x32 = lld.cpu().numpy()[:, off:off + nf]
+        if nf == 0:
+            refs.append(np.full(912, np.nan))
+        else:
+            s32 = _sma32(x32).astype(np.float64)
+            d32 = _delta32(_sma32(x32)).astype(np.float64)
+            with np.errstate(invalid="ignore"):
+                fs, fd = so.functionals12(s32), so.functionals12(d32)
+            bad = np.isnan(x32).any(axis=1)
+            fs[bad] = np.nan
+            fd[bad] = np.nan
+            parts = []
+            for lo, hi in so.LEVELS:
+                parts += [fs[lo:hi].reshape(-1), fd[lo:hi].reshape(-1)]
+            refs.append(np.concatenate(parts))
         off += nf
     ref = np.stack(refs)
     nan_ref = np.isnan(ref)
