@@ -79,6 +79,22 @@ int rsaf_smile_lld_batch(const float* wav, const int64_t* clip_off, const int64_
 int rsaf_smile_functionals(const float* lld, const int64_t* frame_off, int n_clips,
                            int64_t total_frames, float* out, rsaf_stream_t stream);
 
+/* ---- exact-fp32 MFMA GEMM building block ---------------------------------------------------------
+ * C[z][m][n] = act(alpha * sum_k A[z][m][k] * B[z](k,n) + bias[n] + R[z][m][n]).
+ * Replaces the stock PyTorch ops the reference dispatches for every dense contraction of the path:
+ * nn.Linear / nn.Conv1d inside transformers' Wav2Vec2Model (src/foundation_model_extractor.py:115)
+ * and nn.Conv1d / the LSTM input projections of CNNLSTM (src/models.py:49-62,145-152).
+ * B is [N,K] (b_kn = 0, K contiguous) or [K,N] (b_kn = 1).  z = z1*nz2 + z2 with the element strides
+ * strides8_host = {sA1,sA2,sB1,sB2,sC1,sC2,sR1,sR2} (host array, may be NULL = all zero).
+ * a_pad_k > 0: k=3/pad=1 convolution over a channels-last sequence read in place (A points one
+ * row before the sequence, lda = Cin, K = 3*Cin, a_pad_k = Cin).  act: 0 none, 1 GELU(erf), 2 SiLU.
+ * Requirements: A, B 16-byte aligned; lda, ldb, A/B strides multiples of 4; K % 4 == 0 (b_kn = 0)
+ * or N % 4 == 0 (b_kn = 1); nz <= 65535. */
+int rsaf_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* R,
+                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr,
+                  int nz, int nz2, const int64_t* strides8_host, int a_pad_k, int act, float alpha,
+                  int b_kn, rsaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ SIGNATURES = {
     "rsaf_smile_n_frames": (_L, [_L]),
     "rsaf_smile_lld_batch": (_I, [_P, _P, _P, _I, _L, _L, _P, _P]),
     "rsaf_smile_functionals": (_I, [_P, _P, _I, _L, _P, _P]),
+    "rsaf_gemm_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I,
+                           C.POINTER(_L), _I, _I, _F, _I, _P]),
 }
 
 _lib = None

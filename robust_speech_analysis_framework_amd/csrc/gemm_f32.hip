@@ -1,0 +1,240 @@
+// Exact-fp32 MFMA GEMM for gfx950: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bitwise a
+// k-ordered fmaf chain, 157.3 TFLOP/s dense peak).  bf16/fp8 MFMA would break the 1e-4 parity
+// bar of the Wav2Vec2 / CNN-LSTM paths, so every dense contraction of the hot path runs here.
+//
+// Block tile BM x BN x 32, 256 threads = 4 waves, each wave a WM x WN tile of 32x32 MFMA tiles.
+// A/B k-tiles go HBM -> registers (float4, 128-byte rows per 8 lanes) -> LDS with a row stride of
+// 36 floats, which makes the ds_read_b128 fragment reads conflict-free (16 rows x 4 banks cover
+// the 64 banks).  Each float4 fragment feeds four consecutive MFMA k-steps: inside an 8-wide
+// k-group lanes 0-31 supply k = 0..3 and lanes 32-63 k = 4..7, for A and B alike, so every product
+// still pairs equal k.  The next k-tile is prefetched into registers while the current one is
+// multiplied.  Workgroup ids are remapped so that the 8 XCDs each own a contiguous range of tiles
+// (tiles sharing an A row-panel hit the same L2).
+#include "gemm_f32.h"
+
+namespace rsaf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool BKN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    constexpr int BK = 32;
+    constexpr int LDS_K = BK + 4;                 // 36-float rows (NT images)
+    constexpr int LDB_N = BN + 4;                 // KN image row
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int A_IT = BM / 32;                 // float4 per thread per k-tile
+    constexpr int B_IT = BN / 32;
+    constexpr int A_FLOATS = BM * LDS_K;
+    constexpr int B_FLOATS = BKN ? BK * LDB_N : BN * LDS_K;
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+    float* As = smem;
+    float* Bs = smem + A_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- tile coordinates (XCD-aware bijective remap of the 1-D grid) ----
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_n * tiles_m;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int m0 = (wg / tiles_n) * BM;
+    const int n0 = (wg % tiles_n) * BN;
+
+    const int z = blockIdx.y;
+    const int z1 = z / p.nz2, z2 = z - z1 * p.nz2;
+    const float* __restrict__ A = p.A + z1 * p.sA1 + z2 * p.sA2;
+    const float* __restrict__ B = p.B + z1 * p.sB1 + z2 * p.sB2;
+    float* __restrict__ C = p.C + z1 * p.sC1 + z2 * p.sC2;
+    const float* __restrict__ R = p.R ? p.R + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    float4 ra[A_IT], rb[B_IT];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nk = (p.K + BK - 1) / BK;
+
+#define RSAF_GLOAD(KT)                                                                          \
+    do {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
+            const int idx = tid + 256 * i;                                                      \
+            const int row = idx >> 3, c4 = idx & 7;                                             \
+            const int gm = m0 + row, gk = (KT) * BK + c4 * 4;                                   \
+            bool ok = gm < p.M && gk < p.K;                                                     \
+            if (p.a_pad_k > 0) {                                                                \
+                if (gm == 0 && gk < p.a_pad_k) ok = false;                                      \
+                if (gm == p.M - 1 && gk >= p.K - p.a_pad_k) ok = false;                         \
+            }                                                                                   \
+            ra[i] = zero4;                                                                      \
+            if (ok) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)gm * p.lda + gk);     \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \
+            const int idx = tid + 256 * i;                                                      \
+            rb[i] = zero4;                                                                      \
+            if constexpr (!BKN) {                                                               \
+                const int row = idx >> 3, c4 = idx & 7;                                         \
+                const int gn = n0 + row, gk = (KT) * BK + c4 * 4;                               \
+                if (gn < p.N && gk < p.K)                                                       \
+                    rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)gn * p.ldb + gk);     \
+            } else {                                                                            \
+                const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                           \
+                const int gk = (KT) * BK + krow, gn = n0 + c4 * 4;                              \
+                if (gk < p.K && gn < p.N)                                                       \
+                    rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)gk * p.ldb + gn);     \
+            }                                                                                   \
+        }                                                                                       \
+    } while (0)
+
+#define RSAF_LSTORE()                                                                           \
+    do {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
+            const int idx = tid + 256 * i;                                                      \
+            *reinterpret_cast<float4*>(&As[(idx >> 3) * LDS_K + (idx & 7) * 4]) = ra[i];        \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \
+            const int idx = tid + 256 * i;                                                      \
+            if constexpr (!BKN)                                                                 \
+                *reinterpret_cast<float4*>(&Bs[(idx >> 3) * LDS_K + (idx & 7) * 4]) = rb[i];    \
+            else                                                                                \
+                *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB_N + (idx % (BN / 4)) * 4]) = rb[i]; \
+        }                                                                                       \
+    } while (0)
+
+    RSAF_GLOAD(0);
+    RSAF_LSTORE();
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) RSAF_GLOAD(kt + 1);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float af[TM][4], bf[TN][4];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const float4 v = *reinterpret_cast<const float4*>(
+                    &As[(wm0 + mt * 32 + l31) * LDS_K + 8 * g + 4 * h]);
+                af[mt][0] = v.x; af[mt][1] = v.y; af[mt][2] = v.z; af[mt][3] = v.w;
+            }
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                if constexpr (!BKN) {
+                    const float4 v = *reinterpret_cast<const float4*>(
+                        &Bs[(wn0 + nt * 32 + l31) * LDS_K + 8 * g + 4 * h]);
+                    bf[nt][0] = v.x; bf[nt][1] = v.y; bf[nt][2] = v.z; bf[nt][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bf[nt][j] = Bs[(8 * g + 4 * h + j) * LDB_N + wn0 + nt * 32 + l31];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j],
+                                                                           acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            RSAF_LSTORE();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: alpha, bias, residual, activation; C/D map: col = lane&31,
+    //      row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int gn = n0 + wn0 + nt * 32 + l31;
+        const bool n_ok = gn < p.N;
+        const float bv = (p.bias && n_ok) ? p.bias[gn] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int gm = m0 + wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n_ok && gm < p.M) {
+                    float v = p.alpha * acc[mt][nt][e] + bv;
+                    if (R) v += R[(int64_t)gm * p.ldr + gn];
+                    C[(int64_t)gm * p.ldc + gn] = act_apply(v, p.act);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    dim3 grid((unsigned)tiles, (unsigned)p.nz);
+    if (p.b_kn)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, p);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int launch_gemm_f32(const GemmParams& p, hipStream_t stream, const char* tag) {
+    RSAF_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0 && p.nz >= 0, "negative dimension");
+    if (p.M == 0 || p.N == 0 || p.nz == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(p.A && p.B && p.C, "NULL operand");
+    RSAF_CHECK_ARG(p.nz2 >= 1 && p.nz % p.nz2 == 0, "nz must be a multiple of nz2");
+    RSAF_CHECK_ARG(p.nz <= 65535, "at most 65535 batches per launch");
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    RSAF_CHECK_ARG(al16(p.A) && al16(p.B), "A and B must be 16-byte aligned");
+    RSAF_CHECK_ARG(p.lda % 4 == 0 && p.ldb % 4 == 0, "lda/ldb must be multiples of 4 floats");
+    RSAF_CHECK_ARG(p.sA1 % 4 == 0 && p.sA2 % 4 == 0 && p.sB1 % 4 == 0 && p.sB2 % 4 == 0,
+                   "batch strides of A/B must be multiples of 4 floats");
+    if (!p.b_kn) RSAF_CHECK_ARG(p.K % 4 == 0, "K must be a multiple of 4 for B[N,K]");
+    else RSAF_CHECK_ARG(p.N % 4 == 0, "N must be a multiple of 4 for B[K,N]");
+    RSAF_CHECK_ARG(p.a_pad_k % 4 == 0 && p.a_pad_k >= 0, "a_pad_k must be a multiple of 4");
+    RSAF_CHECK_ARG(!p.R || p.ldr > 0, "residual needs ldr");
+    const double flops = 2.0 * p.M * (double)p.N * p.K * p.nz;
+    ProfScope prof(tag ? tag : "gemm_f32", stream, flops, 0.0);
+    if (p.N <= 32) return launch_cfg<128, 32, 32, 32>(p, stream);
+    if (p.N <= 64) return launch_cfg<128, 64, 64, 32>(p, stream);
+    return launch_cfg<128, 128, 64, 64>(p, stream);
+}
+
+}  // namespace rsaf
+
+using namespace rsaf;
+
+extern "C" int rsaf_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* R,
+                             int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr,
+                             int nz, int nz2, const int64_t* strides8_host, int a_pad_k, int act,
+                             float alpha, int b_kn, rsaf_stream_t stream) {
+    GemmParams p = gemm_params_plain(A, B, C, M, N, K, lda, ldb, ldc);
+    p.bias = bias; p.R = R; p.ldr = ldr; p.nz = nz; p.nz2 = nz2 < 1 ? 1 : nz2;
+    if (strides8_host) {
+        p.sA1 = strides8_host[0]; p.sA2 = strides8_host[1]; p.sB1 = strides8_host[2]; p.sB2 = strides8_host[3];
+        p.sC1 = strides8_host[4]; p.sC2 = strides8_host[5]; p.sR1 = strides8_host[6]; p.sR2 = strides8_host[7];
+    }
+    RSAF_CHECK_ARG(act >= 0 && act <= 2, "act must be 0 (none), 1 (gelu) or 2 (silu)");
+    p.a_pad_k = a_pad_k; p.act = act; p.alpha = alpha; p.b_kn = b_kn;
+    return launch_gemm_f32(p, (hipStream_t)stream, "gemm_f32");
+}

@@ -1,0 +1,147 @@
+"""fp32 MFMA GEMM vs a float64 numpy reference (through the C ABI)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref):
+    return np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 96), (1, 32, 64), (257, 48, 36), (513, 768, 512)])
+def test_plain_nt_asymmetric(rsaf_lib, M, N, K):
+    """C = A @ W^T with asymmetric operands (catches a transposed C/D map)."""
+    import torch
+    from robust_speech_analysis_framework_amd import ops
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    W[:, 0] += np.arange(N, dtype=np.float32)          # strongly asymmetric
+    out = ops.linear(torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda())
+    torch.cuda.synchronize()
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    assert _rel(out.cpu().numpy(), ref) < 2e-6
+
+
+def test_identity_a_returns_b_transposed(rsaf_lib):
+    import torch
+    from robust_speech_analysis_framework_amd import ops
+    n = 96
+    A = np.eye(n, dtype=np.float32)
+    W = np.arange(n * n, dtype=np.float32).reshape(n, n)   # exact integers, asymmetric
+    out = ops.linear(torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), W.T)
+
+
+@pytest.mark.parametrize("act", [None, "gelu", "silu"])
+def test_bias_residual_activation(rsaf_lib, act):
+    import torch
+    from robust_speech_analysis_framework_amd import ops
+    rng = np.random.default_rng(5)
+    M, N, K = 200, 130, 64          # N not a multiple of 4: plain [N,K] weights allow it
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / 8).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    out = ops.linear(torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda(), torch.from_numpy(b).cuda(),
+                     act=act, residual=torch.from_numpy(R).cuda())
+    torch.cuda.synchronize()
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + b + R
+    if act == "gelu":
+        ref = _gelu(ref)
+    elif act == "silu":
+        ref = ref / (1.0 + np.exp(-ref))
+    assert _rel(out.cpu().numpy(), ref) < 2e-6
+
+
+def test_two_level_batch_attention_shapes(rsaf_lib):
+    """S = scale * Q K^T and O = P V with (chunk, head) batches over a packed qkv buffer."""
+    import torch
+    from robust_speech_analysis_framework_amd import ops
+    rng = np.random.default_rng(11)
+    nc, nh, T, hd = 3, 4, 249, 64
+    D = nh * hd
+    qkv = rng.standard_normal((nc, T, 3 * D)).astype(np.float32)
+    dq = torch.from_numpy(qkv).cuda()
+    Tp = 256
+    S = torch.zeros((nc, nh, T, Tp), dtype=torch.float32, device="cuda")
+    ops.gemm_f32(dq, dq, S, T, T, hd, 3 * D, 3 * D, Tp, nz=nc * nh, nz2=nh,
+                 strides=[T * 3 * D, hd, T * 3 * D, hd, nh * T * Tp, T * Tp, 0, 0],
+                 alpha=0.125, a_off=0, b_off=D)
+    torch.cuda.synchronize()
+    q = qkv[:, :, :D].reshape(nc, T, nh, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    k = qkv[:, :, D:2 * D].reshape(nc, T, nh, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    v = qkv[:, :, 2 * D:].reshape(nc, T, nh, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    ref = 0.125 * q @ k.transpose(0, 1, 3, 2)
+    got = S.cpu().numpy()
+    assert _rel(got[..., :T], ref) < 2e-6
+    assert (got[..., T:] == 0).all()                     # pad columns untouched
+    # O = P V, B operand [K,N] (N contiguous), K = 249 is not a multiple of 4
+    P = torch.softmax(S[..., :T], dim=-1)
+    Pp = torch.zeros_like(S)
+    Pp[..., :T] = P
+    O = torch.zeros((nc, T, D), dtype=torch.float32, device="cuda")
+    ops.gemm_f32(Pp, dq, O, T, hd, T, Tp, 3 * D, D, nz=nc * nh, nz2=nh,
+                 strides=[nh * T * Tp, T * Tp, T * 3 * D, hd, T * D, hd, 0, 0], b_kn=True, b_off=2 * D)
+    torch.cuda.synchronize()
+    refO = (P.cpu().numpy().astype(np.float64) @ v).transpose(0, 2, 1, 3).reshape(nc, T, D)
+    assert _rel(O.cpu().numpy(), refO) < 2e-6
+
+
+@pytest.mark.parametrize("T", [1, 2, 37, 300])
+def test_conv3_pad1_in_place(rsaf_lib, T):
+    """k=3/pad=1 Conv1d over a channels-last batch, input read in place (a_pad_k)."""
+    import torch
+    import torch.nn.functional as F
+    from robust_speech_analysis_framework_amd import ops
+    rng = np.random.default_rng(T)
+    Bn, Cin, Cout = 3, 32, 48
+    x = rng.standard_normal((Bn, T, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3)) / 4).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dx = torch.from_numpy(x).cuda()
+    wk = torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(Cout, 3 * Cin)).cuda()
+    out = torch.empty((Bn, T, Cout), dtype=torch.float32, device="cuda")
+    ops.gemm_f32(dx, wk, out, T, Cout, 3 * Cin, Cin, 3 * Cin, Cout, bias=torch.from_numpy(b).cuda(),
+                 nz=Bn, nz2=1, strides=[T * Cin, 0, 0, 0, T * Cout, 0, 0, 0], a_pad_k=Cin, a_off=-Cin)
+    torch.cuda.synchronize()
+    ref = F.conv1d(torch.from_numpy(x).double().permute(0, 2, 1), torch.from_numpy(w).double(),
+                   torch.from_numpy(b).double(), padding=1).permute(0, 2, 1).numpy()
+    assert _rel(out.cpu().numpy(), ref) < 2e-6
+
+
+def test_strided_conv_as_gemm(rsaf_lib):
+    """k=3/stride=2 Conv1d (Wav2Vec2 feature encoder) = GEMM with lda = 2*Cin, K = 3*Cin."""
+    import torch
+    import torch.nn.functional as F
+    from robust_speech_analysis_framework_amd import ops
+    rng = np.random.default_rng(3)
+    nb, Tin, Cc = 2, 401, 64
+    Tout = (Tin - 3) // 2 + 1
+    x = rng.standard_normal((nb, Tin, Cc)).astype(np.float32)
+    w = (rng.standard_normal((Cc, Cc, 3)) / 8).astype(np.float32)
+    dx = torch.from_numpy(x).cuda()
+    wk = torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(Cc, 3 * Cc)).cuda()
+    out = torch.empty((nb, Tout, Cc), dtype=torch.float32, device="cuda")
+    ops.gemm_f32(dx, wk, out, Tout, Cc, 3 * Cc, 2 * Cc, 3 * Cc, Cc, nz=nb, nz2=1,
+                 strides=[Tin * Cc, 0, 0, 0, Tout * Cc, 0, 0, 0], act="gelu")
+    torch.cuda.synchronize()
+    ref = F.conv1d(torch.from_numpy(x).double().permute(0, 2, 1), torch.from_numpy(w).double(), stride=2)
+    ref = F.gelu(ref).permute(0, 2, 1).numpy()
+    assert _rel(out.cpu().numpy(), ref) < 2e-6
+
+
+def test_argument_validation(rsaf_lib):
+    import torch
+    from robust_speech_analysis_framework_amd import _lib, ops
+    a = torch.zeros((8, 6), device="cuda")
+    w = torch.zeros((4, 6), device="cuda")
+    with pytest.raises(_lib.RsafError):
+        ops.linear(a, w)                                   # K = 6 is not a multiple of 4
