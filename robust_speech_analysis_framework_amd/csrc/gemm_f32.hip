@@ -72,57 +72,90 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     float4 ra[A_IT], rb[B_IT];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nk = (p.K + BK - 1) / BK;
 
+    // ---- per-thread load coordinates, fixed over the K loop.  Everything below is branch-free:
+    //      masked elements are loaded from an always-valid address and zeroed by a select (a branch
+    //      around a load makes hipcc drain vmcnt(0) per element and serialises the prefetch).
+    const int c4 = tid & 7;                       // float4 column inside the 32-wide k-tile
+    const int r0 = tid >> 3;                      // rows r0 + 32*i
+    const float* aptr[A_IT];
+    int arow_ok[A_IT], alo[A_IT], ahi[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int gm = m0 + r0 + 32 * i;
+        arow_ok[i] = gm < p.M;
+        const int gmc = arow_ok[i] ? gm : p.M - 1;
+        aptr[i] = A + (int64_t)gmc * p.lda;
+        alo[i] = (p.a_pad_k > 0) & (gmc == 0);
+        ahi[i] = (p.a_pad_k > 0) & (gmc == p.M - 1);
+    }
+    const float* bptr[B_IT];
+    int b_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        if constexpr (!BKN) {
+            const int gn = n0 + r0 + 32 * i;
+            b_ok[i] = gn < p.N;
+            bptr[i] = B + (int64_t)(b_ok[i] ? gn : p.N - 1) * p.ldb;
+        } else {
+            const int idx = tid + 256 * i;
+            const int gn = n0 + (idx % (BN / 4)) * 4;
+            b_ok[i] = gn < p.N;
+            bptr[i] = B + (b_ok[i] ? gn : 0);
+        }
+    }
+
+// raw loads only: the zero-select is applied in RSAF_LSTORE (after the MFMAs of the current tile),
+// so nothing consumes the prefetched registers before the multiply and the loads stay in flight
 #define RSAF_GLOAD(KT)                                                                          \
     do {                                                                                        \
+        const int gk = (KT) * BK + c4 * 4;                                                      \
+        const int gkc = (gk < p.K) ? gk : 0;                                                    \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
-            const int idx = tid + 256 * i;                                                      \
-            const int row = idx >> 3, c4 = idx & 7;                                             \
-            const int gm = m0 + row, gk = (KT) * BK + c4 * 4;                                   \
-            bool ok = gm < p.M && gk < p.K;                                                     \
-            if (p.a_pad_k > 0) {                                                                \
-                if (gm == 0 && gk < p.a_pad_k) ok = false;                                      \
-                if (gm == p.M - 1 && gk >= p.K - p.a_pad_k) ok = false;                         \
-            }                                                                                   \
-            ra[i] = zero4;                                                                      \
-            if (ok) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)gm * p.lda + gk);     \
+            const int hit = (alo[i] & (gk < p.a_pad_k)) | (ahi[i] & (gk >= p.K - p.a_pad_k));   \
+            const int off = hit ? p.a_pad_k : gkc;                                              \
+            ra[i] = *reinterpret_cast<const float4*>(aptr[i] + off);                            \
         }                                                                                       \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \
-            const int idx = tid + 256 * i;                                                      \
-            rb[i] = zero4;                                                                      \
             if constexpr (!BKN) {                                                               \
-                const int row = idx >> 3, c4 = idx & 7;                                         \
-                const int gn = n0 + row, gk = (KT) * BK + c4 * 4;                               \
-                if (gn < p.N && gk < p.K)                                                       \
-                    rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)gn * p.ldb + gk);     \
+                rb[i] = *reinterpret_cast<const float4*>(bptr[i] + gkc);                        \
             } else {                                                                            \
-                const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                           \
-                const int gk = (KT) * BK + krow, gn = n0 + c4 * 4;                              \
-                if (gk < p.K && gn < p.N)                                                       \
-                    rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)gk * p.ldb + gn);     \
+                const int krow = (KT) * BK + (tid + 256 * i) / (BN / 4);                        \
+                rb[i] = *reinterpret_cast<const float4*>(                                       \
+                    bptr[i] + (int64_t)((krow < p.K) ? krow : 0) * p.ldb);                      \
             }                                                                                   \
         }                                                                                       \
     } while (0)
 
-#define RSAF_LSTORE()                                                                           \
+#define RSAF_LSTORE(KT)                                                                         \
     do {                                                                                        \
+        const int gk = (KT) * BK + c4 * 4;                                                      \
+        const int kok = gk < p.K;                                                               \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
-            const int idx = tid + 256 * i;                                                      \
-            *reinterpret_cast<float4*>(&As[(idx >> 3) * LDS_K + (idx & 7) * 4]) = ra[i];        \
+            const int hit = (alo[i] & (gk < p.a_pad_k)) | (ahi[i] & (gk >= p.K - p.a_pad_k));   \
+            const int ok = kok & arow_ok[i] & (hit ^ 1);                                        \
+            float4 v = ra[i];                                                                   \
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; \
+            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_K + c4 * 4]) = v;                \
         }                                                                                       \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \
-            const int idx = tid + 256 * i;                                                      \
-            if constexpr (!BKN)                                                                 \
-                *reinterpret_cast<float4*>(&Bs[(idx >> 3) * LDS_K + (idx & 7) * 4]) = rb[i];    \
-            else                                                                                \
-                *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB_N + (idx % (BN / 4)) * 4]) = rb[i]; \
+            float4 v = rb[i];                                                                   \
+            if constexpr (!BKN) {                                                               \
+                const int ok = kok & b_ok[i];                                                   \
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; \
+                *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_K + c4 * 4]) = v;            \
+            } else {                                                                            \
+                const int idx = tid + 256 * i;                                                  \
+                const int ok = (((KT) * BK + idx / (BN / 4)) < p.K) & b_ok[i];                  \
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; \
+                *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB_N + (idx % (BN / 4)) * 4]) = v; \
+            }                                                                                   \
         }                                                                                       \
     } while (0)
 
     RSAF_GLOAD(0);
-    RSAF_LSTORE();
+    RSAF_LSTORE(0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -159,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
         }
         __syncthreads();
         if (kt + 1 < nk) {
-            RSAF_LSTORE();
+            RSAF_LSTORE(kt + 1);
             __syncthreads();
         }
     }
@@ -169,18 +202,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
         const int gn = n0 + wn0 + nt * 32 + l31;
-        const bool n_ok = gn < p.N;
-        const float bv = (p.bias && n_ok) ? p.bias[gn] : 0.0f;
+        const int n_ok = gn < p.N;
+        const int gnc = n_ok ? gn : 0;
+        const float bv = p.bias ? p.bias[gnc] : 0.0f;
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
+            const int gm_base = m0 + wm0 + mt * 32 + 4 * h;
+            float rv[16];
+            if (R) {   // uniform branch; the 16 residual loads are issued together (clamped, unmasked)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int gm = gm_base + (e & 3) + 8 * (e >> 2);
+                    rv[e] = R[(int64_t)(gm < p.M ? gm : 0) * p.ldr + gnc];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rv[e] = 0.0f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int gm = m0 + wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (n_ok && gm < p.M) {
-                    float v = p.alpha * acc[mt][nt][e] + bv;
-                    if (R) v += R[(int64_t)gm * p.ldr + gn];
-                    C[(int64_t)gm * p.ldc + gn] = act_apply(v, p.act);
-                }
+                const int gm = gm_base + (e & 3) + 8 * (e >> 2);
+                const float v = act_apply(p.alpha * acc[mt][nt][e] + bv + rv[e], p.act);
+                if (n_ok & (gm < p.M)) C[(int64_t)gm * p.ldc + gn] = v;
             }
         }
     }

@@ -26,7 +26,7 @@ def test_plain_nt_asymmetric(rsaf_lib, M, N, K):
     out = ops.linear(torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda())
     torch.cuda.synchronize()
     ref = A.astype(np.float64) @ W.astype(np.float64).T
-    assert _rel(out.cpu().numpy(), ref) < 2e-6
+    assert _rel(out.cpu().numpy(), ref) < 5e-6
 
 
 def test_identity_a_returns_b_transposed(rsaf_lib):
