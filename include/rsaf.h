@@ -95,6 +95,25 @@ int rsaf_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
                   int nz, int nz2, const int64_t* strides8_host, int a_pad_k, int act, float alpha,
                   int b_kn, rsaf_stream_t stream);
 
+/* ---- CNN-LSTM-with-attention classifier forward ----------------------------------------------------
+ * Replaces CNNLSTM.forward (src/models.py:161-193) in eval mode: x[B,T,input_dim] float32 ->
+ * logits[B,num_classes].  Zero-padded frames are processed like any other frame (the reference's
+ * collate_fn pads without a mask, src/dl_cv_strategies.py:81-84).
+ * `weights`: one float32 device blob with eval-mode BatchNorm folded into the convolutions,
+ * conv kernels stored tap-major ([Cout][tap*Cin + ci]), LSTM biases summed (b_ih + b_hh) and both
+ * directions concatenated ([fwd 4H | reverse 4H] rows, gate order i,f,g,o).  Segment offsets (in
+ * floats, 16-byte aligned) come from rsaf_cnnlstm_weight_offsets in this order:
+ *   w1 b1 wsc bsc w2 b2 w3 b3 w4 b4  {wih_l bih_l whh_l} x lstm_layers  watt batt wfc bfc
+ * (wsc/bsc = -1 when input_dim == channels: identity shortcut).
+ * act: 1 = gelu, 2 = silu.  hidden must be 64 or 128, T >= 2, B <= 65535.                       */
+int64_t rsaf_cnnlstm_weight_floats(int input_dim, int channels, int hidden, int num_classes, int lstm_layers);
+int rsaf_cnnlstm_weight_offsets(int input_dim, int channels, int hidden, int num_classes, int lstm_layers,
+                                int64_t* offsets_host, int cap, int* n_host);
+int64_t rsaf_cnnlstm_workspace_bytes(int B, int T, int input_dim, int channels, int hidden, int lstm_layers);
+int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channels, int hidden,
+                         int num_classes, int lstm_layers, int act, const float* weights,
+                         void* workspace, int64_t workspace_bytes, float* logits, rsaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,211 @@
+"""CNN-LSTM-with-attention classifier on the HIP path (drop-in for ``src/models.py``).
+
+``CNNLSTM`` keeps the reference's constructor signature, attribute tree and ``state_dict`` keys
+(``src/models.py:129-159``) so the shipped checkpoints load unchanged and
+``model.res_block1.conv1.weight`` style access (``src/dl_cv_strategies.py:336,426``) works.  The
+parameters live in ordinary ``torch.nn`` containers; ``forward`` does not call them: in eval mode
+it folds BatchNorm into the convolutions, packs everything into one device blob and runs
+``rsaf_cnnlstm_forward`` (fp32 MFMA GEMMs + persistent LSTM kernel).
+
+Training (autograd through the HIP kernels) is outside the hot path of this build (SURVEY.md §8f
+rank 3): ``forward`` raises in training mode or for CPU tensors instead of silently using a
+PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+_ACT_CODE = {"gelu": 1, "silu": 2}
+BN_EPS = 1e-5
+
+
+def get_activation_fn(name):
+    """Same contract as ``src/models.py:7-25``: 'silu' / 'gelu', else ValueError."""
+    table = {"silu": F.silu, "gelu": F.gelu}
+    if name not in table:
+        raise ValueError(f"Unsupported activation function: {name}")
+    return table[name]
+
+
+class ResidualBlock(nn.Module):
+    """Parameter container with the reference's layout (``src/models.py:43-62``)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dropout=0.2, activation_fn="silu"):
+        super().__init__()
+        self.activation = get_activation_fn(activation_fn)
+        self.activation_name = activation_fn
+        pad = (kernel_size - 1) // 2
+        self.conv1 = nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding=pad)
+        self.bn1 = nn.BatchNorm1d(out_channels)
+        self.conv2 = nn.Conv1d(out_channels, out_channels, kernel_size, stride, padding=pad)
+        self.bn2 = nn.BatchNorm1d(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.shortcut = nn.Sequential()
+        if in_channels != out_channels:
+            self.shortcut = nn.Sequential(nn.Conv1d(in_channels, out_channels, kernel_size=1, stride=stride),
+                                          nn.BatchNorm1d(out_channels))
+
+    def forward(self, x):
+        raise NotImplementedError("ResidualBlock runs only inside CNNLSTM.forward on the HIP path")
+
+
+class AttentionPooling(nn.Module):
+    """Parameter container (``src/models.py:88-92``)."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.attention_weights = nn.Linear(input_dim, 1)
+
+    def forward(self, lstm_out):
+        raise NotImplementedError("AttentionPooling runs only inside CNNLSTM.forward on the HIP path")
+
+
+def _f64(t):
+    return t.detach().to("cpu", torch.float64).numpy()
+
+
+def _fold_conv_bn(conv, bn):
+    """BN(conv(x)) in eval mode == conv'(x): returns tap-major [Cout, k*Cin] weights and bias."""
+    w, b = _f64(conv.weight), _f64(conv.bias)
+    s = _f64(bn.weight) / np.sqrt(_f64(bn.running_var) + bn.eps)
+    wf = w * s[:, None, None]
+    bf = (b - _f64(bn.running_mean)) * s + _f64(bn.bias)
+    return np.ascontiguousarray(wf.transpose(0, 2, 1)).reshape(w.shape[0], -1), bf
+
+
+def weight_offsets(input_dim, channels, hidden, num_classes, layers):
+    lib = _lib.load()
+    buf = (C.c_int64 * 32)()
+    n = C.c_int(0)
+    _lib.check(lib.rsaf_cnnlstm_weight_offsets(input_dim, channels, hidden, num_classes, layers, buf, 32,
+                                               C.byref(n)), "rsaf_cnnlstm_weight_offsets")
+    total = lib.rsaf_cnnlstm_weight_floats(input_dim, channels, hidden, num_classes, layers)
+    return [int(buf[i]) for i in range(n.value)], int(total)
+
+
+def pack_weights(model: "CNNLSTM") -> np.ndarray:
+    """Fold + pack the module's parameters into the blob layout of ``rsaf_cnnlstm_forward``."""
+    d = model.dims
+    offs, total = weight_offsets(d["input_dim"], d["channels"], d["hidden"], d["num_classes"], d["layers"])
+    blob = np.zeros(total, dtype=np.float32)
+    it = iter(offs)
+
+    def put(arr):
+        o = next(it)
+        if o >= 0:
+            a = np.asarray(arr, dtype=np.float64).reshape(-1)
+            blob[o:o + a.size] = a.astype(np.float32)
+
+    r1, r2 = model.res_block1, model.res_block2
+    for part in _fold_conv_bn(r1.conv1, r1.bn1):
+        put(part)
+    if len(r1.shortcut) > 0:
+        for part in _fold_conv_bn(r1.shortcut[0], r1.shortcut[1]):
+            put(part)
+    else:
+        next(it), next(it)
+    for conv, bn in ((r1.conv2, r1.bn2), (r2.conv1, r2.bn1), (r2.conv2, r2.bn2)):
+        for part in _fold_conv_bn(conv, bn):
+            put(part)
+    for l in range(d["layers"]):
+        g = lambda n: _f64(getattr(model.lstm, n))                                   # noqa: E731
+        put(np.concatenate([g(f"weight_ih_l{l}"), g(f"weight_ih_l{l}_reverse")], axis=0))
+        put(np.concatenate([g(f"bias_ih_l{l}") + g(f"bias_hh_l{l}"),
+                            g(f"bias_ih_l{l}_reverse") + g(f"bias_hh_l{l}_reverse")]))
+        put(np.stack([g(f"weight_hh_l{l}"), g(f"weight_hh_l{l}_reverse")]))
+    put(_f64(model.attention_pooling.attention_weights.weight))
+    put(_f64(model.attention_pooling.attention_weights.bias))
+    put(_f64(model.fc.weight))
+    put(_f64(model.fc.bias))
+    return blob
+
+
+def cnnlstm_forward_packed(x, blob, dims, act, workspace=None, stream=None):
+    """x float32 [B,T,D] on the device, blob = packed weights on the same device -> logits [B,NC]."""
+    lib = _lib.load()
+    if x.dim() != 3 or x.shape[2] != dims["input_dim"]:
+        raise ValueError(f"expected input [B, T, {dims['input_dim']}], got {tuple(x.shape)}")
+    x = x.contiguous()
+    B, T, D = x.shape
+    need = lib.rsaf_cnnlstm_workspace_bytes(B, T, D, dims["channels"], dims["hidden"], dims["layers"])
+    if B > 0 and need < 0:
+        raise ValueError("sequence length must be >= 2")
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(int(need), 16) // 4, dtype=torch.float32, device=x.device)
+    logits = torch.empty((B, dims["num_classes"]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rsaf_cnnlstm_forward(
+        _lib.ptr(x), B, T, D, dims["channels"], dims["hidden"], dims["num_classes"], dims["layers"],
+        _ACT_CODE[act], _lib.ptr(blob), _lib.ptr(workspace), workspace.numel() * 4, _lib.ptr(logits),
+        _lib.stream_ptr(stream)), "rsaf_cnnlstm_forward")
+    return logits, workspace
+
+
+class CNNLSTM(nn.Module):
+    """Drop-in for ``src/models.py:109-193`` (constructor signature and state_dict keys identical)."""
+
+    def __init__(self, input_dim=768, num_classes=2, cnn_out_channels=128, lstm_hidden_dim=128,
+                 lstm_layers=2, dropout_rate=0.5, activation_fn="silu"):
+        super().__init__()
+        get_activation_fn(activation_fn)                       # ValueError for unknown names
+        self.activation_name = activation_fn
+        self.res_block1 = ResidualBlock(input_dim, cnn_out_channels, activation_fn=activation_fn)
+        self.res_block2 = ResidualBlock(cnn_out_channels, cnn_out_channels, activation_fn=activation_fn)
+        self.lstm = nn.LSTM(input_size=cnn_out_channels, hidden_size=lstm_hidden_dim, num_layers=lstm_layers,
+                            batch_first=True, bidirectional=True,
+                            dropout=dropout_rate if lstm_layers > 1 else 0)
+        self.attention_pooling = AttentionPooling(input_dim=lstm_hidden_dim * 2)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.fc = nn.Linear(lstm_hidden_dim * 2, num_classes)
+        self.dims = {"input_dim": input_dim, "channels": cnn_out_channels, "hidden": lstm_hidden_dim,
+                     "num_classes": num_classes, "layers": lstm_layers}
+        self._packed = None
+        self._packed_key = None
+        self._workspace = None
+
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in
+                                      list(self.parameters()) + list(self.buffers()))
+
+    def packed_weights(self, device):
+        """Folded weight blob on ``device`` (rebuilt when any parameter/buffer changed)."""
+        key = self._weights_key(device)
+        if self._packed is None or self._packed_key != key:
+            self._packed = torch.from_numpy(pack_weights(self)).to(device)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError(
+                "CNNLSTM.forward on the MI355X path is inference-only (call .eval()); training/backward "
+                "is outside this build's hot path and there is no PyTorch fallback")
+        if not x.is_cuda:
+            raise _lib.RsafError("CNNLSTM.forward needs a HIP (cuda) tensor: there is no CPU fallback")
+        x = x.to(torch.float32)
+        blob = self.packed_weights(x.device)
+        with torch.no_grad():
+            logits, self._workspace = cnnlstm_forward_packed(x, blob, self.dims, self.activation_name,
+                                                             self._workspace)
+        return logits
+
+
+def collate_zero_pad(seqs, device="cuda"):
+    """Batch assembly of the reference harness (``src/dl_cv_strategies.py:81-84``): right zero-padding
+    to the batch maximum, float32, no mask."""
+    T = max(int(s.shape[0]) for s in seqs)
+    out = torch.zeros((len(seqs), T, int(seqs[0].shape[1])), dtype=torch.float32, device=device)
+    for i, s in enumerate(seqs):
+        out[i, :s.shape[0]] = torch.as_tensor(s, dtype=torch.float32)
+    return out
+
+
+def eval_outputs(logits):
+    """``_eval_model`` post-processing (``src/dl_cv_strategies.py:183-194``): P(class 1) and argmax."""
+    return torch.softmax(logits, dim=1)[:, 1], torch.argmax(logits, dim=1)

@@ -1,0 +1,388 @@
+// CNN-LSTM-with-attention classifier forward for gfx950 (reference: CNNLSTM.forward,
+// src/models.py:161-193, eval mode; harness behaviours of src/dl_cv_strategies.py:81-84 apply:
+// zero-padded frames are NOT masked anywhere).
+//
+//   x[B,T,D] (read in its native layout: the permute of :172 costs nothing)
+//   -> res_block1: act(conv3+BN) -> conv3+BN (+ conv1x1+BN shortcut) -> act     (fp32 MFMA GEMMs,
+//      BN folded into the weights at load time, k=3 padding handled in the A-tile loader)
+//   -> max_pool1d(2) -> res_block2 (identity shortcut)
+//   -> 2-layer bidirectional LSTM: input projections for all time steps as one GEMM per layer
+//      (N = 8H: both directions), then a persistent recurrent kernel
+//   -> attention pooling (online softmax over time) + dropout(identity) + Linear -> logits[B,2]
+//
+// Recurrent kernel: one workgroup = 16 batch rows of one direction for all T' steps (rows are
+// independent, so there is no inter-workgroup traffic).  H/16 waves; wave w owns hidden units
+// 16w..16w+15 for all four gates, and keeps its slice of W_hh permanently in registers as
+// v_mfma_f32_16x16x4_f32 B-fragments (H registers per lane).  Per step: the accumulators start from
+// the prefetched input projection, h_{t-1} is read from LDS as the A operand, the gate nonlinearity
+// and cell update are lane-local (all four gates of a (row, unit) pair land in the same lane and
+// register index), h_t goes to LDS (double-buffered, one barrier per step) and to HBM.
+#include <algorithm>
+
+#include "gemm_f32.h"
+
+namespace rsaf {
+namespace cnnlstm {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct Dims {
+    int D, C, H, NC, L, act;
+};
+
+static inline int64_t pad4(int64_t n) { return (n + 3) & ~int64_t(3); }
+
+// ---- weight blob layout (floats); every segment starts 16-byte aligned -----------------------
+struct Layout {
+    int64_t w1, b1, wsc, bsc, w2, b2, w3, b3, w4, b4;
+    int64_t wih[4], bih[4], whh[4];
+    int64_t watt, batt, wfc, bfc, total;
+};
+
+static Layout make_layout(const Dims& d) {
+    Layout L{};
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t s = o; o += pad4(n); return s; };
+    L.w1 = take((int64_t)d.C * 3 * d.D);
+    L.b1 = take(d.C);
+    if (d.D != d.C) { L.wsc = take((int64_t)d.C * d.D); L.bsc = take(d.C); } else { L.wsc = L.bsc = -1; }
+    L.w2 = take((int64_t)d.C * 3 * d.C); L.b2 = take(d.C);
+    L.w3 = take((int64_t)d.C * 3 * d.C); L.b3 = take(d.C);
+    L.w4 = take((int64_t)d.C * 3 * d.C); L.b4 = take(d.C);
+    for (int l = 0; l < d.L; ++l) {
+        const int in = l == 0 ? d.C : 2 * d.H;
+        L.wih[l] = take((int64_t)8 * d.H * in);
+        L.bih[l] = take(8 * d.H);
+        L.whh[l] = take((int64_t)2 * 4 * d.H * d.H);
+    }
+    L.watt = take(2 * d.H); L.batt = take(1);
+    L.wfc = take((int64_t)d.NC * 2 * d.H); L.bfc = take(d.NC);
+    L.total = o;
+    return L;
+}
+
+static int check_dims(const Dims& d) {
+    RSAF_CHECK_ARG(d.D > 0 && d.D % 4 == 0, "input_dim must be a positive multiple of 4");
+    RSAF_CHECK_ARG(d.C > 0 && d.C % 4 == 0, "cnn_out_channels must be a positive multiple of 4");
+    RSAF_CHECK_ARG(d.H == 64 || d.H == 128, "lstm_hidden_dim must be 64 or 128 (reference search space)");
+    RSAF_CHECK_ARG(d.NC >= 1 && d.NC <= 16, "num_classes must be in [1, 16]");
+    RSAF_CHECK_ARG(d.L >= 1 && d.L <= 4, "lstm_layers must be in [1, 4]");
+    RSAF_CHECK_ARG(d.act == ACT_GELU || d.act == ACT_SILU, "activation must be gelu (1) or silu (2)");
+    return RSAF_OK;
+}
+
+// ---- max_pool1d(kernel_size=2) over time, channels-last ----------------------------------------
+__global__ __launch_bounds__(256) void pool2_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                                    int B, int T, int Tp, int C4) {
+    const int64_t n = (int64_t)B * Tp * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const int64_t bt = i / C4;
+        const int t = (int)(bt % Tp);
+        const int64_t b = bt / Tp;
+        const float4 a = x[(b * T + 2 * t) * C4 + c];
+        const float4 d = x[(b * T + 2 * t + 1) * C4 + c];
+        y[i] = make_float4(fmaxf(a.x, d.x), fmaxf(a.y, d.y), fmaxf(a.z, d.z), fmaxf(a.w, d.w));
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- persistent bidirectional LSTM recurrence ------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* __restrict__ xproj,
+                                                               const float* __restrict__ whh,
+                                                               float* __restrict__ hout, int B, int T) {
+    constexpr int LDH = H + 4;
+    constexpr int KG = H / 16;                   // k-groups of 16 (4 MFMA k-steps each)
+    __shared__ __attribute__((aligned(16))) float hbuf[2][16][LDH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int col = lane & 15;
+    const int q = lane >> 4;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * 16;
+    const int unit = 16 * w + col;
+
+    // W_hh slice as B fragments: element (g, j) of gate gt holds W[gt*H + unit][16g + 4q + j]
+    float breg[4][KG * 4];
+    const float* wd = whh + (int64_t)dir * 4 * H * H;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(wd + (int64_t)(gt * H + unit) * H + 16 * g + 4 * q);
+            breg[gt][4 * g + 0] = v.x; breg[gt][4 * g + 1] = v.y;
+            breg[gt][4 * g + 2] = v.z; breg[gt][4 * g + 3] = v.w;
+        }
+    for (int i = tid; i < 2 * 16 * LDH; i += H / 16 * 64) (&hbuf[0][0][0])[i] = 0.0f;
+
+    // rows of this lane in the C/D map: q*4 + r; clamp for loads, mask for stores
+    int brow[4];
+    int64_t xoff[4], hoff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + q * 4 + r;
+        brow[r] = b < B;
+        const int bc = b < B ? b : B - 1;
+        xoff[r] = (int64_t)bc * T * 8 * H + dir * 4 * H + unit;
+        hoff[r] = (int64_t)bc * T * 2 * H + dir * H + unit;
+    }
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    float xin[4][4];
+    {
+        const int t = dir ? T - 1 : 0;
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xin[gt][r] = xproj[xoff[r] + (int64_t)t * 8 * H + gt * H];
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        f32x4 acc[4];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[gt][r] = xin[gt][r];
+        if (s + 1 < T) {                           // prefetch the next step's input projection
+            const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xin[gt][r] = xproj[xoff[r] + (int64_t)tn * 8 * H + gt * H];
+        }
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&hbuf[cur][col][16 * g + 4 * q]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+                    acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], breg[gt][4 * g + j], acc[gt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = sigmoidf_(acc[0][r]);
+            const float fg = sigmoidf_(acc[1][r]);
+            const float gg = tanhf(acc[2][r]);
+            const float og = sigmoidf_(acc[3][r]);
+            cst[r] = fg * cst[r] + ig * gg;
+            const float hv = og * tanhf(cst[r]);
+            hbuf[cur ^ 1][q * 4 + r][unit] = hv;
+            if (brow[r]) hout[hoff[r] + (int64_t)t * 2 * H] = hv;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---- attention pooling (softmax over time) + final Linear -----------------------------------------
+template <int NF>   // features per lane: 2H = 64*NF
+__global__ __launch_bounds__(256) void attnpool_fc_kernel(const float* __restrict__ seq, const float* __restrict__ watt,
+                                                          const float* __restrict__ batt, const float* __restrict__ wfc,
+                                                          const float* __restrict__ bfc, float* __restrict__ logits,
+                                                          int T, int NC) {
+    constexpr int F = 64 * NF;
+    __shared__ float s_m[4], s_l[4], s_ctx[4][F], s_red[4][16];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const float* sb = seq + (int64_t)b * T * F;
+    float wa[NF], ctx[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) { wa[i] = watt[lane + 64 * i]; ctx[i] = 0.f; }
+    const float ba = batt[0];
+    float m = -INFINITY, l = 0.f;
+    for (int t = w; t < T; t += 4) {
+        float v[NF];
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { v[i] = sb[(int64_t)t * F + lane + 64 * i]; d += v[i] * wa[i]; }
+        const float sc = wave_sum(d) + ba;
+        const float mn = fmaxf(m, sc);
+        const float a = expf(m - mn);
+        const float p = expf(sc - mn);
+        l = l * a + p;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) ctx[i] = ctx[i] * a + p * v[i];
+        m = mn;
+    }
+    if (lane == 0) { s_m[w] = m; s_l[w] = l; }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) s_ctx[w][lane + 64 * i] = ctx[i];
+    __syncthreads();
+    const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    float Lt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Lt += s_l[k] * expf(s_m[k] - M);
+    // thread f (< F) owns pooled feature f
+    float pooled = 0.f;
+    const int f = threadIdx.x;
+    if (f < F) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pooled += s_ctx[k][f] * expf(s_m[k] - M);
+        pooled /= Lt;
+    }
+    for (int c = 0; c < NC; ++c) {
+        float part = (f < F) ? pooled * wfc[(int64_t)c * F + f] : 0.f;
+        part = wave_sum(part);
+        if (lane == 0) s_red[w][c] = part;
+    }
+    __syncthreads();
+    if (threadIdx.x < NC)
+        logits[(int64_t)b * NC + threadIdx.x] =
+            s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x] +
+            bfc[threadIdx.x];
+}
+
+static int conv3(const float* x, const float* wk, const float* bias, const float* R, int64_t ldr, int64_t sR,
+                 float* y, int B, int T, int Cin, int Cout, int act, hipStream_t s) {
+    GemmParams p = gemm_params_plain(x - Cin, wk, y, T, Cout, 3 * Cin, Cin, 3 * Cin, Cout);
+    p.bias = bias; p.R = R; p.ldr = ldr; p.sR1 = sR;
+    p.nz = B; p.nz2 = 1; p.sA1 = (int64_t)T * Cin; p.sC1 = (int64_t)T * Cout;
+    p.a_pad_k = Cin; p.act = act;
+    return launch_gemm_f32(p, s, "cnn_conv_gemm");
+}
+
+}  // namespace cnnlstm
+}  // namespace rsaf
+
+using namespace rsaf;
+using namespace rsaf::cnnlstm;
+
+extern "C" {
+
+int64_t rsaf_cnnlstm_weight_floats(int input_dim, int channels, int hidden, int num_classes, int lstm_layers) {
+    Dims d{input_dim, channels, hidden, num_classes, lstm_layers, ACT_SILU};
+    if (check_dims(d) != RSAF_OK) return -1;
+    return make_layout(d).total;
+}
+
+int rsaf_cnnlstm_weight_offsets(int input_dim, int channels, int hidden, int num_classes, int lstm_layers,
+                                int64_t* offsets_host, int cap, int* n_host) {
+    Dims d{input_dim, channels, hidden, num_classes, lstm_layers, ACT_SILU};
+    int rc = check_dims(d);
+    if (rc != RSAF_OK) return rc;
+    RSAF_CHECK_ARG(offsets_host && n_host, "NULL output");
+    const Layout L = make_layout(d);
+    int64_t v[10 + 12 + 4];
+    int n = 0;
+    v[n++] = L.w1; v[n++] = L.b1; v[n++] = L.wsc; v[n++] = L.bsc; v[n++] = L.w2; v[n++] = L.b2;
+    v[n++] = L.w3; v[n++] = L.b3; v[n++] = L.w4; v[n++] = L.b4;
+    for (int l = 0; l < d.L; ++l) { v[n++] = L.wih[l]; v[n++] = L.bih[l]; v[n++] = L.whh[l]; }
+    v[n++] = L.watt; v[n++] = L.batt; v[n++] = L.wfc; v[n++] = L.bfc;
+    RSAF_CHECK_ARG(cap >= n, "offsets_host too small");
+    for (int i = 0; i < n; ++i) offsets_host[i] = v[i];
+    *n_host = n;
+    return RSAF_OK;
+}
+
+int64_t rsaf_cnnlstm_workspace_bytes(int B, int T, int input_dim, int channels, int hidden, int lstm_layers) {
+    if (B <= 0 || T < 2) return -1;
+    const int64_t Tp = T / 2;
+    const int64_t conv = pad4((int64_t)B * T * channels);
+    const int64_t xp = pad4((int64_t)B * Tp * 8 * hidden);
+    const int64_t sq = pad4((int64_t)B * Tp * 2 * hidden);
+    return (3 * conv + xp + 2 * sq) * (int64_t)sizeof(float);
+}
+
+int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channels, int hidden, int num_classes,
+                         int lstm_layers, int act, const float* weights, void* workspace,
+                         int64_t workspace_bytes, float* logits, rsaf_stream_t stream) {
+    Dims d{input_dim, channels, hidden, num_classes, lstm_layers, act};
+    int rc = check_dims(d);
+    if (rc != RSAF_OK) return rc;
+    RSAF_CHECK_ARG(B >= 0 && B <= 65535, "batch must be in [0, 65535]");
+    if (B == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(T >= 2, "sequence length must be >= 2 (max_pool1d(2) of the reference needs it)");
+    RSAF_CHECK_ARG(x && weights && workspace && logits, "NULL pointer");
+    const int64_t need = rsaf_cnnlstm_workspace_bytes(B, T, input_dim, channels, hidden, lstm_layers);
+    if (workspace_bytes < need) {
+        set_error("rsaf_cnnlstm_forward: workspace too small");
+        return RSAF_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const Layout L = make_layout(d);
+    const int D = d.D, C = d.C, H = d.H, Tp = T / 2;
+    float* ws = static_cast<float*>(workspace);
+    const int64_t conv = pad4((int64_t)B * T * C);
+    float* bufA = ws;
+    float* bufB = ws + conv;
+    float* bufC = ws + 2 * conv;
+    float* xproj = ws + 3 * conv;
+    float* seq0 = xproj + pad4((int64_t)B * Tp * 8 * H);
+    float* seq1 = seq0 + pad4((int64_t)B * Tp * 2 * H);
+    const float* W = weights;
+
+    // res_block1 (src/models.py:64-76, :175)
+    rc = conv3(x, W + L.w1, W + L.b1, nullptr, 0, 0, bufA, B, T, D, C, d.act, s);
+    if (rc) return rc;
+    const float* sc = x;
+    int64_t ldsc = D;
+    if (D != C) {
+        GemmParams p = gemm_params_plain(x, W + L.wsc, bufB, T, C, D, D, D, C);
+        p.bias = W + L.bsc; p.nz = B; p.sA1 = (int64_t)T * D; p.sC1 = (int64_t)T * C;
+        rc = launch_gemm_f32(p, s, "cnn_conv_gemm");
+        if (rc) return rc;
+        sc = bufB; ldsc = C;
+    }
+    rc = conv3(bufA, W + L.w2, W + L.b2, sc, ldsc, (int64_t)T * ldsc, bufC, B, T, C, C, d.act, s);
+    if (rc) return rc;
+    // max_pool1d(2) (:177)
+    {
+        const int64_t n4 = (int64_t)B * Tp * (C / 4);
+        const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
+        ProfScope prof("cnn_pool2", s, 0.0, (double)B * T * C * 4 * 1.5);
+        hipLaunchKernelGGL(pool2_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(bufC),
+                           reinterpret_cast<float4*>(bufA), B, T, Tp, C / 4);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    // res_block2, identity shortcut (:178)
+    rc = conv3(bufA, W + L.w3, W + L.b3, nullptr, 0, 0, bufB, B, Tp, C, C, d.act, s);
+    if (rc) return rc;
+    rc = conv3(bufB, W + L.w4, W + L.b4, bufA, C, (int64_t)Tp * C, bufC, B, Tp, C, C, d.act, s);
+    if (rc) return rc;
+    // LSTM (:184)
+    const float* lin = bufC;
+    int in = C;
+    float* lout = seq0;
+    for (int l = 0; l < d.L; ++l) {
+        const int64_t rows = (int64_t)B * Tp;
+        RSAF_CHECK_ARG(rows <= 0x7fffffffLL, "B*T too large");
+        GemmParams p = gemm_params_plain(lin, W + L.wih[l], xproj, (int)rows, 8 * H, in, in, in, 8 * H);
+        p.bias = W + L.bih[l];
+        rc = launch_gemm_f32(p, s, "lstm_inproj_gemm");
+        if (rc) return rc;
+        {
+            ProfScope prof("lstm_recurrent", s, 2.0 * B * Tp * 2.0 * 4 * H * H, 0.0);
+            dim3 grid((B + 15) / 16, 2);
+            if (H == 128)
+                hipLaunchKernelGGL(lstm_rec_kernel<128>, grid, dim3(512), 0, s, xproj, W + L.whh[l], lout, B, Tp);
+            else
+                hipLaunchKernelGGL(lstm_rec_kernel<64>, grid, dim3(256), 0, s, xproj, W + L.whh[l], lout, B, Tp);
+            RSAF_CHECK_HIP(hipGetLastError());
+        }
+        lin = lout; in = 2 * H;
+        lout = (lout == seq0) ? seq1 : seq0;
+    }
+    // attention pooling + fc (:187-191)
+    {
+        ProfScope prof("attnpool_fc", s, 0.0, (double)B * Tp * 2 * H * 4);
+        if (H == 128)
+            hipLaunchKernelGGL(attnpool_fc_kernel<4>, dim3(B), dim3(256), 0, s, lin, W + L.watt, W + L.batt,
+                               W + L.wfc, W + L.bfc, logits, Tp, d.NC);
+        else
+            hipLaunchKernelGGL(attnpool_fc_kernel<2>, dim3(B), dim3(256), 0, s, lin, W + L.watt, W + L.batt,
+                               W + L.wfc, W + L.bfc, logits, Tp, d.NC);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    return RSAF_OK;
+}
+
+}  // extern "C"

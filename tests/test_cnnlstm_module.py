@@ -1,0 +1,51 @@
+"""Host-side contract of the CNNLSTM drop-in (no GPU): state_dict keys, constructor errors."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from weights import cnnlstm_shapes  # noqa: E402
+
+
+@pytest.mark.parametrize("D,C,H", [(768, 128, 128), (768, 32, 64), (32, 32, 64)])
+def test_state_dict_keys_and_shapes_match_reference_layout(rsaf_lib, D, C, H):
+    from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+    m = CNNLSTM(input_dim=D, cnn_out_channels=C, lstm_hidden_dim=H)
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith("num_batches_tracked")}
+    assert sd == cnnlstm_shapes(D, C, H)
+    assert hasattr(m.res_block1.conv1.weight, "data")          # src/dl_cv_strategies.py:336,426
+
+
+def test_shipped_checkpoint_state_loads_unchanged(rsaf_lib):
+    import torch
+    from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+    sd = dict(np.load(os.path.join(HERE, "golden", "cnnlstm_ckpt_reading_state.npz")))
+    m = CNNLSTM(input_dim=768, cnn_out_channels=32, lstm_hidden_dim=64)
+    res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys
+
+
+def test_packed_blob_layout(rsaf_lib):
+    from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM, pack_weights, weight_offsets
+    m = CNNLSTM(input_dim=16, cnn_out_channels=32, lstm_hidden_dim=64).eval()
+    offs, total = weight_offsets(16, 32, 64, 2, 2)
+    blob = pack_weights(m)
+    assert blob.shape == (total,) and all(o % 4 == 0 for o in offs if o >= 0)
+    # folded conv1: default BN (mean 0, var 1, gamma 1, beta 0) -> w / sqrt(1 + eps), tap-major
+    w = m.res_block1.conv1.weight.detach().numpy()
+    want = (w / np.sqrt(1.0 + 1e-5)).transpose(0, 2, 1).reshape(32, -1)
+    assert np.allclose(blob[offs[0]:offs[0] + want.size].reshape(32, -1), want, atol=1e-7)
+    # identity shortcut when input_dim == channels
+    offs2, _ = weight_offsets(32, 32, 64, 2, 2)
+    assert offs2[2] == -1 and offs2[3] == -1
+
+
+def test_unknown_activation(rsaf_lib):
+    from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM, get_activation_fn
+    with pytest.raises(ValueError):
+        get_activation_fn("tanh")
+    with pytest.raises(ValueError):
+        CNNLSTM(activation_fn="tanh")
