@@ -114,6 +114,35 @@ int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channe
                          int num_classes, int lstm_layers, int act, const float* weights,
                          void* workspace, int64_t workspace_bytes, float* logits, rsaf_stream_t stream);
 
+/* ---- Wav2Vec2 frame embeddings for a batch of equal-length chunks -----------------------------------
+ * Replaces, per chunk, `processor(chunk).input_values` + `Wav2Vec2Model(...)(input_values)
+ * .last_hidden_state` (src/foundation_model_extractor.py:113-116; third-party transformers
+ * modeling_wav2vec2.py / feature_extraction_wav2vec2.py:95), fp32 end to end.
+ * Chunk i covers samples [chunk_start[i], chunk_start[i] + chunk_len) of `wav` (chunk_start: device
+ * int64 array).  out: float32 rows of `hidden` floats; chunk i's T = rsaf_w2v2_frames(chunk_len) frames go
+ * to rows out_row_start[i] .. +T (device int64 array; lets the caller lay chunks out in the
+ * reference's np.vstack order, src/foundation_model_extractor.py:124) or, when out_row_start is
+ * NULL, to rows i*T .. (i+1)*T.
+ * `weights`: one float32 device blob; segment offsets (floats, 16-byte aligned) from
+ * rsaf_w2v2_weight_offsets in this order:
+ *   conv0[C][10] gn_gamma gn_beta conv1..conv6 ([C][tap*C+ci]) fp_ln_g fp_ln_b fp_w[H][C] fp_b
+ *   pos_w ([G][C/G][tap*(H/G)+ci], weight norm folded) pos_b enc_ln_g enc_ln_b
+ *   per layer: wqkv[3H][H] bqkv wo bo ln1_g ln1_b w1[I][H] b1 w2[H][I] b2 ln2_g ln2_b
+ * Feature encoder geometry is wav2vec2's (kernels 10,3,3,3,3,2,2 / strides 5,2,2,2,2,2,2, GroupNorm
+ * on layer 0, no conv bias, post-LN encoder).  n_chunks * max(heads, pos_groups) <= 65535.        */
+int rsaf_w2v2_frames(int chunk_len);
+int64_t rsaf_w2v2_weight_floats(int conv_dim, int hidden, int layers, int heads, int intermediate,
+                                int pos_kernel, int pos_groups);
+int rsaf_w2v2_weight_offsets(int conv_dim, int hidden, int layers, int heads, int intermediate,
+                             int pos_kernel, int pos_groups, int64_t* offsets_host, int cap, int* n_host);
+int64_t rsaf_w2v2_workspace_bytes(int n_chunks, int chunk_len, int conv_dim, int hidden, int layers,
+                                  int heads, int intermediate, int pos_kernel, int pos_groups);
+int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks, int chunk_len,
+                      int conv_dim, int hidden, int layers, int heads, int intermediate, int pos_kernel,
+                      int pos_groups, float layer_norm_eps, const float* weights, void* workspace,
+                      int64_t workspace_bytes, float* out, const int64_t* out_row_start,
+                      rsaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,11 @@ SIGNATURES = {
     "rsaf_cnnlstm_weight_offsets": (_I, [_I, _I, _I, _I, _I, C.POINTER(_L), _I, C.POINTER(_I)]),
     "rsaf_cnnlstm_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "rsaf_cnnlstm_forward": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _P]),
+    "rsaf_w2v2_frames": (_I, [_I]),
+    "rsaf_w2v2_weight_floats": (_L, [_I] * 7),
+    "rsaf_w2v2_weight_offsets": (_I, [_I] * 7 + [C.POINTER(_L), _I, C.POINTER(_I)]),
+    "rsaf_w2v2_workspace_bytes": (_L, [_I] * 9),
+    "rsaf_w2v2_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _L, _P, _P, _P]),
 }
 
 _lib = None

@@ -24,6 +24,7 @@ struct GemmParams {
     int64_t lda, ldb, ldc, ldr;
     int nz, nz2;         // number of batches, inner batch count
     int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+    int64_t sBias2;      // bias offset per inner batch index z2 (grouped convolutions)
     int a_pad_k;
     int act;
     float alpha;
@@ -40,7 +41,7 @@ inline GemmParams gemm_params_plain(const float* A, const float* B, float* C, in
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = 0;
     p.nz = 1; p.nz2 = 1;
     p.sA1 = p.sA2 = p.sB1 = p.sB2 = p.sC1 = p.sC2 = p.sR1 = p.sR2 = 0;
-    p.a_pad_k = 0; p.act = ACT_NONE; p.alpha = 1.0f; p.b_kn = 0;
+    p.sBias2 = 0; p.a_pad_k = 0; p.act = ACT_NONE; p.alpha = 1.0f; p.b_kn = 0;
     return p;
 }
 

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const float* __restrict__ B = p.B + z1 * p.sB1 + z2 * p.sB2;
     float* __restrict__ C = p.C + z1 * p.sC1 + z2 * p.sC2;
     const float* __restrict__ R = p.R ? p.R + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+    const float* __restrict__ bias = p.bias ? p.bias + z2 * p.sBias2 : nullptr;
 
     const int wm0 = (wave / WAVES_N) * WM;
     const int wn0 = (wave % WAVES_N) * WN;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
         const int gn = n0 + wn0 + nt * 32 + l31;
         const int n_ok = gn < p.N;
         const int gnc = n_ok ? gn : 0;
-        const float bv = p.bias ? p.bias[gnc] : 0.0f;
+        const float bv = bias ? bias[gnc] : 0.0f;
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
             const int gm_base = m0 + wm0 + mt * 32 + 4 * h;

@@ -1,0 +1,533 @@
+// Wav2Vec2 frame-embedding forward for gfx950 (fp32 end to end).
+//
+// Replaces, for a batch of equal-length chunks, what the reference runs per chunk at batch 1
+// (src/foundation_model_extractor.py:113-116): HF Wav2Vec2FeatureExtractor normalisation
+// (feature_extraction_wav2vec2.py:95) + transformers' Wav2Vec2Model.forward in eval mode
+// (modeling_wav2vec2.py:254-323 conv stack, :422-434 projection, :326-379 positional conv,
+// :575-608 post-LN encoder layers).  Chunking (80 000-sample windows every 64 000, per-chunk
+// normalisation, duplicated overlap) stays on the host side exactly as the reference does it.
+//
+// Every dense contraction is an exact-fp32 MFMA GEMM (gemm_f32.hip):
+//   conv1..6  : channels-last activations make a k-tap/stride-2 conv a GEMM with lda = 2*C, K = k*C
+//   pos-conv  : activations regrouped to [chunk][group][T+K-1 (zero padded)][C/G], one batched GEMM
+//   attention : S = QK^T/sqrt(d) and O = PV as (chunk, head)-batched GEMMs on the packed qkv buffer
+// conv0 (Cin = 1) + GroupNorm + GELU is recomputed in two passes (stats, apply) instead of
+// materialising the un-normalised 15 999 x 512 activation; LayerNorm / softmax are one wave per row.
+#include <algorithm>
+#include <vector>
+
+#include "gemm_f32.h"
+
+namespace rsaf {
+namespace w2v2 {
+
+struct Cfg {
+    int C, Hd, L, NH, I, PK, PG;
+    float eps;
+};
+
+static inline int64_t pad4(int64_t n) { return (n + 3) & ~int64_t(3); }
+
+static const int KERN[7] = {10, 3, 3, 3, 3, 2, 2};
+static const int STRD[7] = {5, 2, 2, 2, 2, 2, 2};
+
+struct LayerOff {
+    int64_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+};
+struct Layout {
+    int64_t conv0, gng, gnb, conv[6], fplg, fplb, fpw, fpb, posw, posb, elng, elnb;
+    std::vector<LayerOff> layers;
+    int64_t total;
+};
+
+static Layout make_layout(const Cfg& c) {
+    Layout L;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t s = o; o += pad4(n); return s; };
+    L.conv0 = take((int64_t)c.C * 10); L.gng = take(c.C); L.gnb = take(c.C);
+    for (int i = 0; i < 6; ++i) L.conv[i] = take((int64_t)c.C * KERN[i + 1] * c.C);
+    L.fplg = take(c.C); L.fplb = take(c.C); L.fpw = take((int64_t)c.Hd * c.C); L.fpb = take(c.Hd);
+    const int cg = c.Hd / c.PG;
+    L.posw = take((int64_t)c.PG * cg * c.PK * cg); L.posb = take(c.Hd);
+    L.elng = take(c.Hd); L.elnb = take(c.Hd);
+    for (int l = 0; l < c.L; ++l) {
+        LayerOff lo;
+        lo.wqkv = take((int64_t)3 * c.Hd * c.Hd); lo.bqkv = take(3 * c.Hd);
+        lo.wo = take((int64_t)c.Hd * c.Hd); lo.bo = take(c.Hd);
+        lo.ln1g = take(c.Hd); lo.ln1b = take(c.Hd);
+        lo.w1 = take((int64_t)c.I * c.Hd); lo.b1 = take(c.I);
+        lo.w2 = take((int64_t)c.Hd * c.I); lo.b2 = take(c.Hd);
+        lo.ln2g = take(c.Hd); lo.ln2b = take(c.Hd);
+        L.layers.push_back(lo);
+    }
+    L.total = o;
+    return L;
+}
+
+static int check_cfg(const Cfg& c) {
+    RSAF_CHECK_ARG(c.C >= 32 && c.C <= 1024 && c.C % 32 == 0 && (c.C <= 256 || c.C % 256 == 0),
+                   "conv_dim must be a multiple of 32 (<= 256) or of 256 (<= 1024)");
+    RSAF_CHECK_ARG(c.Hd >= 4 && c.Hd <= 1024 && c.Hd % 4 == 0, "hidden_size must be a multiple of 4, <= 1024");
+    RSAF_CHECK_ARG(c.I >= 4 && c.I % 4 == 0, "intermediate_size must be a multiple of 4");
+    RSAF_CHECK_ARG(c.L >= 1 && c.L <= 64, "num_hidden_layers out of range");
+    RSAF_CHECK_ARG(c.NH >= 1 && c.Hd % c.NH == 0 && (c.Hd / c.NH) % 4 == 0, "head_dim must be a multiple of 4");
+    RSAF_CHECK_ARG(c.PG >= 1 && c.Hd % c.PG == 0 && (c.Hd / c.PG) % 4 == 0 && c.PK >= 2 && c.PK % 2 == 0,
+                   "positional conv: channels/group multiple of 4, even kernel");
+    return RSAF_OK;
+}
+
+static void chunk_lengths(int len, int T[7]) {
+    int n = len;
+    for (int i = 0; i < 7; ++i) {
+        n = n >= KERN[i] ? (n - KERN[i]) / STRD[i] + 1 : 0;
+        T[i] = n;
+    }
+}
+
+struct Workspace {
+    int64_t xn, part, ab, bufP, bufQ, lnf, x, y, att, xg, qkv, S, ffn, total;
+    int slabs, Tp;
+};
+constexpr int STAT_SLAB = 512;
+
+static Workspace make_ws(const Cfg& c, int n, int len) {
+    int T[7];
+    chunk_lengths(len, T);
+    Workspace w{};
+    int64_t o = 0;
+    auto take = [&](int64_t k) { int64_t s = o; o += pad4(k); return s; };
+    const int Tt = T[6];
+    w.slabs = (T[0] + STAT_SLAB - 1) / STAT_SLAB;
+    w.Tp = (int)pad4(Tt);
+    w.xn = take((int64_t)n * len);
+    w.part = take((int64_t)n * w.slabs * 2 * c.C);
+    w.ab = take((int64_t)n * 2 * c.C);
+    w.bufP = take((int64_t)n * T[0] * c.C);
+    w.bufQ = take((int64_t)n * T[1] * c.C);
+    w.lnf = take((int64_t)n * Tt * c.C);
+    w.x = take((int64_t)n * Tt * c.Hd);
+    w.y = take((int64_t)n * Tt * c.Hd);
+    w.att = take((int64_t)n * Tt * c.Hd);
+    w.xg = take((int64_t)n * (Tt + c.PK - 1) * c.Hd);
+    w.qkv = take((int64_t)n * Tt * 3 * c.Hd);
+    w.S = take((int64_t)n * c.NH * Tt * w.Tp);
+    w.ffn = take((int64_t)n * Tt * c.I);
+    w.total = o;
+    return w;
+}
+
+// ---- per-chunk zero-mean / unit-variance normalisation -------------------------------------------
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ wav,
+                                                        const int64_t* __restrict__ starts, int len,
+                                                        float* __restrict__ xn) {
+    __shared__ double red[4];
+    __shared__ double bc;
+    const float* x = wav + starts[blockIdx.x];
+    float* o = xn + (int64_t)blockIdx.x * len;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < len; i += 256) s += (double)x[i];
+    s = wave_sum_f64(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = (red[0] + red[1] + red[2] + red[3]) / len;
+    __syncthreads();
+    const double mean = bc;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < len; i += 256) { const double d = (double)x[i] - mean; v += d * d; }
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    const float var = (float)((red[0] + red[1] + red[2] + red[3]) / len);
+    const float mu = (float)mean;
+    const float sd = sqrtf(var + 1e-7f);
+    for (int i = threadIdx.x; i < len; i += 256) o[i] = (x[i] - mu) / sd;
+}
+
+// ---- conv0 (1 -> C, k = 10, s = 5) + GroupNorm(C groups) + GELU, two passes ----------------------
+// thread <-> channel(s); the 10 samples of a frame are wave-uniform (scalar loads)
+template <int CPT, bool APPLY>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn, const float* __restrict__ w0,
+                                                    float* __restrict__ part, const float* __restrict__ ab,
+                                                    float* __restrict__ out, int len, int T0, int C, int slab,
+                                                    int slabs) {
+    const int chunk = blockIdx.y, sl = blockIdx.x;
+    const int t0 = sl * slab, t1 = min(T0, t0 + slab);
+    const float* __restrict__ x = xn + (int64_t)chunk * len;
+    float wr[CPT][10], a[CPT], b[CPT], s[CPT], q[CPT];
+    int ch[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        ch[k] = threadIdx.x + blockDim.x * k;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) wr[k][j] = w0[ch[k] * 10 + j];
+        s[k] = 0.f; q[k] = 0.f;
+        if (APPLY) { a[k] = ab[((int64_t)chunk * 2 + 0) * C + ch[k]]; b[k] = ab[((int64_t)chunk * 2 + 1) * C + ch[k]]; }
+    }
+    for (int t = t0; t < t1; ++t) {
+        float xv[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xv[j] = x[5 * t + j];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) y = fmaf(wr[k][j], xv[j], y);
+            if (APPLY) {
+                const float v = fmaf(y, a[k], b[k]);
+                out[((int64_t)chunk * T0 + t) * C + ch[k]] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            } else {
+                s[k] += y; q[k] += y * y;
+            }
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            part[(((int64_t)chunk * slabs + sl) * 2 + 0) * C + ch[k]] = s[k];
+            part[(((int64_t)chunk * slabs + sl) * 2 + 1) * C + ch[k]] = q[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ g,
+                                                          const float* __restrict__ be, float* __restrict__ ab,
+                                                          int n, int C, int slabs, int T0) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * C) return;
+    const int chunk = (int)(i / C), c = (int)(i % C);
+    double s = 0.0, q = 0.0;
+    for (int sl = 0; sl < slabs; ++sl) {
+        s += (double)part[(((int64_t)chunk * slabs + sl) * 2 + 0) * C + c];
+        q += (double)part[(((int64_t)chunk * slabs + sl) * 2 + 1) * C + c];
+    }
+    const double mean = s / T0;
+    double var = q / T0 - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + 1e-5);
+    const double a = (double)g[c] * rstd;
+    ab[((int64_t)chunk * 2 + 0) * C + c] = (float)a;
+    ab[((int64_t)chunk * 2 + 1) * C + c] = (float)((double)be[c] - mean * a);
+}
+
+// ---- LayerNorm over the last dim (optionally of x + r), one wave per row, D <= 1024 -----------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        float* __restrict__ out, int64_t rows, int D, float eps,
+                                                        const int64_t* __restrict__ out_row_start, int T) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    // optional scatter: row r of chunk i lands at output row out_row_start[i] + r (vstack order)
+    const int64_t orow = out_row_start ? out_row_start[row / T] + row % T : row;
+    const int D4 = D >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + row * D);
+    const float4* r4 = r ? reinterpret_cast<const float4*>(r + row * D) : nullptr;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < D4) {
+            v[i] = x4[idx];
+            if (r4) { const float4 t = r4[idx]; v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w; }
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < D4) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    float4* o4 = reinterpret_cast<float4*>(out + orow * D);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < D4) {
+            const float4 gg = g4[idx], bb = b4[idx];
+            o4[idx] = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                                  (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+        }
+    }
+}
+
+// ---- row softmax in place, one wave per row of length T (row stride Tp, pad columns zeroed) ---------
+__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, int64_t rows, int T, int Tp) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* p = S + row * Tp;
+    float m = -INFINITY;
+    for (int c = lane; c < T; c += 64) m = fmaxf(m, p[c]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+    for (int c = lane; c < T; c += 64) { const float e = expf(p[c] - m); p[c] = e; s += e; }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < Tp; c += 64) p[c] = c < T ? p[c] * inv : 0.0f;
+}
+
+// ---- regroup for the grouped positional conv: xg[chunk][g][tt][ci], zero padded in time -----------
+__global__ __launch_bounds__(256) void regroup_kernel(const float4* __restrict__ x, float4* __restrict__ xg, int n,
+                                                      int T, int Hd4, int G, int K) {
+    const int cg4 = Hd4 / G;
+    const int TT = T + K - 1;
+    const int64_t total = (int64_t)n * G * TT * cg4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % cg4);
+        int64_t r = i / cg4;
+        const int tt = (int)(r % TT); r /= TT;
+        const int g = (int)(r % G);
+        const int64_t chunk = r / G;
+        const int t = tt - K / 2;
+        xg[i] = (t >= 0 && t < T) ? x[(chunk * T + t) * Hd4 + g * cg4 + ci] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
+              float eps, hipStream_t s, const int64_t* out_row_start = nullptr, int T = 1) {
+    const int64_t blocks = (rows + 3) / 4;
+    RSAF_CHECK_ARG(blocks <= 0x7fffffffLL, "too many rows");
+    ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * 4 * (r ? 3 : 2));
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, r, g, b, out, rows, D, eps,
+                       out_row_start, T);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+template <bool APPLY>
+static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* part, const float* ab, float* out,
+                        int n, int len, int T0, int slab, int slabs, hipStream_t s) {
+    const int threads = c.C <= 256 ? c.C : 256;
+    const int cpt = c.C / threads;
+    dim3 grid((unsigned)slabs, (unsigned)n);
+    ProfScope prof(APPLY ? "w2v2_conv0_apply" : "w2v2_conv0_stats", s, 2.0 * 10 * c.C * (double)T0 * n, 0.0);
+#define RSAF_C0(CPT)                                                                                       \
+    hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, out, len, T0, \
+                       c.C, slab, slabs)
+    switch (cpt) {
+        case 1: RSAF_C0(1); break;
+        case 2: RSAF_C0(2); break;
+        case 3: RSAF_C0(3); break;
+        case 4: RSAF_C0(4); break;
+        default: set_error("conv0: unsupported conv_dim"); return RSAF_ERR_ARG;
+    }
+#undef RSAF_C0
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+}  // namespace w2v2
+}  // namespace rsaf
+
+using namespace rsaf;
+using namespace rsaf::w2v2;
+
+extern "C" {
+
+int rsaf_w2v2_frames(int chunk_len) {
+    int T[7];
+    chunk_lengths(chunk_len, T);
+    return T[6];
+}
+
+int64_t rsaf_w2v2_weight_floats(int conv_dim, int hidden, int layers, int heads, int intermediate, int pos_kernel,
+                                int pos_groups) {
+    Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, 1e-5f};
+    if (check_cfg(c) != RSAF_OK) return -1;
+    return make_layout(c).total;
+}
+
+int rsaf_w2v2_weight_offsets(int conv_dim, int hidden, int layers, int heads, int intermediate, int pos_kernel,
+                             int pos_groups, int64_t* offsets_host, int cap, int* n_host) {
+    Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, 1e-5f};
+    int rc = check_cfg(c);
+    if (rc != RSAF_OK) return rc;
+    RSAF_CHECK_ARG(offsets_host && n_host, "NULL output");
+    const Layout L = make_layout(c);
+    std::vector<int64_t> v = {L.conv0, L.gng, L.gnb};
+    for (int i = 0; i < 6; ++i) v.push_back(L.conv[i]);
+    for (int64_t o : {L.fplg, L.fplb, L.fpw, L.fpb, L.posw, L.posb, L.elng, L.elnb}) v.push_back(o);
+    for (const LayerOff& lo : L.layers)
+        for (int64_t o : {lo.wqkv, lo.bqkv, lo.wo, lo.bo, lo.ln1g, lo.ln1b, lo.w1, lo.b1, lo.w2, lo.b2, lo.ln2g, lo.ln2b})
+            v.push_back(o);
+    RSAF_CHECK_ARG(cap >= (int)v.size(), "offsets_host too small");
+    for (size_t i = 0; i < v.size(); ++i) offsets_host[i] = v[i];
+    *n_host = (int)v.size();
+    return RSAF_OK;
+}
+
+int64_t rsaf_w2v2_workspace_bytes(int n_chunks, int chunk_len, int conv_dim, int hidden, int layers, int heads,
+                                  int intermediate, int pos_kernel, int pos_groups) {
+    Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, 1e-5f};
+    if (check_cfg(c) != RSAF_OK || n_chunks <= 0) return -1;
+    if (rsaf_w2v2_frames(chunk_len) <= 0) return -1;
+    return make_ws(c, n_chunks, chunk_len).total * (int64_t)sizeof(float);
+}
+
+int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks, int chunk_len, int conv_dim,
+                      int hidden, int layers, int heads, int intermediate, int pos_kernel, int pos_groups,
+                      float layer_norm_eps, const float* weights, void* workspace, int64_t workspace_bytes,
+                      float* out, const int64_t* out_row_start, rsaf_stream_t stream) {
+    Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, layer_norm_eps};
+    int rc = check_cfg(c);
+    if (rc != RSAF_OK) return rc;
+    RSAF_CHECK_ARG(n_chunks >= 0 && n_chunks <= 65535 / std::max(c.NH, c.PG), "too many chunks per call");
+    if (n_chunks == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && chunk_start && weights && workspace && out, "NULL pointer");
+    int T[7];
+    chunk_lengths(chunk_len, T);
+    RSAF_CHECK_ARG(T[6] >= 1, "chunk shorter than the receptive field of the feature encoder");
+    const Workspace W = make_ws(c, n_chunks, chunk_len);
+    if (workspace_bytes < W.total * (int64_t)sizeof(float)) {
+        set_error("rsaf_w2v2_forward: workspace too small");
+        return RSAF_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const Layout L = make_layout(c);
+    float* ws = static_cast<float*>(workspace);
+    const float* Wt = weights;
+    const int n = n_chunks, C = c.C, Hd = c.Hd, Tt = T[6];
+    const int64_t rows = (int64_t)n * Tt;
+    RSAF_CHECK_ARG(rows <= 0x7fffffffLL, "too many frames per call");
+
+    // 1. per-chunk normalisation (HF feature extractor)
+    {
+        ProfScope prof("w2v2_normalize", s, 0.0, (double)n * chunk_len * 4 * 3);
+        hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, wav, chunk_start, chunk_len, ws + W.xn);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    // 2. conv0 + GroupNorm + GELU (stats pass, finalize, apply pass)
+    rc = conv0_launch<false>(c, ws + W.xn, Wt + L.conv0, ws + W.part, nullptr, nullptr, n, chunk_len, T[0],
+                             STAT_SLAB, W.slabs, s);
+    if (rc) return rc;
+    {
+        const int64_t tot = (int64_t)n * C;
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ws + W.part,
+                           Wt + L.gng, Wt + L.gnb, ws + W.ab, n, C, W.slabs, T[0]);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    {
+        const int slab = 128;
+        rc = conv0_launch<true>(c, ws + W.xn, Wt + L.conv0, nullptr, ws + W.ab, ws + W.bufP, n, chunk_len, T[0],
+                                slab, (T[0] + slab - 1) / slab, s);
+        if (rc) return rc;
+    }
+    // 3. conv1..6 as GEMMs with fused GELU
+    float* cur = ws + W.bufP;
+    float* nxt = ws + W.bufQ;
+    for (int i = 1; i < 7; ++i) {
+        GemmParams p = gemm_params_plain(cur, Wt + L.conv[i - 1], nxt, T[i], C, KERN[i] * C, (int64_t)STRD[i] * C,
+                                         (int64_t)KERN[i] * C, C);
+        p.nz = n; p.sA1 = (int64_t)T[i - 1] * C; p.sC1 = (int64_t)T[i] * C; p.act = ACT_GELU;
+        rc = launch_gemm_f32(p, s, "w2v2_gemm");
+        if (rc) return rc;
+        std::swap(cur, nxt);
+    }
+    // 4. feature projection: LayerNorm + Linear
+    rc = ln(cur, nullptr, Wt + L.fplg, Wt + L.fplb, ws + W.lnf, rows, C, c.eps, s);
+    if (rc) return rc;
+    {
+        GemmParams p = gemm_params_plain(ws + W.lnf, Wt + L.fpw, ws + W.x, (int)rows, Hd, C, C, C, Hd);
+        p.bias = Wt + L.fpb;
+        rc = launch_gemm_f32(p, s, "w2v2_gemm");
+        if (rc) return rc;
+    }
+    // 5. positional conv embedding (grouped, weight norm folded), GELU, x = LN(x + pos)
+    {
+        const int cg = Hd / c.PG;
+        const int TT = Tt + c.PK - 1;
+        const int64_t tot4 = (int64_t)n * TT * (Hd / 4);
+        {
+            ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 32);
+            hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)std::min<int64_t>((tot4 + 255) / 256, 4096)), dim3(256),
+                               0, s, reinterpret_cast<const float4*>(ws + W.x), reinterpret_cast<float4*>(ws + W.xg),
+                               n, Tt, Hd / 4, c.PG, c.PK);
+            RSAF_CHECK_HIP(hipGetLastError());
+        }
+        GemmParams p = gemm_params_plain(ws + W.xg, Wt + L.posw, ws + W.y, Tt, cg, c.PK * cg, cg, (int64_t)c.PK * cg, Hd);
+        p.nz = n * c.PG; p.nz2 = c.PG;
+        p.sA1 = (int64_t)c.PG * TT * cg; p.sA2 = (int64_t)TT * cg;
+        p.sB1 = 0; p.sB2 = (int64_t)cg * c.PK * cg;
+        p.sC1 = (int64_t)Tt * Hd; p.sC2 = cg;
+        p.bias = Wt + L.posb; p.sBias2 = cg; p.act = ACT_GELU;
+        rc = launch_gemm_f32(p, s, "w2v2_gemm");
+        if (rc) return rc;
+        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s);
+        if (rc) return rc;
+    }
+    // 6. encoder layers (post-LN)
+    const int hd = Hd / c.NH;
+    const float scale = 1.0f / sqrtf((float)hd);
+    float* x = ws + W.x;
+    for (int l = 0; l < c.L; ++l) {
+        const LayerOff& lo = L.layers[l];
+        {   // fused q,k,v projection
+            GemmParams p = gemm_params_plain(x, Wt + lo.wqkv, ws + W.qkv, (int)rows, 3 * Hd, Hd, Hd, Hd, 3 * Hd);
+            p.bias = Wt + lo.bqkv;
+            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            if (rc) return rc;
+        }
+        {   // S = scale * Q K^T per (chunk, head)
+            GemmParams p = gemm_params_plain(ws + W.qkv, ws + W.qkv + Hd, ws + W.S, Tt, Tt, hd, 3 * Hd, 3 * Hd, W.Tp);
+            p.nz = n * c.NH; p.nz2 = c.NH;
+            p.sA1 = (int64_t)Tt * 3 * Hd; p.sA2 = hd; p.sB1 = p.sA1; p.sB2 = hd;
+            p.sC1 = (int64_t)c.NH * Tt * W.Tp; p.sC2 = (int64_t)Tt * W.Tp;
+            p.alpha = scale;
+            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            if (rc) return rc;
+        }
+        {
+            const int64_t srows = (int64_t)n * c.NH * Tt;
+            ProfScope prof("w2v2_softmax", s, 0.0, (double)srows * W.Tp * 8);
+            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, s, ws + W.S, srows, Tt,
+                               W.Tp);
+            RSAF_CHECK_HIP(hipGetLastError());
+        }
+        {   // O = P V per (chunk, head), V is [T, hd] with N contiguous
+            GemmParams p = gemm_params_plain(ws + W.S, ws + W.qkv + 2 * Hd, ws + W.att, Tt, hd, Tt, W.Tp, 3 * Hd, Hd);
+            p.nz = n * c.NH; p.nz2 = c.NH; p.b_kn = 1;
+            p.sA1 = (int64_t)c.NH * Tt * W.Tp; p.sA2 = (int64_t)Tt * W.Tp;
+            p.sB1 = (int64_t)Tt * 3 * Hd; p.sB2 = hd;
+            p.sC1 = (int64_t)Tt * Hd; p.sC2 = hd;
+            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            if (rc) return rc;
+        }
+        {   // y = attn Wo^T + bo + x ; x = LN(y)
+            GemmParams p = gemm_params_plain(ws + W.att, Wt + lo.wo, ws + W.y, (int)rows, Hd, Hd, Hd, Hd, Hd);
+            p.bias = Wt + lo.bo; p.R = x; p.ldr = Hd;
+            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            if (rc) return rc;
+            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s);
+            if (rc) return rc;
+        }
+        {   // feed forward
+            GemmParams p = gemm_params_plain(x, Wt + lo.w1, ws + W.ffn, (int)rows, c.I, Hd, Hd, Hd, c.I);
+            p.bias = Wt + lo.b1; p.act = ACT_GELU;
+            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            if (rc) return rc;
+            GemmParams p2 = gemm_params_plain(ws + W.ffn, Wt + lo.w2, ws + W.y, (int)rows, Hd, c.I, c.I, c.I, Hd);
+            p2.bias = Wt + lo.b2; p2.R = x; p2.ldr = Hd;
+            rc = launch_gemm_f32(p2, s, "w2v2_gemm");
+            if (rc) return rc;
+            const bool last = (l == c.L - 1);
+            rc = ln(ws + W.y, nullptr, Wt + lo.ln2g, Wt + lo.ln2b, last ? out : x, rows, Hd, c.eps, s,
+                    last ? out_row_start : nullptr, Tt);
+            if (rc) return rc;
+        }
+    }
+    return RSAF_OK;
+}
+
+}  // extern "C"
