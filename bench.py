@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--stages", type=str, default="all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-clips", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--w2v2-chunks-per-call", type=int, default=256)
     return ap.parse_args()
 
 
@@ -44,22 +45,42 @@ def cpu_baseline(stages, seconds, sample_clips):
     """Time the CPU oracle (kind "port") on a bounded sample of the same synthetic workload.
 
     This is the only place outside tests/ and smoke() that touches oracle/: it is the reported
-    baseline, never the product path."""
+    baseline, never the product path.  DSP stages are numpy (one core), the model stages are
+    torch-CPU float32 with every host core, exactly the ops the reference's CPU path dispatches."""
     import numpy as np
     import torch
-    from oracle import smile_oracle
     from robust_speech_analysis_framework_amd import synth
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    n = sample_clips or 4
+    n = sample_clips or 2
     clips = [synth.synth_clip(900000 + k, seconds) for k in range(n)]
     parts, total = {}, 0.0
     if "smile" in stages:
+        from oracle import smile_oracle
         t0 = time.perf_counter()
         for c in clips:
             smile_oracle.extract(c)
         parts["smile"] = time.perf_counter() - t0
-        total += parts["smile"]
+    seqs = None
+    if "w2v2" in stages:
+        from oracle import w2v2_oracle
+        from robust_speech_analysis_framework_amd.w2v2_config import W2V2Config, random_state_dict
+        cfg = W2V2Config()
+        sd = random_state_dict(cfg, 0)
+        w2v2_oracle.extract_sequence(sd, cfg, clips[0][:16000])          # warm-up
+        t0 = time.perf_counter()
+        seqs = [w2v2_oracle.extract_sequence(sd, cfg, c) for c in clips]
+        parts["w2v2"] = time.perf_counter() - t0
+    if "cnnlstm" in stages and seqs is not None:
+        from oracle import cnnlstm_oracle
+        from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+        torch.manual_seed(0)
+        sdm = {k: v.numpy() for k, v in CNNLSTM().state_dict().items()}
+        x = cnnlstm_oracle.collate_zero_pad(seqs)
+        t0 = time.perf_counter()
+        cnnlstm_oracle.forward_torch(sdm, x, "silu")
+        parts["cnnlstm"] = time.perf_counter() - t0
+    total = sum(parts.values())
     cpu_model = ""
     try:
         for ln in open("/proc/cpuinfo"):
@@ -68,8 +89,11 @@ def cpu_baseline(stages, seconds, sample_clips):
                 break
     except OSError:
         pass
-    return {"value": round(n * seconds / total, 2), "unit": "audio-s/s", "cores": 1 if stages == ["smile"] else cores,
-            "kind": "port", "sample": f"{n} x {seconds:g} s clips, stages {stages}, oracle/ (numpy float64 DSP)",
+    model_stages = [s for s in stages if s in ("w2v2", "cnnlstm")]
+    return {"value": round(n * seconds / total, 2), "unit": "audio-s/s", "cores": cores if model_stages else 1,
+            "kind": "port",
+            "sample": f"{n} x {seconds:g} s clips through stages {stages}: oracle/ (numpy float64 DSP on 1 core; "
+                      f"torch-CPU float32 models on {cores} threads, batch-1 windows like the reference)",
             "host_cpus": cores, "cpu_model": cpu_model,
             "seconds_per_stage": {k: round(v, 3) for k, v in parts.items()}}
 
@@ -100,7 +124,8 @@ def main():
     # synthetic shard of this rank: clip index = rank*clips + i (pool-tiled), resident in HBM
     host = synth.synth_batch(args.clips, args.seconds, pool=args.pool, first=rank * args.pool)
     wav = torch.from_numpy(host).to(dev)
-    pipe = pipeline.Pipeline(stages, device=dev, seconds=args.seconds)
+    pipe = pipeline.Pipeline(stages, device=dev, seconds=args.seconds,
+                             w2v2_chunks_per_call=args.w2v2_chunks_per_call)
     audio_s_per_step = args.clips * args.seconds * world
 
     def step():
@@ -147,7 +172,9 @@ def main():
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds,
                        "stages": [s for s in stages], "sharding": f"clips/{world} ranks, all_gather of result rows"},
             "roofline": roof,
-            "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3)} for k, v in prof.items()},
+            "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                            **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 and v["ms"] > 0 else {})}
+                        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(stages, args.seconds, args.cpu_sample_clips)

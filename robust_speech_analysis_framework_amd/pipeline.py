@@ -2,13 +2,17 @@
 
 This is the build's own runner for equal-length batches that are already resident in HBM
 (bench.py, the multi-GPU driver).  Per clip it emits one fixed-width float32 row
-``[smile 912 | ...]`` that ranks all-gather once per step.
+``[smile 912 | logits 2 | w2v2 frames 1]`` that ranks all-gather once per step.
+The Wav2Vec2 sequences (5.66 MB per 30 s clip) stay on the producing GPU and feed its local
+CNN-LSTM, exactly as notebook 03 feeds the classifier with the extractor's output.
 """
 from __future__ import annotations
 
+import numpy as np
+
 from . import _lib, smile
 
-BUILT_STAGES = ["smile"]
+BUILT_STAGES = ["smile", "w2v2", "cnnlstm"]
 
 # algorithmic traffic per audio-second of the HBM-bound kernels (SURVEY.md §8d):
 #   16 000 float32 samples read + 38 float32 LLDs x 100 frames/s written
@@ -22,11 +26,15 @@ def resolve_stages(spec: str):
     for s in st:
         if s not in BUILT_STAGES:
             raise ValueError(f"stage '{s}' is not built (built: {BUILT_STAGES})")
+    if "cnnlstm" in st and "w2v2" not in st:
+        raise ValueError("stage 'cnnlstm' consumes the output of stage 'w2v2'")
     return st
 
 
 class Pipeline:
-    def __init__(self, stages, device, seconds: float):
+    def __init__(self, stages, device, seconds: float, w2v2_seed: int = 0, cnnlstm_seed: int = 0,
+                 w2v2_chunks_per_call: int = 256):
+        import torch
         _lib.load()
         self.stages = list(stages)
         self.device = device
@@ -34,6 +42,18 @@ class Pipeline:
         self._packed = None
         self._packed_key = None
         self.finite_cols = None
+        self.w2v2 = None
+        self.model = None
+        if "w2v2" in self.stages:
+            from .w2v2 import W2V2Engine
+            from .w2v2_config import W2V2Config, random_state_dict
+            cfg = W2V2Config()
+            self.w2v2 = W2V2Engine(cfg, random_state_dict(cfg, w2v2_seed), device,
+                                   max_chunks_per_call=w2v2_chunks_per_call)
+        if "cnnlstm" in self.stages:
+            from .cnnlstm import CNNLSTM
+            torch.manual_seed(cnnlstm_seed)
+            self.model = CNNLSTM().to(device).eval()          # reference defaults: C = H = 128, silu
 
     def _pack(self, wav):
         key = (wav.data_ptr(), tuple(wav.shape))
@@ -47,8 +67,17 @@ class Pipeline:
         import torch
         cols = []
         p = self._pack(wav)
+        n_clips, n_samp = int(wav.shape[0]), int(wav.shape[1])
         if "smile" in self.stages:
             cols.append(smile.smile_features(p))
+        if self.w2v2 is not None:
+            offs = np.arange(n_clips, dtype=np.int64) * n_samp
+            seq, frame_off = self.w2v2.extract_packed(p.wav, offs, [n_samp] * n_clips)
+            frames = int(frame_off[1]) if n_clips else 0
+            if self.model is not None:
+                logits = self.model(seq.view(n_clips, frames, self.w2v2.cfg.hidden_size))
+                cols.append(logits)
+            cols.append(torch.full((n_clips, 1), float(frames), dtype=torch.float32, device=self.device))
         rows = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
         if self.finite_cols is None:
             self.finite_cols = torch.isfinite(rows[0]).nonzero().flatten()
@@ -58,8 +87,12 @@ class Pipeline:
         parts = []
         if "smile" in self.stages:
             parts.append("openSMILE-style 32/38 LLD + 912 functionals")
-        return (f"{' + '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU "
-                f"(BASELINE config 2 shape; stages not built yet are listed in DESIGN.md)")
+        if "w2v2" in self.stages:
+            parts.append("Wav2Vec2-base frame embeddings (5 s windows / 4 s hop, fp32, seeded random weights)")
+        if "cnnlstm" in self.stages:
+            parts.append("CNN-LSTM-attn forward (C=H=128) on the Wav2Vec2 sequences")
+        return (f"{' -> '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU; "
+                "MSHDS (Praat-style) stage not built yet")
 
 
 def roofline(prof, pipe, clips, seconds, steps, hbm_peak_gbs, mfma_peak_tflops):
@@ -73,6 +106,7 @@ def roofline(prof, pipe, clips, seconds, steps, hbm_peak_gbs, mfma_peak_tflops):
         achieved = rec["flops"] / (rec["ms"] * 1e-3) / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak_tflops,
                 "unit": "TFLOP/s", "frac": round(achieved / mfma_peak_tflops, 4), "traffic": None,
+                "algorithmic_flops_per_launch": rec["flops"] / max(rec["launches"], 1),
                 "avg_launch_ms": round(avg_ms, 4), "launches": rec["launches"]}
     if name == "smile_lld":
         per_launch = SMILE_LLD_BYTES_PER_AUDIO_S * clips * seconds * steps / max(rec["launches"], 1)
