@@ -41,6 +41,34 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 host CPUs but grants a share of them; oversubscribing torch threads stalls for minutes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, int(os.environ.get("RSAF_CPU_THREADS", "16"))))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(stages, seconds, sample_clips):
     """Time the CPU oracle (kind "port") on a bounded sample of the same synthetic workload.
 
@@ -50,9 +78,10 @@ def cpu_baseline(stages, seconds, sample_clips):
     import numpy as np
     import torch
     from robust_speech_analysis_framework_amd import synth
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
-    n = sample_clips or 2
+    n = sample_clips or 1
+    log(f"cpu_baseline: {n} clip(s) on {cores} thread(s)")
     clips = [synth.synth_clip(900000 + k, seconds) for k in range(n)]
     parts, total = {}, 0.0
     if "smile" in stages:
@@ -61,6 +90,7 @@ def cpu_baseline(stages, seconds, sample_clips):
         for c in clips:
             smile_oracle.extract(c)
         parts["smile"] = time.perf_counter() - t0
+        log(f"cpu_baseline smile {parts['smile']:.2f} s")
     seqs = None
     if "w2v2" in stages:
         from oracle import w2v2_oracle
@@ -71,6 +101,7 @@ def cpu_baseline(stages, seconds, sample_clips):
         t0 = time.perf_counter()
         seqs = [w2v2_oracle.extract_sequence(sd, cfg, c) for c in clips]
         parts["w2v2"] = time.perf_counter() - t0
+        log(f"cpu_baseline w2v2 {parts['w2v2']:.2f} s")
     if "cnnlstm" in stages and seqs is not None:
         from oracle import cnnlstm_oracle
         from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
@@ -94,7 +125,7 @@ def cpu_baseline(stages, seconds, sample_clips):
             "kind": "port",
             "sample": f"{n} x {seconds:g} s clips through stages {stages}: oracle/ (numpy float64 DSP on 1 core; "
                       f"torch-CPU float32 models on {cores} threads, batch-1 windows like the reference)",
-            "host_cpus": cores, "cpu_model": cpu_model,
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
             "seconds_per_stage": {k: round(v, 3) for k, v in parts.items()}}
 
 
@@ -119,6 +150,7 @@ def main():
 
     from robust_speech_analysis_framework_amd import _lib, pipeline, synth
     _lib.load()
+    torch.set_num_threads(min(usable_cpus(), 8))
 
     stages = pipeline.resolve_stages(args.stages)
     # synthetic shard of this rank: clip index = rank*clips + i (pool-tiled), resident in HBM
@@ -136,8 +168,13 @@ def main():
             return gathered
         return rows
 
-    for _ in range(args.warmup):
+    if rank == 0:
+        log(f"setup done: stages {stages}, {args.clips} clips x {args.seconds:g} s per GPU, world {world}")
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"warmup step {i + 1}/{args.warmup} done")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,6 +189,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = _lib.prof_end()
+    if rank == 0:
+        log(f"timed region: {args.steps} steps in {dt:.3f} s")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
