@@ -149,6 +149,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from robust_speech_analysis_framework_amd import _lib, pipeline, synth
+    from robust_speech_analysis_framework_amd.dist import gather_rows
     _lib.load()
     torch.set_num_threads(min(usable_cpus(), 8))
 
@@ -162,11 +163,7 @@ def main():
 
     def step():
         rows = pipe.run(wav)                       # [clips, row_width] float32 on device
-        if world > 1:
-            gathered = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=dev)
-            dist.all_gather_into_tensor(gathered, rows)
-            return gathered
-        return rows
+        return gather_rows(rows, args.clips * world)   # one RCCL all-gather of the result rows
 
     if rank == 0:
         log(f"setup done: stages {stages}, {args.clips} clips x {args.seconds:g} s per GPU, world {world}")
