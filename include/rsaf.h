@@ -143,6 +143,40 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
                       int64_t workspace_bytes, float* out, const int64_t* out_row_start,
                       rsaf_stream_t stream);
 
+/* ---- Praat-style analyses behind the MSHDS features (float64) ---------------------------------------
+ * Replace the parselmouth/Praat calls of src/mshds_extractor.py: To Intensity (:41,198), To Pitch
+ * (ac) (:104,143,178,270,355), To Harmonicity (cc) (:36,221), to_spectrogram + spectrum moments
+ * (:356-369) and the statistics taken from them (:144-160,179-180,199-202,222,370-373).
+ * `clip_info`: device array of n_clips records {int64 sample_off; int64 frame_off; double t1;
+ * int32 n_samples; int32 n_frames} (32 bytes) describing, for THIS analysis, where each clip's
+ * samples start in `wav`, where its frames start in the per-frame output buffers, the time of its
+ * first frame and its frame count (Praat's Sampled_shortTermAnalysis grid, computed by the host).
+ * Window tables (`window`, `window_r` = normalised autocorrelation of the window, `twiddle`) are
+ * device float64 arrays prepared by the host.  All outputs are float64.                          */
+int rsaf_mshds_frameout_doubles(void);   /* doubles per frame record: intensity, ncand, freq[16], strength[16] */
+int rsaf_mshds_clip_peak(const float* wav, const void* clip_info, int n_clips, double* gpeak, rsaf_stream_t stream);
+/* db_out[frame]; stats_out[clip][2] = {energy-mean dB, max/min of parabolic extrema} */
+int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, int max_frames,
+                         const double* window, int half_window, double time_step, int subtract_mean,
+                         double* db_out, double* stats_out, rsaf_stream_t stream);
+/* params_host[17] = {dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, octave_jump_cost,
+ *   voiced_unvoiced_cost, nsamp_window, nsamp_period, min_lag, max_lag, brent_ixmax, max_candidates,
+ *   refine_depth, is_cc, dt_window}.  sel_freq / sel_strength: the path finder's choice per frame.
+ * stats_out[clip][8] = {n(f != 0), mean, population sd, mean after |z| <= 2, n voiced, mean Hz,
+ *   sd in semitones (n-1), n after filter}. */
+int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
+                     const double* window, const double* window_r, const double* params_host,
+                     void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
+                     double* stats_out, rsaf_stream_t stream);
+int rsaf_mshds_hnr_mean(const double* sel_freq, const double* sel_strength, const void* clip_info, int n_clips,
+                        double* out, rsaf_stream_t stream);
+/* moments[frame][5] = {gate, CoG, SD, skewness, kurtosis}; stats_out[clip][4] = means over gated frames */
+int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const void* pitch_clip_info, int n_clips,
+                                int max_frames, const double* sel_freq, double pitch_dt, double ceiling,
+                                const double* window, const double* twiddle, int nsamp_window, int nfft,
+                                int nbins, double time_step, double freq_step, double* moments,
+                                double* stats_out, rsaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

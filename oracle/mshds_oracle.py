@@ -1,0 +1,628 @@
+"""CPU restatement of the Praat analyses behind ``src/mshds_extractor.py``.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  PARITY UNPINNED: the arithmetic lives in
+praat-parselmouth 0.4.6 (Praat's C++), which is absent from /root/reference and from this image,
+and the reference records no outputs for inputs we hold.  What IS pinned by the reference are the
+call order, the parameters and the Python-side post-processing (file:line cited below).  The
+algorithms are restated from their publications: Boersma (1993) "Accurate short-term analysis of
+the fundamental frequency and the harmonics-to-noise ratio of a sampled sound" (autocorrelation /
+cross-correlation pitch, path finder, HNR) and the Praat manual pages "Sound: To Intensity...",
+"Sound: To Pitch (ac)...", "Sound: To Harmonicity (cc)...", "Sound: To Spectrogram...",
+"Spectrum: Get centre of gravity / central moment...".  Free choices are documented inline.
+
+Built so far (the rest of the 25 features is NaN, as in ``csrc/mshds.hip``):
+  a3 ``_pitch_values``, a4 ``_extract_pitch``, a5 ``_extract_intensity``, a6 ``_extract_harmonicity``,
+  a10 ``_extract_Spectral_Moments``.
+Arithmetic: float64 on the float32 samples (Praat computes in double).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FS = 16000.0
+DX = 1.0 / FS
+
+FEATURE_NAMES = [
+    "Speaking_Rate", "Articulation_Rate", "Phonation_Ratio", "Pause_Rate", "Mean_Pause_Duration",
+    "mean_F0", "stdev_F0_Semitone", "mean_dB", "range_ratio_dB", "HNR_dB",
+    "Spectral_Slope", "Spectral_Tilt", "Cepstral_Peak_Prominence",
+    "mean_F1_Loc", "std_F1_Loc", "mean_B1_Loc", "std_B1_Loc",
+    "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
+    "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
+]                                                          # src/mshds_extractor.py:397-404
+BUILT = [5, 6, 7, 8, 9, 21, 22, 23, 24]
+
+
+# ---- Sampled helpers (Praat: x1 = 0.5 dx for a Sound read from file) ----------------------------
+def short_term_frames(n_samples, window_duration, time_step):
+    """Sampled_shortTermAnalysis: (number of frames, time of the first frame); frames are centred."""
+    duration = n_samples * DX
+    if window_duration > duration:
+        return 0, 0.0
+    nf = int(np.floor((duration - window_duration) / time_step)) + 1
+    mid = 0.5 * duration
+    t1 = mid - 0.5 * nf * time_step + 0.5 * time_step
+    return nf, t1
+
+
+def x_to_low_index(t):
+    """Sampled_xToLowIndex for the sound, 0-based: floor((t - x1)/dx)."""
+    return np.floor((np.asarray(t) - 0.5 * DX) / DX).astype(np.int64)
+
+
+def x_to_nearest_index(t):
+    return np.floor((np.asarray(t) - 0.5 * DX) / DX + 0.5).astype(np.int64)
+
+
+# ---- Intensity (Praat manual "Sound: To Intensity...") -------------------------------------------
+def _bessel_i0(x):
+    return np.i0(x)
+
+
+def intensity(x, minimum_pitch, time_step, subtract_mean=True):
+    """dB contour + first frame time.  Effective window 3.2/minimum_pitch (physical 6.4/minimum_pitch),
+    Kaiser-20 window (sidelobes below -190 dB), per-frame mean subtracted, reference 4e-10 Pa^2."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    phys = 6.4 / minimum_pitch
+    if time_step <= 0:
+        time_step = 0.8 / minimum_pitch
+    half_dur = 0.5 * phys
+    half = int(np.floor(half_dur / DX))
+    i = np.arange(-half, half + 1)
+    xx = i * DX / half_dur
+    win = _bessel_i0((2.0 * np.pi * np.pi + 0.5) * np.sqrt(np.maximum(0.0, 1.0 - xx * xx)))
+    nf, t1 = short_term_frames(n, phys, time_step)
+    out = np.empty(nf)
+    for f in range(nf):
+        t = t1 + f * time_step
+        mid = int(x_to_nearest_index(t))
+        lo, hi = max(0, mid - half), min(n - 1, mid + half)
+        seg = x[lo:hi + 1]
+        w = win[lo - mid + half: hi - mid + half + 1]
+        if subtract_mean:
+            seg = seg - seg.mean()
+        val = np.sum(seg * seg * w) / np.sum(w) / 4.0e-10
+        out[f] = -300.0 if val < 1e-30 else 10.0 * np.log10(val)
+    return out, t1, time_step
+
+
+def vector_extremum_parabolic(y, maximum=True):
+    """Vector_getMaximum/Minimum with parabolic interpolation (end points count un-interpolated)."""
+    y = np.asarray(y, dtype=np.float64)
+    s = 1.0 if maximum else -1.0
+    z = s * y
+    if len(z) == 0:
+        return np.nan
+    best = max(z[0], z[-1])
+    if len(z) > 2:
+        m = z[1:-1]
+        loc = (m > z[:-2]) & (m >= z[2:])
+        dy = 0.5 * (z[2:] - z[:-2])
+        d2 = 2.0 * m - z[:-2] - z[2:]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            imp = np.where(loc & (d2 != 0), m + 0.5 * dy * dy / d2, -np.inf)
+        imp = np.where(loc & (d2 == 0), m, imp)
+        if loc.any():
+            best = max(best, imp.max())
+    return s * best
+
+
+# ---- sinc interpolation (Praat NUM_interpolate_sinc), vectorised over query points ----------------
+def interpolate_sinc(y, x, depth):
+    """y: [..., n] (0-based samples 0..n-1), x: [...] real positions (0-based).  Raised-cosine
+    windowed sinc of `depth` samples to each side, clipped at the array ends."""
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    n = y.shape[-1]
+    x1 = x + 1.0                                         # Praat is 1-based
+    midleft = np.floor(x1).astype(np.int64)
+    midright = midleft + 1
+    d = np.minimum(np.minimum(depth, midright - 1), n - midleft)
+    d = np.maximum(d, 0)
+    left = midright - d
+    right = midleft + d
+    res = np.zeros_like(x1)
+    k = np.arange(depth)
+    # left half: ix = midleft - k  (k < d)
+    a0 = np.pi * (x1 - midleft)
+    aa0 = a0 / (x1 - left + 1.0)
+    daa = np.pi / (x1 - left + 1.0)
+    a = a0[..., None] + np.pi * k
+    aa = aa0[..., None] + daa[..., None] * k
+    sgn = np.where(k % 2 == 0, 1.0, -1.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wgt = 0.5 * np.sin(a0)[..., None] * sgn / a * (1.0 + np.cos(aa))
+    idx = np.clip(midleft[..., None] - k - 1, 0, n - 1)
+    vals = np.take_along_axis(y, idx, axis=-1) if y.ndim == idx.ndim else y[idx]
+    res = res + np.sum(np.where(k < d[..., None], vals * wgt, 0.0), axis=-1)
+    a0 = np.pi * (midright - x1)
+    aa0 = a0 / (right - x1 + 1.0)
+    daa = np.pi / (right - x1 + 1.0)
+    a = a0[..., None] + np.pi * k
+    aa = aa0[..., None] + daa[..., None] * k
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wgt = 0.5 * np.sin(a0)[..., None] * sgn / a * (1.0 + np.cos(aa))
+    idx = np.clip(midright[..., None] + k - 1, 0, n - 1)
+    vals = np.take_along_axis(y, idx, axis=-1) if y.ndim == idx.ndim else y[idx]
+    res = res + np.sum(np.where(k < d[..., None], vals * wgt, 0.0), axis=-1)
+    # exact sample / out of range
+    ex = np.clip(np.round(x).astype(np.int64), 0, n - 1)
+    vex = np.take_along_axis(y, ex[..., None], axis=-1)[..., 0] if y.ndim > 1 else y[ex]
+    res = np.where((x1 == midleft) | (x1 > n) | (x1 < 1), vex, res)
+    return res
+
+
+GOLD = 0.5 * (3.0 - np.sqrt(5.0))
+N_GOLDEN = 32
+
+
+def improve_maximum_sinc(y, ix, depth=70):
+    """NUMimproveMaximum with sinc interpolation: maximise on [ix-1, ix+1].  Praat uses Brent's
+    method to 1e-10; a 32-step golden-section search (bracket 2 * 0.618^32 = 4e-7 samples, i.e. a
+    frequency error below 1e-8 relative) is the documented free choice here, also used by the HIP
+    kernel so both sides take identical steps."""
+    ix = np.asarray(ix, dtype=np.float64)
+    a, b = ix - 1.0, ix + 1.0
+    c = a + GOLD * (b - a)
+    d = b - GOLD * (b - a)
+    fc, fd = interpolate_sinc(y, c, depth), interpolate_sinc(y, d, depth)
+    for _ in range(N_GOLDEN):
+        left = fc > fd                       # maximum lies in [a, d]
+        b = np.where(left, d, b)
+        a = np.where(left, a, c)
+        nc = a + GOLD * (b - a)
+        nd = b - GOLD * (b - a)
+        # reuse one evaluation per step
+        c_new = np.where(left, nc, d)
+        d_new = np.where(left, c, nd)
+        f_new = interpolate_sinc(y, np.where(left, nc, nd), depth)
+        fc, fd = np.where(left, f_new, fd), np.where(left, fc, f_new)
+        c, d = c_new, d_new
+    xm = 0.5 * (a + b)
+    return xm, interpolate_sinc(y, xm, depth)
+
+
+# ---- Pitch (Boersma 1993) --------------------------------------------------------------------------------
+class PitchResult:
+    def __init__(self, t1, dt, ceiling, freq, strength, ncand, intensity, selected):
+        self.t1, self.dt, self.ceiling = t1, dt, ceiling
+        self.freq, self.strength, self.ncand = freq, strength, ncand     # [nF, maxc] candidate lists
+        self.intensity = intensity
+        self.selected = selected                                          # chosen candidate index per frame
+
+    @property
+    def n_frames(self):
+        return self.freq.shape[0]
+
+    def frequency(self):
+        """selected_array['frequency'] (0 = unvoiced)."""
+        f = self.freq[np.arange(self.n_frames), self.selected] if self.n_frames else np.zeros(0)
+        return f
+
+    def voiced_values(self):
+        f = self.frequency()
+        return f[(f > 0.0) & (f < self.ceiling)]
+
+    def defined_at(self, t):
+        """Pitch 'Get value at time' (Hertz, linear) is defined iff the nearest frame is voiced."""
+        t = np.asarray(t, dtype=np.float64)
+        n = self.n_frames
+        if n == 0:
+            return np.zeros(t.shape, bool)
+        ireal = (t - self.t1) / self.dt
+        ileft = np.floor(ireal)
+        phase = ireal - ileft
+        near = np.where(phase < 0.5, ileft, ileft + 1).astype(np.int64)
+        xmin, xmax = self.t1 - 0.5 * self.dt, self.t1 + (n - 0.5) * self.dt
+        ok = (near >= 0) & (near < n)
+        f = self.frequency()
+        fn = f[np.clip(near, 0, n - 1)]
+        return ok & (fn > 0.0) & (fn < self.ceiling)
+
+
+def _frame_autocorr(frames, nfft):
+    spec = np.fft.rfft(frames, n=nfft, axis=1)
+    return np.fft.irfft(spec.real ** 2 + spec.imag ** 2, n=nfft, axis=1)
+
+
+def _sinc_rows(r, fi, pos, depth, block=2048):
+    """interpolate_sinc(r[fi[k]], pos[k]) in blocks (keeps the temporaries small)."""
+    out = np.empty(len(fi))
+    for b in range(0, len(fi), block):
+        sl = slice(b, b + block)
+        out[sl] = interpolate_sinc(r[fi[sl]], pos[sl], depth)
+    return out
+
+
+def _improve_rows(r, fi, ix, depth, block=2048):
+    xm, ym = np.empty(len(fi)), np.empty(len(fi))
+    for b in range(0, len(fi), block):
+        sl = slice(b, b + block)
+        xm[sl], ym[sl] = improve_maximum_sinc(r[fi[sl]], ix[sl], depth)
+    return xm, ym
+
+
+def _candidates(r, offset_lags, dx_lag, min_lag, max_lag, max_cand, voicing_thr, octave_cost, min_pitch,
+                brent_ixmax, refine_depth=70):
+    """r: [nF, 2*brent_ixmax+1] symmetric normalised correlation, index = lag + brent_ixmax.
+    Boersma (1993) steps 3.10-3.11: local maxima above half the voicing threshold, parabolic
+    position, sinc-interpolated strength, at most max_cand-1 voiced candidates (the weakest by
+    octave-cost-corrected strength is replaced), then refinement of each kept maximum."""
+    nF = r.shape[0]
+    freq = np.zeros((nF, max_cand))
+    stren = np.zeros((nF, max_cand))
+    imax = np.zeros((nF, max_cand), dtype=np.int64)
+    ncand = np.ones(nF, dtype=np.int64)                  # candidate 0 = unvoiced
+    c = brent_ixmax
+    hi = min(max_lag - 1, brent_ixmax - 1)
+    lags = np.arange(max(min_lag, 2), hi + 1)
+    if nF == 0 or lags.size == 0:
+        return freq, stren, ncand
+    v = r[:, c + lags]
+    ok = (v > 0.5 * voicing_thr) & (v > r[:, c + lags - 1]) & (v >= r[:, c + lags + 1])
+    fi, li = np.nonzero(ok)                              # frame-major, ascending lag: Praat's loop order
+    if fi.size:
+        lag = lags[li]
+        y0, y1, y2 = r[fi, c + lag - 1], r[fi, c + lag], r[fi, c + lag + 1]
+        dr = 0.5 * (y2 - y0)
+        d2r = 2.0 * y1 - y0 - y2
+        fmax = 1.0 / DX / (lag + dr / d2r)
+        st = _sinc_rows(r, fi, c + 1.0 / DX / fmax, 30)
+        st = np.where(st > 1.0, 1.0 / st, st)
+        counts = np.bincount(fi, minlength=nF)
+        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        rank = np.arange(fi.size) - first[fi]
+        easy = counts[fi] <= max_cand - 1
+        freq[fi[easy], rank[easy] + 1] = fmax[easy]
+        stren[fi[easy], rank[easy] + 1] = st[easy]
+        imax[fi[easy], rank[easy] + 1] = lag[easy]
+        ncand = np.where(counts <= max_cand - 1, counts + 1, max_cand)
+        for f in np.nonzero(counts > max_cand - 1)[0]:   # frames with more maxima than slots
+            n_in = 1
+            for k in range(first[f], first[f] + counts[f]):
+                if n_in < max_cand:
+                    place = n_in
+                    n_in += 1
+                else:
+                    weakest, place = 2.0, 0
+                    for z in range(1, max_cand):
+                        loc = stren[f, z] - octave_cost * np.log2(min_pitch / freq[f, z])
+                        if loc < weakest:
+                            weakest, place = loc, z
+                    if st[k] - octave_cost * np.log2(min_pitch / fmax[k]) <= weakest:
+                        place = 0
+                if place:
+                    freq[f, place], stren[f, place], imax[f, place] = fmax[k], st[k], lag[k]
+    # second pass: refine every voiced candidate by maximising the sinc-interpolated correlation
+    fi, ci = np.nonzero(freq > 0.0)
+    if fi.size:
+        xm, ym = _improve_rows(r, fi, (imax[fi, ci] + c).astype(np.float64), refine_depth)
+        lag_real = xm - c
+        ym = np.where(ym > 1.0, 1.0 / ym, ym)
+        freq[fi, ci] = 1.0 / DX / lag_real
+        stren[fi, ci] = ym
+    return freq, stren, ncand
+
+
+def _path_finder(freq, stren, ncand, intens, dt, silence_thr, voicing_thr, octave_cost, octave_jump_cost,
+                 vuv_cost, ceiling):
+    """Pitch_pathFinder (Viterbi over candidates); returns the selected candidate per frame."""
+    nF, maxc = freq.shape
+    if nF == 0:
+        return np.zeros(0, dtype=np.int64)
+    corr = 0.01 / dt
+    ojc, vuc = octave_jump_cost * corr, vuv_cost * corr
+    valid = np.arange(maxc)[None, :] < ncand[:, None]
+    voiceless = ~((freq > 0.0) & (freq < ceiling))
+    unv = np.zeros(nF) if silence_thr <= 0 else 2.0 - intens / (silence_thr / (1.0 + voicing_thr))
+    unv = voicing_thr + np.maximum(0.0, unv)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        delta = np.where(voiceless, unv[:, None], stren - octave_cost * np.log2(ceiling / np.where(voiceless, 1.0, freq)))
+    delta = np.where(valid, delta, -1e300)
+    psi = np.zeros((nF, maxc), dtype=np.int64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        logf = np.where(voiceless, 0.0, np.log2(np.where(voiceless, 1.0, freq)))
+    cur = delta[0].copy()
+    for f in range(1, nF):
+        v1, v2 = voiceless[f - 1][:, None], voiceless[f][None, :]
+        tc = np.where(v1 & v2, 0.0, np.where(v1 | v2, vuc, ojc * np.abs(logf[f - 1][:, None] - logf[f][None, :])))
+        val = cur[:, None] - tc + delta[f][None, :]
+        val = np.where(valid[f - 1][:, None], val, -np.inf)
+        psi[f] = np.argmax(val, axis=0)                   # first maximum, like the strict > of Praat
+        cur = np.where(valid[f], val[psi[f], np.arange(maxc)], -1e300)
+    sel = np.zeros(nF, dtype=np.int64)
+    sel[-1] = int(np.argmax(cur))
+    for f in range(nF - 1, 0, -1):
+        sel[f - 1] = psi[f, sel[f]]
+    return sel
+
+
+def _hanning(n):
+    i = np.arange(1, n + 1)
+    return 0.5 - 0.5 * np.cos(i * 2.0 * np.pi / (n + 1))
+
+
+def pitch_ac(x, time_step=0.0, pitch_floor=75.0, max_candidates=15, very_accurate=False, silence_threshold=0.03,
+             voicing_threshold=0.45, octave_cost=0.01, octave_jump_cost=0.35, voiced_unvoiced_cost=0.14,
+             pitch_ceiling=600.0):
+    """Sound: To Pitch (ac)... (Hanning window of 3 longest periods)."""
+    if very_accurate:
+        raise NotImplementedError("very_accurate (Gaussian window) is not used by the reference")
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    ppw = 3.0
+    dt = time_step if time_step > 0 else ppw / pitch_floor / 4.0
+    ceiling = min(pitch_ceiling, 0.5 / DX)
+    dt_window = ppw / pitch_floor
+    nsamp_period = int(np.floor(1.0 / DX / pitch_floor))
+    half_period = nsamp_period // 2 + 1
+    nsamp_window = int(np.floor(dt_window / DX))
+    half_window = nsamp_window // 2 - 1
+    nsamp_window = half_window * 2
+    min_lag = max(2, int(np.floor(1.0 / DX / ceiling)))
+    max_lag = min(int(np.floor(nsamp_window / ppw)) + 2, nsamp_window)
+    nF, t1 = short_term_frames(n, dt_window, dt)
+    interp_depth = 0.5
+    brent_ixmax = int(np.floor(nsamp_window * interp_depth))
+    nfft = 1
+    while nfft < nsamp_window * (1 + interp_depth):
+        nfft *= 2
+    win = _hanning(nsamp_window)
+    wr = _frame_autocorr(win[None, :], nfft)[0]
+    wr = wr / wr[0]
+    xm = x - x.mean()
+    global_peak = np.max(np.abs(xm)) if n else 0.0
+    maxc = max_candidates
+    if nF <= 0:
+        e = np.zeros((0, maxc))
+        return PitchResult(t1, dt, ceiling, e, e.copy(), np.zeros(0, np.int64), np.zeros(0), np.zeros(0, np.int64))
+    t = t1 + np.arange(nF) * dt
+    left = x_to_low_index(t)
+    right = left + 1
+    # local mean over one longest period to each side
+    cs = np.concatenate([[0.0], np.cumsum(x)])
+    s0 = np.clip(right - nsamp_period, 0, n - 1)
+    s1 = np.clip(left + nsamp_period, 0, n - 1)
+    local_mean = (cs[s1 + 1] - cs[s0]) / (2 * nsamp_period)
+    start = right - half_window
+    idx = start[:, None] + np.arange(nsamp_window)[None, :]
+    frames = (x[np.clip(idx, 0, n - 1)] - local_mean[:, None]) * win[None, :]
+    a = max(0, half_window - half_period)
+    b = min(nsamp_window, half_window + half_period)
+    local_peak = np.max(np.abs(frames[:, a:b]), axis=1)
+    intens = np.where(local_peak > global_peak, 1.0, local_peak / global_peak) if global_peak > 0 else np.zeros(nF)
+    ac = _frame_autocorr(frames, nfft)
+    r = np.zeros((nF, 2 * brent_ixmax + 1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pos = ac[:, 1:brent_ixmax + 1] / (ac[:, :1] * wr[None, 1:brent_ixmax + 1])
+    pos = np.where(ac[:, :1] > 0, pos, 0.0)
+    r[:, brent_ixmax] = 1.0
+    r[:, brent_ixmax + 1:] = pos
+    r[:, :brent_ixmax] = pos[:, ::-1]
+    freq, stren, ncand = _candidates(r, 0, DX, min_lag, max_lag, maxc, voicing_threshold, octave_cost, pitch_floor,
+                                     brent_ixmax)
+    if global_peak == 0:
+        ncand[:] = 1
+        freq[:] = 0.0
+    sel = _path_finder(freq, stren, ncand, intens, dt, silence_threshold, voicing_threshold, octave_cost,
+                       octave_jump_cost, voiced_unvoiced_cost, ceiling)
+    return PitchResult(t1, dt, ceiling, freq, stren, ncand, intens, sel)
+
+
+def pitch_cc(x, time_step, pitch_floor, periods_per_window, max_candidates, silence_threshold, voicing_threshold,
+             octave_cost, octave_jump_cost, voiced_unvoiced_cost, pitch_ceiling, accurate=False):
+    """Forward cross-correlation pitch (Boersma 1993 §cc; Praat "To Pitch (cc)")."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    ppw = periods_per_window
+    dt = time_step if time_step > 0 else ppw / pitch_floor / 4.0
+    ceiling = min(pitch_ceiling, 0.5 / DX)
+    dt_window = ppw / pitch_floor
+    nsamp_period = int(np.floor(1.0 / DX / pitch_floor))
+    half_period = nsamp_period // 2 + 1
+    nsamp_window = int(np.floor(dt_window / DX))
+    half_window = nsamp_window // 2 - 1
+    nsamp_window = half_window * 2
+    min_lag = max(2, int(np.floor(1.0 / DX / ceiling)))
+    max_lag = min(int(np.floor(nsamp_window / ppw)) + 2, nsamp_window)
+    nF, t1 = short_term_frames(n, 1.0 / pitch_floor + dt_window, dt)
+    brent_ixmax = int(np.floor(nsamp_window * 1.0))
+    maxc = max_candidates
+    xm = x - x.mean()
+    global_peak = np.max(np.abs(xm)) if n else 0.0
+    if nF <= 0:
+        e = np.zeros((0, maxc))
+        return PitchResult(t1, dt, ceiling, e, e.copy(), np.zeros(0, np.int64), np.zeros(0), np.zeros(0, np.int64))
+    t = t1 + np.arange(nF) * dt
+    left = x_to_low_index(t)
+    right = left + 1
+    cs = np.concatenate([[0.0], np.cumsum(x)])
+    s0 = np.clip(right - nsamp_period, 0, n - 1)
+    s1 = np.clip(left + nsamp_period, 0, n - 1)
+    local_mean = (cs[s1 + 1] - cs[s0]) / (2 * nsamp_period)
+    start_time = t - 0.5 * (1.0 / pitch_floor + dt_window)
+    start = np.maximum(x_to_low_index(start_time), 0)
+    span = np.minimum(max_lag + nsamp_window, n - start)
+    loc_max_lag = span - nsamp_window
+    L = max_lag
+    r = np.zeros((nF, 2 * brent_ixmax + 1))
+    c = brent_ixmax
+    r[:, c] = 1.0
+    idx = start[:, None] + np.arange(nsamp_window + L + 1)[None, :]
+    seg = x[np.clip(idx, 0, n - 1)] - local_mean[:, None]
+    seg = np.where(idx < n, seg, 0.0)
+    base = seg[:, :nsamp_window]
+    sumx2 = np.sum(base * base, axis=1)
+    sq = seg * seg
+    csq = np.concatenate([np.zeros((nF, 1)), np.cumsum(sq, axis=1)], axis=1)
+    for lag in range(1, L + 1):
+        prod = np.sum(base * seg[:, lag:lag + nsamp_window], axis=1)
+        sumy2 = csq[:, lag + nsamp_window] - csq[:, lag]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = prod / np.sqrt(sumx2 * sumy2)
+        v = np.where((lag <= loc_max_lag) & (sumx2 * sumy2 > 0), v, 0.0)
+        r[:, c + lag] = v
+        r[:, c - lag] = v
+    # local peak over half a longest period around the window centre of the FIRST window
+    a = max(0, half_window - half_period)
+    b = min(nsamp_window, half_window + half_period)
+    local_peak = np.max(np.abs(base[:, a:b]), axis=1)
+    intens = np.where(local_peak > global_peak, 1.0, local_peak / global_peak) if global_peak > 0 else np.zeros(nF)
+    freq, stren, ncand = _candidates(r, 0, DX, min_lag, max_lag, maxc, voicing_threshold, octave_cost, pitch_floor,
+                                     brent_ixmax, refine_depth=700 if accurate else 70)
+    if global_peak == 0:
+        ncand[:] = 1
+        freq[:] = 0.0
+    sel = _path_finder(freq, stren, ncand, intens, dt, silence_threshold, voicing_threshold, octave_cost,
+                       octave_jump_cost, voiced_unvoiced_cost, ceiling)
+    return PitchResult(t1, dt, ceiling, freq, stren, ncand, intens, sel)
+
+
+def harmonicity_cc(x, time_step=0.01, minimum_pitch=75.0, silence_threshold=0.1, periods_per_window=1.0):
+    """Sound: To Harmonicity (cc): dB per frame, -200 for unvoiced frames."""
+    p = pitch_cc(x, time_step, minimum_pitch, periods_per_window, 15, silence_threshold, 0.0, 0.0, 0.0, 0.0,
+                 0.5 / DX, accurate=True)
+    f = p.frequency()
+    s = p.strength[np.arange(p.n_frames), p.selected] if p.n_frames else np.zeros(0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        db = np.where(s <= 1e-15, -150.0, np.where(s > 1.0 - 1e-15, 150.0, 10.0 * np.log10(s / (1.0 - s))))
+    return np.where(f == 0.0, -200.0, db)
+
+
+# ---- Spectrogram + spectral moments (Praat manual "Sound: To Spectrogram...", "Spectrum: Get ...") ---
+def spectrogram_power(x, window_length=0.005, maximum_frequency=5000.0, time_step=0.002, frequency_step=20.0):
+    """Gaussian-window spectrogram: (power density [nF, nBins], t1, time step, frequency step)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    nyq = 0.5 / DX
+    phys = 2.0 * window_length
+    eff_t = window_length / np.sqrt(np.pi)
+    eff_f = 1.0 / eff_t
+    tstep = max(time_step, eff_t / 8.0)
+    fstep = max(frequency_step, eff_f / 8.0)
+    duration = n * DX
+    nsamp = int(np.floor(phys / DX))
+    half = nsamp // 2 - 1
+    nsamp = half * 2
+    if phys > duration or half < 1:
+        return np.zeros((0, 0)), 0.0, tstep, fstep
+    nT = 1 + int(np.floor((duration - phys) / tstep))
+    t1 = 0.5 * DX + 0.5 * ((n - 1) * DX - (nT - 1) * tstep)
+    fmax = maximum_frequency if 0 < maximum_frequency <= nyq else nyq
+    nfreq = int(np.floor(fmax / fstep))
+    nfft = 1
+    while nfft < nsamp or nfft < 2 * nfreq * (nyq / fmax):
+        nfft *= 2
+    bw_samples = max(1, int(np.floor(fstep * DX * nfft)))
+    bw_hz = 1.0 / (DX * nfft)
+    fstep = bw_samples * bw_hz
+    nfreq = int(np.floor(fmax / fstep))
+    i = np.arange(1, nsamp + 1)
+    phase = (i - 0.5 * (nsamp + 1)) / nsamp
+    edge = np.exp(-12.0)
+    win = (np.exp(-48.0 * phase * phase) - edge) / (1.0 - edge)
+    one_by = 1.0 / np.sum(win * win) / bw_samples
+    t = t1 + np.arange(nT) * tstep
+    left = x_to_low_index(t)
+    start = left + 1 - half
+    idx = start[:, None] + np.arange(nsamp)[None, :]
+    frames = x[np.clip(idx, 0, n - 1)] * win[None, :]
+    spec = np.fft.rfft(frames, n=nfft, axis=1)
+    pw = spec.real ** 2 + spec.imag ** 2
+    out = np.empty((nT, nfreq))
+    for b in range(nfreq):
+        out[:, b] = pw[:, b * bw_samples:(b + 1) * bw_samples].sum(axis=1) * one_by
+    return out, t1, tstep, fstep
+
+
+def spectral_moments(power, fstep):
+    """CoG, SD, skewness, kurtosis (power = 2) of each spectrum slice; NaN where the slice is empty."""
+    f = np.arange(power.shape[1]) * fstep
+    tot = power.sum(axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cog = (power * f[None, :]).sum(axis=1) / tot
+        d = f[None, :] - cog[:, None]
+        m2 = (power * d ** 2).sum(axis=1) / tot
+        m3 = (power * d ** 3).sum(axis=1) / tot
+        m4 = (power * d ** 4).sum(axis=1) / tot
+        sd = np.sqrt(m2)
+        skew = m3 / (m2 * np.sqrt(m2))
+        kurt = m4 / (m2 * m2) - 3.0
+    return cog, sd, skew, kurt
+
+
+# ---- the reference's helpers ----------------------------------------------------------------------------
+def pitch_values(x):
+    """``_pitch_values`` (src/mshds_extractor.py:127-162) -> (floor, ceiling)."""
+    try:
+        p = pitch_ac(x, time_step=0.005, pitch_floor=50.0, pitch_ceiling=600.0)              # :143
+        v = p.frequency()
+        v = v[v != 0]
+        if len(v) == 0:
+            return 75, 500
+        z = (v - np.mean(v)) / np.std(v)
+        v = v[np.abs(z) <= 2]
+        if len(v) == 0:
+            return 75, 500
+        return (60, 250) if np.mean(v) < 170 else (100, 500)
+    except Exception:
+        return 75, 500
+
+
+def extract_pitch(x, floor, ceiling, frame_shift=0.005, pitch=None):
+    """``_extract_pitch`` (:164-183): mean F0 (Hz), SD in semitones re 100 Hz (sample SD)."""
+    p = pitch if pitch is not None else pitch_ac(x, time_step=frame_shift, pitch_floor=floor, pitch_ceiling=ceiling)
+    v = p.voiced_values()
+    mean = np.mean(v) if len(v) else np.nan
+    st = 12.0 * np.log2(v / 100.0)
+    sd = np.std(st, ddof=1) if len(v) > 1 else np.nan
+    return mean, sd
+
+
+def extract_intensity(x, floor, frame_shift=0.005):
+    """``_extract_intensity`` (:185-205): energy-mean dB and max/min ratio of dB values."""
+    db, _, _ = intensity(x, floor, frame_shift, True)
+    if len(db) == 0:
+        return np.nan, np.nan
+    mean_db = 10.0 * np.log10(np.mean(10.0 ** (db / 10.0)))
+    mn = vector_extremum_parabolic(db, maximum=False)
+    mx = vector_extremum_parabolic(db, maximum=True)
+    return mean_db, (mx / mn if mn != 0 else np.nan)
+
+
+def extract_harmonicity(x, floor, ceiling, frame_shift=0.005):
+    """``_extract_harmonicity`` (:207-225): mean HNR over voiced frames."""
+    h = harmonicity_cc(x, frame_shift, floor, 0.1, 4.5)
+    v = h[h != -200.0]
+    return np.mean(v) if len(v) else np.nan
+
+
+def extract_spectral_moments(x, floor, ceiling, window_size=0.025, frame_shift=0.005, pitch=None):
+    """``_extract_Spectral_Moments`` (:340-376): mean of the 4 moments over frames whose time has a
+    defined pitch value."""
+    p = pitch if pitch is not None else pitch_ac(x, time_step=frame_shift, pitch_floor=floor, pitch_ceiling=ceiling)
+    pw, t1, tstep, fstep = spectrogram_power(x, window_size, 5000.0, frame_shift, 20.0)
+    if pw.shape[0] == 0:
+        return (np.nan,) * 4
+    t = t1 + np.arange(pw.shape[0]) * tstep
+    keep = p.defined_at(t)
+    cog, sd, sk, ku = spectral_moments(pw[keep], fstep)
+    out = []
+    for a in (cog, sd, sk, ku):
+        a = a[~np.isnan(a)]
+        out.append(np.mean(a) if len(a) else np.nan)
+    return tuple(out)
+
+
+def extract(x):
+    """One clip -> 25 features in the reference's column order (unbuilt helpers give NaN)."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.full(25, np.nan)
+    floor, ceiling = pitch_values(x)                                                 # :428
+    p = pitch_ac(x, time_step=0.005, pitch_floor=floor, pitch_ceiling=ceiling)       # :178 == :355
+    out[5], out[6] = extract_pitch(x, floor, ceiling, 0.005, p)                      # :430
+    out[7], out[8] = extract_intensity(x, floor, 0.005)                              # :431
+    out[9] = extract_harmonicity(x, floor, ceiling, 0.005)                           # :432
+    out[21:25] = extract_spectral_moments(x, floor, ceiling, 0.025, 0.005, p)        # :446
+    return out, (floor, ceiling)

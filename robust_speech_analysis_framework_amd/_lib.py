@@ -43,6 +43,13 @@ SIGNATURES = {
     "rsaf_cnnlstm_weight_offsets": (_I, [_I, _I, _I, _I, _I, C.POINTER(_L), _I, C.POINTER(_I)]),
     "rsaf_cnnlstm_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "rsaf_cnnlstm_forward": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _P]),
+    "rsaf_mshds_frameout_doubles": (_I, []),
+    "rsaf_mshds_clip_peak": (_I, [_P, _P, _I, _P, _P]),
+    "rsaf_mshds_intensity": (_I, [_P, _P, _I, _I, _P, _I, C.c_double, _I, _P, _P, _P]),
+    "rsaf_mshds_pitch": (_I, [_P, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_double), _P, _P, _P, _P, _P, _P, _P]),
+    "rsaf_mshds_hnr_mean": (_I, [_P, _P, _P, _I, _P, _P]),
+    "rsaf_mshds_spectral_moments": (_I, [_P, _P, _P, _I, _I, _P, C.c_double, C.c_double, _P, _P, _I, _I, _I,
+                                        C.c_double, C.c_double, _P, _P, _P]),
     "rsaf_w2v2_frames": (_I, [_I]),
     "rsaf_w2v2_weight_floats": (_L, [_I] * 7),
     "rsaf_w2v2_weight_offsets": (_I, [_I] * 7 + [C.POINTER(_L), _I, C.POINTER(_I)]),

@@ -1,0 +1,805 @@
+// Praat-style analyses behind the MSHDS features, float64 kernels for gfx950.
+//
+// Replaces the parselmouth/Praat calls of src/mshds_extractor.py for the helpers built so far:
+//   _pitch_values (:127-162), _extract_pitch (:164-183), _extract_intensity (:185-205),
+//   _extract_harmonicity (:207-225), _extract_Spectral_Moments (:340-376).
+// Algorithms: Boersma (1993) autocorrelation / cross-correlation pitch with sinc-interpolated
+// candidates and the Viterbi path finder; Praat's intensity (Kaiser-weighted mean square) and
+// Gaussian-window spectrogram + spectral moments.  Semantics = oracle/mshds_oracle.py (parity
+// unpinned: Praat itself is not available).  Praat computes in double, so do these kernels
+// (MI355X: 78 TFLOP/s fp64 vector); discrete decisions (voicing, path) then agree with the oracle.
+//
+// Mapping: one 256-thread workgroup per analysis frame for the correlation kernels (frame staged in
+// LDS, 4 lags per thread in registers, candidates refined by wave-cooperative sinc sums), one wave
+// per frame for intensity, one wave per clip for the path finder and the per-clip statistics.
+#include "rsaf_common.h"
+
+namespace rsaf {
+namespace mshds {
+
+constexpr double DXS = 1.0 / 16000.0;
+constexpr double PI = 3.14159265358979323846;
+constexpr int MAXC = 16;            // candidate slots per frame (max_candidates <= 15)
+constexpr int MAX_MAXIMA = 96;      // local maxima considered per frame (in ascending lag order)
+constexpr double GOLD = 0.38196601125010515180;   // (3 - sqrt 5) / 2
+constexpr int N_GOLDEN = 32;
+
+struct ClipInfo {       // one entry per clip of a launch (host-built)
+    int64_t sample_off;
+    int64_t frame_off;  // first frame of this clip in the per-launch frame buffers
+    double t1;          // time of the first frame
+    int n_samples;
+    int n_frames;
+};
+
+struct PitchParams {
+    double dt, min_pitch, ceiling, voicing_thr, octave_cost, dt_window;
+    int nsamp_window, half_window, nsamp_period, half_period, min_lag, max_lag, brent_ixmax, max_cand;
+    int refine_depth, is_cc;
+};
+
+__device__ __forceinline__ int64_t low_index(double t) { return (int64_t)floor((t - 0.5 * DXS) / DXS); }
+
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- per-clip mean and global peak |x - mean| ------------------------------------------------------
+__global__ __launch_bounds__(256) void clip_peak_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                        double* __restrict__ gpeak) {
+    __shared__ double red[4];
+    __shared__ double bc;
+    const ClipInfo c = ci[blockIdx.x];
+    const float* x = wav + c.sample_off;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < c.n_samples; i += 256) s += (double)x[i];
+    s = wave_sum_f64(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = c.n_samples > 0 ? (red[0] + red[1] + red[2] + red[3]) / c.n_samples : 0.0;
+    __syncthreads();
+    const double mean = bc;
+    double m = 0.0;
+    for (int i = threadIdx.x; i < c.n_samples; i += 256) m = fmax(m, fabs((double)x[i] - mean));
+    m = wave_max_f64(m);
+    __syncthreads();
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) gpeak[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// ---- intensity: one wave per frame -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void intensity_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                        const double* __restrict__ win, int half, double dt,
+                                                        int subtract_mean, double* __restrict__ out) {
+    const ClipInfo c = ci[blockIdx.y];
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= c.n_frames) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = wav + c.sample_off;
+    const double t = c.t1 + f * dt;
+    const int64_t mid = (int64_t)floor((t - 0.5 * DXS) / DXS + 0.5);
+    const int64_t lo = mid - half < 0 ? 0 : mid - half;
+    const int64_t hi = mid + half > c.n_samples - 1 ? c.n_samples - 1 : mid + half;
+    double mean = 0.0;
+    if (subtract_mean) {
+        double s = 0.0;
+        for (int64_t i = lo + lane; i <= hi; i += 64) s += (double)x[i];
+        mean = wave_sum_f64(s) / (double)(hi - lo + 1);
+    }
+    double sw = 0.0, sx = 0.0;
+    for (int64_t i = lo + lane; i <= hi; i += 64) {
+        const double w = win[i - mid + half];
+        const double d = (double)x[i] - mean;
+        sw += w;
+        sx += d * d * w;
+    }
+    sw = wave_sum_f64(sw);
+    sx = wave_sum_f64(sx);
+    if (lane == 0) {
+        const double v = sx / sw / 4.0e-10;
+        out[c.frame_off + f] = v < 1e-30 ? -300.0 : 10.0 * log10(v);
+    }
+}
+
+// ---- sinc interpolation of an LDS array, wave-cooperative (Praat NUM_interpolate_sinc) -----------------
+// y: n samples (0-based); x: 0-based real position; only indices in [nz_lo, nz_hi] can be non-zero.
+__device__ double sinc_wave(const double* __restrict__ y, int n, double x, int depth, int nz_lo, int nz_hi, int lane) {
+    const double x1 = x + 1.0;
+    const int midleft = (int)floor(x1), midright = midleft + 1;
+    if (x1 > n) return y[n - 1];
+    if (x1 < 1) return y[0];
+    if (x1 == (double)midleft) return y[midleft - 1];
+    int d = depth;
+    if (d > midright - 1) d = midright - 1;
+    if (d > n - midleft) d = n - midleft;
+    const int left = midright - d, right = midleft + d;
+    double acc = 0.0;
+    {   // left half: 1-based ix = midleft - k, k = 0..d-1
+        const double a0 = PI * (x1 - midleft);
+        const double den = x1 - left + 1.0;
+        const double aa0 = a0 / den, daa = PI / den;
+        const double hs = 0.5 * sin(a0);
+        int kmax = d;                                         // skip the zero tail
+        if (midleft - 1 - (kmax - 1) < nz_lo) kmax = midleft - 1 - nz_lo + 1;
+        for (int k = lane; k < kmax; k += 64) {
+            const int idx = midleft - k - 1;
+            if (idx > nz_hi) continue;
+            const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cos(aa0 + daa * k));
+            acc += y[idx] * w;
+        }
+    }
+    {   // right half: ix = midright + k
+        const double a0 = PI * (midright - x1);
+        const double den = right - x1 + 1.0;
+        const double aa0 = a0 / den, daa = PI / den;
+        const double hs = 0.5 * sin(a0);
+        int kmax = d;
+        if (midright - 1 + (kmax - 1) > nz_hi) kmax = nz_hi - (midright - 1) + 1;
+        for (int k = lane; k < kmax; k += 64) {
+            const int idx = midright + k - 1;
+            if (idx < nz_lo) continue;
+            const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cos(aa0 + daa * k));
+            acc += y[idx] * w;
+        }
+    }
+    return wave_sum_f64(acc);
+}
+
+// maximise the sinc-interpolated curve on [ix-1, ix+1] by golden section (same steps as the oracle)
+__device__ void improve_max_wave(const double* __restrict__ y, int n, double ix, int depth, int nz_lo, int nz_hi,
+                                 int lane, double& xm, double& ym) {
+    double a = ix - 1.0, b = ix + 1.0;
+    double c = a + GOLD * (b - a), d = b - GOLD * (b - a);
+    double fc = sinc_wave(y, n, c, depth, nz_lo, nz_hi, lane);
+    double fd = sinc_wave(y, n, d, depth, nz_lo, nz_hi, lane);
+    for (int it = 0; it < N_GOLDEN; ++it) {
+        if (fc > fd) {
+            b = d;
+            const double nc = a + GOLD * (b - a);
+            d = c; fd = fc;
+            c = nc; fc = sinc_wave(y, n, nc, depth, nz_lo, nz_hi, lane);
+        } else {
+            a = c;
+            const double nd = b - GOLD * (b - a);
+            c = d; fc = fd;
+            d = nd; fd = sinc_wave(y, n, nd, depth, nz_lo, nz_hi, lane);
+        }
+    }
+    xm = 0.5 * (a + b);
+    ym = sinc_wave(y, n, xm, depth, nz_lo, nz_hi, lane);
+}
+
+// ---- pitch candidates per frame (AC: Hanning-windowed autocorrelation; CC: forward cross-correlation) --
+// dynamic LDS: seg[seg_len] doubles, r[2*brent_ixmax+1] doubles
+struct FrameOut {     // per frame, written contiguously: intensity, ncand, freq[MAXC], strength[MAXC]
+    double intensity;
+    double ncand;
+    double freq[MAXC];
+    double strength[MAXC];
+};
+
+__global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                          const double* __restrict__ gpeak, const double* __restrict__ win,
+                                                          const double* __restrict__ wr, const PitchParams P,
+                                                          FrameOut* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const ClipInfo c = ci[blockIdx.y];
+    const int f = blockIdx.x;
+    if (f >= c.n_frames) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nw = P.nsamp_window, L = P.is_cc ? P.max_lag : P.brent_ixmax;
+    const int seg_len = P.is_cc ? nw + P.max_lag + 1 : nw;
+    const int RC = P.brent_ixmax;                   // centre index of r
+    const int RN = 2 * P.brent_ixmax + 1;
+    // all LDS lives in the dynamic region (keeps every double 8-byte aligned, guide G17)
+    double* seg = reinterpret_cast<double*>(smem_raw);
+    double* r = seg + ((seg_len + 1) & ~1);
+    double* s_red = r + ((RN + 1) & ~1);            // [4]
+    double* s_val = s_red + 4;                      // [4]
+    double* s_mfreq = s_val + 4;                    // [MAX_MAXIMA]
+    double* s_mstr = s_mfreq + MAX_MAXIMA;          // [MAX_MAXIMA]
+    double* s_cf = s_mstr + MAX_MAXIMA;             // [MAXC]
+    double* s_cs = s_cf + MAXC;                     // [MAXC]
+    int* s_maxlag = reinterpret_cast<int*>(s_cs + MAXC);   // [MAX_MAXIMA]
+    int* s_place = s_maxlag + MAX_MAXIMA;           // [MAXC]
+    int* s_cnt = s_place + MAXC;                    // [0] = nmax, [1] = ncand
+#define s_nmax s_cnt[0]
+#define s_ncand s_cnt[1]
+
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples;
+    const double t = c.t1 + f * P.dt;
+    const int64_t left = low_index(t), right = left + 1;
+    // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat)
+    {
+        int64_t s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
+        s0 = s0 < 0 ? 0 : (s0 > n - 1 ? n - 1 : s0);
+        s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
+        double s = 0.0;
+        for (int64_t i = s0 + tid; i <= s1; i += 256) s += (double)x[i];
+        s = wave_sum_f64(s);
+        if (lane == 0) s_red[wv] = s;
+    }
+    __syncthreads();
+    const double local_mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (2.0 * P.nsamp_period);
+    int64_t start;
+    int loc_max_lag = P.max_lag;
+    if (!P.is_cc) {
+        start = right - P.half_window;
+        for (int j = tid; j < nw; j += 256) {
+            int64_t i = start + j;
+            i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+            seg[j] = ((double)x[i] - local_mean) * win[j];
+        }
+    } else {
+        start = 0;
+    }
+    __syncthreads();
+    if (P.is_cc) {
+        // Praat: startTime = t - 0.5 * (1 / minimumPitch + dt_window), dt_window = periods / minimumPitch
+        const double start_time = t - 0.5 * (1.0 / P.min_pitch + P.dt_window);
+        start = low_index(start_time);
+        if (start < 0) start = 0;
+        int64_t span = P.max_lag + nw;
+        if (span > n - start) span = n - start;
+        loc_max_lag = (int)(span - nw);
+        for (int j = tid; j < seg_len; j += 256) {
+            const int64_t i = start + j;
+            seg[j] = i < n ? ((double)x[i < 0 ? 0 : i] - local_mean) : 0.0;
+        }
+    }
+    for (int j = tid; j < RN; j += 256) r[j] = 0.0;
+    __syncthreads();
+    // local peak over half a longest period around the window centre
+    {
+        int a = P.half_window - P.half_period, b = P.half_window + P.half_period;
+        a = a < 0 ? 0 : a;
+        b = b > nw ? nw : b;
+        double m = 0.0;
+        for (int j = a + tid; j < b; j += 256) m = fmax(m, fabs(seg[j]));
+        m = wave_max_f64(m);
+        if (lane == 0) s_val[wv] = m;
+    }
+    __syncthreads();
+    const double local_peak = fmax(fmax(s_val[0], s_val[1]), fmax(s_val[2], s_val[3]));
+    const double gp = gpeak[blockIdx.y];
+    const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
+
+    // ---- correlation: 4 consecutive lags per thread ----
+    const int ngroups = (L + 4) / 4;                   // lags 0..L
+    for (int g = tid; g < ngroups; g += 256) {
+        const int l0 = 4 * g;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (!P.is_cc) {
+            const int jmax = nw - l0;                   // pairs (j, j+lag) with j+lag < nw
+            double y0 = seg[l0 < nw ? l0 : nw - 1], y1 = (l0 + 1 < nw) ? seg[l0 + 1] : 0.0,
+                   y2 = (l0 + 2 < nw) ? seg[l0 + 2] : 0.0;
+            for (int j = 0; j < jmax; ++j) {
+                const double xj = seg[j];
+                const double y3 = (j + l0 + 3 < nw) ? seg[j + l0 + 3] : 0.0;
+                a0 += xj * y0; a1 += xj * y1; a2 += xj * y2; a3 += xj * y3;
+                y0 = y1; y1 = y2; y2 = y3;
+            }
+        } else {
+            double y0 = seg[l0], y1 = (l0 + 1 < seg_len) ? seg[l0 + 1] : 0.0, y2 = (l0 + 2 < seg_len) ? seg[l0 + 2] : 0.0;
+            for (int j = 0; j < nw; ++j) {
+                const double xj = seg[j];
+                const double y3 = (j + l0 + 3 < seg_len) ? seg[j + l0 + 3] : 0.0;
+                a0 += xj * y0; a1 += xj * y1; a2 += xj * y2; a3 += xj * y3;
+                y0 = y1; y1 = y2; y2 = y3;
+            }
+        }
+        const double av[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (l0 + q <= L) r[RC + l0 + q] = av[q];   // raw sums for now
+    }
+    __syncthreads();
+    // ---- normalise ----
+    if (!P.is_cc) {
+        const double r0 = r[RC];
+        __syncthreads();
+        for (int l = 1 + tid; l <= L; l += 256) {
+            const double v = r0 > 0.0 ? r[RC + l] / (r0 * wr[l]) : 0.0;
+            r[RC + l] = v;
+            r[RC - l] = v;
+        }
+        if (tid == 0) r[RC] = 1.0;
+    } else {
+        const double sumx2 = r[RC];
+        __syncthreads();
+        // sumy2(lag) = sum_{j=lag}^{lag+nw-1} seg[j]^2 : running update done serially per thread range
+        for (int l = 1 + tid; l <= L; l += 256) {
+            double sy = 0.0;
+            for (int j = l; j < l + nw; ++j) sy += seg[j] * seg[j];
+            const double den = sumx2 * sy;
+            const double v = (l <= loc_max_lag && den > 0.0) ? r[RC + l] / sqrt(den) : 0.0;
+            r[RC + l] = v;
+            r[RC - l] = v;
+        }
+        if (tid == 0) r[RC] = 1.0;
+    }
+    if (tid == 0) s_nmax = 0;
+    __syncthreads();
+    // ---- local maxima in ascending lag order (wave 0, ballot + prefix) ----
+    const int lag_lo = P.min_lag > 2 ? P.min_lag : 2;
+    int lag_hi = P.max_lag - 1;
+    if (lag_hi > P.brent_ixmax - 1) lag_hi = P.brent_ixmax - 1;
+    if (wv == 0) {
+        int count = 0;
+        for (int base = lag_lo; base <= lag_hi; base += 64) {
+            const int l = base + lane;
+            bool ok = false;
+            if (l <= lag_hi) {
+                const double v = r[RC + l];
+                ok = (v > 0.5 * P.voicing_thr) && (v > r[RC + l - 1]) && (v >= r[RC + l + 1]);
+            }
+            const unsigned long long m = __ballot(ok);
+            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && pos < MAX_MAXIMA) s_maxlag[pos] = l;
+            count += __popcll(m);
+        }
+        if (lane == 0) s_nmax = count < MAX_MAXIMA ? count : MAX_MAXIMA;
+    }
+    __syncthreads();
+    const int nmax = s_nmax;
+    const int nz_lo = RC - L, nz_hi = RC + L;
+    // ---- first estimate of every maximum: parabolic position, sinc(30) strength ----
+    for (int m = wv; m < nmax; m += 4) {
+        const int l = s_maxlag[m];
+        const double y0 = r[RC + l - 1], y1 = r[RC + l], y2 = r[RC + l + 1];
+        const double dr = 0.5 * (y2 - y0), d2r = 2.0 * y1 - y0 - y2;
+        const double fm = 1.0 / DXS / (l + dr / d2r);
+        double st = sinc_wave(r, RN, RC + 1.0 / DXS / fm, 30, nz_lo, nz_hi, lane);
+        if (st > 1.0) st = 1.0 / st;
+        if (lane == 0) { s_mfreq[m] = fm; s_mstr[m] = st; }
+    }
+    __syncthreads();
+    // ---- candidate list with replacement of the weakest (thread 0, sequential as in Praat) ----
+    if (tid == 0) {
+        int nc = 1;
+        s_cf[0] = 0.0; s_cs[0] = 0.0; s_place[0] = 0;
+        for (int m = 0; m < nmax; ++m) {
+            int place;
+            if (nc < P.max_cand) {
+                place = nc++;
+            } else {
+                double weakest = 2.0;
+                place = 0;
+                for (int z = 1; z < P.max_cand; ++z) {
+                    const double loc = s_cs[z] - P.octave_cost * log2(P.min_pitch / s_cf[z]);
+                    if (loc < weakest) { weakest = loc; place = z; }
+                }
+                if (s_mstr[m] - P.octave_cost * log2(P.min_pitch / s_mfreq[m]) <= weakest) place = 0;
+            }
+            if (place) { s_cf[place] = s_mfreq[m]; s_cs[place] = s_mstr[m]; s_place[place] = s_maxlag[m]; }
+        }
+        s_ncand = nc;
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    // ---- refine every kept candidate: maximise the sinc-interpolated correlation ----
+    for (int k = 1 + wv; k < ncand; k += 4) {
+        double xm, ym;
+        improve_max_wave(r, RN, (double)(s_place[k] + RC), P.refine_depth, nz_lo, nz_hi, lane, xm, ym);
+        if (ym > 1.0) ym = 1.0 / ym;
+        if (lane == 0) { s_cf[k] = 1.0 / DXS / (xm - RC); s_cs[k] = ym; }
+    }
+    __syncthreads();
+    FrameOut* o = out + c.frame_off + f;
+    if (tid == 0) {
+        o->intensity = intensity;
+        o->ncand = gp > 0.0 ? (double)ncand : 1.0;
+    }
+    if (tid < MAXC) {
+        const bool on = tid < ncand && gp > 0.0;
+        o->freq[tid] = on ? s_cf[tid] : 0.0;
+        o->strength[tid] = on ? s_cs[tid] : 0.0;
+    }
+}
+
+// ---- Viterbi path finder: one wave per clip (lane = candidate of the current frame) -------------------
+__global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ fr, const ClipInfo* __restrict__ ci,
+                                                  double dt, double silence_thr, double voicing_thr, double octave_cost,
+                                                  double octave_jump_cost, double vuv_cost, double ceiling,
+                                                  unsigned char* __restrict__ psi, int* __restrict__ end_state) {
+    const ClipInfo c = ci[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int nF = c.n_frames;
+    if (nF <= 0) return;
+    const FrameOut* F = fr + c.frame_off;
+    unsigned char* P = psi + c.frame_off * MAXC;
+    const double corr = 0.01 / dt;
+    const double ojc = octave_jump_cost * corr, vuc = vuv_cost * corr;
+    const int cl = lane < MAXC ? lane : MAXC - 1;
+    double cur = -1e300, prev_logf = 0.0;
+    int prev_vl = 1, prev_valid = 0;
+    for (int f = 0; f < nF; ++f) {
+        const int nc = (int)F[f].ncand;
+        const double fq = F[f].freq[cl], st = F[f].strength[cl];
+        const int valid = lane < nc;
+        const int vl = !(fq > 0.0 && fq < ceiling);
+        double unv = silence_thr <= 0.0 ? 0.0 : 2.0 - F[f].intensity / (silence_thr / (1.0 + voicing_thr));
+        unv = voicing_thr + fmax(0.0, unv);
+        const double delta = valid ? (vl ? unv : st - octave_cost * log2(ceiling / fq)) : -1e300;
+        const double logf = vl ? 0.0 : log2(fq);
+        double best = -INFINITY;
+        int place = 0;
+        if (f == 0) {
+            best = delta;
+        } else {
+            for (int c1 = 0; c1 < MAXC; ++c1) {
+                const double pc = __shfl(cur, c1, 64);
+                const double pl = __shfl(prev_logf, c1, 64);
+                const int pv = __shfl(prev_vl, c1, 64);
+                const int pval = __shfl(prev_valid, c1, 64);
+                const double tc = (pv && vl) ? 0.0 : ((pv || vl) ? vuc : ojc * fabs(pl - logf));
+                const double v = pval ? pc - tc + delta : -INFINITY;
+                if (v > best) { best = v; place = c1; }
+            }
+            if (!valid) best = -1e300;
+        }
+        if (lane < MAXC) P[(int64_t)f * MAXC + lane] = (unsigned char)place;
+        cur = best;
+        prev_logf = logf; prev_vl = vl; prev_valid = valid;
+    }
+    // best end state: first maximum
+    double bv = lane < MAXC ? cur : -INFINITY;
+    int bi = lane;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) end_state[blockIdx.x] = bi;
+}
+
+// backtrack in its own launch: the kernel boundary makes the psi stores of path_kernel visible
+__global__ __launch_bounds__(64) void backtrack_kernel(const FrameOut* __restrict__ fr, const ClipInfo* __restrict__ ci,
+                                                       const unsigned char* __restrict__ psi,
+                                                       const int* __restrict__ end_state, double* __restrict__ sel_freq,
+                                                       double* __restrict__ sel_strength) {
+    const ClipInfo c = ci[blockIdx.x];
+    if (threadIdx.x != 0 || c.n_frames <= 0) return;
+    const FrameOut* F = fr + c.frame_off;
+    const unsigned char* P = psi + c.frame_off * MAXC;
+    int s = end_state[blockIdx.x];
+    for (int f = c.n_frames - 1; f >= 0; --f) {
+        sel_freq[c.frame_off + f] = F[f].freq[s];
+        sel_strength[c.frame_off + f] = F[f].strength[s];
+        if (f > 0) s = P[(int64_t)f * MAXC + s];
+    }
+}
+
+// ---- per-clip statistics of a selected pitch track ------------------------------------------------------
+// out[clip][8]: 0 n_nonzero, 1 mean(nonzero), 2 std(nonzero, population), 3 mean after |z|<=2 filter,
+//               4 n_voiced (0<f<ceiling), 5 mean Hz, 6 sd semitones (n-1), 7 count after filter
+__global__ __launch_bounds__(64) void pitch_stats_kernel(const double* __restrict__ sel_freq, const ClipInfo* __restrict__ ci,
+                                                         double ceiling, double* __restrict__ out) {
+    const ClipInfo c = ci[blockIdx.x];
+    const int lane = threadIdx.x;
+    const double* f = sel_freq + c.frame_off;
+    double n0 = 0, s0 = 0, nv = 0, sv = 0, sst = 0;
+    for (int i = lane; i < c.n_frames; i += 64) {
+        const double v = f[i];
+        if (v != 0.0) { n0 += 1; s0 += v; }
+        if (v > 0.0 && v < ceiling) { nv += 1; sv += v; sst += 12.0 * log2(v / 100.0); }
+    }
+    n0 = wave_sum_f64(n0); s0 = wave_sum_f64(s0); nv = wave_sum_f64(nv); sv = wave_sum_f64(sv); sst = wave_sum_f64(sst);
+    const double m0 = n0 > 0 ? s0 / n0 : 0.0, mst = nv > 0 ? sst / nv : 0.0;
+    double q0 = 0, qst = 0;
+    for (int i = lane; i < c.n_frames; i += 64) {
+        const double v = f[i];
+        if (v != 0.0) q0 += (v - m0) * (v - m0);
+        if (v > 0.0 && v < ceiling) { const double d = 12.0 * log2(v / 100.0) - mst; qst += d * d; }
+    }
+    q0 = wave_sum_f64(q0); qst = wave_sum_f64(qst);
+    const double sd0 = n0 > 0 ? sqrt(q0 / n0) : 0.0;
+    double nf = 0, sf = 0;
+    for (int i = lane; i < c.n_frames; i += 64) {
+        const double v = f[i];
+        if (v != 0.0 && fabs((v - m0) / sd0) <= 2.0) { nf += 1; sf += v; }
+    }
+    nf = wave_sum_f64(nf); sf = wave_sum_f64(sf);
+    if (lane == 0) {
+        double* o = out + (int64_t)blockIdx.x * 8;
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        o[0] = n0; o[1] = m0; o[2] = sd0; o[3] = nf > 0 ? sf / nf : qn;
+        o[4] = nv; o[5] = nv > 0 ? sv / nv : qn; o[6] = nv > 1 ? sqrt(qst / (nv - 1)) : qn; o[7] = nf;
+    }
+}
+
+// ---- intensity statistics: energy mean, parabolic max / min -----------------------------------------------
+__global__ __launch_bounds__(64) void intensity_stats_kernel(const double* __restrict__ db, const ClipInfo* __restrict__ ci,
+                                                             double* __restrict__ out) {
+    const ClipInfo c = ci[blockIdx.x];
+    const int lane = threadIdx.x, n = c.n_frames;
+    const double* y = db + c.frame_off;
+    const double qn = __longlong_as_double(0x7ff8000000000000LL);
+    if (n <= 0) {
+        if (lane == 0) { out[blockIdx.x * 2] = qn; out[blockIdx.x * 2 + 1] = qn; }
+        return;
+    }
+    double se = 0.0, mx = -INFINITY, mn = -INFINITY;      // mn holds the maximum of -y
+    for (int i = lane; i < n; i += 64) {
+        const double v = y[i];
+        se += pow(10.0, v / 10.0);
+        if (i == 0 || i == n - 1) { mx = fmax(mx, v); mn = fmax(mn, -v); }
+        if (i > 0 && i < n - 1) {
+            const double a = y[i - 1], b = y[i + 1];
+            if (v > a && v >= b) {
+                const double dy = 0.5 * (b - a), d2 = 2.0 * v - a - b;
+                mx = fmax(mx, d2 != 0.0 ? v + 0.5 * dy * dy / d2 : v);
+            }
+            if (-v > -a && -v >= -b) {
+                const double dy = 0.5 * (a - b), d2 = -2.0 * v + a + b;
+                mn = fmax(mn, d2 != 0.0 ? -v + 0.5 * dy * dy / d2 : -v);
+            }
+        }
+    }
+    se = wave_sum_f64(se); mx = wave_max_f64(mx); mn = wave_max_f64(mn);
+    if (lane == 0) {
+        const double mean_db = 10.0 * log10(se / n);
+        const double minv = -mn;
+        out[blockIdx.x * 2] = mean_db;
+        out[blockIdx.x * 2 + 1] = minv != 0.0 ? mx / minv : qn;
+    }
+}
+
+// ---- HNR mean: 10 log10(r / (1 - r)) over voiced frames of a cc pitch track -------------------------------
+__global__ __launch_bounds__(64) void hnr_stats_kernel(const double* __restrict__ sel_freq, const double* __restrict__ sel_str,
+                                                       const ClipInfo* __restrict__ ci, double* __restrict__ out) {
+    const ClipInfo c = ci[blockIdx.x];
+    const int lane = threadIdx.x;
+    double n = 0, s = 0;
+    for (int i = lane; i < c.n_frames; i += 64) {
+        const double f = sel_freq[c.frame_off + i], r = sel_str[c.frame_off + i];
+        if (f != 0.0) {
+            n += 1;
+            s += r <= 1e-15 ? -150.0 : (r > 1.0 - 1e-15 ? 150.0 : 10.0 * log10(r / (1.0 - r)));
+        }
+    }
+    n = wave_sum_f64(n); s = wave_sum_f64(s);
+    if (lane == 0) out[blockIdx.x] = n > 0 ? s / n : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// ---- Gaussian-window spectrogram slice + spectral moments, gated by pitch definedness ----------------------
+// one workgroup per frame; direct DFT of the windowed frame for bins 0..nbins-1 (bin width 1/(dx*nfft))
+__global__ __launch_bounds__(256) void spec_moments_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                           const ClipInfo* __restrict__ pitch_ci, const double* __restrict__ sel_freq,
+                                                           double pitch_dt, double ceiling, const double* __restrict__ win,
+                                                           const double2* __restrict__ tw, int nsamp, int half, int nfft,
+                                                           int nbins, double tstep, double fstep,
+                                                           double* __restrict__ mom /* [frames][5]: ok, cog, sd, skew, kurt */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* seg = reinterpret_cast<double*>(smem_raw);          // nsamp
+    double* pw = seg + ((nsamp + 1) & ~1);                       // nbins
+    __shared__ double s_red[4][4];
+    const ClipInfo c = ci[blockIdx.y];
+    const int f = blockIdx.x;
+    if (f >= c.n_frames) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* o = mom + (c.frame_off + f) * 5;
+    const double t = c.t1 + f * tstep;
+    // gate: Pitch "Get value at time" defined iff the nearest pitch frame is voiced
+    {
+        const ClipInfo pc = pitch_ci[blockIdx.y];
+        const double ireal = (t - pc.t1) / pitch_dt;
+        const double il = floor(ireal);
+        const int64_t near = (ireal - il < 0.5) ? (int64_t)il : (int64_t)il + 1;
+        bool ok = near >= 0 && near < pc.n_frames;
+        if (ok) {
+            const double pf = sel_freq[pc.frame_off + near];
+            ok = pf > 0.0 && pf < ceiling;
+        }
+        if (!ok) {
+            if (tid == 0) o[0] = 0.0;
+            return;
+        }
+    }
+    const float* x = wav + c.sample_off;
+    const int64_t start = low_index(t) + 1 - half;
+    for (int j = tid; j < nsamp; j += 256) {
+        int64_t i = start + j;
+        i = i < 0 ? 0 : (i > c.n_samples - 1 ? c.n_samples - 1 : i);
+        seg[j] = (double)x[i] * win[j];
+    }
+    __syncthreads();
+    const int mask = nfft - 1;
+    for (int k = tid; k < nbins; k += 256) {
+        double re = 0.0, im = 0.0;
+        int ph = 0;
+        for (int j = 0; j < nsamp; ++j) {
+            const double2 w = tw[ph];
+            const double v = seg[j];
+            re += v * w.x;
+            im += v * w.y;
+            ph = (ph + k) & mask;
+        }
+        pw[k] = re * re + im * im;
+    }
+    __syncthreads();
+    double s0 = 0, s1 = 0;
+    for (int k = tid; k < nbins; k += 256) { s0 += pw[k]; s1 += pw[k] * (k * fstep); }
+    s0 = wave_sum_f64(s0); s1 = wave_sum_f64(s1);
+    if (lane == 0) { s_red[wv][0] = s0; s_red[wv][1] = s1; }
+    __syncthreads();
+    const double tot = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+    const double cog = (s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1]) / tot;
+    __syncthreads();
+    double m2 = 0, m3 = 0, m4 = 0;
+    for (int k = tid; k < nbins; k += 256) {
+        const double d = k * fstep - cog, p = pw[k];
+        const double d2 = d * d;
+        m2 += p * d2; m3 += p * d2 * d; m4 += p * d2 * d2;
+    }
+    m2 = wave_sum_f64(m2); m3 = wave_sum_f64(m3); m4 = wave_sum_f64(m4);
+    if (lane == 0) { s_red[wv][0] = m2; s_red[wv][1] = m3; s_red[wv][2] = m4; }
+    __syncthreads();
+    if (tid == 0) {
+        const double u2 = (s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0]) / tot;
+        const double u3 = (s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1]) / tot;
+        const double u4 = (s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2]) / tot;
+        o[0] = 1.0;
+        o[1] = cog;
+        o[2] = sqrt(u2);
+        o[3] = u3 / (u2 * sqrt(u2));
+        o[4] = u4 / (u2 * u2) - 3.0;
+    }
+}
+
+// mean of each moment over gated frames whose value is not NaN (reference :366-374)
+__global__ __launch_bounds__(64) void moments_stats_kernel(const double* __restrict__ mom, const ClipInfo* __restrict__ ci,
+                                                           double* __restrict__ out) {
+    const ClipInfo c = ci[blockIdx.x];
+    const int lane = threadIdx.x;
+    double n[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
+    for (int i = lane; i < c.n_frames; i += 64) {
+        const double* m = mom + (c.frame_off + i) * 5;
+        if (m[0] != 0.0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = m[1 + q];
+                if (v == v) { n[q] += 1; s[q] += v; }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { n[q] = wave_sum_f64(n[q]); s[q] = wave_sum_f64(s[q]); }
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            out[blockIdx.x * 4 + q] = n[q] > 0 ? s[q] / n[q] : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+}  // namespace mshds
+}  // namespace rsaf
+
+using namespace rsaf;
+using namespace rsaf::mshds;
+
+extern "C" {
+
+int rsaf_mshds_frameout_doubles(void) { return (int)(sizeof(FrameOut) / sizeof(double)); }
+
+int rsaf_mshds_clip_peak(const float* wav, const void* clip_info, int n_clips, double* gpeak, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0, "negative n_clips");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && clip_info && gpeak, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("mshds_clip_peak", s, 0.0, 0.0);
+    hipLaunchKernelGGL(clip_peak_kernel, dim3(n_clips), dim3(256), 0, s, wav, (const ClipInfo*)clip_info, gpeak);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* window,
+                         int half_window, double time_step, int subtract_mean, double* db_out, double* stats_out,
+                         rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_frames >= 0, "bad clip/frame count");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && clip_info && window && db_out && stats_out, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (max_frames > 0) {
+        ProfScope prof("mshds_intensity", s, 0.0, 0.0);
+        hipLaunchKernelGGL(intensity_kernel, dim3((max_frames + 3) / 4, n_clips), dim3(256), 0, s, wav,
+                           (const ClipInfo*)clip_info, window, half_window, time_step, subtract_mean, db_out);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(intensity_stats_kernel, dim3(n_clips), dim3(64), 0, s, db_out, (const ClipInfo*)clip_info, stats_out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
+                     const double* window, const double* window_r, const double* params_host /* 17 doubles */,
+                     void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
+                     rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_frames >= 0, "bad clip/frame count");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && clip_info && gpeak && params_host && frame_out && psi && end_state && sel_freq &&
+                   sel_strength && stats_out, "NULL pointer");
+    const double* h = params_host;
+    PitchParams P;
+    P.dt = h[0]; P.min_pitch = h[1]; P.ceiling = h[2]; P.voicing_thr = h[3]; P.octave_cost = h[4];
+    const double silence_thr = h[5], octave_jump = h[6], vuv = h[7];
+    P.nsamp_window = (int)h[8]; P.nsamp_period = (int)h[9]; P.min_lag = (int)h[10]; P.max_lag = (int)h[11];
+    P.brent_ixmax = (int)h[12]; P.max_cand = (int)h[13]; P.refine_depth = (int)h[14]; P.is_cc = (int)h[15];
+    P.dt_window = h[16];
+    P.half_window = P.nsamp_window / 2;
+    P.half_period = P.nsamp_period / 2 + 1;
+    RSAF_CHECK_ARG(P.max_cand >= 2 && P.max_cand <= MAXC - 1, "max_candidates must be in [2, 15]");
+    RSAF_CHECK_ARG(P.nsamp_window >= 4 && P.brent_ixmax >= 2 && P.max_lag >= 2, "window too short");
+    RSAF_CHECK_ARG(P.is_cc || (window && window_r), "AC needs the window tables");
+    const int seg_len = P.is_cc ? P.nsamp_window + P.max_lag + 1 : P.nsamp_window;
+    const size_t lds = (size_t)(((seg_len + 1) & ~1) + ((2 * P.brent_ixmax + 2) & ~1) + 8 + 2 * MAX_MAXIMA + 2 * MAXC) *
+                           sizeof(double) + (size_t)(MAX_MAXIMA + MAXC + 4) * sizeof(int);
+    RSAF_CHECK_ARG(lds <= 150 * 1024, "analysis window too long for LDS");
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 48 * 1024)
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+    if (max_frames > 0) {
+        ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s, 0.0, 0.0);
+        hipLaunchKernelGGL(pitch_frame_kernel, dim3(max_frames, n_clips), dim3(256), lds, s, wav,
+                           (const ClipInfo*)clip_info, gpeak, window, window_r, P, (FrameOut*)frame_out);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    {
+        ProfScope prof("mshds_pitch_path", s, 0.0, 0.0);
+        hipLaunchKernelGGL(path_kernel, dim3(n_clips), dim3(64), 0, s, (const FrameOut*)frame_out,
+                           (const ClipInfo*)clip_info, P.dt, silence_thr, P.voicing_thr, P.octave_cost, octave_jump, vuv,
+                           P.ceiling, psi, end_state);
+        RSAF_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(backtrack_kernel, dim3(n_clips), dim3(64), 0, s, (const FrameOut*)frame_out,
+                           (const ClipInfo*)clip_info, psi, end_state, sel_freq, sel_strength);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(pitch_stats_kernel, dim3(n_clips), dim3(64), 0, s, sel_freq, (const ClipInfo*)clip_info, P.ceiling,
+                       stats_out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_hnr_mean(const double* sel_freq, const double* sel_strength, const void* clip_info, int n_clips,
+                        double* out, rsaf_stream_t stream) {
+    if (n_clips <= 0) return RSAF_OK;
+    RSAF_CHECK_ARG(sel_freq && sel_strength && clip_info && out, "NULL pointer");
+    hipLaunchKernelGGL(hnr_stats_kernel, dim3(n_clips), dim3(64), 0, (hipStream_t)stream, sel_freq, sel_strength,
+                       (const ClipInfo*)clip_info, out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const void* pitch_clip_info, int n_clips,
+                                int max_frames, const double* sel_freq, double pitch_dt, double ceiling,
+                                const double* window, const double* twiddle, int nsamp_window, int nfft, int nbins,
+                                double time_step, double freq_step, double* moments, double* stats_out,
+                                rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_frames >= 0, "bad clip/frame count");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && clip_info && pitch_clip_info && sel_freq && window && twiddle && moments && stats_out,
+                   "NULL pointer");
+    RSAF_CHECK_ARG(nfft > 0 && (nfft & (nfft - 1)) == 0 && nbins > 0 && nbins <= nfft / 2 + 1, "bad FFT geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)(((nsamp_window + 1) & ~1) + nbins) * sizeof(double);
+    RSAF_CHECK_ARG(lds <= 60 * 1024, "spectrogram window too long");
+    if (max_frames > 0) {
+        ProfScope prof("mshds_spec_moments", s, 0.0, 0.0);
+        hipLaunchKernelGGL(spec_moments_kernel, dim3(max_frames, n_clips), dim3(256), lds, s, wav,
+                           (const ClipInfo*)clip_info, (const ClipInfo*)pitch_clip_info, sel_freq, pitch_dt, ceiling,
+                           window, (const double2*)twiddle, nsamp_window, nsamp_window / 2, nfft, nbins, time_step,
+                           freq_step, moments);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(moments_stats_kernel, dim3(n_clips), dim3(64), 0, s, moments, (const ClipInfo*)clip_info, stats_out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+}  // extern "C"

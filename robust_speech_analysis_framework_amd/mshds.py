@@ -1,0 +1,345 @@
+"""MSHDS (Praat-style) feature extractor on the HIP path (drop-in for ``src/mshds_extractor.py``).
+
+The reference runs ~10 Praat analyses per file through parselmouth, one file at a time, with Python
+loops per pulse / per frame (``src/mshds_extractor.py:11-376``).  Here the analyses of a whole batch
+run as float64 HIP kernels (``csrc/mshds.hip``); the host only builds the frame grids (Praat's
+``Sampled_shortTermAnalysis`` arithmetic), the window tables, and routes each clip to the
+speaker-adapted pitch range that ``_pitch_values`` chooses (``:127-162``).
+
+Built so far: mean_F0, stdev_F0_Semitone, mean_dB, range_ratio_dB, HNR_dB, Spectral_Gravity,
+Spectral_Std_Dev, Spectral_Skewness, Spectral_Kurtosis.  The 16 other columns are NaN until their
+kernels exist (speech rate, LTAS slope/tilt, CPPS, formants): there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import _lib
+from .wavio import read_wav_mono
+
+FS = 16000.0
+DX = 1.0 / FS
+SAMPLE_RATE = 16000
+
+FEATURE_NAMES = [
+    "Speaking_Rate", "Articulation_Rate", "Phonation_Ratio", "Pause_Rate", "Mean_Pause_Duration",
+    "mean_F0", "stdev_F0_Semitone", "mean_dB", "range_ratio_dB", "HNR_dB",
+    "Spectral_Slope", "Spectral_Tilt", "Cepstral_Peak_Prominence",
+    "mean_F1_Loc", "std_F1_Loc", "mean_B1_Loc", "std_B1_Loc",
+    "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
+    "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
+]                                                            # src/mshds_extractor.py:397-404
+BUILT_COLUMNS = [5, 6, 7, 8, 9, 21, 22, 23, 24]
+
+CLIP_INFO = np.dtype([("sample_off", "<i8"), ("frame_off", "<i8"), ("t1", "<f8"),
+                      ("n_samples", "<i4"), ("n_frames", "<i4")])
+assert CLIP_INFO.itemsize == 32
+
+
+def short_term_frames(n_samples: int, window_duration: float, time_step: float):
+    """Praat Sampled_shortTermAnalysis: (frames, time of first frame); integer-exact contract."""
+    duration = n_samples * DX
+    if window_duration > duration:
+        return 0, 0.0
+    nf = int(math.floor((duration - window_duration) / time_step)) + 1
+    t1 = 0.5 * duration - 0.5 * nf * time_step + 0.5 * time_step
+    return nf, t1
+
+
+def _clip_info(sample_offs, lengths, grid):
+    """grid(n_samples) -> (n_frames, t1).  Returns (structured host array, total frames, max frames)."""
+    ci = np.zeros(len(lengths), dtype=CLIP_INFO)
+    off = 0
+    for i, (so, n) in enumerate(zip(sample_offs, lengths)):
+        nf, t1 = grid(int(n))
+        ci[i] = (int(so), off, t1, int(n), nf)
+        off += nf
+    return ci, off, int(ci["n_frames"].max()) if len(ci) else 0
+
+
+def _dev(arr, device):
+    import torch
+    a = np.ascontiguousarray(arr)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device) if a.dtype == CLIP_INFO else \
+        torch.from_numpy(a).to(device)
+
+
+class _PitchGeom:
+    """Window geometry of Sound: To Pitch (ac/cc) for one parameter set (Boersma 1993)."""
+
+    def __init__(self, time_step, floor, ceiling, periods, is_cc):
+        self.periods, self.is_cc, self.floor = periods, is_cc, float(floor)
+        self.dt = time_step if time_step > 0 else periods / floor / 4.0
+        self.ceiling = min(float(ceiling), 0.5 / DX)
+        self.dt_window = periods / floor
+        self.nsamp_period = int(math.floor(1.0 / DX / floor))
+        nsw = int(math.floor(self.dt_window / DX))
+        self.half_window = nsw // 2 - 1
+        self.nsamp_window = self.half_window * 2
+        self.min_lag = max(2, int(math.floor(1.0 / DX / self.ceiling)))
+        self.max_lag = min(int(math.floor(self.nsamp_window / periods)) + 2, self.nsamp_window)
+        self.brent_ixmax = int(math.floor(self.nsamp_window * (1.0 if is_cc else 0.5)))
+        self.frame_window = (1.0 / floor + self.dt_window) if is_cc else self.dt_window
+
+    def grid(self, n):
+        if self.half_window < 2:
+            return 0, 0.0
+        return short_term_frames(n, self.frame_window, self.dt)
+
+    def tables(self):
+        if self.is_cc:
+            return None, None
+        n = self.nsamp_window
+        i = np.arange(1, n + 1)
+        win = 0.5 - 0.5 * np.cos(i * 2.0 * np.pi / (n + 1))
+        nfft = 1
+        while nfft < n * 1.5:
+            nfft *= 2
+        sp = np.fft.rfft(win, n=nfft)
+        wr = np.fft.irfft(sp.real ** 2 + sp.imag ** 2, n=nfft)
+        wr = wr / wr[0]
+        return win, wr[:self.brent_ixmax + 1].copy()
+
+
+class MshdsEngine:
+    def __init__(self, device="cuda"):
+        import torch
+        _lib.load()
+        _lib.require_gpu()
+        self.device = torch.device(device)
+        self._tables = {}
+        self.fo_doubles = _lib.load().rsaf_mshds_frameout_doubles()
+
+    # ---- cached device tables ----
+    def _table(self, key, builder):
+        if key not in self._tables:
+            self._tables[key] = tuple(None if a is None else _dev(np.asarray(a, dtype=np.float64), self.device)
+                                      for a in builder())
+        return self._tables[key]
+
+    # ---- one pitch analysis over a set of clips ----
+    def pitch(self, wav, sample_offs, lengths, gpeak, *, time_step, floor, ceiling, max_candidates=15,
+              silence_threshold=0.03, voicing_threshold=0.45, octave_cost=0.01, octave_jump_cost=0.35,
+              voiced_unvoiced_cost=0.14, periods=3.0, is_cc=False, refine_depth=70, stream=None):
+        import torch
+        lib = _lib.load()
+        g = _PitchGeom(time_step, floor, ceiling, periods, is_cc)
+        ci, total, mx = _clip_info(sample_offs, lengths, g.grid)
+        n = len(lengths)
+        dev = self.device
+        ci_d = _dev(ci, dev)
+        win, wr = self._table(("pitch", g.nsamp_window, is_cc), g.tables)
+        tf = max(total, 1)
+        frame_out = torch.empty(tf * self.fo_doubles, dtype=torch.float64, device=dev)
+        psi = torch.empty(tf * 16, dtype=torch.uint8, device=dev)
+        end_state = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        sel_f = torch.zeros(tf, dtype=torch.float64, device=dev)
+        sel_s = torch.zeros(tf, dtype=torch.float64, device=dev)
+        stats = torch.empty((max(n, 1), 8), dtype=torch.float64, device=dev)
+        params = (C.c_double * 17)(g.dt, g.floor, g.ceiling, voicing_threshold, octave_cost, silence_threshold,
+                                   octave_jump_cost, voiced_unvoiced_cost, g.nsamp_window, g.nsamp_period, g.min_lag,
+                                   g.max_lag, g.brent_ixmax, max_candidates, refine_depth, 1 if is_cc else 0,
+                                   g.dt_window)
+        if n and g.half_window >= 2:
+            _lib.check(lib.rsaf_mshds_pitch(
+                _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak),
+                _lib.ptr(win) if win is not None else None, _lib.ptr(wr) if wr is not None else None, params,
+                _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
+                _lib.ptr(stats), _lib.stream_ptr(stream)), "rsaf_mshds_pitch")
+        else:
+            stats.fill_(float("nan"))
+            stats[:, 0] = 0
+        return {"geom": g, "ci": ci, "ci_dev": ci_d, "sel_freq": sel_f, "sel_strength": sel_s, "stats": stats[:n],
+                "frame_out": frame_out, "total_frames": total, "max_frames": mx}
+
+    def intensity(self, wav, sample_offs, lengths, minimum_pitch, time_step, subtract_mean=True, stream=None):
+        import torch
+        lib = _lib.load()
+        phys = 6.4 / minimum_pitch
+        dt = time_step if time_step > 0 else 0.8 / minimum_pitch
+        half_dur = 0.5 * phys
+        half = int(math.floor(half_dur / DX))
+
+        def build():
+            i = np.arange(-half, half + 1)
+            xx = i * DX / half_dur
+            return (np.i0((2.0 * np.pi * np.pi + 0.5) * np.sqrt(np.maximum(0.0, 1.0 - xx * xx))),)
+        (win,) = self._table(("intensity", half, minimum_pitch), build)
+        ci, total, mx = _clip_info(sample_offs, lengths, lambda n: short_term_frames(n, phys, dt))
+        n = len(lengths)
+        db = torch.empty(max(total, 1), dtype=torch.float64, device=self.device)
+        stats = torch.empty((max(n, 1), 2), dtype=torch.float64, device=self.device)
+        if n:
+            _lib.check(lib.rsaf_mshds_intensity(_lib.ptr(wav), _lib.ptr(_dev(ci, self.device)), n, mx, _lib.ptr(win),
+                                                half, dt, 1 if subtract_mean else 0, _lib.ptr(db), _lib.ptr(stats),
+                                                _lib.stream_ptr(stream)), "rsaf_mshds_intensity")
+        return {"db": db, "ci": ci, "stats": stats[:n], "dt": dt}
+
+    def spectral_moments(self, wav, sample_offs, lengths, pitch, window_length=0.025, time_step=0.005,
+                         maximum_frequency=5000.0, frequency_step=20.0, stream=None):
+        import torch
+        lib = _lib.load()
+        nyq = 0.5 / DX
+        phys = 2.0 * window_length
+        eff_t = window_length / math.sqrt(math.pi)
+        tstep = max(time_step, eff_t / 8.0)
+        fstep = max(frequency_step, (1.0 / eff_t) / 8.0)
+        nsamp = int(math.floor(phys / DX))
+        half = nsamp // 2 - 1
+        nsamp = half * 2
+        fmax = maximum_frequency if 0 < maximum_frequency <= nyq else nyq
+        nfreq = int(math.floor(fmax / fstep))
+        nfft = 1
+        while nfft < nsamp or nfft < 2 * nfreq * (nyq / fmax):
+            nfft *= 2
+        bw_samples = max(1, int(math.floor(fstep * DX * nfft)))
+        if bw_samples != 1:
+            raise _lib.RsafError("spectrogram: only one FFT bin per frequency band is implemented")
+        fstep = 1.0 / (DX * nfft)
+        nfreq = int(math.floor(fmax / fstep))
+
+        def build():
+            i = np.arange(1, nsamp + 1)
+            phase = (i - 0.5 * (nsamp + 1)) / nsamp
+            edge = math.exp(-12.0)
+            win = (np.exp(-48.0 * phase * phase) - edge) / (1.0 - edge)
+            k = np.arange(nfft)
+            tw = np.stack([np.cos(2.0 * np.pi * k / nfft), -np.sin(2.0 * np.pi * k / nfft)], axis=1)
+            return win, tw.reshape(-1)
+        win, tw = self._table(("spec", nsamp, nfft), build)
+
+        def grid(n):
+            duration = n * DX
+            if phys > duration or half < 1:
+                return 0, 0.0
+            nt = 1 + int(math.floor((duration - phys) / tstep))
+            return nt, 0.5 * DX + 0.5 * ((n - 1) * DX - (nt - 1) * tstep)
+        ci, total, mx = _clip_info(sample_offs, lengths, grid)
+        n = len(lengths)
+        mom = torch.empty(max(total, 1) * 5, dtype=torch.float64, device=self.device)
+        stats = torch.empty((max(n, 1), 4), dtype=torch.float64, device=self.device)
+        if n:
+            _lib.check(lib.rsaf_mshds_spectral_moments(
+                _lib.ptr(wav), _lib.ptr(_dev(ci, self.device)), _lib.ptr(pitch["ci_dev"]), n, mx,
+                _lib.ptr(pitch["sel_freq"]), pitch["geom"].dt, pitch["geom"].ceiling, _lib.ptr(win), _lib.ptr(tw),
+                nsamp, nfft, nfreq, tstep, fstep, _lib.ptr(mom), _lib.ptr(stats), _lib.stream_ptr(stream)),
+                "rsaf_mshds_spectral_moments")
+        return {"stats": stats[:n], "moments": mom, "ci": ci, "fstep": fstep, "tstep": tstep}
+
+    def hnr_mean(self, pitch_cc, stream=None):
+        import torch
+        n = len(pitch_cc["ci"])
+        out = torch.empty(max(n, 1), dtype=torch.float64, device=self.device)
+        if n:
+            _lib.check(_lib.load().rsaf_mshds_hnr_mean(_lib.ptr(pitch_cc["sel_freq"]), _lib.ptr(pitch_cc["sel_strength"]),
+                                                       _lib.ptr(pitch_cc["ci_dev"]), n, _lib.ptr(out),
+                                                       _lib.stream_ptr(stream)), "rsaf_mshds_hnr_mean")
+        return out[:n]
+
+    def clip_peaks(self, wav, sample_offs, lengths, stream=None):
+        import torch
+        n = len(lengths)
+        ci, _, _ = _clip_info(sample_offs, lengths, lambda k: (0, 0.0))
+        gp = torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)
+        if n:
+            _lib.check(_lib.load().rsaf_mshds_clip_peak(_lib.ptr(wav), _lib.ptr(_dev(ci, self.device)), n, _lib.ptr(gp),
+                                                        _lib.stream_ptr(stream)), "rsaf_mshds_clip_peak")
+        return gp
+
+    # ---- the reference's orchestration for a packed batch ----
+    def extract_packed(self, wav, sample_offs, lengths, stream=None):
+        """wav: 1-D float32 device tensor with the clips back to back -> (float64 [n, 25] device tensor,
+        list of (floor, ceiling) per clip)."""
+        import torch
+        n = len(lengths)
+        out = torch.full((n, 25), float("nan"), dtype=torch.float64, device=self.device)
+        if n == 0:
+            return out, []
+        sample_offs = [int(v) for v in sample_offs]
+        lengths = [int(v) for v in lengths]
+        gpeak = self.clip_peaks(wav, sample_offs, lengths, stream)
+        # _pitch_values (:127-162): wide search, outlier-trimmed mean -> speaker range
+        wide = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.005, floor=50.0, ceiling=600.0, stream=stream)
+        st = wide["stats"].cpu().numpy()                       # one small D2H per batch
+        ranges = []
+        for i in range(n):
+            if st[i, 0] == 0 or not st[i, 7] > 0:
+                ranges.append((75, 500))                       # :146,151 and the except path :161-162
+            else:
+                ranges.append((60, 250) if st[i, 3] < 170 else (100, 500))
+        for rng in sorted(set(ranges)):
+            ids = [i for i in range(n) if ranges[i] == rng]
+            so = [sample_offs[i] for i in ids]
+            ln = [lengths[i] for i in ids]
+            idx = torch.tensor(ids, dtype=torch.long, device=self.device)
+            gp = gpeak[idx].contiguous()
+            floor, ceiling = float(rng[0]), float(rng[1])
+            p = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=ceiling, stream=stream)   # :178 == :355
+            inten = self.intensity(wav, so, ln, floor, 0.005, True, stream)                                  # :198
+            cc = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=0.5 / DX, max_candidates=15,
+                            silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
+                            voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700, stream=stream)  # :221
+            hnr = self.hnr_mean(cc, stream)
+            sm = self.spectral_moments(wav, so, ln, p, 0.025, 0.005, stream=stream)                          # :356
+            out[idx, 5] = p["stats"][:, 5]
+            out[idx, 6] = p["stats"][:, 6]
+            out[idx, 7] = inten["stats"][:, 0]
+            out[idx, 8] = inten["stats"][:, 1]
+            out[idx, 9] = hnr
+            out[idx, 21:25] = sm["stats"]
+        return out, ranges
+
+
+_ENGINE = None
+
+
+def get_engine(device="cuda"):
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = MshdsEngine(device)
+    return _ENGINE
+
+
+def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True, batch_files=32):
+    """Drop-in for ``src/mshds_extractor.py:379-459``: one row per input row, in input order,
+    columns ``filename`` + the 25 feature names; a file that cannot be processed gives a NaN row
+    (``:450-457``).  Columns whose kernels are not built yet are NaN."""
+    import pandas as pd
+    import torch
+    eng = get_engine()
+    rows = []
+    paths = list(input_df[audio_file_column])
+    for b0 in range(0, len(paths), batch_files):
+        batch = paths[b0:b0 + batch_files]
+        clips, ok_idx = [], []
+        for j, pth in enumerate(batch):
+            filename = os.path.basename(pth)
+            try:
+                x, fs = read_wav_mono(pth)
+                if fs != SAMPLE_RATE:
+                    raise ValueError(f"sample rate {fs} Hz: resampling is not built yet (16 kHz input only)")
+                if len(x) == 0:
+                    raise ValueError("empty file")
+                clips.append(x)
+                ok_idx.append(j)
+            except Exception as e:
+                if verbose:
+                    print(f"ERROR processing file '{filename}': {e}. Appending NaNs.")
+        feats = np.full((len(batch), 25), np.nan)
+        if clips:
+            lengths = [len(c) for c in clips]
+            offs = np.zeros(len(clips) + 1, dtype=np.int64)
+            offs[1:] = np.cumsum(lengths)
+            wav = torch.from_numpy(np.concatenate(clips)).to(eng.device)
+            vals, _ = eng.extract_packed(wav, offs[:-1], lengths)
+            torch.cuda.synchronize()
+            feats[ok_idx] = vals.cpu().numpy()
+        for j, pth in enumerate(batch):
+            d = {"filename": os.path.basename(pth)}
+            d.update({nme: feats[j, k] for k, nme in enumerate(FEATURE_NAMES)})
+            rows.append(d)
+    return pd.DataFrame(rows)

@@ -1,0 +1,158 @@
+"""HIP Praat-style MSHDS kernels vs the CPU oracle (parity unpinned: no Praat binary exists here)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mshds_oracle as mo
+from robust_speech_analysis_framework_amd import synth
+
+TOL = 1e-4
+
+
+def _pack(clips):
+    import torch
+    lengths = [len(c) for c in clips]
+    offs = np.concatenate([[0], np.cumsum(lengths)])[:-1]
+    wav = torch.from_numpy(np.concatenate(clips)).cuda()
+    return wav, [int(o) for o in offs], lengths
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.fixture(scope="module")
+def eng(rsaf_lib):
+    from robust_speech_analysis_framework_amd.mshds import MshdsEngine
+    return MshdsEngine()
+
+
+def test_intensity_contour_and_stats(eng):
+    import torch
+    clips = [synth.synth_clip(100, 2.0), synth.synth_clip(101, 1.3)]
+    wav, offs, lens = _pack(clips)
+    for floor in (60.0, 100.0):
+        r = eng.intensity(wav, offs, lens, floor, 0.005, True)
+        torch.cuda.synchronize()
+        db = r["db"].cpu().numpy()
+        st = r["stats"].cpu().numpy()
+        for i, c in enumerate(clips):
+            ref, t1, _ = mo.intensity(c, floor, 0.005, True)
+            ci = r["ci"][i]
+            assert ci["n_frames"] == len(ref) and abs(ci["t1"] - t1) < 1e-15       # integer-exact grid
+            got = db[ci["frame_off"]:ci["frame_off"] + ci["n_frames"]]
+            assert np.abs(got - ref).max() < 1e-8
+            m, rr = mo.extract_intensity(c, floor, 0.005)
+            assert abs(st[i, 0] - m) < 1e-8 and abs(st[i, 1] - rr) < 1e-8
+
+
+@pytest.mark.parametrize("floor,ceil", [(50.0, 600.0), (100.0, 500.0), (60.0, 250.0)])
+def test_pitch_ac_track_matches_oracle(eng, floor, ceil):
+    import torch
+    clips = [synth.synth_clip(110, 1.5), synth.synth_clip(111, 2.2)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    r = eng.pitch(wav, offs, lens, gp, time_step=0.005, floor=floor, ceiling=ceil)
+    torch.cuda.synchronize()
+    sel = r["sel_freq"].cpu().numpy()
+    st = r["stats"].cpu().numpy()
+    for i, c in enumerate(clips):
+        p = mo.pitch_ac(c, 0.005, floor, pitch_ceiling=ceil)
+        ci = r["ci"][i]
+        assert ci["n_frames"] == p.n_frames
+        got = sel[ci["frame_off"]:ci["frame_off"] + ci["n_frames"]]
+        ref = p.frequency()
+        assert np.array_equal(got > 0, ref > 0)                                  # voicing decisions identical
+        assert _rel(got, ref) < 1e-7
+        mean, sd = mo.extract_pitch(c, floor, ceil, 0.005, p)
+        assert abs(st[i, 5] - mean) / mean < 1e-7 and abs(st[i, 6] - sd) / sd < 1e-6
+        assert st[i, 4] == len(p.voiced_values())
+
+
+def test_pitch_ac_few_candidates_replacement_rule(eng):
+    """The 4-candidate pass of _speechrate (:104): more maxima than slots -> weakest is replaced."""
+    import torch
+    clips = [synth.synth_clip(112, 2.0)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    kw = dict(time_step=0.02, floor=30.0, ceiling=450.0, max_candidates=4, silence_threshold=0.03,
+              voicing_threshold=0.25, octave_cost=0.01, octave_jump_cost=0.35, voiced_unvoiced_cost=0.25)
+    r = eng.pitch(wav, offs, lens, gp, **kw)
+    torch.cuda.synchronize()
+    p = mo.pitch_ac(clips[0], 0.02, 30.0, 4, False, 0.03, 0.25, 0.01, 0.35, 0.25, 450.0)
+    got = r["sel_freq"].cpu().numpy()[:p.n_frames]
+    assert r["ci"][0]["n_frames"] == p.n_frames
+    assert np.array_equal(got > 0, p.frequency() > 0) and _rel(got, p.frequency()) < 1e-7
+
+
+def test_harmonicity_cc_mean(eng):
+    import torch
+    clips = [synth.synth_clip(120, 1.2), synth.synth_clip(121, 1.6)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    for floor in (100.0, 60.0):
+        cc = eng.pitch(wav, offs, lens, gp, time_step=0.005, floor=floor, ceiling=8000.0, max_candidates=15,
+                       silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
+                       voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700)
+        h = eng.hnr_mean(cc)
+        torch.cuda.synchronize()
+        for i, c in enumerate(clips):
+            ref = mo.extract_harmonicity(c, floor, None, 0.005)
+            assert abs(h[i].item() - ref) < 1e-6 * max(1.0, abs(ref)), (floor, i, h[i].item(), ref)
+
+
+def test_spectral_moments_gated_by_pitch(eng):
+    import torch
+    clips = [synth.synth_clip(130, 1.5), synth.synth_clip(131, 2.0)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    p = eng.pitch(wav, offs, lens, gp, time_step=0.005, floor=100.0, ceiling=500.0)
+    sm = eng.spectral_moments(wav, offs, lens, p, 0.025, 0.005)
+    torch.cuda.synchronize()
+    assert abs(sm["fstep"] - 15.625) < 1e-12
+    got = sm["stats"].cpu().numpy()
+    for i, c in enumerate(clips):
+        ref = np.array(mo.extract_spectral_moments(c, 100, 500, 0.025, 0.005))
+        assert np.abs(got[i] - ref).max() / np.abs(ref).max() < 1e-7, (got[i], ref)
+        pw, t1, ts, fs = mo.spectrogram_power(c, 0.025, 5000.0, 0.005, 20.0)
+        assert sm["ci"][i]["n_frames"] == pw.shape[0] and abs(sm["ci"][i]["t1"] - t1) < 1e-15
+
+
+def test_extract_packed_matches_oracle_and_uses_both_speaker_ranges(eng):
+    import torch
+    ids = [140, 141, 142, 143, 144, 145]
+    clips = [synth.synth_clip(k, 1.5) for k in ids] + [np.zeros(300, np.float32)]
+    wav, offs, lens = _pack(clips)
+    out, ranges = eng.extract_packed(wav, offs, lens)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    seen = set()
+    for i, c in enumerate(clips):
+        ref, rng = mo.extract(c)
+        assert tuple(rng) == tuple(ranges[i])                                   # integer outputs exact
+        seen.add(tuple(rng))
+        assert np.array_equal(np.isnan(got[i]), np.isnan(ref)), (i, got[i], ref)
+        ok = ~np.isnan(ref)
+        if ok.any():
+            assert np.abs(got[i][ok] - ref[ok]).max() <= TOL * np.abs(ref[ok]).max()
+            assert (np.abs(got[i][ok] - ref[ok]) <= TOL * np.maximum(np.abs(ref[ok]), 1e-3)).all(), (i, got[i][ok], ref[ok])
+    assert {(60, 250), (100, 500)} <= seen and (75, 500) in seen
+
+
+def test_dropin_dataframe_contract(eng, tmp_path):
+    import pandas as pd
+    from robust_speech_analysis_framework_amd.mshds import FEATURE_NAMES, extract_mshds_features
+    paths = synth.write_synth_corpus(str(tmp_path), 2, 1.2, first=150)
+    bad = tmp_path / "broken.wav"
+    bad.write_bytes(b"junk")
+    df = pd.DataFrame({"filepath": [paths[0], str(bad), paths[1]]})
+    out = extract_mshds_features(df, verbose=False)
+    assert list(out.columns) == ["filename"] + FEATURE_NAMES and len(out) == 3
+    assert list(out["filename"]) == ["synth_00150.wav", "broken.wav", "synth_00151.wav"]
+    assert out.iloc[1, 1:].isna().all()                                         # failed file -> NaN row (:450-457)
+    ref, _ = mo.extract(synth.synth_clip(150, 1.2))
+    row = out.iloc[0, 1:].to_numpy(dtype=np.float64)
+    ok = ~np.isnan(ref)
+    assert np.array_equal(np.isnan(row), ~ok)
+    assert (np.abs(row[ok] - ref[ok]) <= TOL * np.maximum(np.abs(ref[ok]), 1e-3)).all()

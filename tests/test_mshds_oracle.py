@@ -1,0 +1,67 @@
+"""Analytic known-answer vectors for the Praat-style oracle (parity unpinned: no Praat binary;
+the oracle is pinned by closed-form cases and by the integer frame-grid contract)."""
+import numpy as np
+
+from oracle import mshds_oracle as mo
+
+
+def _sine(f, seconds, amp=0.3):
+    t = np.arange(int(seconds * 16000)) / 16000.0
+    return (amp * np.sin(2 * np.pi * f * t)).astype(np.float32)
+
+
+def test_frame_grid_contract():
+    # 30 s clip, AC pitch with floor 50: window 0.06 s -> floor((30-0.06)/0.005)+1 frames, centred
+    nf, t1 = mo.short_term_frames(480000, 0.06, 0.005)
+    assert nf == 5989 and abs(t1 - (15.0 - 0.5 * 5989 * 0.005 + 0.0025)) < 1e-12
+    assert mo.short_term_frames(100, 0.06, 0.005) == (0, 0.0)
+
+
+def test_intensity_of_sine_matches_closed_form():
+    x = _sine(200.0, 1.0)
+    db, _, _ = mo.intensity(x, 100.0, 0.005)
+    want = 10 * np.log10(0.3 ** 2 / 2 / 4e-10)
+    assert np.abs(db - want).max() < 0.01
+    m, r = mo.extract_intensity(x, 100.0)
+    assert abs(m - want) < 0.01 and abs(r - 1.0) < 1e-3
+
+
+def test_pitch_of_sine_and_silence():
+    p = mo.pitch_ac(_sine(200.0, 1.0), 0.005, 75.0, pitch_ceiling=500.0)
+    f = p.frequency()
+    assert (f > 0).all() and np.abs(f - 200.0).max() < 0.05
+    mean, sd = mo.extract_pitch(None, 75, 500, pitch=p)
+    assert abs(mean - 200.0) < 0.05 and sd < 1e-3
+    z = mo.pitch_ac(np.zeros(16000, np.float32), 0.005, 75.0)
+    assert (z.frequency() == 0).all()
+    assert mo.pitch_values(np.zeros(16000, np.float32)) == (75, 500)
+    assert mo.pitch_values(_sine(120.0, 1.0)) == (60, 250) and mo.pitch_values(_sine(220.0, 1.0)) == (100, 500)
+
+
+def test_sinc_interpolation_reproduces_samples_and_band_limited_values():
+    n = np.arange(400)
+    y = np.sin(2 * np.pi * 0.031 * n)
+    assert abs(mo.interpolate_sinc(y, np.array(123.0), 70) - y[123]) < 1e-15
+    x = np.array(200.37)
+    assert abs(mo.interpolate_sinc(y, x, 70) - np.sin(2 * np.pi * 0.031 * 200.37)) < 1e-3
+    xm, ym = mo.improve_maximum_sinc(y[None, :], np.array([np.argmax(y[180:220]) + 180.0]), 70)
+    assert abs(ym[0] - 1.0) < 1e-3
+
+
+def test_hnr_of_sine_is_high_and_noise_is_low():
+    rng = np.random.default_rng(0)
+    assert mo.extract_harmonicity(_sine(150.0, 0.6), 75.0, 500.0) > 30.0
+    noise = (0.1 * rng.standard_normal(9600)).astype(np.float32)
+    h = mo.extract_harmonicity(noise, 75.0, 500.0)
+    assert np.isnan(h) or h < 5.0
+
+
+def test_spectrogram_geometry_and_moments_of_sine():
+    pw, t1, ts, fs = mo.spectrogram_power(_sine(1000.0, 0.5), 0.025, 5000.0, 0.005, 20.0)
+    assert pw.shape[1] == 320 and fs == 15.625 and ts == 0.005
+    cog, sd, sk, ku = mo.spectral_moments(pw, fs)
+    assert np.abs(cog - 1000.0).max() < 1.0 and sd.max() < 30.0
+
+
+def test_feature_order_matches_reference():
+    assert len(mo.FEATURE_NAMES) == 25 and mo.FEATURE_NAMES[5] == "mean_F0" and mo.FEATURE_NAMES[-1] == "Spectral_Kurtosis"
