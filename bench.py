@@ -91,6 +91,14 @@ def cpu_baseline(stages, seconds, sample_clips):
             smile_oracle.extract(c)
         parts["smile"] = time.perf_counter() - t0
         log(f"cpu_baseline smile {parts['smile']:.2f} s")
+    if "mshds" in stages:
+        from oracle import mshds_oracle
+        sub = clips[0][:int(16000 * min(seconds, 5.0))]          # bounded: 5 s of one clip (Python oracle)
+        t0 = time.perf_counter()
+        mshds_oracle.extract(sub)
+        dt_m = time.perf_counter() - t0
+        parts["mshds"] = dt_m * (n * seconds) / (len(sub) / 16000.0)   # scaled to the sample's audio-seconds
+        log(f"cpu_baseline mshds {dt_m:.2f} s for {len(sub) / 16000.0:g} audio-s (scaled to {parts['mshds']:.1f} s)")
     seqs = None
     if "w2v2" in stages:
         from oracle import w2v2_oracle
@@ -123,8 +131,9 @@ def cpu_baseline(stages, seconds, sample_clips):
     model_stages = [s for s in stages if s in ("w2v2", "cnnlstm")]
     return {"value": round(n * seconds / total, 2), "unit": "audio-s/s", "cores": cores if model_stages else 1,
             "kind": "port",
-            "sample": f"{n} x {seconds:g} s clips through stages {stages}: oracle/ (numpy float64 DSP on 1 core; "
-                      f"torch-CPU float32 models on {cores} threads, batch-1 windows like the reference)",
+            "sample": f"{n} x {seconds:g} s clips through stages {stages}: oracle/ (numpy float64 DSP on 1 core, "
+                      f"MSHDS timed on 5 s and scaled linearly; torch-CPU float32 models on {cores} threads, "
+                      f"batch-1 windows like the reference)",
             "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
             "seconds_per_stage": {k: round(v, 3) for k, v in parts.items()}}
 

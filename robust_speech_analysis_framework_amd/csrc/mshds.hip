@@ -14,6 +14,11 @@
 // per frame for intensity, one wave per clip for the path finder and the per-clip statistics.
 #include "rsaf_common.h"
 
+// Frame times sit exactly on half-sample positions, where Praat's nearest/low index rounding is
+// decided by the last bit: evaluate t1 + f*dt etc. as separately rounded IEEE operations (no FMA
+// contraction), exactly like the float64 host arithmetic of the oracle.
+#pragma clang fp contract(off)
+
 namespace rsaf {
 namespace mshds {
 

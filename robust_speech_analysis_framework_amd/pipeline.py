@@ -2,7 +2,7 @@
 
 This is the build's own runner for equal-length batches that are already resident in HBM
 (bench.py, the multi-GPU driver).  Per clip it emits one fixed-width float32 row
-``[smile 912 | logits 2 | w2v2 frames 1]`` that ranks all-gather once per step.
+``[mshds 25 | smile 912 | logits 2 | w2v2 frames 1]`` that ranks all-gather once per step.
 The Wav2Vec2 sequences (5.66 MB per 30 s clip) stay on the producing GPU and feed its local
 CNN-LSTM, exactly as notebook 03 feeds the classifier with the extractor's output.
 """
@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib, smile
 
-BUILT_STAGES = ["smile", "w2v2", "cnnlstm"]
+BUILT_STAGES = ["mshds", "smile", "w2v2", "cnnlstm"]
 
 # algorithmic traffic per audio-second of the HBM-bound kernels:
 #   16 000 float32 samples read + 38 float32 LLDs x 100 frames/s written
@@ -44,6 +44,10 @@ class Pipeline:
         self.finite_cols = None
         self.w2v2 = None
         self.model = None
+        self.mshds = None
+        if "mshds" in self.stages:
+            from .mshds import MshdsEngine
+            self.mshds = MshdsEngine(device)
         if "w2v2" in self.stages:
             from .w2v2 import W2V2Engine
             from .w2v2_config import W2V2Config, random_state_dict
@@ -68,6 +72,10 @@ class Pipeline:
         cols = []
         p = self._pack(wav)
         n_clips, n_samp = int(wav.shape[0]), int(wav.shape[1])
+        if self.mshds is not None:
+            offs = np.arange(n_clips, dtype=np.int64) * n_samp
+            feats, _ = self.mshds.extract_packed(p.wav, offs, [n_samp] * n_clips)
+            cols.append(feats.to(torch.float32))
         if "smile" in self.stages:
             cols.append(smile.smile_features(p))
         if self.w2v2 is not None:
@@ -85,6 +93,8 @@ class Pipeline:
 
     def describe(self, clips, seconds):
         parts = []
+        if "mshds" in self.stages:
+            parts.append("MSHDS Praat-style 9/25 features (pitch, intensity, HNR, spectral moments; fp64)")
         if "smile" in self.stages:
             parts.append("openSMILE-style 32/38 LLD + 912 functionals")
         if "w2v2" in self.stages:
@@ -92,7 +102,7 @@ class Pipeline:
         if "cnnlstm" in self.stages:
             parts.append("CNN-LSTM-attn forward (C=H=128) on the Wav2Vec2 sequences")
         return (f"{' -> '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU; "
-                "MSHDS (Praat-style) stage not built yet")
+                "columns whose kernels are not built yet are NaN (DESIGN.md)")
 
 
 def roofline(prof, pipe, clips, seconds, steps, hbm_peak_gbs, mfma_peak_tflops):
