@@ -12,6 +12,8 @@
 // Mapping: one 256-thread workgroup per analysis frame for the correlation kernels (frame staged in
 // LDS, 4 lags per thread in registers, candidates refined by wave-cooperative sinc sums), one wave
 // per frame for intensity, one wave per clip for the path finder and the per-clip statistics.
+#include <algorithm>
+
 #include "rsaf_common.h"
 
 // Frame times sit exactly on half-sample positions, where Praat's nearest/low index rounding is
@@ -123,6 +125,8 @@ __device__ double sinc_wave(const double* __restrict__ y, int n, double x, int d
     if (d > n - midleft) d = n - midleft;
     const int left = midright - d, right = midleft + d;
     double acc = 0.0;
+    // cos(aa0 + daa*k) for k = lane, lane+64, ... advances by a fixed rotation of 64*daa per step:
+    // one sincos per lane and per half instead of one cos per term (fp64 cos costs hundreds of cycles)
     {   // left half: 1-based ix = midleft - k, k = 0..d-1
         const double a0 = PI * (x1 - midleft);
         const double den = x1 - left + 1.0;
@@ -130,11 +134,18 @@ __device__ double sinc_wave(const double* __restrict__ y, int n, double x, int d
         const double hs = 0.5 * sin(a0);
         int kmax = d;                                         // skip the zero tail
         if (midleft - 1 - (kmax - 1) < nz_lo) kmax = midleft - 1 - nz_lo + 1;
+        double cs, sn, rc, rs;
+        sincos(aa0 + daa * lane, &sn, &cs);
+        sincos(64.0 * daa, &rs, &rc);
         for (int k = lane; k < kmax; k += 64) {
             const int idx = midleft - k - 1;
-            if (idx > nz_hi) continue;
-            const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cos(aa0 + daa * k));
-            acc += y[idx] * w;
+            if (idx <= nz_hi) {
+                const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cs);
+                acc += y[idx] * w;
+            }
+            const double c2 = cs * rc - sn * rs;
+            sn = sn * rc + cs * rs;
+            cs = c2;
         }
     }
     {   // right half: ix = midright + k
@@ -144,11 +155,18 @@ __device__ double sinc_wave(const double* __restrict__ y, int n, double x, int d
         const double hs = 0.5 * sin(a0);
         int kmax = d;
         if (midright - 1 + (kmax - 1) > nz_hi) kmax = nz_hi - (midright - 1) + 1;
+        double cs, sn, rc, rs;
+        sincos(aa0 + daa * lane, &sn, &cs);
+        sincos(64.0 * daa, &rs, &rc);
         for (int k = lane; k < kmax; k += 64) {
             const int idx = midright + k - 1;
-            if (idx < nz_lo) continue;
-            const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cos(aa0 + daa * k));
-            acc += y[idx] * w;
+            if (idx >= nz_lo) {
+                const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cs);
+                acc += y[idx] * w;
+            }
+            const double c2 = cs * rc - sn * rs;
+            sn = sn * rc + cs * rs;
+            cs = c2;
         }
     }
     return wave_sum_f64(acc);
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     int* s_maxlag = reinterpret_cast<int*>(s_cs + MAXC);   // [MAX_MAXIMA]
     int* s_place = s_maxlag + MAX_MAXIMA;           // [MAXC]
     int* s_cnt = s_place + MAXC;                    // [0] = nmax, [1] = ncand
+    double* s_part = reinterpret_cast<double*>(s_cnt + 4);   // [4][4 * ngroups] partial correlations
 #define s_nmax s_cnt[0]
 #define s_ncand s_cnt[1]
 
@@ -274,34 +293,34 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     const double gp = gpeak[blockIdx.y];
     const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
 
-    // ---- correlation: 4 consecutive lags per thread ----
+    // ---- correlation: 4 consecutive lags per thread, the sample range split over `parts` threads ----
     const int ngroups = (L + 4) / 4;                   // lags 0..L
-    for (int g = tid; g < ngroups; g += 256) {
+    int parts = 256 / ngroups;
+    parts = parts < 1 ? 1 : (parts > 4 ? 4 : parts);
+    const int pstride = 4 * ngroups;
+    for (int w = tid; w < ngroups * parts; w += 256) {
+        const int g = w % ngroups, part = w / ngroups;
         const int l0 = 4 * g;
+        const int lim = P.is_cc ? seg_len : nw;         // valid indices of seg for the shifted operand
+        const int jtot = P.is_cc ? nw : nw - l0;        // pairs (j, j+lag) that exist for the smallest lag
+        const int j0 = (int)((int64_t)jtot * part / parts), j1 = (int)((int64_t)jtot * (part + 1) / parts);
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        if (!P.is_cc) {
-            const int jmax = nw - l0;                   // pairs (j, j+lag) with j+lag < nw
-            double y0 = seg[l0 < nw ? l0 : nw - 1], y1 = (l0 + 1 < nw) ? seg[l0 + 1] : 0.0,
-                   y2 = (l0 + 2 < nw) ? seg[l0 + 2] : 0.0;
-            for (int j = 0; j < jmax; ++j) {
-                const double xj = seg[j];
-                const double y3 = (j + l0 + 3 < nw) ? seg[j + l0 + 3] : 0.0;
-                a0 += xj * y0; a1 += xj * y1; a2 += xj * y2; a3 += xj * y3;
-                y0 = y1; y1 = y2; y2 = y3;
-            }
-        } else {
-            double y0 = seg[l0], y1 = (l0 + 1 < seg_len) ? seg[l0 + 1] : 0.0, y2 = (l0 + 2 < seg_len) ? seg[l0 + 2] : 0.0;
-            for (int j = 0; j < nw; ++j) {
-                const double xj = seg[j];
-                const double y3 = (j + l0 + 3 < seg_len) ? seg[j + l0 + 3] : 0.0;
-                a0 += xj * y0; a1 += xj * y1; a2 += xj * y2; a3 += xj * y3;
-                y0 = y1; y1 = y2; y2 = y3;
-            }
+        double y0 = (j0 + l0 < lim) ? seg[j0 + l0] : 0.0, y1 = (j0 + l0 + 1 < lim) ? seg[j0 + l0 + 1] : 0.0,
+               y2 = (j0 + l0 + 2 < lim) ? seg[j0 + l0 + 2] : 0.0;
+        for (int j = j0; j < j1; ++j) {
+            const double xj = seg[j];
+            const double y3 = (j + l0 + 3 < lim) ? seg[j + l0 + 3] : 0.0;
+            a0 += xj * y0; a1 += xj * y1; a2 += xj * y2; a3 += xj * y3;
+            y0 = y1; y1 = y2; y2 = y3;
         }
-        const double av[4] = {a0, a1, a2, a3};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (l0 + q <= L) r[RC + l0 + q] = av[q];   // raw sums for now
+        double* dst = s_part + part * pstride + l0;
+        dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+    }
+    __syncthreads();
+    for (int l = tid; l <= L; l += 256) {
+        double v = 0.0;
+        for (int q = 0; q < parts; ++q) v += s_part[q * pstride + l];
+        r[RC + l] = v;                                   // raw sums for now
     }
     __syncthreads();
     // ---- normalise ----
@@ -575,7 +594,7 @@ __global__ __launch_bounds__(64) void hnr_stats_kernel(const double* __restrict_
 
 // ---- Gaussian-window spectrogram slice + spectral moments, gated by pitch definedness ----------------------
 // one workgroup per frame; direct DFT of the windowed frame for bins 0..nbins-1 (bin width 1/(dx*nfft))
-__global__ __launch_bounds__(256) void spec_moments_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+__global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                            const ClipInfo* __restrict__ pitch_ci, const double* __restrict__ sel_freq,
                                                            double pitch_dt, double ceiling, const double* __restrict__ win,
                                                            const double2* __restrict__ tw, int nsamp, int half, int nfft,
@@ -584,11 +603,11 @@ __global__ __launch_bounds__(256) void spec_moments_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* seg = reinterpret_cast<double*>(smem_raw);          // nsamp
     double* pw = seg + ((nsamp + 1) & ~1);                       // nbins
-    __shared__ double s_red[4][4];
+    __shared__ double s_red[8][4];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
     if (f >= c.n_frames) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
     double* o = mom + (c.frame_off + f) * 5;
     const double t = c.t1 + f * tstep;
     // gate: Pitch "Get value at time" defined iff the nearest pitch frame is voiced
@@ -609,36 +628,40 @@ __global__ __launch_bounds__(256) void spec_moments_kernel(const float* __restri
     }
     const float* x = wav + c.sample_off;
     const int64_t start = low_index(t) + 1 - half;
-    for (int j = tid; j < nsamp; j += 256) {
+    for (int j = tid; j < nsamp; j += blockDim.x) {
         int64_t i = start + j;
         i = i < 0 ? 0 : (i > c.n_samples - 1 ? c.n_samples - 1 : i);
         seg[j] = (double)x[i] * win[j];
     }
     __syncthreads();
-    const int mask = nfft - 1;
-    for (int k = tid; k < nbins; k += 256) {
-        double re = 0.0, im = 0.0;
-        int ph = 0;
+    // direct DFT of the nsamp-sample frame, one bin per thread; the twiddle of bin k advances by a
+    // fixed rotation exp(-2 pi i k / nfft) per sample (seg[j] is an LDS broadcast read)
+    const int nthr = blockDim.x;
+    for (int k = tid; k < nbins; k += nthr) {
+        const double2 step = tw[k & (nfft - 1)];
+        double wr_ = 1.0, wi_ = 0.0, re = 0.0, im = 0.0;
         for (int j = 0; j < nsamp; ++j) {
-            const double2 w = tw[ph];
             const double v = seg[j];
-            re += v * w.x;
-            im += v * w.y;
-            ph = (ph + k) & mask;
+            re += v * wr_;
+            im += v * wi_;
+            const double t2 = wr_ * step.x - wi_ * step.y;
+            wi_ = wr_ * step.y + wi_ * step.x;
+            wr_ = t2;
         }
         pw[k] = re * re + im * im;
     }
     __syncthreads();
     double s0 = 0, s1 = 0;
-    for (int k = tid; k < nbins; k += 256) { s0 += pw[k]; s1 += pw[k] * (k * fstep); }
+    for (int k = tid; k < nbins; k += nthr) { s0 += pw[k]; s1 += pw[k] * (k * fstep); }
     s0 = wave_sum_f64(s0); s1 = wave_sum_f64(s1);
     if (lane == 0) { s_red[wv][0] = s0; s_red[wv][1] = s1; }
     __syncthreads();
-    const double tot = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-    const double cog = (s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1]) / tot;
+    double tot = 0.0, cog = 0.0;
+    for (int q = 0; q < nwv; ++q) { tot += s_red[q][0]; cog += s_red[q][1]; }
+    cog /= tot;
     __syncthreads();
     double m2 = 0, m3 = 0, m4 = 0;
-    for (int k = tid; k < nbins; k += 256) {
+    for (int k = tid; k < nbins; k += nthr) {
         const double d = k * fstep - cog, p = pw[k];
         const double d2 = d * d;
         m2 += p * d2; m3 += p * d2 * d; m4 += p * d2 * d2;
@@ -647,9 +670,9 @@ __global__ __launch_bounds__(256) void spec_moments_kernel(const float* __restri
     if (lane == 0) { s_red[wv][0] = m2; s_red[wv][1] = m3; s_red[wv][2] = m4; }
     __syncthreads();
     if (tid == 0) {
-        const double u2 = (s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0]) / tot;
-        const double u3 = (s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1]) / tot;
-        const double u4 = (s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2]) / tot;
+        double u2 = 0.0, u3 = 0.0, u4 = 0.0;
+        for (int q = 0; q < nwv; ++q) { u2 += s_red[q][0]; u3 += s_red[q][1]; u4 += s_red[q][2]; }
+        u2 /= tot; u3 /= tot; u4 /= tot;
         o[0] = 1.0;
         o[1] = cog;
         o[2] = sqrt(u2);
@@ -743,7 +766,8 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
     RSAF_CHECK_ARG(P.is_cc || (window && window_r), "AC needs the window tables");
     const int seg_len = P.is_cc ? P.nsamp_window + P.max_lag + 1 : P.nsamp_window;
     const size_t lds = (size_t)(((seg_len + 1) & ~1) + ((2 * P.brent_ixmax + 2) & ~1) + 8 + 2 * MAX_MAXIMA + 2 * MAXC) *
-                           sizeof(double) + (size_t)(MAX_MAXIMA + MAXC + 4) * sizeof(int);
+                           sizeof(double) + (size_t)(MAX_MAXIMA + MAXC + 4) * sizeof(int) +
+                       (size_t)4 * 4 * (((P.is_cc ? P.max_lag : P.brent_ixmax) + 4) / 4) * sizeof(double);
     RSAF_CHECK_ARG(lds <= 150 * 1024, "analysis window too long for LDS");
     hipStream_t s = (hipStream_t)stream;
     if (lds > 48 * 1024)
@@ -796,7 +820,8 @@ int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const v
     RSAF_CHECK_ARG(lds <= 60 * 1024, "spectrogram window too long");
     if (max_frames > 0) {
         ProfScope prof("mshds_spec_moments", s, 0.0, 0.0);
-        hipLaunchKernelGGL(spec_moments_kernel, dim3(max_frames, n_clips), dim3(256), lds, s, wav,
+        const int threads = std::min(512, ((nbins + 63) / 64) * 64);
+        hipLaunchKernelGGL(spec_moments_kernel, dim3(max_frames, n_clips), dim3(threads), lds, s, wav,
                            (const ClipInfo*)clip_info, (const ClipInfo*)pitch_clip_info, sel_freq, pitch_dt, ceiling,
                            window, (const double2*)twiddle, nsamp_window, nsamp_window / 2, nfft, nbins, time_step,
                            freq_step, moments);
