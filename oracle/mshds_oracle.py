@@ -154,33 +154,60 @@ def interpolate_sinc(y, x, depth):
 
 
 GOLD = 0.5 * (3.0 - np.sqrt(5.0))
-N_GOLDEN = 32
+SQRT_EPS = np.sqrt(np.finfo(np.float64).eps)
+BRENT_ITMAX = 60
 
 
-def improve_maximum_sinc(y, ix, depth=70):
-    """NUMimproveMaximum with sinc interpolation: maximise on [ix-1, ix+1].  Praat uses Brent's
-    method to 1e-10; a 32-step golden-section search (bracket 2 * 0.618^32 = 4e-7 samples, i.e. a
-    frequency error below 1e-8 relative) is the documented free choice here, also used by the HIP
-    kernel so both sides take identical steps."""
+def improve_maximum_sinc(y, ix, depth=70, tol=1e-10):
+    """NUMimproveMaximum with sinc interpolation: Brent's minimiser (the netlib ``fminbr`` form Praat
+    uses: golden-section steps with safeguarded parabolic interpolation, tolerance
+    sqrt(eps)*|x| + tol/3 on the 1-based position, at most 60 iterations) applied to -sinc on
+    [ix-1, ix+1].  Vectorised over candidates with masks; y: [m, n], ix: [m] 0-based positions.
+    Returns (position, value) like Praat (the value is the one found during the search)."""
     ix = np.asarray(ix, dtype=np.float64)
-    a, b = ix - 1.0, ix + 1.0
-    c = a + GOLD * (b - a)
-    d = b - GOLD * (b - a)
-    fc, fd = interpolate_sinc(y, c, depth), interpolate_sinc(y, d, depth)
-    for _ in range(N_GOLDEN):
-        left = fc > fd                       # maximum lies in [a, d]
-        b = np.where(left, d, b)
-        a = np.where(left, a, c)
-        nc = a + GOLD * (b - a)
-        nd = b - GOLD * (b - a)
-        # reuse one evaluation per step
-        c_new = np.where(left, nc, d)
-        d_new = np.where(left, c, nd)
-        f_new = interpolate_sinc(y, np.where(left, nc, nd), depth)
-        fc, fd = np.where(left, f_new, fd), np.where(left, fc, f_new)
-        c, d = c_new, d_new
-    xm = 0.5 * (a + b)
-    return xm, interpolate_sinc(y, xm, depth)
+    f = lambda x1: -interpolate_sinc(y, x1 - 1.0, depth)        # x1 is 1-based like Praat's index
+    a, b = ix + 1.0 - 1.0, ix + 1.0 + 1.0
+    v = a + GOLD * (b - a)
+    fv = f(v)
+    x, w, fx, fw = v.copy(), v.copy(), fv.copy(), fv.copy()
+    active = np.ones(ix.shape, dtype=bool)
+    for _ in range(BRENT_ITMAX):
+        rng = b - a
+        mid = 0.5 * (a + b)
+        tol_act = SQRT_EPS * np.abs(x) + tol / 3.0
+        active &= ~(np.abs(x - mid) + 0.5 * rng <= 2.0 * tol_act)
+        if not active.any():
+            break
+        step = GOLD * np.where(x < mid, b - x, a - x)
+        t = (x - w) * (fx - fv)
+        q = (x - v) * (fx - fw)
+        p = (x - v) * q - (x - w) * t
+        q = 2.0 * (q - t)
+        p = np.where(q > 0.0, -p, p)
+        q = np.abs(q)
+        use = (np.abs(x - w) >= tol_act) & (np.abs(p) < np.abs(step * q)) & \
+              (p > q * (a - x + 2.0 * tol_act)) & (p < q * (b - x - 2.0 * tol_act))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            step = np.where(use, p / q, step)
+        step = np.where(np.abs(step) < tol_act, np.where(step > 0.0, tol_act, -tol_act), step)
+        tt = x + step
+        ft = f(tt)
+        better = ft <= fx
+        # better: shrink towards tt, shift the history
+        a_n = np.where(better, np.where(tt < x, a, x), np.where(tt < x, tt, a))
+        b_n = np.where(better, np.where(tt < x, x, b), np.where(tt < x, b, tt))
+        c1 = ~better & ((ft <= fw) | (w == x))
+        c2 = ~better & ~c1 & ((ft <= fv) | (v == x) | (v == w))
+        v_n = np.where(better, w, np.where(c1, w, np.where(c2, tt, v)))
+        fv_n = np.where(better, fw, np.where(c1, fw, np.where(c2, ft, fv)))
+        w_n = np.where(better, x, np.where(c1, tt, w))
+        fw_n = np.where(better, fx, np.where(c1, ft, fw))
+        x_n = np.where(better, tt, x)
+        fx_n = np.where(better, ft, fx)
+        a, b = np.where(active, a_n, a), np.where(active, b_n, b)
+        v, fv, w, fw = np.where(active, v_n, v), np.where(active, fv_n, fv), np.where(active, w_n, w), np.where(active, fw_n, fw)
+        x, fx = np.where(active, x_n, x), np.where(active, fx_n, fx)
+    return x - 1.0, -fx
 
 
 # ---- Pitch (Boersma 1993) --------------------------------------------------------------------------------

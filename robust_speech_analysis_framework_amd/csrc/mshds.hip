@@ -112,88 +112,122 @@ __global__ __launch_bounds__(256) void intensity_kernel(const float* __restrict_
     }
 }
 
-// ---- sinc interpolation of an LDS array, wave-cooperative (Praat NUM_interpolate_sinc) -----------------
+// cos(x) for x in [0, pi] (all arguments of the sinc window are): fold to [0, pi/2] and evaluate the
+// degree-18 Taylor polynomial in x^2 (remainder (pi/2)^20/20! = 3.4e-15).  The library cos/sincos cost
+// ~1k cycles each in fp64 and dominated this kernel; this is ~12 FMAs.
+__device__ __forceinline__ double cos_0_pi(double x) {
+    const bool hi = x > 0.5 * PI;
+    const double y = hi ? PI - x : x;
+    const double z = y * y;
+    double p = -1.0 / 6402373705728000.0;              // -1/18!
+    p = p * z + 1.0 / 20922789888000.0;                // 1/16!
+    p = p * z - 1.0 / 87178291200.0;                   // -1/14!
+    p = p * z + 1.0 / 479001600.0;                     // 1/12!
+    p = p * z - 1.0 / 3628800.0;                       // -1/10!
+    p = p * z + 1.0 / 40320.0;                         // 1/8!
+    p = p * z - 1.0 / 720.0;                           // -1/6!
+    p = p * z + 1.0 / 24.0;
+    p = p * z - 0.5;
+    p = p * z + 1.0;
+    return hi ? -p : p;
+}
+__device__ __forceinline__ double sin_0_pi(double x) { return cos_0_pi(fabs(0.5 * PI - x)); }
+
+__device__ __forceinline__ double group16_sum(double v) {
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+
+// ---- sinc interpolation of an LDS array by a 16-lane group (Praat NUM_interpolate_sinc) ----------------
 // y: n samples (0-based); x: 0-based real position; only indices in [nz_lo, nz_hi] can be non-zero.
-__device__ double sinc_wave(const double* __restrict__ y, int n, double x, int depth, int nz_lo, int nz_hi, int lane) {
+// Every lane of the wave must call this (the four groups of a wave evaluate four different x).
+__device__ double sinc_group(const double* __restrict__ y, int n, double x, int depth, int nz_lo, int nz_hi, int l16) {
     const double x1 = x + 1.0;
     const int midleft = (int)floor(x1), midright = midleft + 1;
-    if (x1 > n) return y[n - 1];
-    if (x1 < 1) return y[0];
-    if (x1 == (double)midleft) return y[midleft - 1];
+    const bool special = (x1 > n) | (x1 < 1) | (x1 == (double)midleft);
+    int si = x1 > n ? n - 1 : (x1 < 1 ? 0 : midleft - 1);
+    si = si < 0 ? 0 : (si > n - 1 ? n - 1 : si);
     int d = depth;
     if (d > midright - 1) d = midright - 1;
     if (d > n - midleft) d = n - midleft;
+    if (d < 0 || special) d = 0;
     const int left = midright - d, right = midleft + d;
     double acc = 0.0;
-    // cos(aa0 + daa*k) for k = lane, lane+64, ... advances by a fixed rotation of 64*daa per step:
-    // one sincos per lane and per half instead of one cos per term (fp64 cos costs hundreds of cycles)
-    {   // left half: 1-based ix = midleft - k, k = 0..d-1
-        const double a0 = PI * (x1 - midleft);
+    const double a0l = PI * (x1 - midleft);               // in (0, pi) unless special
+    const double hs = special ? 0.0 : 0.5 * sin_0_pi(a0l); // sin(pi - a) = sin(a): same for both halves
+    {   // left half: 1-based ix = midleft - k, k = 0..d-1; window angle (a0 + pi k)/den stays in (0, pi)
         const double den = x1 - left + 1.0;
-        const double aa0 = a0 / den, daa = PI / den;
-        const double hs = 0.5 * sin(a0);
+        const double aa0 = a0l / den, daa = PI / den;
         int kmax = d;                                         // skip the zero tail
         if (midleft - 1 - (kmax - 1) < nz_lo) kmax = midleft - 1 - nz_lo + 1;
-        double cs, sn, rc, rs;
-        sincos(aa0 + daa * lane, &sn, &cs);
-        sincos(64.0 * daa, &rs, &rc);
-        for (int k = lane; k < kmax; k += 64) {
+        for (int k = l16; k < kmax; k += 16) {
             const int idx = midleft - k - 1;
-            if (idx <= nz_hi) {
-                const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cs);
-                acc += y[idx] * w;
-            }
-            const double c2 = cs * rc - sn * rs;
-            sn = sn * rc + cs * rs;
-            cs = c2;
+            if (idx > nz_hi) continue;
+            const double w = ((k & 1) ? -hs : hs) / (a0l + PI * k) * (1.0 + cos_0_pi(aa0 + daa * k));
+            acc += y[idx] * w;
         }
     }
     {   // right half: ix = midright + k
         const double a0 = PI * (midright - x1);
         const double den = right - x1 + 1.0;
         const double aa0 = a0 / den, daa = PI / den;
-        const double hs = 0.5 * sin(a0);
         int kmax = d;
         if (midright - 1 + (kmax - 1) > nz_hi) kmax = nz_hi - (midright - 1) + 1;
-        double cs, sn, rc, rs;
-        sincos(aa0 + daa * lane, &sn, &cs);
-        sincos(64.0 * daa, &rs, &rc);
-        for (int k = lane; k < kmax; k += 64) {
+        for (int k = l16; k < kmax; k += 16) {
             const int idx = midright + k - 1;
-            if (idx >= nz_lo) {
-                const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cs);
-                acc += y[idx] * w;
-            }
-            const double c2 = cs * rc - sn * rs;
-            sn = sn * rc + cs * rs;
-            cs = c2;
+            if (idx < nz_lo) continue;
+            const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cos_0_pi(aa0 + daa * k));
+            acc += y[idx] * w;
         }
     }
-    return wave_sum_f64(acc);
+    acc = group16_sum(acc);
+    return special ? y[si] : acc;
 }
 
-// maximise the sinc-interpolated curve on [ix-1, ix+1] by golden section (same steps as the oracle)
-__device__ void improve_max_wave(const double* __restrict__ y, int n, double ix, int depth, int nz_lo, int nz_hi,
-                                 int lane, double& xm, double& ym) {
-    double a = ix - 1.0, b = ix + 1.0;
-    double c = a + GOLD * (b - a), d = b - GOLD * (b - a);
-    double fc = sinc_wave(y, n, c, depth, nz_lo, nz_hi, lane);
-    double fd = sinc_wave(y, n, d, depth, nz_lo, nz_hi, lane);
-    for (int it = 0; it < N_GOLDEN; ++it) {
-        if (fc > fd) {
-            b = d;
-            const double nc = a + GOLD * (b - a);
-            d = c; fd = fc;
-            c = nc; fc = sinc_wave(y, n, nc, depth, nz_lo, nz_hi, lane);
-        } else {
-            a = c;
-            const double nd = b - GOLD * (b - a);
-            c = d; fc = fd;
-            d = nd; fd = sinc_wave(y, n, nd, depth, nz_lo, nz_hi, lane);
+// Praat NUMimproveMaximum (sinc): Brent's minimiser in the netlib fminbr form on -sinc over [ix-1, ix+1],
+// tolerance sqrt(eps)*|x| + tol/3 on the 1-based position, <= 60 iterations.  One 16-lane group per
+// candidate; `live` = this group holds a real candidate (others just keep the wave's shuffles uniform).
+__device__ void improve_max_group(const double* __restrict__ y, int n, double ix0, int depth, int nz_lo, int nz_hi,
+                                  int l16, bool live, double& xm, double& ym) {
+    const double SQRT_EPS = 1.4901161193847656e-08, TOL3 = 1e-10 / 3.0;
+    double a = ix0 + 1.0 - 1.0, b = ix0 + 1.0 + 1.0;     // 1-based bracket
+    double v = a + GOLD * (b - a);
+    double fv = -sinc_group(y, n, v - 1.0, depth, nz_lo, nz_hi, l16);
+    double x = v, w = v, fx = fv, fw = fv;
+    bool active = live;
+    for (int it = 0; it < 60; ++it) {
+        const double rng = b - a, mid = 0.5 * (a + b);
+        const double tol_act = SQRT_EPS * fabs(x) + TOL3;
+        if (fabs(x - mid) + 0.5 * rng <= 2.0 * tol_act) active = false;
+        if (!__any(active)) break;
+        double step = GOLD * (x < mid ? b - x : a - x);
+        if (fabs(x - w) >= tol_act) {
+            const double t = (x - w) * (fx - fv);
+            double q = (x - v) * (fx - fw);
+            double p = (x - v) * q - (x - w) * t;
+            q = 2.0 * (q - t);
+            if (q > 0.0) p = -p; else q = -q;
+            if (fabs(p) < fabs(step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
+                step = p / q;
+        }
+        if (fabs(step) < tol_act) step = step > 0.0 ? tol_act : -tol_act;
+        const double tt = x + step;
+        const double ft = -sinc_group(y, n, tt - 1.0, depth, nz_lo, nz_hi, l16);
+        if (active) {
+            if (ft <= fx) {
+                if (tt < x) b = x; else a = x;
+                v = w; w = x; x = tt;
+                fv = fw; fw = fx; fx = ft;
+            } else {
+                if (tt < x) a = tt; else b = tt;
+                if (ft <= fw || w == x) { v = w; w = tt; fv = fw; fw = ft; }
+                else if (ft <= fv || v == x || v == w) { v = tt; fv = ft; }
+            }
         }
     }
-    xm = 0.5 * (a + b);
-    ym = sinc_wave(y, n, xm, depth, nz_lo, nz_hi, lane);
+    xm = x - 1.0;
+    ym = -fx;
 }
 
 // ---- pitch candidates per frame (AC: Hanning-windowed autocorrelation; CC: forward cross-correlation) --
@@ -372,15 +406,18 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     __syncthreads();
     const int nmax = s_nmax;
     const int nz_lo = RC - L, nz_hi = RC + L;
-    // ---- first estimate of every maximum: parabolic position, sinc(30) strength ----
-    for (int m = wv; m < nmax; m += 4) {
-        const int l = s_maxlag[m];
+    // ---- first estimate of every maximum: parabolic position, sinc(30) strength (16 maxima per round) ----
+    const int l16 = lane & 15, gidx = wv * 4 + (lane >> 4);
+    for (int mb = 0; mb < nmax; mb += 16) {
+        const int m = mb + gidx;
+        const bool live = m < nmax;
+        const int l = s_maxlag[live ? m : 0];
         const double y0 = r[RC + l - 1], y1 = r[RC + l], y2 = r[RC + l + 1];
         const double dr = 0.5 * (y2 - y0), d2r = 2.0 * y1 - y0 - y2;
         const double fm = 1.0 / DXS / (l + dr / d2r);
-        double st = sinc_wave(r, RN, RC + 1.0 / DXS / fm, 30, nz_lo, nz_hi, lane);
+        double st = sinc_group(r, RN, RC + 1.0 / DXS / fm, 30, nz_lo, nz_hi, l16);
         if (st > 1.0) st = 1.0 / st;
-        if (lane == 0) { s_mfreq[m] = fm; s_mstr[m] = st; }
+        if (live && l16 == 0) { s_mfreq[m] = fm; s_mstr[m] = st; }
     }
     __syncthreads();
     // ---- candidate list with replacement of the weakest (thread 0, sequential as in Praat) ----
@@ -406,12 +443,14 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     }
     __syncthreads();
     const int ncand = s_ncand;
-    // ---- refine every kept candidate: maximise the sinc-interpolated correlation ----
-    for (int k = 1 + wv; k < ncand; k += 4) {
+    // ---- refine every kept candidate: maximise the sinc-interpolated correlation (16 at a time) ----
+    for (int kb = 1; kb < ncand; kb += 16) {
+        const int k = kb + gidx;
+        const bool live = k < ncand;
         double xm, ym;
-        improve_max_wave(r, RN, (double)(s_place[k] + RC), P.refine_depth, nz_lo, nz_hi, lane, xm, ym);
+        improve_max_group(r, RN, (double)(s_place[live ? k : 1] + RC), P.refine_depth, nz_lo, nz_hi, l16, live, xm, ym);
         if (ym > 1.0) ym = 1.0 / ym;
-        if (lane == 0) { s_cf[k] = 1.0 / DXS / (xm - RC); s_cs[k] = ym; }
+        if (live && l16 == 0) { s_cf[k] = 1.0 / DXS / (xm - RC); s_cs[k] = ym; }
     }
     __syncthreads();
     FrameOut* o = out + c.frame_off + f;
