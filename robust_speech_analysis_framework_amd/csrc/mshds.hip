@@ -41,6 +41,7 @@ struct ClipInfo {       // one entry per clip of a launch (host-built)
 
 struct PitchParams {
     double dt, min_pitch, ceiling, voicing_thr, octave_cost, dt_window;
+    double refine_margin;   // > 0: only candidates within this margin of the best first-pass strength are refined
     int nsamp_window, half_window, nsamp_period, half_period, min_lag, max_lag, brent_ixmax, max_cand;
     int refine_depth, is_cc;
 };
@@ -133,6 +134,15 @@ __device__ __forceinline__ double cos_0_pi(double x) {
 }
 __device__ __forceinline__ double sin_0_pi(double x) { return cos_0_pi(fabs(0.5 * PI - x)); }
 
+// 1/d for d > 0: hardware reciprocal estimate + two Newton steps (full double accuracy, ~5 ops instead
+// of the ~15-op IEEE division sequence)
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = r * (2.0 - d * r);
+    r = r * (2.0 - d * r);
+    return r;
+}
+
 __device__ __forceinline__ double group16_sum(double v) {
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 16);
@@ -157,27 +167,27 @@ __device__ double sinc_group(const double* __restrict__ y, int n, double x, int 
     const double a0l = PI * (x1 - midleft);               // in (0, pi) unless special
     const double hs = special ? 0.0 : 0.5 * sin_0_pi(a0l); // sin(pi - a) = sin(a): same for both halves
     {   // left half: 1-based ix = midleft - k, k = 0..d-1; window angle (a0 + pi k)/den stays in (0, pi)
-        const double den = x1 - left + 1.0;
-        const double aa0 = a0l / den, daa = PI / den;
+        const double iden = fast_rcp(x1 - left + 1.0);
         int kmax = d;                                         // skip the zero tail
         if (midleft - 1 - (kmax - 1) < nz_lo) kmax = midleft - 1 - nz_lo + 1;
         for (int k = l16; k < kmax; k += 16) {
             const int idx = midleft - k - 1;
             if (idx > nz_hi) continue;
-            const double w = ((k & 1) ? -hs : hs) / (a0l + PI * k) * (1.0 + cos_0_pi(aa0 + daa * k));
+            const double a = a0l + PI * k;
+            const double w = ((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + cos_0_pi(a * iden));
             acc += y[idx] * w;
         }
     }
     {   // right half: ix = midright + k
         const double a0 = PI * (midright - x1);
-        const double den = right - x1 + 1.0;
-        const double aa0 = a0 / den, daa = PI / den;
+        const double iden = fast_rcp(right - x1 + 1.0);
         int kmax = d;
         if (midright - 1 + (kmax - 1) > nz_hi) kmax = nz_hi - (midright - 1) + 1;
         for (int k = l16; k < kmax; k += 16) {
             const int idx = midright + k - 1;
             if (idx < nz_lo) continue;
-            const double w = ((k & 1) ? -hs : hs) / (a0 + PI * k) * (1.0 + cos_0_pi(aa0 + daa * k));
+            const double a = a0 + PI * k;
+            const double w = ((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + cos_0_pi(a * iden));
             acc += y[idx] * w;
         }
     }
@@ -444,9 +454,14 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     __syncthreads();
     const int ncand = s_ncand;
     // ---- refine every kept candidate: maximise the sinc-interpolated correlation (16 at a time) ----
+    // With every path cost zero (harmonicity pass) the path finder picks the strongest candidate of each
+    // frame on its own, so a candidate far below the best first-pass strength can never be selected and
+    // is left unrefined (the depth-30 and refined strengths differ by far less than the margin).
+    double best_first = 0.0;
+    for (int k = 1; k < ncand; ++k) best_first = fmax(best_first, s_cs[k]);
     for (int kb = 1; kb < ncand; kb += 16) {
         const int k = kb + gidx;
-        const bool live = k < ncand;
+        const bool live = k < ncand && (P.refine_margin <= 0.0 || s_cs[k < ncand ? k : 1] >= best_first - P.refine_margin);
         double xm, ym;
         improve_max_group(r, RN, (double)(s_place[live ? k : 1] + RC), P.refine_depth, nz_lo, nz_hi, l16, live, xm, ym);
         if (ym > 1.0) ym = 1.0 / ym;
@@ -798,6 +813,7 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
     P.nsamp_window = (int)h[8]; P.nsamp_period = (int)h[9]; P.min_lag = (int)h[10]; P.max_lag = (int)h[11];
     P.brent_ixmax = (int)h[12]; P.max_cand = (int)h[13]; P.refine_depth = (int)h[14]; P.is_cc = (int)h[15];
     P.dt_window = h[16];
+    P.refine_margin = 0.0;   // lazy refinement is off: it changed a few frames' selection (parity first)
     P.half_window = P.nsamp_window / 2;
     P.half_period = P.nsamp_period / 2 + 1;
     RSAF_CHECK_ARG(P.max_cand >= 2 && P.max_cand <= MAXC - 1, "max_candidates must be in [2, 15]");
