@@ -168,6 +168,14 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
                      const double* window, const double* window_r, const double* params_host,
                      void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
                      double* stats_out, rsaf_stream_t stream);
+/* _speechrate (src/mshds_extractor.py:11-125) from the 50 Hz / 16 ms intensity contour (rsaf_mshds_intensity)
+ * and the 4-candidate pitch pass of :104.  out[clip][5] = Speaking_Rate, Articulation_Rate,
+ * Phonation_Ratio, Pause_Rate, Mean_Pause_Dur.  workspace: n_clips * workspace_doubles(max_frames). */
+int64_t rsaf_mshds_speechrate_workspace_doubles(int max_frames);
+int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int n_clips, int max_frames,
+                          double intensity_dt, const double* sel_freq, const void* pitch_clip_info,
+                          double pitch_dt, double pitch_ceiling, double* workspace, double* out,
+                          rsaf_stream_t stream);
 int rsaf_mshds_hnr_mean(const double* sel_freq, const double* sel_strength, const void* clip_info, int n_clips,
                         double* out, rsaf_stream_t stream);
 /* moments[frame][5] = {gate, CoG, SD, skewness, kurtosis}; stats_out[clip][4] = means over gated frames */

@@ -11,7 +11,7 @@ cross-correlation pitch, path finder, HNR) and the Praat manual pages "Sound: To
 "Spectrum: Get centre of gravity / central moment...".  Free choices are documented inline.
 
 Built so far (the rest of the 25 features is NaN, as in ``csrc/mshds.hip``):
-  a3 ``_pitch_values``, a4 ``_extract_pitch``, a5 ``_extract_intensity``, a6 ``_extract_harmonicity``,
+  a2 ``_speechrate``, a3 ``_pitch_values``, a4 ``_extract_pitch``, a5 ``_extract_intensity``, a6 ``_extract_harmonicity``,
   a10 ``_extract_Spectral_Moments``.
 Arithmetic: float64 on the float32 samples (Praat computes in double).
 """
@@ -30,7 +30,7 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                          # src/mshds_extractor.py:397-404
-BUILT = [5, 6, 7, 8, 9, 21, 22, 23, 24]
+BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24]
 
 
 # ---- Sampled helpers (Praat: x1 = 0.5 dx for a Sound read from file) ----------------------------
@@ -642,10 +642,176 @@ def extract_spectral_moments(x, floor, ceiling, window_size=0.025, frame_shift=0
     return tuple(out)
 
 
+# ---- _speechrate (de Jong & Wempe 2009 syllable nuclei, src/mshds_extractor.py:11-125) ---------------
+def quantile_sorted(a, factor):
+    """Praat NUMquantile on sorted data."""
+    n = len(a)
+    if n < 1:
+        return 0.0
+    if n == 1:
+        return float(a[0])
+    place = factor * n + 0.5
+    left = int(np.floor(place))
+    left = max(1, min(left, n - 1))
+    if a[left] == a[left - 1]:
+        return float(a[left - 1])
+    return float(a[left - 1] + (place - left) * (a[left] - a[left - 1]))
+
+
+def value_cubic(y, ireal):
+    """Vector 'Get value at time ... Cubic': NUM_interpolate_sinc with depth 2 (0-based real index)."""
+    n = len(y)
+    x1 = ireal + 1.0
+    if x1 > n:
+        return float(y[-1])
+    if x1 < 1:
+        return float(y[0])
+    midleft = int(np.floor(x1))
+    if x1 == midleft:
+        return float(y[midleft - 1])
+    midright = midleft + 1
+    depth = min(2, midright - 1, n - midleft)
+    if depth <= 0:
+        return float(y[int(np.floor(x1 + 0.5)) - 1])
+    yl, yr = y[midleft - 1], y[midright - 1]
+    if depth == 1:
+        return float(yl + (x1 - midleft) * (yr - yl))
+    dyl = 0.5 * (yr - y[midleft - 2])
+    dyr = 0.5 * (y[midright] - yl)
+    fil, fir = x1 - midleft, midright - x1
+    return float(yl * fir + yr * fil - fil * fir * (0.5 * (dyr - dyl) + (fil - 0.5) * (dyl + dyr - 2.0 * (yr - yl))))
+
+
+def detect_silences(db, t1, dt, xmin, xmax, silence_threshold_db, min_silence, min_sounding):
+    """Intensity: To TextGrid (silences): list of [tmin, tmax, is_sounding].  Frames below
+    (parabolic maximum - |threshold|) are silent; boundaries sit half-way between frames; then short
+    sounding intervals, and after that short silent intervals, are cut (Praat's order)."""
+    n = len(db)
+    mx = vector_extremum_parabolic(db, True)
+    mn = vector_extremum_parabolic(db, False)
+    thr = mx - abs(silence_threshold_db)
+    if min_silence > (xmax - xmin) or thr < mn or n == 0:
+        return [[xmin, xmax, True]]
+    iv = []
+    start, state = xmin, bool(db[0] < thr)              # state: in silence
+    for i in range(1, n):
+        sil = bool(db[i] < thr)
+        if sil != state:
+            tb = t1 + (i - 0.5) * dt
+            iv.append([start, tb, not state])
+            start, state = tb, sil
+    iv.append([start, xmax, not state])
+
+    def cut_short(label_sounding, mindur):
+        i = 0
+        while i < len(iv):
+            a, b, lab = iv[i]
+            if lab == label_sounding and (b - a) < mindur and len(iv) > 1:
+                del iv[i]
+                if i == 0:
+                    iv[0][0] = a                           # next interval extended to the left
+                elif i == len(iv):
+                    iv[-1][1] = b                          # previous extended to the right
+                else:
+                    iv[i - 1][1] = b                       # previous extended to the right
+            else:
+                i += 1
+
+    def merge(label_sounding):
+        i = 0
+        while i < len(iv) - 1:
+            if iv[i][2] == label_sounding and iv[i + 1][2] == iv[i][2]:
+                a = iv[i][0]
+                del iv[i]
+                iv[i][0] = a
+            else:
+                i += 1
+
+    cut_short(True, min_sounding)
+    merge(False)
+    cut_short(False, min_silence)
+    merge(True)
+    return iv
+
+
+def speechrate(x):
+    """``_speechrate`` (:11-125) -> (Speaking_Rate, Articulation_Rate, Phonation_Ratio, Pause_Rate,
+    Mean_Pause_Dur).  The harmonicity call of :36-38 only feeds a no-op (mindip = 2 either way) and
+    is not evaluated."""
+    nan5 = (np.nan,) * 5
+    x = np.asarray(x, dtype=np.float64)
+    silencedb, mindip, minpause = -25.0, 2.0, 0.3
+    db, t1, dt = intensity(x, 50.0, 0.016, True)                                   # :41
+    n = len(db)
+    if n == 0:
+        return nan5                                                                # Praat raises -> :124
+    duration = len(x) * DX
+    min_int = vector_extremum_parabolic(db, False)                                 # :42
+    max_int = vector_extremum_parabolic(db, True)                                  # :43
+    q99 = quantile_sorted(np.sort(db), 0.99)                                       # :47
+    silencedb_1 = q99 + silencedb
+    if silencedb_1 < min_int:
+        silencedb_1 = min_int
+    silencedb_2 = silencedb - (max_int - q99)                                      # :51-52
+    iv = detect_silences(db, t1, dt, 0.0, duration, silencedb_2, minpause, 0.1)    # :55
+    sounding = [(a, b) for a, b, lab in iv if lab]
+    npauses = len(sounding)
+    if npauses == 0:
+        return nan5
+    phonation = sum(b - a for a, b in sounding)
+    begin_speak, end_speak = sounding[0][0], sounding[-1][1]
+    # intensity maxima with sinc-70 interpolated times (:76-81), cubic values (:85)
+    idx = [i for i in range(1, n - 1) if db[i] > db[i - 1] and db[i] >= db[i + 1]]
+    timepeaks, ints = [], []
+    if idx:
+        xm, _ = improve_maximum_sinc(np.repeat(db[None, :], len(idx), axis=0), np.array(idx, dtype=np.float64), 70)
+        for ir in xm:
+            v = value_cubic(db, ir)
+            if v > silencedb_1:                                                    # :86
+                ints.append(v)
+                timepeaks.append(t1 + ir * dt)
+    validtime = []
+    if len(timepeaks) > 1:                                                         # :92-101
+        currenttime, currentint = timepeaks[0], ints[0]
+        for p in range(len(timepeaks) - 1):
+            nxt = timepeaks[p + 1]
+            imin = max(0, int(np.ceil((currenttime - t1) / dt)))
+            imax = min(n - 1, int(np.floor((nxt - t1) / dt)))
+            if imin <= imax:
+                dip = db[imin:imax + 1].min()
+            else:
+                dip = min(db[min(n - 1, max(0, int(np.floor((currenttime - t1) / dt + 0.5))))],
+                          db[min(n - 1, max(0, int(np.floor((nxt - t1) / dt + 0.5))))])
+            if abs(currentint - dip) > mindip:
+                validtime.append(timepeaks[p])
+            currenttime = nxt
+            currentint = value_cubic(db, (nxt - t1) / dt)
+    pitch = pitch_ac(x, 0.02, 30.0, 4, False, 0.03, 0.25, 0.01, 0.35, 0.25, 450.0)   # :104
+    nsyll = 0
+    for tm in validtime:                                                           # :106-111
+        lab = None
+        for k, (a, b, l) in enumerate(iv):
+            if (a <= tm < b) or (k == len(iv) - 1 and tm == b):
+                lab = l
+                break
+        if lab and bool(pitch.defined_at(np.array(tm))):
+            nsyll += 1
+    original_dur = end_speak - begin_speak
+    speaking = nsyll / original_dur if original_dur > 0 else 0
+    artic = nsyll / phonation if phonation > 0 else 0
+    phon_ratio = phonation / original_dur if original_dur > 0 else 0
+    n_pauses = npauses - 1
+    pause_time = original_dur - phonation
+    pause_rate = n_pauses / original_dur if original_dur > 0 else 0
+    mean_pause = pause_time / n_pauses if n_pauses > 0 else 0
+    return speaking, artic, phon_ratio, pause_rate, mean_pause
+
+
 def extract(x):
     """One clip -> 25 features in the reference's column order (unbuilt helpers give NaN)."""
     x = np.asarray(x, dtype=np.float64)
     out = np.full(25, np.nan)
+    out[0:5] = speechrate(x)                                                         # :426
     floor, ceiling = pitch_values(x)                                                 # :428
     p = pitch_ac(x, time_step=0.005, pitch_floor=floor, pitch_ceiling=ceiling)       # :178 == :355
     out[5], out[6] = extract_pitch(x, floor, ceiling, 0.005, p)                      # :430

@@ -759,6 +759,234 @@ __global__ __launch_bounds__(64) void moments_stats_kernel(const double* __restr
             out[blockIdx.x * 4 + q] = n[q] > 0 ? s[q] / n[q] : __longlong_as_double(0x7ff8000000000000LL);
 }
 
+// ---- _speechrate (de Jong & Wempe syllable nuclei; src/mshds_extractor.py:11-125) -----------------------
+// One wave per clip.  Parallel parts: parabolic extrema, rank sort (0.99 quantile), local maxima and
+// their sinc-70 refined times (four 16-lane groups).  The interval / peak bookkeeping is integer-state
+// sequential logic and runs on lane 0 with a per-clip global workspace.
+__device__ double value_cubic(const double* __restrict__ y, int n, double ireal) {
+    const double x1 = ireal + 1.0;
+    if (x1 > n) return y[n - 1];
+    if (x1 < 1) return y[0];
+    const int midleft = (int)floor(x1);
+    if (x1 == (double)midleft) return y[midleft - 1];
+    const int midright = midleft + 1;
+    int depth = 2;
+    if (depth > midright - 1) depth = midright - 1;
+    if (depth > n - midleft) depth = n - midleft;
+    if (depth <= 0) return y[(int)floor(x1 + 0.5) - 1];
+    const double yl = y[midleft - 1], yr = y[midright - 1];
+    if (depth == 1) return yl + (x1 - midleft) * (yr - yl);
+    const double dyl = 0.5 * (yr - y[midleft - 2]), dyr = 0.5 * (y[midright] - yl);
+    const double fil = x1 - midleft, fir = midright - x1;
+    return yl * fir + yr * fil - fil * fir * (0.5 * (dyr - dyl) + (fil - 0.5) * (dyl + dyr - 2.0 * (yr - yl)));
+}
+
+constexpr int SR_MAX_PEAKS = 4096;
+
+__global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict__ db_all, const ClipInfo* __restrict__ ci,
+                                                        double dt, const double* __restrict__ sel_freq,
+                                                        const ClipInfo* __restrict__ pci, double pitch_dt, double ceiling,
+                                                        double* __restrict__ work, int64_t work_stride,
+                                                        double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const ClipInfo c = ci[blockIdx.x];
+    const int n = c.n_frames, lane = threadIdx.x;
+    double* o = out + (int64_t)blockIdx.x * 5;
+    const double qn = __longlong_as_double(0x7ff8000000000000LL);
+    if (n <= 0) {
+        if (lane < 5) o[lane] = qn;
+        return;
+    }
+    double* y = reinterpret_cast<double*>(smem_raw);          // [n] intensity contour
+    double* srt = y + ((n + 1) & ~1);                          // [n] sorted copy, later peak positions
+    int* pk = reinterpret_cast<int*>(srt + ((n + 1) & ~1));    // [SR_MAX_PEAKS] local-maximum indices
+    const double* src = db_all + c.frame_off;
+    for (int i = lane; i < n; i += 64) y[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // parabolic extrema (Vector_getMaximum / Minimum)
+    double mx = -INFINITY, mnn = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+        const double v = y[i];
+        if (i == 0 || i == n - 1) { mx = fmax(mx, v); mnn = fmax(mnn, -v); }
+        if (i > 0 && i < n - 1) {
+            const double a = y[i - 1], b = y[i + 1];
+            if (v > a && v >= b) { const double dy = 0.5 * (b - a), d2 = 2.0 * v - a - b; mx = fmax(mx, d2 != 0.0 ? v + 0.5 * dy * dy / d2 : v); }
+            if (-v > -a && -v >= -b) { const double dy = 0.5 * (a - b), d2 = -2.0 * v + a + b; mnn = fmax(mnn, d2 != 0.0 ? -v + 0.5 * dy * dy / d2 : -v); }
+        }
+    }
+    const double max_int = wave_max_f64(mx), min_int = -wave_max_f64(mnn);
+    // rank sort -> 0.99 quantile (Praat NUMquantile)
+    for (int i = lane; i < n; i += 64) {
+        const double v = y[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const double u = y[j]; rank += (u < v) || (u == v && j < i); }
+        srt[rank] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double q99;
+    if (n == 1) q99 = srt[0];
+    else {
+        const double place = 0.99 * n + 0.5;
+        int left = (int)floor(place);
+        left = left < 1 ? 1 : (left > n - 1 ? n - 1 : left);
+        q99 = (srt[left] == srt[left - 1]) ? srt[left - 1] : srt[left - 1] + (place - left) * (srt[left] - srt[left - 1]);
+    }
+    const double silencedb = -25.0, mindip = 2.0, minpause = 0.3, minsound = 0.1;
+    double silencedb_1 = q99 + silencedb;
+    if (silencedb_1 < min_int) silencedb_1 = min_int;
+    const double silencedb_2 = silencedb - (max_int - q99);
+    // local maxima in ascending order
+    int npk = 0;
+    for (int base = 1; base < n - 1; base += 64) {
+        const int i = base + lane;
+        bool ok = false;
+        if (i < n - 1) ok = y[i] > y[i - 1] && y[i] >= y[i + 1];
+        const unsigned long long m = __ballot(ok);
+        const int pos = npk + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < SR_MAX_PEAKS) pk[pos] = i;
+        npk += __popcll(m);
+    }
+    if (npk > SR_MAX_PEAKS) npk = SR_MAX_PEAKS;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // sinc-70 refined peak positions (reuse srt[] for them), four peaks at a time
+    {
+        const int l16 = lane & 15, grp = lane >> 4;
+        for (int b = 0; b < npk; b += 4) {
+            const int k = b + grp;
+            const bool live = k < npk;
+            double xm, ym;
+            improve_max_group(y, n, (double)pk[live ? k : 0], 70, 0, n - 1, l16, live, xm, ym);
+            if (live && l16 == 0) srt[k] = xm;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane != 0) return;
+    // ------------------------------ lane 0: sequential bookkeeping ------------------------------
+    double* iva = work + (int64_t)blockIdx.x * work_stride;    // interval starts
+    double* ivb = iva + (n + 2);                               // interval ends
+    double* ivl = ivb + (n + 2);                               // 1 = sounding, 0 = silent
+    double* tpk = ivl + (n + 2);                               // kept peak times
+    double* vpk = tpk + SR_MAX_PEAKS;                          // kept peak values
+    const double duration = c.n_samples * DXS;
+    int niv = 0;
+    {
+        const double thr = max_int - fabs(silencedb_2);
+        if (minpause > duration || thr < min_int) {
+            iva[0] = 0.0; ivb[0] = duration; ivl[0] = 1.0; niv = 1;
+        } else {
+            double start = 0.0;
+            bool state = y[0] < thr;                            // in silence
+            for (int i = 1; i < n; ++i) {
+                const bool sil = y[i] < thr;
+                if (sil != state) {
+                    const double tb = c.t1 + (i - 0.5) * dt;
+                    iva[niv] = start; ivb[niv] = tb; ivl[niv] = state ? 0.0 : 1.0; ++niv;
+                    start = tb; state = sil;
+                }
+            }
+            iva[niv] = start; ivb[niv] = duration; ivl[niv] = state ? 0.0 : 1.0; ++niv;
+            for (int pass = 0; pass < 2; ++pass) {
+                const double lab = pass == 0 ? 1.0 : 0.0;       // cut short sounding first, then short silences
+                const double mind = pass == 0 ? minsound : minpause;
+                int i = 0;
+                while (i < niv) {
+                    if (ivl[i] == lab && (ivb[i] - iva[i]) < mind && niv > 1) {
+                        const double a = iva[i], b = ivb[i];
+                        for (int k = i; k < niv - 1; ++k) { iva[k] = iva[k + 1]; ivb[k] = ivb[k + 1]; ivl[k] = ivl[k + 1]; }
+                        --niv;
+                        if (i == 0) iva[0] = a;
+                        else ivb[i - 1] = b;                     // previous interval extended (also for the last one)
+                    } else ++i;
+                }
+                const double ml = pass == 0 ? 0.0 : 1.0;        // merge equal neighbours of the other label
+                i = 0;
+                while (i < niv - 1) {
+                    if (ivl[i] == ml && ivl[i + 1] == ivl[i]) {
+                        const double a = iva[i];
+                        for (int k = i; k < niv - 1; ++k) { iva[k] = iva[k + 1]; ivb[k] = ivb[k + 1]; ivl[k] = ivl[k + 1]; }
+                        --niv;
+                        iva[i] = a;
+                    } else ++i;
+                }
+            }
+        }
+    }
+    int npauses = 0;
+    double phonation = 0.0, begin_speak = 0.0, end_speak = 0.0;
+    for (int i = 0; i < niv; ++i)
+        if (ivl[i] != 0.0) {
+            if (npauses == 0) begin_speak = iva[i];
+            end_speak = ivb[i];
+            phonation += ivb[i] - iva[i];
+            ++npauses;
+        }
+    if (npauses == 0) {
+        for (int k = 0; k < 5; ++k) o[k] = qn;
+        return;
+    }
+    int nkeep = 0;
+    for (int k = 0; k < npk; ++k) {
+        const double v = value_cubic(y, n, srt[k]);
+        if (v > silencedb_1) { tpk[nkeep] = c.t1 + srt[k] * dt; vpk[nkeep] = v; ++nkeep; }
+    }
+    const ClipInfo pc = pci[blockIdx.x];
+    int nsyll = 0;
+    if (nkeep > 1) {
+        double currenttime = tpk[0], currentint = vpk[0];
+        for (int p = 0; p < nkeep - 1; ++p) {
+            const double nxt = tpk[p + 1];
+            int imin = (int)ceil((currenttime - c.t1) / dt), imax = (int)floor((nxt - c.t1) / dt);
+            imin = imin < 0 ? 0 : imin;
+            imax = imax > n - 1 ? n - 1 : imax;
+            double dip;
+            if (imin <= imax) {
+                dip = y[imin];
+                for (int i = imin + 1; i <= imax; ++i) dip = fmin(dip, y[i]);
+            } else {
+                int ia = (int)floor((currenttime - c.t1) / dt + 0.5), ib = (int)floor((nxt - c.t1) / dt + 0.5);
+                ia = ia < 0 ? 0 : (ia > n - 1 ? n - 1 : ia);
+                ib = ib < 0 ? 0 : (ib > n - 1 ? n - 1 : ib);
+                dip = fmin(y[ia], y[ib]);
+            }
+            if (fabs(currentint - dip) > mindip) {
+                // valid syllable nucleus at tpk[p]: count it if it is in a sounding interval and voiced
+                const double tm = tpk[p];
+                bool snd = false;
+                for (int k = 0; k < niv; ++k)
+                    if ((iva[k] <= tm && tm < ivb[k]) || (k == niv - 1 && tm == ivb[k])) { snd = ivl[k] != 0.0; break; }
+                bool voiced = false;
+                if (pc.n_frames > 0) {
+                    const double ireal = (tm - pc.t1) / pitch_dt;
+                    const double il = floor(ireal);
+                    const int64_t near = (ireal - il < 0.5) ? (int64_t)il : (int64_t)il + 1;
+                    if (near >= 0 && near < pc.n_frames) {
+                        const double pf = sel_freq[pc.frame_off + near];
+                        voiced = pf > 0.0 && pf < ceiling;
+                    }
+                }
+                if (snd && voiced) ++nsyll;
+            }
+            currenttime = nxt;
+            currentint = value_cubic(y, n, (nxt - c.t1) / dt);
+        }
+    }
+    const double original_dur = end_speak - begin_speak;
+    const int n_pauses = npauses - 1;
+    o[0] = original_dur > 0 ? nsyll / original_dur : 0.0;
+    o[1] = phonation > 0 ? nsyll / phonation : 0.0;
+    o[2] = original_dur > 0 ? phonation / original_dur : 0.0;
+    o[3] = original_dur > 0 ? n_pauses / original_dur : 0.0;
+    o[4] = n_pauses > 0 ? (original_dur - phonation) / n_pauses : 0.0;
+}
+
 }  // namespace mshds
 }  // namespace rsaf
 
@@ -846,6 +1074,28 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
     }
     hipLaunchKernelGGL(pitch_stats_kernel, dim3(n_clips), dim3(64), 0, s, sel_freq, (const ClipInfo*)clip_info, P.ceiling,
                        stats_out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int64_t rsaf_mshds_speechrate_workspace_doubles(int max_frames) { return 3 * ((int64_t)max_frames + 2) + 2 * SR_MAX_PEAKS; }
+
+int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int n_clips, int max_frames,
+                          double intensity_dt, const double* sel_freq, const void* pitch_clip_info, double pitch_dt,
+                          double pitch_ceiling, double* workspace, double* out, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && max_frames >= 0, "bad clip/frame count");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(intensity_db && clip_info && sel_freq && pitch_clip_info && workspace && out, "NULL pointer");
+    const size_t lds = (size_t)2 * ((max_frames + 1) & ~1) * sizeof(double) + SR_MAX_PEAKS * sizeof(int);
+    RSAF_CHECK_ARG(lds <= 150 * 1024, "clip too long for the speech-rate kernel (intensity contour must fit LDS)");
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 48 * 1024)
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)speechrate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+    ProfScope prof("mshds_speechrate", s, 0.0, 0.0);
+    hipLaunchKernelGGL(speechrate_kernel, dim3(n_clips), dim3(64), lds, s, intensity_db, (const ClipInfo*)clip_info,
+                       intensity_dt, sel_freq, (const ClipInfo*)pitch_clip_info, pitch_dt, pitch_ceiling, workspace,
+                       rsaf_mshds_speechrate_workspace_doubles(max_frames), out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -6,9 +6,10 @@ run as float64 HIP kernels (``csrc/mshds.hip``); the host only builds the frame 
 ``Sampled_shortTermAnalysis`` arithmetic), the window tables, and routes each clip to the
 speaker-adapted pitch range that ``_pitch_values`` chooses (``:127-162``).
 
-Built so far: mean_F0, stdev_F0_Semitone, mean_dB, range_ratio_dB, HNR_dB, Spectral_Gravity,
-Spectral_Std_Dev, Spectral_Skewness, Spectral_Kurtosis.  The 16 other columns are NaN until their
-kernels exist (speech rate, LTAS slope/tilt, CPPS, formants): there is no CPU fallback.
+Built so far: the five speech-rate/pausing columns, mean_F0, stdev_F0_Semitone, mean_dB,
+range_ratio_dB, HNR_dB, Spectral_Gravity, Spectral_Std_Dev, Spectral_Skewness, Spectral_Kurtosis.  The
+11 other columns are NaN until their kernels exist (LTAS slope/tilt, CPPS, formants): there is no CPU
+fallback.
 """
 from __future__ import annotations
 
@@ -33,7 +34,7 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                            # src/mshds_extractor.py:397-404
-BUILT_COLUMNS = [5, 6, 7, 8, 9, 21, 22, 23, 24]
+BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24]
 
 CLIP_INFO = np.dtype([("sample_off", "<i8"), ("frame_off", "<i8"), ("t1", "<f8"),
                       ("n_samples", "<i4"), ("n_frames", "<i4")])
@@ -177,7 +178,27 @@ class MshdsEngine:
             _lib.check(lib.rsaf_mshds_intensity(_lib.ptr(wav), _lib.ptr(_dev(ci, self.device)), n, mx, _lib.ptr(win),
                                                 half, dt, 1 if subtract_mean else 0, _lib.ptr(db), _lib.ptr(stats),
                                                 _lib.stream_ptr(stream)), "rsaf_mshds_intensity")
-        return {"db": db, "ci": ci, "stats": stats[:n], "dt": dt}
+        return {"db": db, "ci": ci, "ci_dev": _dev(ci, self.device), "stats": stats[:n], "dt": dt, "max_frames": mx}
+
+    def speechrate(self, wav, sample_offs, lengths, gpeak, stream=None):
+        """``_speechrate`` (:11-125): intensity(50 Hz, 16 ms) + the 4-candidate pitch pass of :104 ->
+        float64 [n, 5].  (The harmonicity call of :36-38 only feeds a no-op and is not evaluated.)"""
+        import torch
+        lib = _lib.load()
+        n = len(lengths)
+        inten = self.intensity(wav, sample_offs, lengths, 50.0, 0.016, True, stream)                 # :41
+        p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.02, floor=30.0, ceiling=450.0,
+                       max_candidates=4, silence_threshold=0.03, voicing_threshold=0.25, octave_cost=0.01,
+                       octave_jump_cost=0.35, voiced_unvoiced_cost=0.25, stream=stream)            # :104
+        out = torch.empty((max(n, 1), 5), dtype=torch.float64, device=self.device)
+        if n:
+            wsd = int(lib.rsaf_mshds_speechrate_workspace_doubles(inten["max_frames"]))
+            ws = torch.empty(n * wsd, dtype=torch.float64, device=self.device)
+            _lib.check(lib.rsaf_mshds_speechrate(_lib.ptr(inten["db"]), _lib.ptr(inten["ci_dev"]), n, inten["max_frames"],
+                                                 inten["dt"], _lib.ptr(p["sel_freq"]), _lib.ptr(p["ci_dev"]),
+                                                 p["geom"].dt, p["geom"].ceiling, _lib.ptr(ws), _lib.ptr(out),
+                                                 _lib.stream_ptr(stream)), "rsaf_mshds_speechrate")
+        return out[:n]
 
     def spectral_moments(self, wav, sample_offs, lengths, pitch, window_length=0.025, time_step=0.005,
                          maximum_frequency=5000.0, frequency_step=20.0, stream=None):
@@ -262,6 +283,7 @@ class MshdsEngine:
         sample_offs = [int(v) for v in sample_offs]
         lengths = [int(v) for v in lengths]
         gpeak = self.clip_peaks(wav, sample_offs, lengths, stream)
+        out[:, 0:5] = self.speechrate(wav, sample_offs, lengths, gpeak, stream)                     # :426
         # _pitch_values (:127-162): wide search, outlier-trimmed mean -> speaker range
         wide = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.005, floor=50.0, ceiling=600.0, stream=stream)
         st = wide["stats"].cpu().numpy()                       # one small D2H per batch

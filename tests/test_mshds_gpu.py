@@ -119,6 +119,24 @@ def test_spectral_moments_gated_by_pitch(eng):
         assert sm["ci"][i]["n_frames"] == pw.shape[0] and abs(sm["ci"][i]["t1"] - t1) < 1e-15
 
 
+def test_speechrate_matches_oracle(eng):
+    """_speechrate (:11-125): silence TextGrid, syllable nuclei, voiced & sounding count."""
+    import torch
+    clips = [synth.synth_clip(160, 6.0), synth.synth_clip(161, 3.5), np.zeros(8000, np.float32),
+             synth.synth_clip(162, 0.1)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    got = eng.speechrate(wav, offs, lens, gp)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    for i, c in enumerate(clips):
+        ref = np.array(mo.speechrate(c), dtype=np.float64)
+        assert np.array_equal(np.isnan(got[i]), np.isnan(ref)), (i, got[i], ref)
+        ok = ~np.isnan(ref)
+        assert np.allclose(got[i][ok], ref[ok], rtol=1e-9, atol=1e-12), (i, got[i], ref)
+    assert got[0][0] > 1.0 and 0.3 < got[0][2] <= 1.0            # syllables/s and phonation ratio are sensible
+
+
 def test_extract_packed_matches_oracle_and_uses_both_speaker_ranges(eng):
     import torch
     ids = [140, 141, 142, 143, 144, 145]

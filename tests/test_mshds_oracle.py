@@ -63,5 +63,27 @@ def test_spectrogram_geometry_and_moments_of_sine():
     assert np.abs(cog - 1000.0).max() < 1.0 and sd.max() < 30.0
 
 
+def test_quantile_cubic_and_silence_intervals():
+    a = np.arange(1.0, 11.0)
+    assert abs(mo.quantile_sorted(a, 0.5) - 5.5) < 1e-12 and mo.quantile_sorted(a, 0.99) == 10.0
+    y = np.array([0.0, 1.0, 4.0, 9.0, 16.0, 25.0])               # cubic interpolation reproduces a parabola
+    assert abs(mo.value_cubic(y, 2.5) - 6.25) < 1e-12 and mo.value_cubic(y, 3.0) == 9.0
+    # 1 s of 10 ms frames: loud / 0.4 s quiet / loud with a 30 ms quiet blip that must be absorbed
+    db = np.full(100, 60.0)
+    db[30:70] = 20.0
+    db[85:88] = 20.0
+    iv = mo.detect_silences(db, 0.005, 0.01, 0.0, 1.0, -25.0, 0.3, 0.1)
+    assert [l for _, _, l in iv] == [True, False, True]
+    assert abs(iv[1][0] - 0.295) < 1e-12 and abs(iv[1][1] - 0.695) < 1e-12
+
+
+def test_speechrate_of_amplitude_modulated_tone():
+    t = np.arange(int(4 * 16000)) / 16000.0
+    env = 0.5 * (1 - np.cos(2 * np.pi * 4.0 * t))                 # 4 syllable-like bursts per second
+    x = (0.3 * env * np.sin(2 * np.pi * 150.0 * t)).astype(np.float32)
+    sp, ar, ratio, prate, mpause = mo.speechrate(x)
+    assert 3.0 < sp < 5.0 and 0.9 < ratio <= 1.0 and prate == 0 and mpause == 0
+
+
 def test_feature_order_matches_reference():
     assert len(mo.FEATURE_NAMES) == 25 and mo.FEATURE_NAMES[5] == "mean_F0" and mo.FEATURE_NAMES[-1] == "Spectral_Kurtosis"
