@@ -65,7 +65,8 @@ def test_spectrogram_geometry_and_moments_of_sine():
 
 def test_quantile_cubic_and_silence_intervals():
     a = np.arange(1.0, 11.0)
-    assert abs(mo.quantile_sorted(a, 0.5) - 5.5) < 1e-12 and mo.quantile_sorted(a, 0.99) == 10.0
+    assert abs(mo.quantile_sorted(a, 0.5) - 5.5) < 1e-12
+    assert abs(mo.quantile_sorted(a, 0.99) - 10.4) < 1e-12          # NUMquantile extrapolates linearly past the last pair
     y = np.array([0.0, 1.0, 4.0, 9.0, 16.0, 25.0])               # cubic interpolation reproduces a parabola
     assert abs(mo.value_cubic(y, 2.5) - 6.25) < 1e-12 and mo.value_cubic(y, 3.0) == 9.0
     # 1 s of 10 ms frames: loud / 0.4 s quiet / loud with a 30 ms quiet blip that must be absorbed
