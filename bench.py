@@ -218,6 +218,14 @@ def main():
         value = audio_s_per_step * args.steps / dt
         roof = pipeline.roofline(prof, pipe, args.clips, args.seconds, args.steps,
                                  HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS)
+        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
+        # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM); PMC cannot run inside this process
+        tpath = os.path.join(ROOT, "profiles", "r01", "pmc_bench_traffic.json")
+        if roof and roof.get("kernel") == "w2v2_gemm" and os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            roof["traffic"] = round(tj["traffic_bytes_per_launch_fetch_x2_plus_write"])
+            roof["traffic_source"] = "profiles/r01/pmc_bench_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
         line = {
             "metric": "audio-seconds processed/sec (extract+CNN-LSTM fwd)",
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,

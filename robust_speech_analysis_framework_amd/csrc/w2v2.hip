@@ -262,11 +262,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---- row softmax in place, one wave per row of length T (row stride Tp, pad columns zeroed) ---------
+// Tp <= 256 (every Wav2Vec2 window: T <= 249): the row lives in one float4 per lane, one load + one store
+template <bool SMALL>
 __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, int64_t rows, int T, int Tp) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     float* p = S + row * Tp;
+    if (SMALL) {
+        const int c0 = 4 * lane;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (c0 < Tp) v = reinterpret_cast<const float4*>(p)[lane];
+        float e[4] = {v.x, v.y, v.z, v.w};
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { if (c0 + i >= T) e[i] = -INFINITY; m = fmaxf(m, e[i]); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { e[i] = (c0 + i < T) ? expf(e[i] - m) : 0.f; s += e[i]; }
+        s = wave_sum(s);
+        const float inv = 1.0f / s;
+        if (c0 < Tp) reinterpret_cast<float4*>(p)[lane] = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
+        return;
+    }
     float m = -INFINITY;
     for (int c = lane; c < T; c += 64) m = fmaxf(m, p[c]);
 #pragma unroll
@@ -491,8 +511,12 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         {
             const int64_t srows = (int64_t)n * c.NH * Tt;
             ProfScope prof("w2v2_softmax", s, 0.0, (double)srows * W.Tp * 8);
-            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, s, ws + W.S, srows, Tt,
-                               W.Tp);
+            if (W.Tp <= 256)
+                hipLaunchKernelGGL(softmax_kernel<true>, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, s, ws + W.S,
+                                   srows, Tt, W.Tp);
+            else
+                hipLaunchKernelGGL(softmax_kernel<false>, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, s, ws + W.S,
+                                   srows, Tt, W.Tp);
             RSAF_CHECK_HIP(hipGetLastError());
         }
         {   // O = P V per (chunk, head), V is [T, hd] with N contiguous
