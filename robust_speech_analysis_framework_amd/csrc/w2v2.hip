@@ -482,7 +482,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         p.sB1 = 0; p.sB2 = (int64_t)cg * c.PK * cg;
         p.sC1 = (int64_t)Tt * Hd; p.sC2 = cg;
         p.bias = Wt + L.posb; p.sBias2 = cg; p.act = ACT_GELU;
-        rc = launch_gemm_f32(p, s, "w2v2_gemm");
+        rc = launch_gemm_f32(p, s, "w2v2_posconv_gemm");
         if (rc) return rc;
         rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s);
         if (rc) return rc;
@@ -505,7 +505,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             p.sA1 = (int64_t)Tt * 3 * Hd; p.sA2 = hd; p.sB1 = p.sA1; p.sB2 = hd;
             p.sC1 = (int64_t)c.NH * Tt * W.Tp; p.sC2 = (int64_t)Tt * W.Tp;
             p.alpha = scale;
-            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
         }
         {
@@ -525,7 +525,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             p.sA1 = (int64_t)c.NH * Tt * W.Tp; p.sA2 = (int64_t)Tt * W.Tp;
             p.sB1 = (int64_t)Tt * 3 * Hd; p.sB2 = hd;
             p.sC1 = (int64_t)Tt * Hd; p.sC2 = hd;
-            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
         }
         {   // y = attn Wo^T + bo + x ; x = LN(y)

@@ -33,7 +33,7 @@ def resolve_stages(spec: str):
 
 class Pipeline:
     def __init__(self, stages, device, seconds: float, w2v2_seed: int = 0, cnnlstm_seed: int = 0,
-                 w2v2_chunks_per_call: int = 256):
+                 w2v2_chunks_per_call: int = 256, overlap: bool = True):
         import torch
         _lib.load()
         self.stages = list(stages)
@@ -45,6 +45,16 @@ class Pipeline:
         self.w2v2 = None
         self.model = None
         self.mshds = None
+        # MSHDS is fp64-VALU work, Wav2Vec2/CNN-LSTM is MFMA work: different pipes of the same CUs.  With
+        # `overlap` the two run on separate HIP streams so the dispatcher co-schedules their workgroups.
+        self.overlap = overlap and "mshds" in self.stages and "w2v2" in self.stages
+        self._aux = torch.cuda.Stream(device=device) if self.overlap else None
+        self._pool = None
+        if self.overlap:
+            # the main stream's launch queue back-pressures its host thread (thousands of launches per
+            # step), so the auxiliary stream is driven by its own host thread
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rsaf-mshds")
         if "mshds" in self.stages:
             from .mshds import MshdsEngine
             self.mshds = MshdsEngine(device)
@@ -72,10 +82,25 @@ class Pipeline:
         cols = []
         p = self._pack(wav)
         n_clips, n_samp = int(wav.shape[0]), int(wav.shape[1])
-        if self.mshds is not None:
+        main = torch.cuda.current_stream()
+        mshds_cols = None
+        if self.mshds is not None and not self.overlap:
             offs = np.arange(n_clips, dtype=np.int64) * n_samp
             feats, _ = self.mshds.extract_packed(p.wav, offs, [n_samp] * n_clips)
-            cols.append(feats.to(torch.float32))
+            mshds_cols = feats.to(torch.float32)
+        fut = None
+        if self.overlap:
+            self._aux.wait_stream(main)
+
+            def _mshds_job():
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self._aux):
+                    offs_ = np.arange(n_clips, dtype=np.int64) * n_samp
+                    feats_, _ = self.mshds.extract_packed(p.wav, offs_, [n_samp] * n_clips)
+                    return feats_.to(torch.float32)
+            fut = self._pool.submit(_mshds_job)
+        if self.mshds is not None and not self.overlap:
+            cols.append(mshds_cols)
         if "smile" in self.stages:
             cols.append(smile.smile_features(p))
         if self.w2v2 is not None:
@@ -86,6 +111,11 @@ class Pipeline:
                 logits = self.model(seq.view(n_clips, frames, self.w2v2.cfg.hidden_size))
                 cols.append(logits)
             cols.append(torch.full((n_clips, 1), float(frames), dtype=torch.float32, device=self.device))
+        if self.overlap:
+            mshds_cols = fut.result()
+            main.wait_stream(self._aux)
+            mshds_cols.record_stream(main)
+            cols.insert(0, mshds_cols)
         rows = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
         if self.finite_cols is None:
             self.finite_cols = torch.isfinite(rows[0]).nonzero().flatten()
