@@ -11,7 +11,7 @@ cross-correlation pitch, path finder, HNR) and the Praat manual pages "Sound: To
 "Spectrum: Get centre of gravity / central moment...".  Free choices are documented inline.
 
 Built so far (the rest of the 25 features is NaN, as in ``csrc/mshds.hip``):
-  a2 ``_speechrate``, a3 ``_pitch_values``, a4 ``_extract_pitch``, a5 ``_extract_intensity``, a6 ``_extract_harmonicity``,
+  a2 ``_speechrate``, a9 ``_measureFormants``, a3 ``_pitch_values``, a4 ``_extract_pitch``, a5 ``_extract_intensity``, a6 ``_extract_harmonicity``,
   a10 ``_extract_Spectral_Moments``.
 Arithmetic: float64 on the float32 samples (Praat computes in double).
 """
@@ -30,7 +30,7 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                          # src/mshds_extractor.py:397-404
-BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24]
+BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 
 # ---- Sampled helpers (Praat: x1 = 0.5 dx for a Sound read from file) ----------------------------
@@ -807,6 +807,320 @@ def speechrate(x):
     return speaking, artic, phon_ratio, pause_rate, mean_pause
 
 
+# ---- glottal pulses: Sound & Pitch: To PointProcess (cc) -----------------------------------------------
+def pitch_value_at(p, t):
+    """Pitch 'Get value at time' (Hertz, linear); NaN where undefined."""
+    n = p.n_frames
+    if n == 0:
+        return np.nan
+    f = p.frequency()
+    ireal = (t - p.t1) / p.dt
+    ileft = int(np.floor(ireal))
+    phase = ireal - ileft
+    if phase < 0.5:
+        inear, ifar = ileft, ileft + 1
+    else:
+        inear, ifar, phase = ileft + 1, ileft, 1.0 - phase
+    if inear < 0 or inear >= n:
+        return np.nan
+    fn = f[inear]
+    if not (0.0 < fn < p.ceiling):
+        return np.nan
+    if ifar < 0 or ifar >= n:
+        return fn
+    ff = f[ifar]
+    if not (0.0 < ff < p.ceiling):
+        return fn
+    return fn + phase * (ff - fn)
+
+
+def _find_extremum(x, tmin, tmax):
+    """Sound_findExtremum (absolute extremum, parabolic position)."""
+    n = len(x)
+    imin = max(0, int(x_to_low_index(tmin)))
+    imax = min(n - 1, int(np.ceil((tmax - 0.5 * DX) / DX)))
+    cnt = imax - imin + 1
+    if cnt <= 0:
+        return 0.5 * (tmin + tmax)
+    seg = x[imin:imax + 1]
+    if cnt == 1:
+        ie = 1.0
+    elif cnt == 2:
+        a, b = abs(seg[0]), abs(seg[1])
+        ie = 1.0 if a > b else (2.0 if a < b else 1.5)
+    else:
+        jmin, jmax = int(np.argmin(seg)), int(np.argmax(seg))
+        mn, mx = seg[jmin], seg[jmax]
+        if mn == mx:
+            ie = 0.5 * (cnt + 1.0)
+        else:
+            j = jmin if abs(mn) > abs(mx) else jmax
+            if j == 0:
+                ie = 1.0
+            elif j == cnt - 1:
+                ie = float(cnt)
+            else:
+                vm, vl, vr = seg[j], seg[j - 1], seg[j + 1]
+                ie = (j + 1) + 0.5 * (vr - vl) / (2.0 * vm - vl - vr)
+    return 0.5 * DX + (imin + ie - 1.0) * DX
+
+
+def _max_correlation(x, t1, window, tmin2, tmax2):
+    """Sound_findMaximumCorrelation -> (correlation, tout, peak)."""
+    n = len(x)
+    half = 0.5 * window
+    ileft1 = int(x_to_nearest_index(t1 - half))
+    iright1 = int(x_to_nearest_index(t1 + half))
+    ileft2min = int(x_to_low_index(tmin2 - half))
+    ileft2max = int(np.ceil((tmax2 - half - 0.5 * DX) / DX))
+    best, r1, r2, r3 = -1.0, 0.0, 0.0, 0.0
+    r1b = r3b = 0.0
+    ir = 0.0
+    peak = 0.0
+    i1 = np.arange(ileft1, iright1 + 1)
+    for ileft2 in range(ileft2min, ileft2max + 1):
+        i2 = i1 - ileft1 + ileft2
+        ok = (i1 >= 0) & (i1 < n) & (i2 >= 0) & (i2 < n)
+        a1, a2 = x[i1[ok]], x[i2[ok]]
+        norm1, norm2, prod = np.dot(a1, a1), np.dot(a2, a2), np.dot(a1, a2)
+        local_peak = np.max(np.abs(a2)) if a2.size else 0.0
+        r1, r2 = r2, r3
+        r3 = prod / np.sqrt(norm1 * norm2) if prod != 0.0 else 0.0
+        if r2 > best and r2 >= r1 and r2 >= r3:
+            r1b, best, r3b = r1, r2, r3
+            ir = ileft2 - 1
+            peak = local_peak
+    tout = t1
+    if best > -1.0:
+        d2r = 2.0 * best - r1b - r3b
+        if d2r != 0.0:
+            dr = 0.5 * (r3b - r1b)
+            best += 0.5 * dr * dr / d2r
+            ir += dr / d2r
+        tout = t1 + (ir - ileft1) * DX
+    return best, tout, peak
+
+
+def point_process_cc(x, p):
+    """Pulse times (Praat Sound_Pitch_to_PointProcess_cc)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    duration = n * DX
+    f = p.frequency()
+    voiced = (f > 0.0) & (f < p.ceiling)
+    nF = p.n_frames
+    pts = []
+    global_peak = np.max(np.abs(x)) if n else 0.0
+    t = 0.0
+    added_right = -1e308
+    while True:
+        il = int(np.ceil((t - p.t1) / p.dt))                      # Sampled_xToHighIndex, 0-based
+        il = max(il, 0)
+        while il < nF and not voiced[il]:
+            il += 1
+        if il >= nF:
+            break
+        irr = il
+        while irr < nF and voiced[irr]:
+            irr += 1
+        irr -= 1
+        tleft = p.t1 + il * p.dt - 0.5 * p.dt
+        tright = p.t1 + irr * p.dt + 0.5 * p.dt
+        if tleft >= duration - 0.5 * p.dt:
+            break
+        tleft, tright = max(tleft, 0.0), min(tright, duration)
+        tmid = 0.5 * (tleft + tright)
+        f0mid = pitch_value_at(p, tmid)
+        if np.isnan(f0mid):
+            t = tright
+            continue
+        tmax = _find_extremum(x, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid)
+        pts.append(tmax)
+        tsave = tmax
+        while True:                                              # to the left
+            f0 = pitch_value_at(p, tmax)
+            if np.isnan(f0):
+                break
+            corr, tmax, peak = _max_correlation(x, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0)
+            if corr == -1.0:
+                tmax -= 1.0 / f0
+            if tmax < tleft:
+                if corr > 0.7 and peak > 0.023333 * global_peak and tmax - added_right > 0.8 / f0:
+                    pts.append(tmax)
+                break
+            if corr > 0.3 and (peak == 0.0 or peak > 0.01 * global_peak):
+                if tmax - added_right > 0.8 / f0:
+                    pts.append(tmax)
+        tmax = tsave
+        while True:                                              # to the right
+            f0 = pitch_value_at(p, tmax)
+            if np.isnan(f0):
+                break
+            corr, tmax, peak = _max_correlation(x, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0)
+            if corr == -1.0:
+                tmax += 1.0 / f0
+            if tmax > tright:
+                if corr > 0.7 and peak > 0.023333 * global_peak:
+                    pts.append(tmax)
+                    added_right = tmax
+                break
+            if corr > 0.3 and (peak == 0.0 or peak > 0.01 * global_peak):
+                pts.append(tmax)
+                added_right = tmax
+        t = tright
+    return np.sort(np.array(pts, dtype=np.float64))
+
+
+# ---- resampling to 10 kHz + Formant (burg) -------------------------------------------------------------
+RS_DEPTH = 500          # Praat resamples with sinc precision 500 for formant analysis
+RS_RATE = 10000.0
+
+
+def resample_10k(x):
+    """Band-limited resampling 16 kHz -> 10 kHz.  Praat low-passes with a brick-wall FFT filter over the
+    whole sound and then sinc-interpolates (depth 500); here both steps are one raised-cosine windowed
+    sinc of half-width 500 input samples with its cut-off at the new Nyquist (documented free choice:
+    it avoids a 2^19-point FFT per clip and differs only in the transition band at 5 kHz)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    duration = n * DX
+    m = int(np.floor(duration * RS_RATE + 0.5))
+    dxo = 1.0 / RS_RATE
+    x1o = 0.5 * (duration - (m - 1) * dxo)
+    ratio = RS_RATE / FS                                           # 0.625 = relative cut-off
+    out = np.empty(m)
+    k = np.arange(-RS_DEPTH, RS_DEPTH + 1)
+    for i0 in range(0, m, 4096):
+        idx = np.arange(i0, min(m, i0 + 4096))
+        pos = (x1o + idx * dxo - 0.5 * DX) / DX                    # real index into x
+        base = np.floor(pos).astype(np.int64)
+        j = base[:, None] + k[None, :]
+        d = pos[:, None] - j
+        w = ratio * np.sinc(ratio * d) * (0.5 + 0.5 * np.cos(np.pi * d / (RS_DEPTH + 1.0)))
+        w = np.where(np.abs(d) <= RS_DEPTH + 1.0, w, 0.0)
+        ok = (j >= 0) & (j < n)
+        out[idx] = np.sum(np.where(ok, x[np.clip(j, 0, n - 1)] * w, 0.0), axis=1)
+    return out, x1o, dxo
+
+
+def _burg(x, m):
+    """NUMburg: LPC coefficients a[1..m] (x[n] ~ sum a_k x[n-k])."""
+    n = len(x)
+    a = np.zeros(m + 1)
+    p = np.dot(x, x)
+    if p <= 0.0:
+        return a[1:]
+    b1 = np.zeros(n + 1)
+    b2 = np.zeros(n + 1)
+    aa = np.zeros(m + 1)
+    b1[1] = x[0]
+    b2[n - 1] = x[n - 1]
+    b1[2:n] = x[1:n - 1]
+    b2[1:n - 1] = x[1:n - 1]
+    for i in range(1, m + 1):
+        num = np.dot(b1[1:n - i + 1], b2[1:n - i + 1])
+        den = np.dot(b1[1:n - i + 1], b1[1:n - i + 1]) + np.dot(b2[1:n - i + 1], b2[1:n - i + 1])
+        if den <= 0.0:
+            return np.zeros(m)
+        a[i] = 2.0 * num / den
+        for j in range(1, i):
+            a[j] = aa[j] - a[i] * aa[i - j]
+        if i < m:
+            aa[1:i + 1] = a[1:i + 1]
+            nb1 = b1[1:n - i] - aa[i] * b2[1:n - i]
+            nb2 = b2[2:n - i + 1] - aa[i] * b1[2:n - i + 1]
+            b1[1:n - i], b2[1:n - i] = nb1, nb2
+    return a[1:]
+
+
+def formant_burg(x, time_step=0.005, n_formants=5, max_freq=5000.0, half_window=0.025, preemph_from=50.0,
+                 safety=50.0):
+    """Sound: To Formant (burg): returns (freq [nF, 5], bw [nF, 5] (NaN padded), t1, dt)."""
+    y, x1o, dxo = resample_10k(x)
+    n = len(y)
+    nyq = 0.5 / dxo
+    npoles = 2 * n_formants
+    dt_window = 2.0 * half_window
+    duration = n * dxo
+    if dt_window > duration:
+        return np.zeros((0, n_formants)), np.zeros((0, n_formants)), 0.0, time_step
+    nF = int(np.floor((duration - dt_window) / time_step)) + 1
+    t1 = x1o - 0.5 * dxo + 0.5 * duration - 0.5 * nF * time_step + 0.5 * time_step
+    nsw = int(np.floor(dt_window / dxo))
+    half = nsw // 2
+    y = y.copy()
+    y[1:] = y[1:] - np.exp(-2.0 * np.pi * preemph_from * dxo) * y[:-1]          # Sound_preEmphasis
+    i = np.arange(1, nsw + 1)
+    imid, edge = 0.5 * (nsw + 1), np.exp(-12.0)
+    win = (np.exp(-48.0 * (i - imid) ** 2 / (nsw + 1) ** 2) - edge) / (1.0 - edge)
+    F = np.full((nF, n_formants), np.nan)
+    B = np.full((nF, n_formants), np.nan)
+    for fr in range(nF):
+        t = t1 + fr * time_step
+        left = int(np.floor((t - x1o) / dxo))
+        start, end = left + 1 - half, left + half
+        start, end = max(start, 0), min(end, n - 1)
+        seg = y[start:end + 1]
+        if seg.size < npoles + 2 or np.max(seg * seg) == 0.0:
+            continue
+        a = _burg(seg * win[:seg.size], npoles)
+        poly = np.concatenate([[1.0], -a])                          # z^m - a1 z^(m-1) - ... - am
+        r = np.roots(poly)
+        for _ in range(3):                                          # polish (Newton) like Praat
+            pv = np.polyval(poly, r)
+            dv = np.polyval(np.polyder(poly), r)
+            r = r - np.where(dv != 0, pv / np.where(dv != 0, dv, 1.0), 0.0)
+        big = np.abs(r) > 1.0
+        r = np.where(big, 1.0 / np.conj(np.where(big, r, 1.0)), r)    # Roots_fixIntoUnitCircle
+        r = r[r.imag >= 0]
+        fq = np.abs(np.arctan2(r.imag, r.real)) * nyq / np.pi
+        bw = -np.log(r.real ** 2 + r.imag ** 2) * nyq / np.pi
+        keep = (fq >= safety) & (fq <= nyq - safety)
+        fq, bw = fq[keep], bw[keep]
+        o = np.argsort(fq, kind="stable")[:n_formants]
+        F[fr, :len(o)] = fq[o]
+        B[fr, :len(o)] = bw[o]
+    return F, B, t1, time_step
+
+
+def sampled_value_linear(vals, t1, dt, t):
+    """Sampled_getValueAtX with linear interpolation over possibly-undefined (NaN) samples."""
+    n = len(vals)
+    if n == 0:
+        return np.nan
+    ireal = (t - t1) / dt
+    ileft = int(np.floor(ireal))
+    phase = ireal - ileft
+    if phase < 0.5:
+        inear, ifar = ileft, ileft + 1
+    else:
+        inear, ifar, phase = ileft + 1, ileft, 1.0 - phase
+    if inear < 0 or inear >= n or np.isnan(vals[inear]):
+        return np.nan
+    if ifar < 0 or ifar >= n or np.isnan(vals[ifar]):
+        return vals[inear]
+    return vals[inear] + phase * (vals[ifar] - vals[inear])
+
+
+def measure_formants(x, floor, ceiling, frame_shift=0.005):
+    """``_measureFormants`` (:303-338): F1, B1, F2, B2 at every glottal pulse -> mean and sample SD."""
+    x = np.asarray(x, dtype=np.float64)
+    F, B, ft1, fdt = formant_burg(x, frame_shift, 5, 5000.0, 0.025, 50.0)                    # :319
+    p = pitch_cc(x, frame_shift, floor, 1.0, 15, 0.03, 0.45, 0.01, 0.35, 0.14, ceiling)      # :320
+    pulses = point_process_cc(x, p)                                                          # :321
+    lists = [[], [], [], []]
+    for t in pulses:                                                                         # :326-331
+        for k, arr in enumerate((F[:, 0], B[:, 0], F[:, 1], B[:, 1])):
+            v = sampled_value_linear(arr, ft1, fdt, t) if len(arr) else np.nan
+            if not np.isnan(v):
+                lists[k].append(v)
+    out = []
+    for l in lists:                                                                          # :333-336
+        out.append(np.mean(l) if l else np.nan)
+        out.append(np.std(l, ddof=1) if len(l) > 1 else np.nan)
+    return tuple(out)
+
+
 def extract(x):
     """One clip -> 25 features in the reference's column order (unbuilt helpers give NaN)."""
     x = np.asarray(x, dtype=np.float64)
@@ -817,5 +1131,6 @@ def extract(x):
     out[5], out[6] = extract_pitch(x, floor, ceiling, 0.005, p)                      # :430
     out[7], out[8] = extract_intensity(x, floor, 0.005)                              # :431
     out[9] = extract_harmonicity(x, floor, ceiling, 0.005)                           # :432
+    out[13:21] = measure_formants(x, floor, ceiling, 0.005)                          # :441
     out[21:25] = extract_spectral_moments(x, floor, ceiling, 0.025, 0.005, p)        # :446
     return out, (floor, ceiling)

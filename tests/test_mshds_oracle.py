@@ -86,5 +86,42 @@ def test_speechrate_of_amplitude_modulated_tone():
     assert 3.0 < sp < 5.0 and 0.9 < ratio <= 1.0 and prate == 0 and mpause == 0
 
 
+def test_formants_of_two_resonators_and_pulse_period():
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(1)
+    fs = 16000.0
+
+    def res(fc, bw):
+        r = np.exp(-np.pi * bw / fs)
+        return [1.0], [1.0, -2 * r * np.cos(2 * np.pi * fc / fs), r * r]
+    # impulse train at 125 Hz through resonators at 500 Hz and 1500 Hz (cascade = all-pole vowel model)
+    n = 16000
+    src = np.zeros(n)
+    src[::128] = 1.0
+    y = src + 1e-4 * rng.standard_normal(n)
+    for fc, bw in ((500.0, 60.0), (1500.0, 90.0)):
+        b, a = res(fc, bw)
+        y = lfilter(b, a, y)
+    y = (0.5 * y / np.abs(y).max()).astype(np.float32)
+    F, B, t1, dt = mo.formant_burg(y)
+    assert abs(np.nanmedian(F[:, 0]) - 500.0) < 25.0 and abs(np.nanmedian(F[:, 1]) - 1500.0) < 40.0
+    p = mo.pitch_cc(y, 0.005, 75.0, 1.0, 15, 0.03, 0.45, 0.01, 0.35, 0.14, 500.0)
+    pts = mo.point_process_cc(y, p)
+    d = np.diff(pts)
+    assert len(pts) > 100 and abs(np.median(d) - 128 / 16000.0) < 1e-4      # one pulse per period
+    out = mo.measure_formants(y, 75, 500)
+    assert abs(out[0] - 500.0) < 25.0 and abs(out[4] - 1500.0) < 40.0
+
+
+def test_resampler_preserves_in_band_tone():
+    t = (np.arange(16000) + 0.5) / 16000.0                               # Praat: sample j sits at (j + 0.5) dx
+    y, x1, dxo = mo.resample_10k(np.sin(2 * np.pi * 1000.0 * t))
+    to = x1 + np.arange(len(y)) * dxo
+    mid = slice(1000, len(y) - 1000)
+    assert len(y) == 10000 and np.abs(y[mid] - np.sin(2 * np.pi * 1000.0 * to[mid])).max() < 2e-3
+    z, _, _ = mo.resample_10k(np.sin(2 * np.pi * 6500.0 * t))             # above the new Nyquist: removed
+    assert np.abs(z[mid]).max() < 2e-2
+
+
 def test_feature_order_matches_reference():
     assert len(mo.FEATURE_NAMES) == 25 and mo.FEATURE_NAMES[5] == "mean_F0" and mo.FEATURE_NAMES[-1] == "Spectral_Kurtosis"
