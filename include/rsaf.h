@@ -176,6 +176,26 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
                           double intensity_dt, const double* sel_freq, const void* pitch_clip_info,
                           double pitch_dt, double pitch_ceiling, double* workspace, double* out,
                           rsaf_stream_t stream);
+/* _measureFormants (src/mshds_extractor.py:303-338): To Formant (burg) 5 ms / 5 formants / 5 kHz / 25 ms /
+ * 50 Hz on a 10 kHz resampling of the clip, To Pitch (cc) (rsaf_mshds_pitch, is_cc), To PointProcess (cc),
+ * then F1,B1,F2,B2 linearly interpolated at every pulse -> mean and sample SD.
+ * resample_info: device array of {int64 sample_off; int64 out_off; double pos0; double x1o; int32 n_in;
+ * int32 n_out; int32 table; int32 pad} (48 bytes); tables: [n_tables][5][2*depth+1] float64 windowed-sinc
+ * weights; phase_base: [n_tables][5] int32 = floor(pos0 + 1.6 r) (output m = 5q + r reads input 8q + base).
+ * frames_out: per frame {double f[5]; double b[5]} (NaN padded); pulses: [n_clips][max_pulses] times (unsorted);
+ * stats out[clip][8] = mean/SD of F1, B1, F2, B2 in the reference's column order. */
+int rsaf_mshds_resample10k(const float* wav, const void* resample_info, int n_clips, int max_out,
+                           const double* tables, const int* phase_base, int depth, double* out,
+                           rsaf_stream_t stream);
+int rsaf_mshds_formants(const double* y10, const void* resample_info, const void* clip_info, int n_clips,
+                        int max_frames, const double* window, int nsamp_window, double time_step, double dx_out,
+                        double preemph_factor, void* frames_out, rsaf_stream_t stream);
+int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips, const double* sel_freq,
+                      double pitch_dt, double pitch_ceiling, double* pulses, int max_pulses, int* n_pulses,
+                      rsaf_stream_t stream);
+int rsaf_mshds_formant_stats(const void* frames, const void* clip_info, int n_clips, double time_step,
+                             const double* pulses, int max_pulses, const int* n_pulses, double* out,
+                             rsaf_stream_t stream);
 int rsaf_mshds_hnr_mean(const double* sel_freq, const double* sel_strength, const void* clip_info, int n_clips,
                         double* out, rsaf_stream_t stream);
 /* moments[frame][5] = {gate, CoG, SD, skewness, kurtosis}; stats_out[clip][4] = means over gated frames */

@@ -987,6 +987,406 @@ __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict
     o[4] = n_pauses > 0 ? (original_dur - phonation) / n_pauses : 0.0;
 }
 
+// ---- 16 kHz -> 10 kHz band-limited resampling (front end of To Formant (burg)) ----------------------------
+// out[m] = sum_k x[base + k] * W[phase][k + D]: the ratio 5/8 gives 5 distinct fractional offsets, whose
+// windowed-sinc weights (half-width D input samples) the host tabulates in float64.
+struct ResampleInfo {        // per clip (host-built), 48 bytes
+    int64_t sample_off;      // into wav
+    int64_t out_off;         // into the 10 kHz buffer
+    double pos0;             // real input index of output sample 0
+    double x1o;              // time of output sample 0
+    int n_in, n_out;
+    int table;               // index of this clip's weight table (one per distinct pos0)
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ wav, const ResampleInfo* __restrict__ ri,
+                                                       const double* __restrict__ tables,
+                                                       const int* __restrict__ phase_base, int depth,
+                                                       double* __restrict__ out) {
+    const ResampleInfo c = ri[blockIdx.y];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= c.n_out) return;
+    const float* x = wav + c.sample_off;
+    // m = 5q + r  ->  position pos0 + 8q + 1.6r: integer part 8q + floor(pos0 + 1.6r) (host table), so the
+    // tap alignment is integer-exact and the 5 fractional offsets select the weight row
+    const int q = m / 5, r = m - 5 * q;
+    const int base = 8 * q + phase_base[c.table * 5 + r];
+    const int taps = 2 * depth + 1;
+    const double* w = tables + ((int64_t)c.table * 5 + r) * taps;
+    double acc = 0.0;
+    for (int k = 0; k < taps; ++k) {
+        const int j = base - depth + k;
+        if (j >= 0 && j < c.n_in) acc += (double)x[j] * w[k];
+    }
+    out[c.out_off + m] = acc;
+}
+
+// ---- Formant (burg): one wave per frame -----------------------------------------------------------------------
+// Gaussian-windowed 50 ms frame of the pre-emphasised 10 kHz signal -> Burg LPC (order 10) -> roots by
+// Aberth-Ehrlich iteration (all ten simultaneously, lanes 0..9) + Newton polish -> reflect into the unit
+// circle -> (frequency, bandwidth) of the roots in the upper half plane, ascending, at most 5.
+constexpr int FB_ORDER = 10;
+struct FormantFrame { double f[5]; double b[5]; };
+
+__global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__ y10, const ResampleInfo* __restrict__ ri,
+                                                      const ClipInfo* __restrict__ ci, const double* __restrict__ win,
+                                                      int nsw, double dt, double dxo, double preemph,
+                                                      FormantFrame* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ClipInfo c = ci[blockIdx.y];
+    const int f = blockIdx.x * 4 + wv;
+    if (f >= c.n_frames) return;
+    const ResampleInfo r = ri[blockIdx.y];
+    double* b1 = reinterpret_cast<double*>(smem_raw) + (size_t)wv * 2 * (nsw + 2);
+    double* b2 = b1 + (nsw + 2);
+    const double* y = y10 + r.out_off;
+    const int n = r.n_out;
+    const double x1o = r.x1o;
+    const double t = c.t1 + f * dt;
+    const int left = (int)floor((t - x1o) / dxo);
+    const int half = nsw / 2;
+    int start = left + 1 - half, end = left + half;
+    start = start < 0 ? 0 : start;
+    end = end > n - 1 ? n - 1 : end;
+    const int len = end - start + 1;
+    FormantFrame* o = out + c.frame_off + f;
+    const double qn = __longlong_as_double(0x7ff8000000000000LL);
+    // pre-emphasised, windowed frame into b1[1..len] (Burg's 1-based arrays); also the max intensity
+    double mxi = 0.0, p = 0.0;
+    for (int j = lane; j < len; j += 64) {
+        const int i = start + j;
+        const double v = (i > 0) ? y[i] - preemph * y[i - 1] : y[i];
+        mxi = fmax(mxi, v * v);
+        const double xv = v * win[j];
+        b1[j + 1] = xv;
+        p += xv * xv;
+    }
+    mxi = wave_max_f64(mxi);
+    p = wave_sum_f64(p);
+    if (len < FB_ORDER + 2 || mxi == 0.0 || p <= 0.0) {
+        if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // NUMburg.  x = b1 copy: b2[j] = x[j+1] for j = 1..len-1, b1[j] = x[j] for j = 1..len-1
+    for (int j = 1 + lane; j <= len - 1; j += 64) b2[j] = b1[j + 1];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double a[FB_ORDER + 1], aa[FB_ORDER + 1];
+#pragma unroll
+    for (int i = 0; i <= FB_ORDER; ++i) { a[i] = 0.0; aa[i] = 0.0; }
+    bool bad = false;
+    for (int i = 1; i <= FB_ORDER; ++i) {
+        double num = 0.0, den = 0.0;
+        for (int j = 1 + lane; j <= len - i; j += 64) { const double u = b1[j], v = b2[j]; num += u * v; den += u * u + v * v; }
+        num = wave_sum_f64(num);
+        den = wave_sum_f64(den);
+        if (den <= 0.0) { bad = true; break; }
+        a[i] = 2.0 * num / den;
+        for (int j = 1; j < i; ++j) a[j] = aa[j] - a[i] * aa[i - j];
+        if (i < FB_ORDER) {
+            for (int j = 1; j <= i; ++j) aa[j] = a[j];
+            const double k = aa[i];
+            // b1[j] -= k*b2[j]; b2[j] = b2[j+1] - k*b1[j+1] (old b1) for j = 1..len-i-1
+            for (int j0 = 1; j0 <= len - i - 1; j0 += 64) {
+                const int j = j0 + lane;
+                double nb1 = 0.0, nb2 = 0.0;
+                const bool on = j <= len - i - 1;
+                if (on) { nb1 = b1[j] - k * b2[j]; nb2 = b2[j + 1] - k * b1[j + 1]; }
+                __builtin_amdgcn_wave_barrier();
+                if (on) { b1[j] = nb1; b2[j] = nb2; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+    }
+    if (bad) {
+        if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
+        return;
+    }
+    // polynomial z^10 - a1 z^9 - ... - a10 ; c[k] = coefficient of z^(10-k)
+    double cf[FB_ORDER + 1];
+    cf[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= FB_ORDER; ++k) cf[k] = -a[k];
+    // Aberth-Ehrlich: lane i < 10 owns root i; start on a circle of radius 0.9
+    double zr = 0.0, zi = 0.0;
+    const int li = lane < FB_ORDER ? lane : 0;
+    { double sn, cs; sincos(2.0 * PI * (li + 0.35) / FB_ORDER, &sn, &cs); zr = 0.9 * cs; zi = 0.9 * sn; }
+    for (int it = 0; it < 80; ++it) {
+        // p(z), p'(z) by Horner
+        double pr = cf[0], pi_ = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+        for (int k = 1; k <= FB_ORDER; ++k) {
+            const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi_;
+            dr = ndr; di = ndi;
+            const double npr = pr * zr - pi_ * zi + cf[k], npi = pr * zi + pi_ * zr;
+            pr = npr; pi_ = npi;
+        }
+        // w = p/p'
+        const double dd = dr * dr + di * di;
+        double wr_ = 0.0, wi_ = 0.0;
+        if (dd > 0.0) { wr_ = (pr * dr + pi_ * di) / dd; wi_ = (pi_ * dr - pr * di) / dd; }
+        // s = sum_{j != i} 1/(z_i - z_j)
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int j = 0; j < FB_ORDER; ++j) {
+            const double or_ = __shfl(zr, j, 64), oi = __shfl(zi, j, 64);
+            const double ex = zr - or_, ey = zi - oi;
+            const double ee = ex * ex + ey * ey;
+            if (j != li && ee > 0.0) { sr += ex / ee; si -= ey / ee; }
+        }
+        // delta = w / (1 - w*s)
+        const double qr = 1.0 - (wr_ * sr - wi_ * si), qi = -(wr_ * si + wi_ * sr);
+        const double qq = qr * qr + qi * qi;
+        double er = wr_, ei = wi_;
+        if (qq > 0.0) { er = (wr_ * qr + wi_ * qi) / qq; ei = (wi_ * qr - wr_ * qi) / qq; }
+        zr -= er; zi -= ei;
+        const double step = (lane < FB_ORDER) ? fabs(er) + fabs(ei) : 0.0;
+        if (wave_max_f64(step) < 1e-14) break;
+    }
+    for (int it = 0; it < 3; ++it) {                              // Newton polish on the original polynomial
+        double pr = cf[0], pi_ = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+        for (int k = 1; k <= FB_ORDER; ++k) {
+            const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi_;
+            dr = ndr; di = ndi;
+            const double npr = pr * zr - pi_ * zi + cf[k], npi = pr * zi + pi_ * zr;
+            pr = npr; pi_ = npi;
+        }
+        const double dd = dr * dr + di * di;
+        if (dd > 0.0) { zr -= (pr * dr + pi_ * di) / dd; zi -= (pi_ * dr - pr * di) / dd; }
+    }
+    // fix into the unit circle, keep the upper half plane, convert
+    const double nyq = 0.5 / dxo;
+    double mag2 = zr * zr + zi * zi;
+    if (mag2 > 1.0) { zr /= mag2; zi /= mag2; mag2 = zr * zr + zi * zi; }   // z -> 1/conj(z)
+    double fq = fabs(atan2(zi, zr)) * nyq / PI;
+    const double bw = -log(mag2) * nyq / PI;
+    const bool keep = lane < FB_ORDER && zi >= 0.0 && fq >= 50.0 && fq <= nyq - 50.0;
+    if (!keep) fq = 1e300;
+    // rank among kept roots (stable by lane), write the first five
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < FB_ORDER; ++j) {
+        const double of = __shfl(fq, j, 64);
+        rank += (of < fq) || (of == fq && j < lane);
+    }
+    if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (keep && rank < 5) { o->f[rank] = fq; o->b[rank] = bw; }
+}
+
+// ---- glottal pulses: Sound & Pitch: To PointProcess (cc), one wave per clip ----------------------------------
+__device__ double pitch_value_at(const double* __restrict__ f, int n, double t1, double dt, double ceiling, double t) {
+    const double qn = __longlong_as_double(0x7ff8000000000000LL);
+    if (n <= 0) return qn;
+    const double ireal = (t - t1) / dt;
+    const int64_t ileft = (int64_t)floor(ireal);
+    double phase = ireal - (double)ileft;
+    int64_t inear, ifar;
+    if (phase < 0.5) { inear = ileft; ifar = ileft + 1; } else { inear = ileft + 1; ifar = ileft; phase = 1.0 - phase; }
+    if (inear < 0 || inear >= n) return qn;
+    const double fn = f[inear];
+    if (!(fn > 0.0 && fn < ceiling)) return qn;
+    if (ifar < 0 || ifar >= n) return fn;
+    const double ff = f[ifar];
+    if (!(ff > 0.0 && ff < ceiling)) return fn;
+    return fn + phase * (ff - fn);
+}
+
+// Sound_findMaximumCorrelation with the shifts spread over the lanes; returns corr, *tout, *peak (uniform)
+__device__ double max_correlation_wave(const float* __restrict__ x, int n, double t1, double window, double tmin2,
+                                       double tmax2, int lane, double* tout, double* peak) {
+    const double half = 0.5 * window;
+    const int64_t ileft1 = (int64_t)floor((t1 - half - 0.5 * DXS) / DXS + 0.5);
+    const int64_t iright1 = (int64_t)floor((t1 + half - 0.5 * DXS) / DXS + 0.5);
+    const int64_t l2min = low_index(tmin2 - half);
+    const int64_t l2max = (int64_t)ceil((tmax2 - half - 0.5 * DXS) / DXS);
+    double best = -1.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r1b = 0.0, r3b = 0.0, ir = 0.0, pk = 0.0;
+    for (int64_t b = l2min; b <= l2max; b += 64) {
+        const int64_t ileft2 = b + lane;
+        double norm1 = 0.0, norm2 = 0.0, prod = 0.0, lp = 0.0;
+        if (ileft2 <= l2max) {
+            for (int64_t i1 = ileft1, i2 = ileft2; i1 <= iright1; ++i1, ++i2) {
+                if (i1 < 0 || i1 >= n || i2 < 0 || i2 >= n) continue;
+                const double a1 = x[i1], a2 = x[i2];
+                norm1 += a1 * a1; norm2 += a2 * a2; prod += a1 * a2;
+                lp = fmax(lp, fabs(a2));
+            }
+        }
+        const double rr = prod != 0.0 ? prod / sqrt(norm1 * norm2) : 0.0;
+        const int cnt = (int)((l2max - b + 1) < 64 ? (l2max - b + 1) : 64);
+        for (int k = 0; k < cnt; ++k) {                          // sequential r1/r2/r3 scan (uniform)
+            const double rk = __shfl(rr, k, 64), lk = __shfl(lp, k, 64);
+            r1 = r2; r2 = r3; r3 = rk;
+            if (r2 > best && r2 >= r1 && r2 >= r3) { r1b = r1; best = r2; r3b = r3; ir = (double)(b + k - 1); pk = lk; }
+        }
+    }
+    *peak = pk;
+    *tout = t1;
+    if (best > -1.0) {
+        const double d2r = 2.0 * best - r1b - r3b;
+        if (d2r != 0.0) { const double dr = 0.5 * (r3b - r1b); best += 0.5 * dr * dr / d2r; ir += dr / d2r; }
+        *tout = t1 + (ir - (double)ileft1) * DXS;
+    }
+    return best;
+}
+
+__device__ double find_extremum_wave(const float* __restrict__ x, int n, double tmin, double tmax, int lane) {
+    int64_t imin = low_index(tmin), imax = (int64_t)ceil((tmax - 0.5 * DXS) / DXS);
+    imin = imin < 0 ? 0 : imin;
+    imax = imax > n - 1 ? n - 1 : imax;
+    const int cnt = (int)(imax - imin + 1);
+    if (cnt <= 0) return 0.5 * (tmin + tmax);
+    double ie;
+    if (cnt == 1) ie = 1.0;
+    else if (cnt == 2) {
+        const double a = fabs((double)x[imin]), b = fabs((double)x[imin + 1]);
+        ie = a > b ? 1.0 : (a < b ? 2.0 : 1.5);
+    } else {
+        // first minimum / first maximum (strict comparisons in index order) via (value, index) reductions
+        double mn = INFINITY, mx = -INFINITY;
+        int jmn = 0x7fffffff, jmx = 0x7fffffff;
+        for (int j = lane; j < cnt; j += 64) {
+            const double v = x[imin + j];
+            if (v < mn) { mn = v; jmn = j; }
+            if (v > mx) { mx = v; jmx = j; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double omn = __shfl_xor(mn, o, 64), omx = __shfl_xor(mx, o, 64);
+            const int ojmn = __shfl_xor(jmn, o, 64), ojmx = __shfl_xor(jmx, o, 64);
+            if (omn < mn || (omn == mn && ojmn < jmn)) { mn = omn; jmn = ojmn; }
+            if (omx > mx || (omx == mx && ojmx < jmx)) { mx = omx; jmx = ojmx; }
+        }
+        if (mn == mx) ie = 0.5 * (cnt + 1.0);
+        else {
+            const int j = fabs(mn) > fabs(mx) ? jmn : jmx;
+            if (j == 0) ie = 1.0;
+            else if (j == cnt - 1) ie = (double)cnt;
+            else {
+                const double vm = x[imin + j], vl = x[imin + j - 1], vr = x[imin + j + 1];
+                ie = (j + 1) + 0.5 * (vr - vl) / (2.0 * vm - vl - vr);
+            }
+        }
+    }
+    return 0.5 * DXS + ((double)imin + ie - 1.0) * DXS;
+}
+
+__global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ pci,
+                                                    const double* __restrict__ sel_freq, double pdt, double ceiling,
+                                                    double* __restrict__ pulses, int max_pulses, int* __restrict__ n_pulses) {
+    const ClipInfo c = pci[blockIdx.x];
+    const int lane = threadIdx.x;
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples, nF = c.n_frames;
+    const double* f = sel_freq + c.frame_off;
+    double* pts = pulses + (int64_t)blockIdx.x * max_pulses;
+    const double duration = n * DXS;
+    double gp = 0.0;
+    for (int i = lane; i < n; i += 64) gp = fmax(gp, fabs((double)x[i]));
+    gp = wave_max_f64(gp);
+    int np_ = 0;
+    double t = 0.0, added_right = -1e308;
+    for (int guard = 0; guard < nF + 2; ++guard) {
+        int64_t il = (int64_t)ceil((t - c.t1) / pdt);
+        il = il < 0 ? 0 : il;
+        while (il < nF && !(f[il] > 0.0 && f[il] < ceiling)) ++il;
+        if (il >= nF) break;
+        int64_t irr = il;
+        while (irr < nF && (f[irr] > 0.0 && f[irr] < ceiling)) ++irr;
+        --irr;
+        double tleft = c.t1 + il * pdt - 0.5 * pdt, tright = c.t1 + irr * pdt + 0.5 * pdt;
+        if (tleft >= duration - 0.5 * pdt) break;
+        tleft = tleft < 0.0 ? 0.0 : tleft;
+        tright = tright > duration ? duration : tright;
+        const double tmid = 0.5 * (tleft + tright);
+        const double f0mid = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmid);
+        if (!(f0mid == f0mid)) { t = tright; continue; }
+        double tmax = find_extremum_wave(x, n, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid, lane);
+        if (np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
+        const double tsave = tmax;
+        for (int g2 = 0; g2 < 200000; ++g2) {                      // to the left
+            const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
+            if (!(f0 == f0)) break;
+            double peak, tout;
+            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, lane, &tout, &peak);
+            tmax = tout;
+            if (corr == -1.0) tmax -= 1.0 / f0;
+            if (tmax < tleft) {
+                if (corr > 0.7 && peak > 0.023333 * gp && tmax - added_right > 0.8 / f0 && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
+                break;
+            }
+            if (corr > 0.3 && (peak == 0.0 || peak > 0.01 * gp) && tmax - added_right > 0.8 / f0 && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
+        }
+        tmax = tsave;
+        for (int g2 = 0; g2 < 200000; ++g2) {                      // to the right
+            const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
+            if (!(f0 == f0)) break;
+            double peak, tout;
+            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, lane, &tout, &peak);
+            tmax = tout;
+            if (corr == -1.0) tmax += 1.0 / f0;
+            if (tmax > tright) {
+                if (corr > 0.7 && peak > 0.023333 * gp && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; added_right = tmax; }
+                break;
+            }
+            if (corr > 0.3 && (peak == 0.0 || peak > 0.01 * gp) && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; added_right = tmax; }
+        }
+        t = tright;
+    }
+    if (lane == 0) n_pulses[blockIdx.x] = np_;
+}
+
+// ---- _measureFormants statistics: F1, B1, F2, B2 linearly interpolated at every pulse ------------------------
+__global__ __launch_bounds__(64) void formant_stats_kernel(const FormantFrame* __restrict__ ff, const ClipInfo* __restrict__ fci,
+                                                           double fdt, const double* __restrict__ pulses, int max_pulses,
+                                                           const int* __restrict__ n_pulses, double* __restrict__ out) {
+    const ClipInfo c = fci[blockIdx.x];
+    const int lane = threadIdx.x, np_ = n_pulses[blockIdx.x], nF = c.n_frames;
+    const FormantFrame* F = ff + c.frame_off;
+    const double* pts = pulses + (int64_t)blockIdx.x * max_pulses;
+    const double qn = __longlong_as_double(0x7ff8000000000000LL);
+    double cnt[4] = {0, 0, 0, 0}, sum[4] = {0, 0, 0, 0};
+    auto value = [&](int k, double t) -> double {      // k: 0 F1, 1 B1, 2 F2, 3 B2
+        if (nF <= 0) return qn;
+        const double ireal = (t - c.t1) / fdt;
+        const int64_t ileft = (int64_t)floor(ireal);
+        double phase = ireal - (double)ileft;
+        int64_t inear, ifar;
+        if (phase < 0.5) { inear = ileft; ifar = ileft + 1; } else { inear = ileft + 1; ifar = ileft; phase = 1.0 - phase; }
+        if (inear < 0 || inear >= nF) return qn;
+        const int fi = k >> 1;
+        const double vn = (k & 1) ? F[inear].b[fi] : F[inear].f[fi];
+        if (!(vn == vn)) return qn;
+        if (ifar < 0 || ifar >= nF) return vn;
+        const double vf = (k & 1) ? F[ifar].b[fi] : F[ifar].f[fi];
+        if (!(vf == vf)) return vn;
+        return vn + phase * (vf - vn);
+    };
+    for (int i = lane; i < np_; i += 64)
+        for (int k = 0; k < 4; ++k) { const double v = value(k, pts[i]); if (v == v) { cnt[k] += 1; sum[k] += v; } }
+    double mean[4];
+    for (int k = 0; k < 4; ++k) { cnt[k] = wave_sum_f64(cnt[k]); sum[k] = wave_sum_f64(sum[k]); mean[k] = cnt[k] > 0 ? sum[k] / cnt[k] : qn; }
+    double sq[4] = {0, 0, 0, 0};
+    for (int i = lane; i < np_; i += 64)
+        for (int k = 0; k < 4; ++k) { const double v = value(k, pts[i]); if (v == v) { const double d = v - mean[k]; sq[k] += d * d; } }
+    for (int k = 0; k < 4; ++k) sq[k] = wave_sum_f64(sq[k]);
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k) {
+            out[blockIdx.x * 8 + 2 * k] = mean[k];
+            out[blockIdx.x * 8 + 2 * k + 1] = cnt[k] > 1 ? sqrt(sq[k] / (cnt[k] - 1)) : qn;
+        }
+}
+
 }  // namespace mshds
 }  // namespace rsaf
 
@@ -1096,6 +1496,61 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
     hipLaunchKernelGGL(speechrate_kernel, dim3(n_clips), dim3(64), lds, s, intensity_db, (const ClipInfo*)clip_info,
                        intensity_dt, sel_freq, (const ClipInfo*)pitch_clip_info, pitch_dt, pitch_ceiling, workspace,
                        rsaf_mshds_speechrate_workspace_doubles(max_frames), out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_resample10k(const float* wav, const void* resample_info, int n_clips, int max_out, const double* tables,
+                           const int* phase_base, int depth, double* out, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_out >= 0 && depth >= 1, "bad argument");
+    if (n_clips == 0 || max_out == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && resample_info && tables && phase_base && out, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("mshds_resample10k", s, 0.0, 0.0);
+    hipLaunchKernelGGL(resample_kernel, dim3((max_out + 255) / 256, n_clips), dim3(256), 0, s, wav,
+                       (const ResampleInfo*)resample_info, tables, phase_base, depth, out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_formants(const double* y10, const void* resample_info, const void* clip_info, int n_clips, int max_frames,
+                        const double* window, int nsamp_window, double time_step, double dx_out, double preemph_factor,
+                        void* frames_out, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_frames >= 0 && nsamp_window >= 16, "bad argument");
+    if (n_clips == 0 || max_frames == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(y10 && resample_info && clip_info && window && frames_out, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * 2 * (nsamp_window + 2) * sizeof(double);
+    RSAF_CHECK_ARG(lds <= 150 * 1024, "formant window too long");
+    if (lds > 48 * 1024)
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)formant_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof("mshds_formant_frames", s, 0.0, 0.0);
+    hipLaunchKernelGGL(formant_kernel, dim3((max_frames + 3) / 4, n_clips), dim3(256), lds, s, y10,
+                       (const ResampleInfo*)resample_info, (const ClipInfo*)clip_info, window, nsamp_window, time_step,
+                       dx_out, preemph_factor, (FormantFrame*)frames_out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips, const double* sel_freq, double pitch_dt,
+                      double pitch_ceiling, double* pulses, int max_pulses, int* n_pulses, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && max_pulses >= 1, "bad argument");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && pitch_clip_info && sel_freq && pulses && n_pulses, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("mshds_pulses", s, 0.0, 0.0);
+    hipLaunchKernelGGL(pulses_kernel, dim3(n_clips), dim3(64), 0, s, wav, (const ClipInfo*)pitch_clip_info, sel_freq,
+                       pitch_dt, pitch_ceiling, pulses, max_pulses, n_pulses);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_formant_stats(const void* frames, const void* clip_info, int n_clips, double time_step, const double* pulses,
+                             int max_pulses, const int* n_pulses, double* out, rsaf_stream_t stream) {
+    if (n_clips <= 0) return RSAF_OK;
+    RSAF_CHECK_ARG(frames && clip_info && pulses && n_pulses && out, "NULL pointer");
+    hipLaunchKernelGGL(formant_stats_kernel, dim3(n_clips), dim3(64), 0, (hipStream_t)stream, (const FormantFrame*)frames,
+                       (const ClipInfo*)clip_info, time_step, pulses, max_pulses, n_pulses, out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

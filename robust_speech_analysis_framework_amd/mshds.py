@@ -7,9 +7,9 @@ run as float64 HIP kernels (``csrc/mshds.hip``); the host only builds the frame 
 speaker-adapted pitch range that ``_pitch_values`` chooses (``:127-162``).
 
 Built so far: the five speech-rate/pausing columns, mean_F0, stdev_F0_Semitone, mean_dB,
-range_ratio_dB, HNR_dB, Spectral_Gravity, Spectral_Std_Dev, Spectral_Skewness, Spectral_Kurtosis.  The
-11 other columns are NaN until their kernels exist (LTAS slope/tilt, CPPS, formants): there is no CPU
-fallback.
+range_ratio_dB, HNR_dB, the eight F1/B1/F2/B2 statistics, Spectral_Gravity, Spectral_Std_Dev,
+Spectral_Skewness, Spectral_Kurtosis.  The 3 other columns are NaN until their kernels exist (LTAS
+slope/tilt, CPPS): there is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -34,11 +34,16 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                            # src/mshds_extractor.py:397-404
-BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24]
+BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 CLIP_INFO = np.dtype([("sample_off", "<i8"), ("frame_off", "<i8"), ("t1", "<f8"),
                       ("n_samples", "<i4"), ("n_frames", "<i4")])
 assert CLIP_INFO.itemsize == 32
+RESAMPLE_INFO = np.dtype([("sample_off", "<i8"), ("out_off", "<i8"), ("pos0", "<f8"), ("x1o", "<f8"),
+                          ("n_in", "<i4"), ("n_out", "<i4"), ("table", "<i4"), ("pad", "<i4")])
+assert RESAMPLE_INFO.itemsize == 48
+RS_DEPTH = 500
+RS_RATE = 10000.0
 
 
 def short_term_frames(n_samples: int, window_duration: float, time_step: float):
@@ -65,7 +70,7 @@ def _clip_info(sample_offs, lengths, grid):
 def _dev(arr, device):
     import torch
     a = np.ascontiguousarray(arr)
-    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device) if a.dtype == CLIP_INFO else \
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device) if a.dtype in (CLIP_INFO, RESAMPLE_INFO) else \
         torch.from_numpy(a).to(device)
 
 
@@ -251,6 +256,90 @@ class MshdsEngine:
                 "rsaf_mshds_spectral_moments")
         return {"stats": stats[:n], "moments": mom, "ci": ci, "fstep": fstep, "tstep": tstep}
 
+    def formants(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None):
+        """``_measureFormants`` (:303-338) -> float64 [n, 8] (mean/SD of F1, B1, F2, B2 at the pulses)."""
+        import torch
+        lib = _lib.load()
+        n = len(lengths)
+        dev = self.device
+        dxo = 1.0 / RS_RATE
+        ratio = RS_RATE / FS
+        ri = np.zeros(n, dtype=RESAMPLE_INFO)
+        tabs, bases, key_to_table = [], [], {}
+        out_off = 0
+        k = np.arange(-RS_DEPTH, RS_DEPTH + 1)
+        for i, (so, nn) in enumerate(zip(sample_offs, lengths)):
+            duration = nn * DX
+            m = int(math.floor(duration * RS_RATE + 0.5))
+            x1o = 0.5 * (duration - (m - 1) * dxo)
+            pos0 = (x1o - 0.5 * DX) / DX
+            if pos0 not in key_to_table:
+                key_to_table[pos0] = len(tabs)
+                rows, bs = [], []
+                for r in range(5):
+                    pr = pos0 + 1.6 * r
+                    b = int(math.floor(pr))
+                    d = (pr - b) - k
+                    w = ratio * np.sinc(ratio * d) * (0.5 + 0.5 * np.cos(np.pi * d / (RS_DEPTH + 1.0)))
+                    rows.append(np.where(np.abs(d) <= RS_DEPTH + 1.0, w, 0.0))
+                    bs.append(b)
+                tabs.append(np.stack(rows))
+                bases.append(bs)
+            ri[i] = (int(so), out_off, pos0, x1o, int(nn), m, key_to_table[pos0], 0)
+            out_off += m
+        max_out = int(ri["n_out"].max()) if n else 0
+        y10 = torch.empty(max(out_off, 1), dtype=torch.float64, device=dev)
+        out = torch.full((max(n, 1), 8), float("nan"), dtype=torch.float64, device=dev)
+        if n == 0:
+            return out[:0]
+        ri_d = _dev(ri, dev)
+        tab_d = torch.from_numpy(np.ascontiguousarray(np.stack(tabs)).reshape(-1)).to(dev)
+        base_d = torch.from_numpy(np.asarray(bases, dtype=np.int32).reshape(-1)).to(dev)
+        _lib.check(lib.rsaf_mshds_resample10k(_lib.ptr(wav), _lib.ptr(ri_d), n, max_out, _lib.ptr(tab_d), _lib.ptr(base_d),
+                                              RS_DEPTH, _lib.ptr(y10), _lib.stream_ptr(stream)), "rsaf_mshds_resample10k")
+        # Formant (burg): 5 ms, 5 formants, 5 kHz, 25 ms half-window, pre-emphasis from 50 Hz  (:319)
+        dt_window = 0.05
+        nsw = int(math.floor(dt_window / dxo))
+
+        def build():
+            i = np.arange(1, nsw + 1)
+            imid, edge = 0.5 * (nsw + 1), math.exp(-12.0)
+            return ((np.exp(-48.0 * (i - imid) ** 2 / (nsw + 1) ** 2) - edge) / (1.0 - edge),)
+        (win,) = self._table(("formant", nsw), build)
+        ci = np.zeros(n, dtype=CLIP_INFO)
+        foff = 0
+        for i in range(n):
+            m, x1o = int(ri[i]["n_out"]), float(ri[i]["x1o"])
+            duration = m * dxo
+            if dt_window > duration:
+                nf, t1 = 0, 0.0
+            else:
+                nf = int(math.floor((duration - dt_window) / frame_shift)) + 1
+                t1 = x1o - 0.5 * dxo + 0.5 * duration - 0.5 * nf * frame_shift + 0.5 * frame_shift
+            ci[i] = (int(ri[i]["out_off"]), foff, t1, m, nf)
+            foff += nf
+        mxf = int(ci["n_frames"].max())
+        frames = torch.empty(max(foff, 1) * 10, dtype=torch.float64, device=dev)
+        ci_d = _dev(ci, dev)
+        _lib.check(lib.rsaf_mshds_formants(_lib.ptr(y10), _lib.ptr(ri_d), _lib.ptr(ci_d), n, mxf, _lib.ptr(win), nsw,
+                                           frame_shift, dxo, math.exp(-2.0 * math.pi * 50.0 * dxo), _lib.ptr(frames),
+                                           _lib.stream_ptr(stream)), "rsaf_mshds_formants")
+        # To Pitch (cc) with parselmouth's defaults (:320) and the pulses (:321)
+        p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=frame_shift, floor=floor, ceiling=ceiling,
+                       periods=1.0, is_cc=True, refine_depth=70, stream=stream)
+        max_pulses = int(max(lengths) * DX * ceiling * 1.5) + 16
+        pulses = torch.empty(n * max_pulses, dtype=torch.float64, device=dev)
+        npul = torch.zeros(n, dtype=torch.int32, device=dev)
+        _lib.check(lib.rsaf_mshds_pulses(_lib.ptr(wav), _lib.ptr(p["ci_dev"]), n, _lib.ptr(p["sel_freq"]), p["geom"].dt,
+                                         p["geom"].ceiling, _lib.ptr(pulses), max_pulses, _lib.ptr(npul),
+                                         _lib.stream_ptr(stream)), "rsaf_mshds_pulses")
+        _lib.check(lib.rsaf_mshds_formant_stats(_lib.ptr(frames), _lib.ptr(ci_d), n, frame_shift, _lib.ptr(pulses),
+                                                max_pulses, _lib.ptr(npul), _lib.ptr(out), _lib.stream_ptr(stream)),
+                   "rsaf_mshds_formant_stats")
+        self._last_formants = {"frames": frames, "ci": ci, "pulses": pulses, "n_pulses": npul, "max_pulses": max_pulses,
+                               "y10": y10, "ri": ri, "pitch": p}
+        return out[:n]
+
     def hnr_mean(self, pitch_cc, stream=None):
         import torch
         n = len(pitch_cc["ci"])
@@ -307,6 +396,7 @@ class MshdsEngine:
                             voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700, stream=stream)  # :221
             hnr = self.hnr_mean(cc, stream)
             sm = self.spectral_moments(wav, so, ln, p, 0.025, 0.005, stream=stream)                          # :356
+            out[idx, 13:21] = self.formants(wav, so, ln, gp, floor, ceiling, 0.005, stream)                  # :441
             out[idx, 5] = p["stats"][:, 5]
             out[idx, 6] = p["stats"][:, 6]
             out[idx, 7] = inten["stats"][:, 0]

@@ -137,6 +137,39 @@ def test_speechrate_matches_oracle(eng):
     assert got[0][0] > 1.0 and 0.3 < got[0][2] <= 1.0            # syllables/s and phonation ratio are sensible
 
 
+def test_formants_resampler_pulses_and_statistics(eng):
+    """_measureFormants (:303-338): 10 kHz resampling, Burg + roots per frame, cc pulses, per-pulse stats."""
+    import torch
+    clips = [synth.synth_clip(170, 1.5), synth.synth_clip(171, 1.0003125)]       # 2nd: odd resampled length
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    got = eng.formants(wav, offs, lens, gp, 100.0, 500.0, 0.005)
+    torch.cuda.synchronize()
+    L = eng._last_formants
+    y10 = L["y10"].cpu().numpy()
+    fr = L["frames"].cpu().numpy().reshape(-1, 10)
+    pul = L["pulses"].cpu().numpy().reshape(len(clips), L["max_pulses"])
+    npul = L["n_pulses"].cpu().numpy()
+    for i, c in enumerate(clips):
+        yr, x1o, dxo = mo.resample_10k(c)
+        ri = L["ri"][i]
+        assert ri["n_out"] == len(yr) and abs(ri["x1o"] - x1o) < 1e-18
+        assert np.abs(y10[ri["out_off"]:ri["out_off"] + ri["n_out"]] - yr).max() < 1e-12
+        F, B, t1, dt = mo.formant_burg(c)
+        ci = L["ci"][i]
+        assert ci["n_frames"] == F.shape[0] and abs(ci["t1"] - t1) < 1e-15
+        g = fr[ci["frame_off"]:ci["frame_off"] + ci["n_frames"]]
+        assert np.array_equal(np.isnan(g[:, :5]), np.isnan(F))
+        ok = ~np.isnan(F)
+        assert np.abs(g[:, :5][ok] - F[ok]).max() < 1e-5 and np.abs(g[:, 5:][ok] - B[ok]).max() < 1e-5
+        p = mo.pitch_cc(c, 0.005, 100.0, 1.0, 15, 0.03, 0.45, 0.01, 0.35, 0.14, 500.0)
+        pts = mo.point_process_cc(c.astype(np.float64), p)
+        assert npul[i] == len(pts)                                               # integer-exact pulse count
+        assert np.abs(np.sort(pul[i, :npul[i]]) - pts).max() < 1e-9
+        ref = np.array(mo.measure_formants(c, 100, 500))
+        assert np.abs(got[i].cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-6, (got[i], ref)
+
+
 def test_extract_packed_matches_oracle_and_uses_both_speaker_ranges(eng):
     import torch
     ids = [140, 141, 142, 143, 144, 145]
