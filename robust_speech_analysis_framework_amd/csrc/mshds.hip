@@ -44,6 +44,7 @@ struct PitchParams {
     double refine_margin;   // > 0: only candidates within this margin of the best first-pass strength are refined
     int nsamp_window, half_window, nsamp_period, half_period, min_lag, max_lag, brent_ixmax, max_cand;
     int refine_depth, is_cc;
+    int debug_stop;         // profiling aid (env RSAF_PITCH_STOP): leave the frame kernel after phase k; 0 = run all
 };
 
 __device__ __forceinline__ int64_t low_index(double t) { return (int64_t)floor((t - 0.5 * DXS) / DXS); }
@@ -143,16 +144,38 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return r;
 }
 
-__device__ __forceinline__ double group16_sum(double v) {
-#pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 16);
-    return v;
+__device__ __forceinline__ double readlane_f64(double v, int l) {      // l must be wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// ---- sinc interpolation of an LDS array by a 16-lane group (Praat NUM_interpolate_sinc) ----------------
+// Sum over each aligned group of G lanes, result in every lane of the group.  The 16-lane part is four DPP
+// steps (xor 1, xor 2, half-row mirror, row mirror: VALU latency, no LDS crossbar); rows are then combined
+// through scalar registers.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);     // row_half_mirror
+    v += dpp_f64<0x140>(v);     // row_mirror
+    if (G == 16) return v;
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    if (G == 64) return (r0 + r1) + (r2 + r3);
+    return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
+}
+
+// ---- sinc interpolation of an LDS array by a G-lane group (Praat NUM_interpolate_sinc) -----------------
 // y: n samples (0-based); x: 0-based real position; only indices in [nz_lo, nz_hi] can be non-zero.
-// Every lane of the wave must call this (the four groups of a wave evaluate four different x).
-__device__ double sinc_group(const double* __restrict__ y, int n, double x, int depth, int nz_lo, int nz_hi, int l16) {
+// Every lane of the wave must call this (the 64/G groups of a wave evaluate different x).
+// RECUR: the raised-cosine window angle advances by a fixed step per term, so each lane rotates
+// (cos, sin) by the group stride instead of evaluating the polynomial per term (pays for long kernels).
+template <int G, bool RECUR>
+__device__ double sinc_group(const double* __restrict__ y, int n, double x, int depth, int nz_lo, int nz_hi, int lg) {
     const double x1 = x + 1.0;
     const int midleft = (int)floor(x1), midright = midleft + 1;
     const bool special = (x1 > n) | (x1 < 1) | (x1 == (double)midleft);
@@ -166,44 +189,56 @@ __device__ double sinc_group(const double* __restrict__ y, int n, double x, int 
     double acc = 0.0;
     const double a0l = PI * (x1 - midleft);               // in (0, pi) unless special
     const double hs = special ? 0.0 : 0.5 * sin_0_pi(a0l); // sin(pi - a) = sin(a): same for both halves
-    {   // left half: 1-based ix = midleft - k, k = 0..d-1; window angle (a0 + pi k)/den stays in (0, pi)
-        const double iden = fast_rcp(x1 - left + 1.0);
-        int kmax = d;                                         // skip the zero tail
-        if (midleft - 1 - (kmax - 1) < nz_lo) kmax = midleft - 1 - nz_lo + 1;
-        for (int k = l16; k < kmax; k += 16) {
-            const int idx = midleft - k - 1;
-            if (idx > nz_hi) continue;
-            const double a = a0l + PI * k;
-            const double w = ((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + cos_0_pi(a * iden));
-            acc += y[idx] * w;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        // left half: 1-based ix = midleft - k; right half: ix = midright + k; k = 0..d-1.  The window
+        // angle (a0 + pi k) / den stays in (0, pi).  [kmin, kmax) drops the all-zero parts of y.
+        const double a0 = half == 0 ? a0l : PI * (midright - x1);
+        const double iden = fast_rcp(half == 0 ? x1 - left + 1.0 : right - x1 + 1.0);
+        int kmin, kmax = d;
+        if (half == 0) {
+            kmin = midleft - 1 - nz_hi;
+            if (midleft - kmax < nz_lo) kmax = midleft - nz_lo;
+        } else {
+            kmin = nz_lo - midright + 1;
+            if (midright + kmax - 2 > nz_hi) kmax = nz_hi - midright + 2;
+        }
+        kmin = kmin < 0 ? 0 : kmin;
+        const int k0 = kmin + lg;
+        if (RECUR) {
+            const double th = (a0 + PI * k0) * iden, st = (PI * G) * iden;   // st < pi whenever a lane has 2+ terms
+            double c = cos_0_pi(fmin(th, PI)), sn = sin_0_pi(fmin(th, PI));
+            const double C = cos_0_pi(fmin(st, PI)), S = sin_0_pi(fmin(st, PI));
+            for (int k = k0; k < kmax; k += G) {
+                const int idx = half == 0 ? midleft - k - 1 : midright + k - 1;
+                const double a = a0 + PI * k;
+                acc += y[idx] * (((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + c));
+                const double c2 = c * C - sn * S;
+                sn = sn * C + c * S;
+                c = c2;
+            }
+        } else {
+            for (int k = k0; k < kmax; k += G) {
+                const int idx = half == 0 ? midleft - k - 1 : midright + k - 1;
+                const double a = a0 + PI * k;
+                acc += y[idx] * (((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + cos_0_pi(a * iden)));
+            }
         }
     }
-    {   // right half: ix = midright + k
-        const double a0 = PI * (midright - x1);
-        const double iden = fast_rcp(right - x1 + 1.0);
-        int kmax = d;
-        if (midright - 1 + (kmax - 1) > nz_hi) kmax = nz_hi - (midright - 1) + 1;
-        for (int k = l16; k < kmax; k += 16) {
-            const int idx = midright + k - 1;
-            if (idx < nz_lo) continue;
-            const double a = a0 + PI * k;
-            const double w = ((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + cos_0_pi(a * iden));
-            acc += y[idx] * w;
-        }
-    }
-    acc = group16_sum(acc);
+    acc = group_sum<G>(acc);
     return special ? y[si] : acc;
 }
 
 // Praat NUMimproveMaximum (sinc): Brent's minimiser in the netlib fminbr form on -sinc over [ix-1, ix+1],
-// tolerance sqrt(eps)*|x| + tol/3 on the 1-based position, <= 60 iterations.  One 16-lane group per
+// tolerance sqrt(eps)*|x| + tol/3 on the 1-based position, <= 60 iterations.  One G-lane group per
 // candidate; `live` = this group holds a real candidate (others just keep the wave's shuffles uniform).
+template <int G, bool RECUR>
 __device__ void improve_max_group(const double* __restrict__ y, int n, double ix0, int depth, int nz_lo, int nz_hi,
-                                  int l16, bool live, double& xm, double& ym) {
+                                  int lg, bool live, double& xm, double& ym) {
     const double SQRT_EPS = 1.4901161193847656e-08, TOL3 = 1e-10 / 3.0;
     double a = ix0 + 1.0 - 1.0, b = ix0 + 1.0 + 1.0;     // 1-based bracket
     double v = a + GOLD * (b - a);
-    double fv = -sinc_group(y, n, v - 1.0, depth, nz_lo, nz_hi, l16);
+    double fv = -sinc_group<G, RECUR>(y, n, v - 1.0, depth, nz_lo, nz_hi, lg);
     double x = v, w = v, fx = fv, fw = fv;
     bool active = live;
     for (int it = 0; it < 60; ++it) {
@@ -223,7 +258,7 @@ __device__ void improve_max_group(const double* __restrict__ y, int n, double ix
         }
         if (fabs(step) < tol_act) step = step > 0.0 ? tol_act : -tol_act;
         const double tt = x + step;
-        const double ft = -sinc_group(y, n, tt - 1.0, depth, nz_lo, nz_hi, l16);
+        const double ft = -sinc_group<G, RECUR>(y, n, tt - 1.0, depth, nz_lo, nz_hi, lg);
         if (active) {
             if (ft <= fx) {
                 if (tt < x) b = x; else a = x;
@@ -249,6 +284,68 @@ struct FrameOut {     // per frame, written contiguously: intensity, ncand, freq
     double strength[MAXC];
 };
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+// doubles of the region shared by the skewed window copy and the per-wave partial correlations
+__host__ __device__ inline int pitch_part_doubles(int nw, int L) {
+    const int a = 4 * 256 * ((L + 256) / 256), b = nw + (nw >> 4) + 2;
+    return (a > b ? a : b + (b & 1));
+}
+
+// One wave's share [s0, s1) of the k steps of one 256-lag tile.  Four steps per trip with all eight operand
+// loads issued ahead of the four MFMAs, two accumulators so consecutive MFMAs do not depend on each other.
+// Operand indices: A reads seg[y0 + 4 s] (zero at and beyond seg_len), B reads window sample x0 + 4 s
+// (zero outside [0, nw)) from the skewed copy.  Loads are unconditional from clamped addresses.
+__device__ __forceinline__ double4_t corr_tile(const double* __restrict__ seg, const double* __restrict__ xs, int seg_len,
+                                               int nw, int y0, int x0, int s0, int s1) {
+    double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+    auto ld_a = [&](int st) {
+        const int yi = y0 + 4 * st;
+        const double v = seg[yi < seg_len ? yi : seg_len - 1];
+        return yi < seg_len ? v : 0.0;
+    };
+    auto ld_b = [&](int st) {
+        const int xi = x0 + 4 * st;
+        const int xc = xi < 0 ? 0 : (xi < nw ? xi : nw - 1);
+        const double v = xs[xc + (xc >> 4)];
+        return (xi >= 0 && xi < nw) ? v : 0.0;
+    };
+    int st = s0;
+    for (; st + 4 <= s1; st += 4) {
+        const double a0 = ld_a(st), a1 = ld_a(st + 1), a2 = ld_a(st + 2), a3 = ld_a(st + 3);
+        const double b0 = ld_b(st), b1 = ld_b(st + 1), b2 = ld_b(st + 2), b3 = ld_b(st + 3);
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, c1, 0, 0, 0);
+    }
+    for (; st < s1; ++st) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_a(st), ld_b(st), c0, 0, 0, 0);
+    return c0 + c1;
+}
+
+struct RefineArgs {
+    const double* r; int RN, RC, depth, nz_lo, nz_hi, ncand; double margin;
+    const int* place; double* cf; double* cs;
+};
+// refine every kept candidate: maximise the sinc-interpolated correlation, 256/G candidates per round.
+// With every path cost zero (harmonicity pass) a candidate far below the best first-pass strength could
+// be left unrefined (margin > 0); that is off by default because it moved a few frames' selection.
+template <int G, bool RECUR>
+__device__ void refine_candidates(const RefineArgs& A, int tid) {
+    const int lane = tid & 63, lg = lane & (G - 1), gidx = (tid >> 6) * (64 / G) + lane / G;
+    double best_first = 0.0;
+    for (int k = 1; k < A.ncand; ++k) best_first = fmax(best_first, A.cs[k]);
+    __syncthreads();
+    for (int kb = 1; kb < A.ncand; kb += 256 / G) {
+        const int k = kb + gidx;
+        const bool live = k < A.ncand && (A.margin <= 0.0 || A.cs[k < A.ncand ? k : 1] >= best_first - A.margin);
+        double xm, ym;
+        improve_max_group<G, RECUR>(A.r, A.RN, (double)(A.place[live ? k : 1] + A.RC), A.depth, A.nz_lo, A.nz_hi, lg,
+                                    live, xm, ym);
+        if (ym > 1.0) ym = 1.0 / ym;
+        if (live && lg == 0) { A.cf[k] = 1.0 / DXS / (xm - A.RC); A.cs[k] = ym; }
+    }
+}
+
 __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                           const double* __restrict__ gpeak, const double* __restrict__ win,
                                                           const double* __restrict__ wr, const PitchParams P,
@@ -262,6 +359,7 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     const int seg_len = P.is_cc ? nw + P.max_lag + 1 : nw;
     const int RC = P.brent_ixmax;                   // centre index of r
     const int RN = 2 * P.brent_ixmax + 1;
+    const int part_doubles = pitch_part_doubles(nw, L);
     // all LDS lives in the dynamic region (keeps every double 8-byte aligned, guide G17)
     double* seg = reinterpret_cast<double*>(smem_raw);
     double* r = seg + ((seg_len + 1) & ~1);
@@ -269,15 +367,25 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     double* s_val = s_red + 4;                      // [4]
     double* s_mfreq = s_val + 4;                    // [MAX_MAXIMA]
     double* s_mstr = s_mfreq + MAX_MAXIMA;          // [MAX_MAXIMA]
-    double* s_cf = s_mstr + MAX_MAXIMA;             // [MAXC]
+    double* s_mloc = s_mstr + MAX_MAXIMA;           // [MAX_MAXIMA] strength - octave cost (Praat's "local strength")
+    double* s_cf = s_mloc + MAX_MAXIMA;             // [MAXC]
     double* s_cs = s_cf + MAXC;                     // [MAXC]
-    int* s_maxlag = reinterpret_cast<int*>(s_cs + MAXC);   // [MAX_MAXIMA]
+    double* s_cloc = s_cs + MAXC;                   // [MAXC]
+    int* s_maxlag = reinterpret_cast<int*>(s_cloc + MAXC);   // [MAX_MAXIMA]
     int* s_place = s_maxlag + MAX_MAXIMA;           // [MAXC]
     int* s_cnt = s_place + MAXC;                    // [0] = nmax, [1] = ncand
-    double* s_part = reinterpret_cast<double*>(s_cnt + 4);   // [4][4 * ngroups] partial correlations
+    double* s_part = reinterpret_cast<double*>(s_cnt + 4);   // [4][256 * NT] partial correlations of the four waves
+    double* xs = s_part;                                     // skewed copy of seg[0, nw) until the partials are written
 #define s_nmax s_cnt[0]
 #define s_ncand s_cnt[1]
 
+    FrameOut* o = out + c.frame_off + f;
+#define RSAF_PITCH_DBG_STOP(k)                                                                       \
+    if (P.debug_stop == (k)) {                                                                       \
+        if (tid == 0) { o->intensity = 0.0; o->ncand = 1.0; }                                        \
+        if (tid < MAXC) { o->freq[tid] = 0.0; o->strength[tid] = 0.0; }                              \
+        return;                                                                                      \
+    }
     const float* x = wav + c.sample_off;
     const int n = c.n_samples;
     const double t = c.t1 + f * P.dt;
@@ -324,6 +432,7 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     __syncthreads();
     // local peak over half a longest period around the window centre
     {
+        for (int j = tid; j < nw; j += 256) xs[j + (j >> 4)] = seg[j];
         int a = P.half_window - P.half_period, b = P.half_window + P.half_period;
         a = a < 0 ? 0 : a;
         b = b > nw ? nw : b;
@@ -337,36 +446,48 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     const double gp = gpeak[blockIdx.y];
     const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
 
-    // ---- correlation: 4 consecutive lags per thread, the sample range split over `parts` threads ----
-    const int ngroups = (L + 4) / 4;                   // lags 0..L
-    int parts = 256 / ngroups;
-    parts = parts < 1 ? 1 : (parts > 4 ? 4 : parts);
-    const int pstride = 4 * ngroups;
-    for (int w = tid; w < ngroups * parts; w += 256) {
-        const int g = w % ngroups, part = w / ngroups;
-        const int l0 = 4 * g;
-        const int lim = P.is_cc ? seg_len : nw;         // valid indices of seg for the shifted operand
-        const int jtot = P.is_cc ? nw : nw - l0;        // pairs (j, j+lag) that exist for the smallest lag
-        const int j0 = (int)((int64_t)jtot * part / parts), j1 = (int)((int64_t)jtot * (part + 1) / parts);
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        double y0 = (j0 + l0 < lim) ? seg[j0 + l0] : 0.0, y1 = (j0 + l0 + 1 < lim) ? seg[j0 + l0 + 1] : 0.0,
-               y2 = (j0 + l0 + 2 < lim) ? seg[j0 + l0 + 2] : 0.0;
-        for (int j = j0; j < j1; ++j) {
-            const double xj = seg[j];
-            const double y3 = (j + l0 + 3 < lim) ? seg[j + l0 + 3] : 0.0;
-            a0 += xj * y0; a1 += xj * y1; a2 += xj * y2; a3 += xj * y3;
-            y0 = y1; y1 = y2; y2 = y3;
+    RSAF_PITCH_DBG_STOP(1)
+    // ---- correlation on the fp64 matrix pipe ----
+    // R[m + 16 n + 256 tile] = sum_j' seg[j' + m] * xm[j' - 16 n - 256 tile], xm = seg restricted to [0, nw):
+    // a 16 x 16 tile of lags per v_mfma_f64_16x16x4_f64 with j' as the k dimension (A[m][k] = seg[j'+m] is read
+    // straight from `seg`; B[k][n] has a lane stride of 16 samples and is read from the copy `xs`, skewed by
+    // one element per 16 so that the 16 lanes of a row hit 16 different bank pairs).  The four waves split j'.
+    // D layout (probed by tools/mfma_f64_layout.hip): lane l, register v -> row l/16 + 4 v, column l%16.
+    const int NT = (L + 256) / 256;                      // 256-lag tiles covering lags 0..L  (<= 4)
+    const int pstride = 256 * NT;
+    {
+        const int kq = lane >> 4, nn = lane & 15;
+        double4_t acc[4];
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            acc[tile] = double4_t{0.0, 0.0, 0.0, 0.0};
+            if (tile < NT) {
+                const int j_lo = 256 * tile;
+                int j_hi = nw + 240 + 256 * tile;
+                j_hi = j_hi < seg_len ? j_hi : seg_len;
+                const int steps = j_hi > j_lo ? (j_hi - j_lo + 3) / 4 : 0;
+                const int s0 = steps * wv / 4, s1 = steps * (wv + 1) / 4;
+                acc[tile] = corr_tile(seg, xs, seg_len, nw, j_lo + kq + nn, kq - 16 * nn, s0, s1);
+            }
         }
-        double* dst = s_part + part * pstride + l0;
-        dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+        __syncthreads();                                  // every wave is done with xs (it aliases s_part)
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            if (tile < NT) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    s_part[wv * pstride + 256 * tile + kq + 4 * v + 16 * nn] = acc[tile][v];
+            }
+        }
     }
     __syncthreads();
     for (int l = tid; l <= L; l += 256) {
         double v = 0.0;
-        for (int q = 0; q < parts; ++q) v += s_part[q * pstride + l];
+        for (int q = 0; q < 4; ++q) v += s_part[q * pstride + l];
         r[RC + l] = v;                                   // raw sums for now
     }
     __syncthreads();
+    RSAF_PITCH_DBG_STOP(2)
     // ---- normalise ----
     if (!P.is_cc) {
         const double r0 = r[RC];
@@ -380,10 +501,28 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     } else {
         const double sumx2 = r[RC];
         __syncthreads();
-        // sumy2(lag) = sum_{j=lag}^{lag+nw-1} seg[j]^2 : running update done serially per thread range
+        // sumy2(lag) = sum_{j=lag}^{lag+nw-1} seg[j]^2 = csq[lag+nw] - csq[lag] with the exclusive prefix sums
+        // csq[j] = sum_{i<j} seg[i]^2 (block scan; the O(L*nw) direct loop was a quarter of this kernel)
+        double* csq = s_part + part_doubles;                 // [seg_len + 1]
+        {
+            const int C = (seg_len + 255) / 256;
+            const int j0 = tid * C, j1 = (j0 + C < seg_len) ? j0 + C : seg_len;
+            double loc = 0.0;
+            for (int j = j0; j < j1; ++j) loc += seg[j] * seg[j];
+            double inc = loc;                                 // inclusive scan inside the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
+            if (lane == 63) s_red[wv] = inc;
+            __syncthreads();
+            double off = inc - loc;
+            for (int q = 0; q < wv; ++q) off += s_red[q];
+            double run = off;
+            for (int j = j0; j < j1; ++j) { csq[j] = run; run += seg[j] * seg[j]; }
+            if (j1 == seg_len && j0 < seg_len) csq[seg_len] = run;
+        }
+        __syncthreads();
         for (int l = 1 + tid; l <= L; l += 256) {
-            double sy = 0.0;
-            for (int j = l; j < l + nw; ++j) sy += seg[j] * seg[j];
+            const double sy = csq[l + nw] - csq[l];
             const double den = sumx2 * sy;
             const double v = (l <= loc_max_lag && den > 0.0) ? r[RC + l] / sqrt(den) : 0.0;
             r[RC + l] = v;
@@ -414,6 +553,7 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
         if (lane == 0) s_nmax = count < MAX_MAXIMA ? count : MAX_MAXIMA;
     }
     __syncthreads();
+    RSAF_PITCH_DBG_STOP(3)
     const int nmax = s_nmax;
     const int nz_lo = RC - L, nz_hi = RC + L;
     // ---- first estimate of every maximum: parabolic position, sinc(30) strength (16 maxima per round) ----
@@ -425,11 +565,12 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
         const double y0 = r[RC + l - 1], y1 = r[RC + l], y2 = r[RC + l + 1];
         const double dr = 0.5 * (y2 - y0), d2r = 2.0 * y1 - y0 - y2;
         const double fm = 1.0 / DXS / (l + dr / d2r);
-        double st = sinc_group(r, RN, RC + 1.0 / DXS / fm, 30, nz_lo, nz_hi, l16);
+        double st = sinc_group<16, false>(r, RN, RC + 1.0 / DXS / fm, 30, nz_lo, nz_hi, l16);
         if (st > 1.0) st = 1.0 / st;
-        if (live && l16 == 0) { s_mfreq[m] = fm; s_mstr[m] = st; }
+        if (live && l16 == 0) { s_mfreq[m] = fm; s_mstr[m] = st; s_mloc[m] = st - P.octave_cost * log2(P.min_pitch / fm); }
     }
     __syncthreads();
+    RSAF_PITCH_DBG_STOP(4)
     // ---- candidate list with replacement of the weakest (thread 0, sequential as in Praat) ----
     if (tid == 0) {
         int nc = 1;
@@ -442,33 +583,33 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
                 double weakest = 2.0;
                 place = 0;
                 for (int z = 1; z < P.max_cand; ++z) {
-                    const double loc = s_cs[z] - P.octave_cost * log2(P.min_pitch / s_cf[z]);
+                    const double loc = s_cloc[z];
                     if (loc < weakest) { weakest = loc; place = z; }
                 }
-                if (s_mstr[m] - P.octave_cost * log2(P.min_pitch / s_mfreq[m]) <= weakest) place = 0;
+                if (s_mloc[m] <= weakest) place = 0;
             }
-            if (place) { s_cf[place] = s_mfreq[m]; s_cs[place] = s_mstr[m]; s_place[place] = s_maxlag[m]; }
+            if (place) { s_cf[place] = s_mfreq[m]; s_cs[place] = s_mstr[m]; s_cloc[place] = s_mloc[m]; s_place[place] = s_maxlag[m]; }
         }
         s_ncand = nc;
     }
     __syncthreads();
     const int ncand = s_ncand;
+    RSAF_PITCH_DBG_STOP(5)
     // ---- refine every kept candidate: maximise the sinc-interpolated correlation (16 at a time) ----
     // With every path cost zero (harmonicity pass) the path finder picks the strongest candidate of each
     // frame on its own, so a candidate far below the best first-pass strength can never be selected and
     // is left unrefined (the depth-30 and refined strengths differ by far less than the margin).
-    double best_first = 0.0;
-    for (int k = 1; k < ncand; ++k) best_first = fmax(best_first, s_cs[k]);
-    for (int kb = 1; kb < ncand; kb += 16) {
-        const int k = kb + gidx;
-        const bool live = k < ncand && (P.refine_margin <= 0.0 || s_cs[k < ncand ? k : 1] >= best_first - P.refine_margin);
-        double xm, ym;
-        improve_max_group(r, RN, (double)(s_place[live ? k : 1] + RC), P.refine_depth, nz_lo, nz_hi, l16, live, xm, ym);
-        if (ym > 1.0) ym = 1.0 / ym;
-        if (live && l16 == 0) { s_cf[k] = 1.0 / DXS / (xm - RC); s_cs[k] = ym; }
+    // Lanes per candidate follow the candidate count (uniform per frame): few candidates (the usual AC case)
+    // get a whole wave each, a full list gets 16 lanes each, so one or two rounds cover every frame.
+    {
+        const int nref = ncand - 1;
+        const int span = P.refine_depth < 2 * L ? P.refine_depth : 2 * L;    // longest half kernel
+        RefineArgs A{r, RN, RC, P.refine_depth, nz_lo, nz_hi, ncand, P.refine_margin, s_place, s_cf, s_cs};
+        if (nref <= 4) { if (span >= 6 * 64) refine_candidates<64, true>(A, tid); else refine_candidates<64, false>(A, tid); }
+        else if (nref <= 8) { if (span >= 6 * 32) refine_candidates<32, true>(A, tid); else refine_candidates<32, false>(A, tid); }
+        else { if (span >= 6 * 16) refine_candidates<16, true>(A, tid); else refine_candidates<16, false>(A, tid); }
     }
     __syncthreads();
-    FrameOut* o = out + c.frame_off + f;
     if (tid == 0) {
         o->intensity = intensity;
         o->ncand = gp > 0.0 ? (double)ncand : 1.0;
@@ -481,6 +622,9 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
 }
 
 // ---- Viterbi path finder: one wave per clip (lane = candidate of the current frame) -------------------
+struct PathIn { double nc, fq, st, inten; };
+struct PathNode { double delta, logf; int vl, valid; };
+
 __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ fr, const ClipInfo* __restrict__ ci,
                                                   double dt, double silence_thr, double voicing_thr, double octave_cost,
                                                   double octave_jump_cost, double vuv_cost, double ceiling,
@@ -494,36 +638,47 @@ __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ f
     const double corr = 0.01 / dt;
     const double ojc = octave_jump_cost * corr, vuc = vuv_cost * corr;
     const int cl = lane < MAXC ? lane : MAXC - 1;
-    double cur = -1e300, prev_logf = 0.0;
-    int prev_vl = 1, prev_valid = 0;
-    for (int f = 0; f < nF; ++f) {
-        const int nc = (int)F[f].ncand;
-        const double fq = F[f].freq[cl], st = F[f].strength[cl];
-        const int valid = lane < nc;
-        const int vl = !(fq > 0.0 && fq < ceiling);
-        double unv = silence_thr <= 0.0 ? 0.0 : 2.0 - F[f].intensity / (silence_thr / (1.0 + voicing_thr));
+    // The only loop-carried chain is `cur`; the frame's own costs (two log2 per lane) are computed one frame
+    // ahead and its loads are issued two frames ahead so that neither sits on the chain.
+    auto load = [&](int f) {
+        f = f < nF ? f : nF - 1;
+        return PathIn{F[f].ncand, F[f].freq[cl], F[f].strength[cl], F[f].intensity};
+    };
+    auto derive = [&](const PathIn& in) {
+        PathNode nd;
+        nd.valid = lane < (int)in.nc;
+        nd.vl = !(in.fq > 0.0 && in.fq < ceiling);
+        double unv = silence_thr <= 0.0 ? 0.0 : 2.0 - in.inten / (silence_thr / (1.0 + voicing_thr));
         unv = voicing_thr + fmax(0.0, unv);
-        const double delta = valid ? (vl ? unv : st - octave_cost * log2(ceiling / fq)) : -1e300;
-        const double logf = vl ? 0.0 : log2(fq);
+        nd.delta = nd.valid ? (nd.vl ? unv : in.st - octave_cost * log2(ceiling / in.fq)) : -1e300;
+        nd.logf = nd.vl ? 0.0 : log2(in.fq);
+        return nd;
+    };
+    PathNode nd = derive(load(0));
+    PathIn in1 = load(1);
+    double cur = nd.delta, prev_logf = nd.logf;
+    int prev_vl = nd.vl, prev_valid = nd.valid;
+    if (lane < MAXC) P[lane] = 0;
+    for (int f = 1; f < nF; ++f) {
+        const PathIn in2 = load(f + 1);
+        nd = derive(in1);
+        in1 = in2;
         double best = -INFINITY;
         int place = 0;
-        if (f == 0) {
-            best = delta;
-        } else {
-            for (int c1 = 0; c1 < MAXC; ++c1) {
-                const double pc = __shfl(cur, c1, 64);
-                const double pl = __shfl(prev_logf, c1, 64);
-                const int pv = __shfl(prev_vl, c1, 64);
-                const int pval = __shfl(prev_valid, c1, 64);
-                const double tc = (pv && vl) ? 0.0 : ((pv || vl) ? vuc : ojc * fabs(pl - logf));
-                const double v = pval ? pc - tc + delta : -INFINITY;
-                if (v > best) { best = v; place = c1; }
-            }
-            if (!valid) best = -1e300;
+#pragma unroll
+        for (int c1 = 0; c1 < MAXC; ++c1) {
+            const double pc = readlane_f64(cur, c1);
+            const double pl = readlane_f64(prev_logf, c1);
+            const int pv = __builtin_amdgcn_readlane(prev_vl, c1);
+            const int pval = __builtin_amdgcn_readlane(prev_valid, c1);
+            const double tc = (pv && nd.vl) ? 0.0 : ((pv || nd.vl) ? vuc : ojc * fabs(pl - nd.logf));
+            const double v = pval ? pc - tc + nd.delta : -INFINITY;
+            if (v > best) { best = v; place = c1; }
         }
+        if (!nd.valid) best = -1e300;
         if (lane < MAXC) P[(int64_t)f * MAXC + lane] = (unsigned char)place;
         cur = best;
-        prev_logf = logf; prev_vl = vl; prev_valid = valid;
+        prev_logf = nd.logf; prev_vl = nd.vl; prev_valid = nd.valid;
     }
     // best end state: first maximum
     double bv = lane < MAXC ? cur : -INFINITY;
@@ -537,20 +692,44 @@ __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ f
     if (lane == 0) end_state[blockIdx.x] = bi;
 }
 
-// backtrack in its own launch: the kernel boundary makes the psi stores of path_kernel visible
-__global__ __launch_bounds__(64) void backtrack_kernel(const FrameOut* __restrict__ fr, const ClipInfo* __restrict__ ci,
-                                                       const unsigned char* __restrict__ psi,
-                                                       const int* __restrict__ end_state, double* __restrict__ sel_freq,
-                                                       double* __restrict__ sel_strength) {
+// backtrack in its own launch: the kernel boundary makes the psi stores of path_kernel visible.
+// The back-pointer walk is a dependent chain of byte loads, so the table is staged in LDS chunk by chunk
+// (from the last frame backwards), one thread walks the chunk, then all threads gather the selected values.
+constexpr int BT_CHUNK = 3072;
+__global__ __launch_bounds__(256) void backtrack_kernel(const FrameOut* __restrict__ fr, const ClipInfo* __restrict__ ci,
+                                                        const unsigned char* __restrict__ psi,
+                                                        const int* __restrict__ end_state, double* __restrict__ sel_freq,
+                                                        double* __restrict__ sel_strength) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_psi[BT_CHUNK * MAXC];
+    __shared__ unsigned char s_state[BT_CHUNK];
+    __shared__ int s_carry;
     const ClipInfo c = ci[blockIdx.x];
-    if (threadIdx.x != 0 || c.n_frames <= 0) return;
+    if (c.n_frames <= 0) return;
+    const int tid = threadIdx.x;
     const FrameOut* F = fr + c.frame_off;
     const unsigned char* P = psi + c.frame_off * MAXC;
-    int s = end_state[blockIdx.x];
-    for (int f = c.n_frames - 1; f >= 0; --f) {
-        sel_freq[c.frame_off + f] = F[f].freq[s];
-        sel_strength[c.frame_off + f] = F[f].strength[s];
-        if (f > 0) s = P[(int64_t)f * MAXC + s];
+    if (tid == 0) s_carry = end_state[blockIdx.x];
+    for (int hi = c.n_frames; hi > 0; hi -= BT_CHUNK) {        // frames [lo, hi)
+        const int lo = hi > BT_CHUNK ? hi - BT_CHUNK : 0, cnt = hi - lo;
+        const uint4* src = reinterpret_cast<const uint4*>(P + (int64_t)lo * MAXC);   // MAXC == 16 bytes per frame
+        uint4* dst = reinterpret_cast<uint4*>(s_psi);
+        for (int i = tid; i < cnt; i += 256) dst[i] = src[i];
+        __syncthreads();
+        if (tid == 0) {
+            int s = s_carry;                                    // state of frame hi-1
+            for (int f = cnt - 1; f >= 0; --f) {
+                s_state[f] = (unsigned char)s;
+                if (lo + f > 0) s = s_psi[f * MAXC + s];        // state of frame lo+f-1
+            }
+            s_carry = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256) {
+            const int st = s_state[i];
+            sel_freq[c.frame_off + lo + i] = F[lo + i].freq[st];
+            sel_strength[c.frame_off + lo + i] = F[lo + i].strength[st];
+        }
+        __syncthreads();
     }
 }
 
@@ -861,7 +1040,7 @@ __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict
             const int k = b + grp;
             const bool live = k < npk;
             double xm, ym;
-            improve_max_group(y, n, (double)pk[live ? k : 0], 70, 0, n - 1, l16, live, xm, ym);
+            improve_max_group<16, false>(y, n, (double)pk[live ? k : 0], 70, 0, n - 1, l16, live, xm, ym);
             if (live && l16 == 0) srt[k] = xm;
         }
     }
@@ -1000,26 +1179,45 @@ struct ResampleInfo {        // per clip (host-built), 48 bytes
     int pad;
 };
 
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ wav, const ResampleInfo* __restrict__ ri,
+// 320-thread workgroup = 64 consecutive q x 5 phases (wave r owns phase r, so its weight row is a wave-
+// uniform LDS broadcast); the input tile is staged once in LDS as float with a 33/32 skew so that the
+// stride-8 reads of a wave fall on 32 different banks.
+constexpr int RS_QT = 64;
+__global__ __launch_bounds__(320) void resample_kernel(const float* __restrict__ wav, const ResampleInfo* __restrict__ ri,
                                                        const double* __restrict__ tables,
                                                        const int* __restrict__ phase_base, int depth,
                                                        double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const ResampleInfo c = ri[blockIdx.y];
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= c.n_out) return;
-    const float* x = wav + c.sample_off;
-    // m = 5q + r  ->  position pos0 + 8q + 1.6r: integer part 8q + floor(pos0 + 1.6r) (host table), so the
-    // tap alignment is integer-exact and the 5 fractional offsets select the weight row
-    const int q = m / 5, r = m - 5 * q;
-    const int base = 8 * q + phase_base[c.table * 5 + r];
+    const int q0 = blockIdx.x * RS_QT;
+    if (5 * q0 >= c.n_out) return;
     const int taps = 2 * depth + 1;
-    const double* w = tables + ((int64_t)c.table * 5 + r) * taps;
+    double* wl = reinterpret_cast<double*>(smem_raw);                 // [5][taps]
+    float* xs = reinterpret_cast<float*>(wl + 5 * taps);             // skewed input tile
+    const int tid = threadIdx.x;
+    const int* pb = phase_base + c.table * 5;
+    int bmin = pb[0], bmax = pb[0];
+    for (int r = 1; r < 5; ++r) { bmin = min(bmin, pb[r]); bmax = max(bmax, pb[r]); }
+    const int lo = 8 * q0 + bmin - depth;                             // first input index of the tile
+    const int span = 8 * (RS_QT - 1) + (bmax - bmin) + taps;
+    const double* wg = tables + (int64_t)c.table * 5 * taps;
+    for (int i = tid; i < 5 * taps; i += 320) wl[i] = wg[i];
+    const float* x = wav + c.sample_off;
+    for (int i = tid; i < span; i += 320) {
+        const int j = lo + i;
+        xs[i + (i >> 5)] = (j >= 0 && j < c.n_in) ? x[j] : 0.0f;
+    }
+    __syncthreads();
+    const int r = tid >> 6, ql = tid & 63;
+    const int m = 5 * (q0 + ql) + r;
+    const double* w = wl + r * taps;
+    const int i0 = 8 * ql + pb[r] - bmin;                             // tile index of tap 0
     double acc = 0.0;
     for (int k = 0; k < taps; ++k) {
-        const int j = base - depth + k;
-        if (j >= 0 && j < c.n_in) acc += (double)x[j] * w[k];
+        const int i = i0 + k;
+        acc += (double)xs[i + (i >> 5)] * w[k];
     }
-    out[c.out_off + m] = acc;
+    if (m < c.n_out) out[c.out_off + m] = acc;
 }
 
 // ---- Formant (burg): one wave per frame -----------------------------------------------------------------------
@@ -1203,23 +1401,47 @@ __device__ double pitch_value_at(const double* __restrict__ f, int n, double t1,
 }
 
 // Sound_findMaximumCorrelation with the shifts spread over the lanes; returns corr, *tout, *peak (uniform)
+constexpr int PULSE_LDS = 1536;
 __device__ double max_correlation_wave(const float* __restrict__ x, int n, double t1, double window, double tmin2,
-                                       double tmax2, int lane, double* tout, double* peak) {
+                                       double tmax2, int lane, double* tout, double* peak, float* ps1, float* ps2) {
     const double half = 0.5 * window;
     const int64_t ileft1 = (int64_t)floor((t1 - half - 0.5 * DXS) / DXS + 0.5);
     const int64_t iright1 = (int64_t)floor((t1 + half - 0.5 * DXS) / DXS + 0.5);
     const int64_t l2min = low_index(tmin2 - half);
     const int64_t l2max = (int64_t)ceil((tmax2 - half - 0.5 * DXS) / DXS);
     double best = -1.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r1b = 0.0, r3b = 0.0, ir = 0.0, pk = 0.0;
+    // stage the fixed window and the union of the shifted windows in LDS (float): every lane then reads
+    // the fixed window as a broadcast and its own shifted window with unit stride
+    const int wlen = (int)(iright1 - ileft1 + 1);
+    const int slen = (int)(l2max - l2min) + wlen;
+    const bool staged = wlen > 0 && wlen <= PULSE_LDS && slen > 0 && slen <= PULSE_LDS;
+    if (staged) {
+        for (int i = lane; i < wlen; i += 64) { const int64_t j = ileft1 + i; ps1[i] = (j >= 0 && j < n) ? x[j] : 0.0f; }
+        for (int i = lane; i < slen; i += 64) { const int64_t j = l2min + i; ps2[i] = (j >= 0 && j < n) ? x[j] : 0.0f; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     for (int64_t b = l2min; b <= l2max; b += 64) {
         const int64_t ileft2 = b + lane;
         double norm1 = 0.0, norm2 = 0.0, prod = 0.0, lp = 0.0;
         if (ileft2 <= l2max) {
-            for (int64_t i1 = ileft1, i2 = ileft2; i1 <= iright1; ++i1, ++i2) {
-                if (i1 < 0 || i1 >= n || i2 < 0 || i2 >= n) continue;
-                const double a1 = x[i1], a2 = x[i2];
-                norm1 += a1 * a1; norm2 += a2 * a2; prod += a1 * a2;
-                lp = fmax(lp, fabs(a2));
+            if (staged) {
+                const int o2 = (int)(ileft2 - l2min);
+                for (int i = 0; i < wlen; ++i) {
+                    const int64_t i1 = ileft1 + i, i2 = ileft2 + i;
+                    if (i1 < 0 || i1 >= n || i2 < 0 || i2 >= n) continue;      // Praat skips pairs outside the sound
+                    const double a1 = ps1[i], a2 = ps2[o2 + i];
+                    norm1 += a1 * a1; norm2 += a2 * a2; prod += a1 * a2;
+                    lp = fmax(lp, fabs(a2));
+                }
+            } else {
+                for (int64_t i1 = ileft1, i2 = ileft2; i1 <= iright1; ++i1, ++i2) {
+                    if (i1 < 0 || i1 >= n || i2 < 0 || i2 >= n) continue;
+                    const double a1 = x[i1], a2 = x[i2];
+                    norm1 += a1 * a1; norm2 += a2 * a2; prod += a1 * a2;
+                    lp = fmax(lp, fabs(a2));
+                }
             }
         }
         const double rr = prod != 0.0 ? prod / sqrt(norm1 * norm2) : 0.0;
@@ -1284,6 +1506,7 @@ __device__ double find_extremum_wave(const float* __restrict__ x, int n, double 
 __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ pci,
                                                     const double* __restrict__ sel_freq, double pdt, double ceiling,
                                                     double* __restrict__ pulses, int max_pulses, int* __restrict__ n_pulses) {
+    __shared__ float ps1[PULSE_LDS], ps2[PULSE_LDS];
     const ClipInfo c = pci[blockIdx.x];
     const int lane = threadIdx.x;
     const float* x = wav + c.sample_off;
@@ -1318,7 +1541,7 @@ __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wa
             const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
             if (!(f0 == f0)) break;
             double peak, tout;
-            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, lane, &tout, &peak);
+            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, lane, &tout, &peak, ps1, ps2);
             tmax = tout;
             if (corr == -1.0) tmax -= 1.0 / f0;
             if (tmax < tleft) {
@@ -1332,7 +1555,7 @@ __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wa
             const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
             if (!(f0 == f0)) break;
             double peak, tout;
-            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, lane, &tout, &peak);
+            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, lane, &tout, &peak, ps1, ps2);
             tmax = tout;
             if (corr == -1.0) tmax += 1.0 / f0;
             if (tmax > tright) {
@@ -1441,16 +1664,19 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
     P.nsamp_window = (int)h[8]; P.nsamp_period = (int)h[9]; P.min_lag = (int)h[10]; P.max_lag = (int)h[11];
     P.brent_ixmax = (int)h[12]; P.max_cand = (int)h[13]; P.refine_depth = (int)h[14]; P.is_cc = (int)h[15];
     P.dt_window = h[16];
+    { const char* e = getenv("RSAF_PITCH_STOP"); P.debug_stop = e ? atoi(e) : 0; }
     P.refine_margin = 0.0;   // lazy refinement is off: it changed a few frames' selection (parity first)
     P.half_window = P.nsamp_window / 2;
     P.half_period = P.nsamp_period / 2 + 1;
     RSAF_CHECK_ARG(P.max_cand >= 2 && P.max_cand <= MAXC - 1, "max_candidates must be in [2, 15]");
     RSAF_CHECK_ARG(P.nsamp_window >= 4 && P.brent_ixmax >= 2 && P.max_lag >= 2, "window too short");
     RSAF_CHECK_ARG(P.is_cc || (window && window_r), "AC needs the window tables");
+    RSAF_CHECK_ARG((P.is_cc ? P.max_lag : P.brent_ixmax) <= 1023, "more than 1023 lags (pitch floor below ~16 Hz) is not supported");
     const int seg_len = P.is_cc ? P.nsamp_window + P.max_lag + 1 : P.nsamp_window;
-    const size_t lds = (size_t)(((seg_len + 1) & ~1) + ((2 * P.brent_ixmax + 2) & ~1) + 8 + 2 * MAX_MAXIMA + 2 * MAXC) *
+    const size_t lds = (size_t)(((seg_len + 1) & ~1) + ((2 * P.brent_ixmax + 2) & ~1) + 8 + 3 * MAX_MAXIMA + 3 * MAXC) *
                            sizeof(double) + (size_t)(MAX_MAXIMA + MAXC + 4) * sizeof(int) +
-                       (size_t)4 * 4 * (((P.is_cc ? P.max_lag : P.brent_ixmax) + 4) / 4) * sizeof(double);
+                       (size_t)pitch_part_doubles(P.nsamp_window, P.is_cc ? P.max_lag : P.brent_ixmax) * sizeof(double) +
+                       (P.is_cc ? (size_t)(seg_len + 2) * sizeof(double) : 0);
     RSAF_CHECK_ARG(lds <= 150 * 1024, "analysis window too long for LDS");
     hipStream_t s = (hipStream_t)stream;
     if (lds > 48 * 1024)
@@ -1468,7 +1694,7 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
                            (const ClipInfo*)clip_info, P.dt, silence_thr, P.voicing_thr, P.octave_cost, octave_jump, vuv,
                            P.ceiling, psi, end_state);
         RSAF_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(backtrack_kernel, dim3(n_clips), dim3(64), 0, s, (const FrameOut*)frame_out,
+        hipLaunchKernelGGL(backtrack_kernel, dim3(n_clips), dim3(256), 0, s, (const FrameOut*)frame_out,
                            (const ClipInfo*)clip_info, psi, end_state, sel_freq, sel_strength);
         RSAF_CHECK_HIP(hipGetLastError());
     }
@@ -1506,8 +1732,15 @@ int rsaf_mshds_resample10k(const float* wav, const void* resample_info, int n_cl
     if (n_clips == 0 || max_out == 0) return RSAF_OK;
     RSAF_CHECK_ARG(wav && resample_info && tables && phase_base && out, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
+    const int taps = 2 * depth + 1;
+    const int span = 8 * (RS_QT - 1) + 8 + taps;                       // phase bases differ by < 8
+    const size_t lds = (size_t)5 * taps * sizeof(double) + (size_t)(span + span / 32 + 2) * sizeof(float);
+    RSAF_CHECK_ARG(lds <= 150 * 1024, "resampler depth too large for LDS");
+    if (lds > 48 * 1024)
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof("mshds_resample10k", s, 0.0, 0.0);
-    hipLaunchKernelGGL(resample_kernel, dim3((max_out + 255) / 256, n_clips), dim3(256), 0, s, wav,
+    const int nq = (max_out + 4) / 5;
+    hipLaunchKernelGGL(resample_kernel, dim3((nq + RS_QT - 1) / RS_QT, n_clips), dim3(320), lds, s, wav,
                        (const ResampleInfo*)resample_info, tables, phase_base, depth, out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
