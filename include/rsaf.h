@@ -193,6 +193,14 @@ int rsaf_mshds_formants(const double* y10, const void* resample_info, const void
 int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips, const double* sel_freq,
                       double pitch_dt, double pitch_ceiling, double* pulses, int max_pulses, int* n_pulses,
                       rsaf_stream_t stream);
+/* Ltas (pitch-corrected) 0-5000 Hz in 100 Hz bands from the time-sorted pulses of rsaf_mshds_pulses, then
+ * "Get slope" (50-1000 vs 1000-4000 Hz, dB) and the slope of the robust line fit over 100-5000 Hz:
+ * out[clip][2] = {Spectral_Slope, Spectral_Tilt}, NaN where Praat raises.
+ * Replaces call(snd, "To Ltas (pitch-corrected)...") + "Get slope" + "Report spectral tilt",
+ * src/mshds_extractor.py:239-249.  clip_info rows need sample_off and n_samples only. */
+int rsaf_mshds_ltas_slope_tilt(const float* wav, const void* clip_info, int n_clips, const double* pulses,
+                               int max_pulses, const int* n_pulses, double shortest_period, double longest_period,
+                               double max_period_factor, double* out, rsaf_stream_t stream);
 int rsaf_mshds_formant_stats(const void* frames, const void* clip_info, int n_clips, double time_step,
                              const double* pulses, int max_pulses, const int* n_pulses, double* out,
                              rsaf_stream_t stream);

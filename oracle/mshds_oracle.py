@@ -12,7 +12,7 @@ cross-correlation pitch, path finder, HNR) and the Praat manual pages "Sound: To
 
 Built so far (the rest of the 25 features is NaN, as in ``csrc/mshds.hip``):
   a2 ``_speechrate``, a9 ``_measureFormants``, a3 ``_pitch_values``, a4 ``_extract_pitch``, a5 ``_extract_intensity``, a6 ``_extract_harmonicity``,
-  a10 ``_extract_Spectral_Moments``.
+  a10 ``_extract_Spectral_Moments``, a7 ``_extract_Slope_Tilt``.
 Arithmetic: float64 on the float32 samples (Praat computes in double).
 """
 from __future__ import annotations
@@ -30,7 +30,7 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                          # src/mshds_extractor.py:397-404
-BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
+BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 
 # ---- Sampled helpers (Praat: x1 = 0.5 dx for a Sound read from file) ----------------------------
@@ -1121,6 +1121,141 @@ def measure_formants(x, floor, ceiling, frame_shift=0.005):
     return tuple(out)
 
 
+# ---- Ltas (pitch-corrected), slope and tilt  (src/mshds_extractor.py:227-251) ---------------------------
+def ltas_pitch_corrected(x, floor, ceiling, max_freq=5000.0, bandwidth=100.0, shortest=0.0001, longest=0.02,
+                         max_factor=1.3):
+    """Praat "Sound: To Ltas (pitch-corrected)...": pulses from Sound_to_PointProcess_periodic_cc (AC pitch with
+    the standard settings and the automatic time step, then the cc pulse train); every pulse whose two
+    neighbouring intervals are plausible periods contributes the energy spectrum of the one period around
+    it (rectangular extract, DFT of exactly that many samples); band energies are averaged per band and
+    redistributed so that every band weighs the same.  Returns the dB values of the bands or None
+    (Praat raises -> the reference returns NaN, NaN)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    p = pitch_ac(x, 0.0, floor, pitch_ceiling=ceiling)
+    pulses = point_process_cc(x, p)
+    nb = int(max_freq / bandwidth)
+    if len(pulses) - 2 < 1:
+        return None
+    energy = np.zeros(nb)
+    numbers = np.zeros(nb)
+    n_periods = 0
+    for i in range(1, len(pulses) - 1):
+        left, right = pulses[i] - pulses[i - 1], pulses[i + 1] - pulses[i]
+        factor = left / right if left > right else right / left
+        if not (shortest <= left <= longest and shortest <= right <= longest and factor <= max_factor):
+            continue
+        t1, t2 = pulses[i] - 0.5 * left, pulses[i] + 0.5 * right
+        ix1 = int(np.ceil((t1 - 0.5 * DX) / DX))                 # 0-based; samples outside the sound are zero
+        ix2 = int(np.floor((t2 - 0.5 * DX) / DX))
+        if ix2 < ix1:
+            return None                                           # "Extracted Sound would contain no samples"
+        m = ix2 - ix1 + 1
+        seg = np.zeros(m)
+        a, b = max(ix1, 0), min(ix2, n - 1)
+        if b >= a:
+            seg[a - ix1:b - ix1 + 1] = x[a:b + 1]
+        spec = np.fft.rfft(seg) * DX                              # Sound_to_Spectrum (fast = no)
+        sdx = 1.0 / (DX * m)
+        for k in range(len(spec)):
+            band = int(np.ceil(k * sdx / bandwidth))
+            if 1 <= band <= nb:
+                energy[band - 1] += (spec[k].real ** 2 + spec[k].imag ** 2) * 2.0 * sdx
+                numbers[band - 1] += 1
+        n_periods += 1
+    if n_periods < 1:
+        return None
+    total = numbers.sum()
+    z = np.full(nb, np.nan)
+    duration = n * DX
+    for b in range(nb):
+        if numbers[b] > 0:
+            mean_e = energy[b] / numbers[b]
+            z[b] = 10.0 * np.log10(mean_e * (total / nb) / bandwidth / duration / 4.0e-10)
+    if np.all(np.isnan(z)):
+        return None
+    out = z.copy()
+    for b in range(nb):                                           # undefined bands: copy / interpolate
+        if np.isnan(z[b]):
+            bl, br = b - 1, b + 1
+            while bl >= 0 and np.isnan(z[bl]):
+                bl -= 1
+            while br < nb and np.isnan(z[br]):
+                br += 1
+            if bl < 0:
+                out[b] = z[br]
+            elif br >= nb:
+                out[b] = z[bl]
+            else:
+                out[b] = ((br - b) * z[bl] + (b - bl) * z[br]) / (br - bl)
+    return out
+
+
+def sampled_mean_rect(z, x1, dx, xmin, xmax):
+    """Praat Sampled_getMean without interpolation: every sample is a bar of width dx."""
+    nx = len(z)
+    xmin, xmax = max(xmin, x1 - 0.5 * dx), min(xmax, x1 + (nx - 0.5) * dx)
+    if not xmin < xmax:
+        return np.nan
+    rimin, rimax = (xmin - x1) / dx + 1.0, (xmax - x1) / dx + 1.0       # 1-based real indices
+    total, rng = 0.0, 0.0
+    if rimax >= 0.5 and rimin < nx + 0.5:
+        imin = 0 if rimin < 0.5 else int(np.floor(rimin + 0.5))
+        imax = nx + 1 if rimax >= nx + 0.5 else int(np.floor(rimax + 0.5))
+        for i in range(imin + 1, imax):
+            if not np.isnan(z[i - 1]):
+                rng += 1.0
+                total += z[i - 1]
+        if imin == imax:
+            if 1 <= imin <= nx and not np.isnan(z[imin - 1]):
+                ph = rimax - rimin
+                rng += ph
+                total += ph * z[imin - 1]
+        else:
+            if imin >= 1 and not np.isnan(z[imin - 1]):
+                ph = imin - rimin + 0.5
+                rng += ph
+                total += ph * z[imin - 1]
+            if imax <= nx and not np.isnan(z[imax - 1]):
+                ph = rimax - imax + 0.5
+                rng += ph
+                total += ph * z[imax - 1]
+    return total / rng if rng > 0.0 else np.nan
+
+
+def line_fit_theil_incomplete(xv, yv):
+    """Praat NUMlineFit_theil (incomplete method = the "Robust" choice): median of the slopes between
+    point i and point i + ceil(n/2)."""
+    n = len(xv)
+    if n < 2:
+        return 0.0
+    nc = n // 2
+    n2 = nc + 1 if n % 2 == 1 else nc
+    slopes = np.sort([(yv[n2 + i] - yv[i]) / (xv[n2 + i] - xv[i]) for i in range(nc)])
+    return quantile_sorted(slopes, 0.5)
+
+
+def extract_slope_tilt(x, floor, ceiling):
+    """src/mshds_extractor.py:227-251: Ltas "Get slope" 50-1000 vs 1000-4000 Hz in dB and the slope of the
+    robust line fit over 100-5000 Hz (linear frequency) read from "Report spectral tilt"."""
+    z = ltas_pitch_corrected(x, floor, ceiling)
+    if z is None:
+        return np.nan, np.nan
+    bw = 100.0
+    x1 = 0.5 * bw
+    low = sampled_mean_rect(z, x1, bw, 50.0, 1000.0)
+    high = sampled_mean_rect(z, x1, bw, 1000.0, 4000.0)
+    slope = high - low
+    nb = len(z)
+    imin = max(1, 1 + int(np.ceil((100.0 - x1) / bw)))
+    imax = min(nb, 1 + int(np.floor((5000.0 - x1) / bw)))
+    if imax - imin + 1 < 2:
+        return np.nan, np.nan                                      # the report raises -> both NaN in the reference
+    fx = x1 + (np.arange(imin, imax + 1) - 1) * bw
+    tilt = line_fit_theil_incomplete(fx, z[imin - 1:imax])
+    return slope, tilt
+
+
 def extract(x):
     """One clip -> 25 features in the reference's column order (unbuilt helpers give NaN)."""
     x = np.asarray(x, dtype=np.float64)
@@ -1131,6 +1266,7 @@ def extract(x):
     out[5], out[6] = extract_pitch(x, floor, ceiling, 0.005, p)                      # :430
     out[7], out[8] = extract_intensity(x, floor, 0.005)                              # :431
     out[9] = extract_harmonicity(x, floor, ceiling, 0.005)                           # :432
+    out[10], out[11] = extract_slope_tilt(x, floor, ceiling)                         # :433
     out[13:21] = measure_formants(x, floor, ceiling, 0.005)                          # :441
     out[21:25] = extract_spectral_moments(x, floor, ceiling, 0.025, 0.005, p)        # :446
     return out, (floor, ceiling)

@@ -1535,6 +1535,7 @@ __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wa
         const double f0mid = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmid);
         if (!(f0mid == f0mid)) { t = tright; continue; }
         double tmax = find_extremum_wave(x, n, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid, lane);
+        const int first = np_;
         if (np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
         const double tsave = tmax;
         for (int g2 = 0; g2 < 200000; ++g2) {                      // to the left
@@ -1550,6 +1551,14 @@ __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wa
             }
             if (corr > 0.3 && (peak == 0.0 || peak > 0.01 * gp) && tmax - added_right > 0.8 / f0 && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
         }
+        // the block [first .. np_) holds the middle pulse followed by the left-going pulses in descending time:
+        // reverse it so that the clip's pulses come out in ascending time like a Praat PointProcess
+        __threadfence_block();
+        for (int i = first + lane, j = np_ - 1 - lane; i < j; i += 64, j -= 64) {
+            const double a = pts[i], b = pts[j];
+            pts[i] = b; pts[j] = a;
+        }
+        __threadfence_block();
         tmax = tsave;
         for (int g2 = 0; g2 < 200000; ++g2) {                      // to the right
             const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
@@ -1567,6 +1576,181 @@ __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wa
         t = tright;
     }
     if (lane == 0) n_pulses[blockIdx.x] = np_;
+}
+
+// ---- Ltas (pitch-corrected) -> "Get slope" and robust tilt (src/mshds_extractor.py:227-251) ---------------
+// One workgroup per clip; every wave takes every fourth pulse.  A pulse whose two neighbouring intervals are
+// plausible periods contributes the energy spectrum of the one period around it: a DFT of exactly that many
+// samples (lane = frequency bin, rotation recurrence over the samples), binned into 100 Hz bands.
+// Per-wave band sums are combined in a fixed order, so the result does not depend on scheduling.
+constexpr int LTAS_NB = 50;            // maximum frequency 5000 Hz / bandwidth 100 Hz
+constexpr double LTAS_BW = 100.0;
+constexpr int LTAS_MAXN = 1024;        // samples of one period that fit the LDS staging (longest period 20 ms = 320)
+
+__device__ double ltas_mean_rect(const double* z, int nx, double x1, double dx, double xmin, double xmax) {
+    const double qn = __longlong_as_double(0x7ff8000000000000LL);
+    xmin = fmax(xmin, x1 - 0.5 * dx);
+    xmax = fmin(xmax, x1 + (nx - 0.5) * dx);
+    if (!(xmin < xmax)) return qn;
+    const double rimin = (xmin - x1) / dx + 1.0, rimax = (xmax - x1) / dx + 1.0;
+    double total = 0.0, rng = 0.0;
+    if (rimax >= 0.5 && rimin < nx + 0.5) {
+        const int imin = rimin < 0.5 ? 0 : (int)floor(rimin + 0.5);
+        const int imax = rimax >= nx + 0.5 ? nx + 1 : (int)floor(rimax + 0.5);
+        for (int i = imin + 1; i < imax; ++i) { rng += 1.0; total += z[i - 1]; }
+        if (imin == imax) {
+            if (imin >= 1 && imin <= nx) { const double ph = rimax - rimin; rng += ph; total += ph * z[imin - 1]; }
+        } else {
+            if (imin >= 1) { const double ph = imin - rimin + 0.5; rng += ph; total += ph * z[imin - 1]; }
+            if (imax <= nx) { const double ph = rimax - imax + 0.5; rng += ph; total += ph * z[imax - 1]; }
+        }
+    }
+    return rng > 0.0 ? total / rng : qn;
+}
+
+__global__ __launch_bounds__(256) void ltas_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                   const double* __restrict__ pulses, int max_pulses,
+                                                   const int* __restrict__ n_pulses, double shortest, double longest,
+                                                   double max_factor, double* __restrict__ out) {
+    __shared__ double s_energy[4][LTAS_NB], s_count[4][LTAS_NB], s_z[LTAS_NB], s_slopes[LTAS_NB];
+    __shared__ float s_x[4][LTAS_MAXN];
+    __shared__ int s_periods[4], s_fail[4];
+    const ClipInfo c = ci[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples;
+    const double* pts = pulses + (int64_t)blockIdx.x * max_pulses;
+    const int np_ = n_pulses[blockIdx.x];
+    const double qn = __longlong_as_double(0x7ff8000000000000LL);
+    for (int b = lane; b < LTAS_NB; b += 64) { s_energy[wv][b] = 0.0; s_count[wv][b] = 0.0; }
+    int periods = 0, fail = 0;
+    for (int ip = 1 + wv; ip < np_ - 1; ip += 4) {
+        const double tl = pts[ip - 1], tm = pts[ip], tr = pts[ip + 1];
+        const double left = tm - tl, right = tr - tm;
+        const double factor = left > right ? left / right : right / left;
+        if (!(left >= shortest && left <= longest && right >= shortest && right <= longest && factor <= max_factor)) continue;
+        const double t1 = tm - 0.5 * left, t2 = tm + 0.5 * right;
+        const int64_t ix1 = (int64_t)ceil((t1 - 0.5 * DXS) / DXS), ix2 = (int64_t)floor((t2 - 0.5 * DXS) / DXS);
+        if (ix2 < ix1 || ix2 - ix1 + 1 > LTAS_MAXN) { fail = 1; continue; }   // Praat: "no samples" aborts the analysis
+        const int m = (int)(ix2 - ix1 + 1);
+        for (int j = lane; j < m; j += 64) { const int64_t i = ix1 + j; s_x[wv][j] = (i >= 0 && i < n) ? x[i] : 0.0f; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const double sdx = 1.0 / (DXS * m);
+        const int nfreq = m / 2 + 1;
+        // bins k = 1 .. nfreq-1 whose band ceil(k*sdx/100) is within 1..50 (k = 0 falls into band 0)
+        for (int kb = 1; kb < nfreq; kb += 64) {
+            const int k = kb + lane;
+            const double freq = k * sdx;
+            int band = (int)ceil(freq / LTAS_BW);
+            const bool on = k < nfreq && band >= 1 && band <= LTAS_NB;
+            double e = 0.0;
+            if (__any(on)) {
+                // sum_j x_j exp(-2 pi i k j / m): rotate (c, s) by the bin's angle, which lies in (0, pi]
+                const double th = 2.0 * PI * (double)(k < nfreq ? k : 0) / (double)m;
+                const double C = cos_0_pi(th), S = sin_0_pi(th);
+                double cr = 1.0, sr = 0.0, re = 0.0, im = 0.0;
+                for (int j = 0; j < m; ++j) {
+                    const double v = s_x[wv][j];
+                    re += v * cr; im -= v * sr;
+                    const double c2 = cr * C - sr * S;
+                    sr = sr * C + cr * S;
+                    cr = c2;
+                }
+                re *= DXS; im *= DXS;
+                e = (re * re + im * im) * 2.0 * sdx;
+            }
+            if (!on) { band = -1 - lane; e = 0.0; }
+            // bands are non-decreasing in k: the first lane of a run adds the whole run (<= 4 bins per band)
+            const int bprev = __shfl_up(band, 1, 64);
+            const bool head = on && (lane == 0 || bprev != band);
+            double sum = e, cnt = 1.0;
+#pragma unroll
+            for (int d = 1; d <= 7; ++d) {
+                const int bn = __shfl_down(band, d, 64);
+                const double en = __shfl_down(e, d, 64);
+                if (lane + d < 64 && bn == band) { sum += en; cnt += 1.0; }
+            }
+            // a run can continue in the next 64-bin round: LDS accumulation below handles that (same wave, ordered)
+            if (head) { s_energy[wv][band - 1] += sum; s_count[wv][band - 1] += cnt; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        ++periods;
+    }
+    if (lane == 0) { s_periods[wv] = periods; s_fail[wv] = fail; }
+    __syncthreads();
+    if (tid == 0) {
+        const int total_periods = s_periods[0] + s_periods[1] + s_periods[2] + s_periods[3];
+        const int failed = s_fail[0] | s_fail[1] | s_fail[2] | s_fail[3];
+        double slope = qn, tilt = qn;
+        if (np_ - 2 >= 1 && total_periods >= 1 && !failed) {
+            double total = 0.0;
+            for (int b = 0; b < LTAS_NB; ++b) {
+                s_energy[0][b] = (s_energy[0][b] + s_energy[1][b]) + (s_energy[2][b] + s_energy[3][b]);
+                s_count[0][b] = (s_count[0][b] + s_count[1][b]) + (s_count[2][b] + s_count[3][b]);
+                total += s_count[0][b];
+            }
+            const double duration = n * DXS;
+            bool any = false;
+            for (int b = 0; b < LTAS_NB; ++b) {
+                if (s_count[0][b] > 0.0) {
+                    const double mean_e = s_energy[0][b] / s_count[0][b];
+                    s_z[b] = 10.0 * log10(mean_e * (total / LTAS_NB) / LTAS_BW / duration / 4.0e-10);
+                    any = true;
+                } else {
+                    s_z[b] = qn;
+                }
+            }
+            if (any) {
+                for (int b = 0; b < LTAS_NB; ++b) s_slopes[b] = s_z[b];     // defined values before filling
+                for (int b = 0; b < LTAS_NB; ++b) {
+                    if (s_slopes[b] == s_slopes[b]) continue;
+                    int bl = b - 1, br = b + 1;
+                    while (bl >= 0 && !(s_slopes[bl] == s_slopes[bl])) --bl;
+                    while (br < LTAS_NB && !(s_slopes[br] == s_slopes[br])) ++br;
+                    if (bl < 0) s_z[b] = s_slopes[br];
+                    else if (br >= LTAS_NB) s_z[b] = s_slopes[bl];
+                    else s_z[b] = ((br - b) * s_slopes[bl] + (b - bl) * s_slopes[br]) / (double)(br - bl);
+                }
+                const double x1 = 0.5 * LTAS_BW;
+                const double low = ltas_mean_rect(s_z, LTAS_NB, x1, LTAS_BW, 50.0, 1000.0);
+                const double high = ltas_mean_rect(s_z, LTAS_NB, x1, LTAS_BW, 1000.0, 4000.0);
+                slope = high - low;
+                // Theil's incomplete method over the bands centred in [100, 5000] Hz
+                int imin = 1 + (int)ceil((100.0 - x1) / LTAS_BW), imax = 1 + (int)floor((5000.0 - x1) / LTAS_BW);
+                imin = imin < 1 ? 1 : imin;
+                imax = imax > LTAS_NB ? LTAS_NB : imax;
+                const int cntp = imax - imin + 1, nc = cntp / 2, n2 = (cntp & 1) ? nc + 1 : nc;
+                for (int i = 0; i < nc; ++i) {
+                    const double xa = x1 + (imin - 1 + i) * LTAS_BW, xb = x1 + (imin - 1 + n2 + i) * LTAS_BW;
+                    s_slopes[i] = (s_z[imin - 1 + n2 + i] - s_z[imin - 1 + i]) / (xb - xa);
+                }
+                for (int i = 1; i < nc; ++i) {                              // insertion sort (<= 24 values)
+                    const double v = s_slopes[i];
+                    int j = i - 1;
+                    while (j >= 0 && s_slopes[j] > v) { s_slopes[j + 1] = s_slopes[j]; --j; }
+                    s_slopes[j + 1] = v;
+                }
+                if (nc >= 1) {                                              // NUMquantile(0.5)
+                    if (nc == 1) tilt = s_slopes[0];
+                    else {
+                        const double place = 0.5 * nc + 0.5;
+                        int lf = (int)floor(place);
+                        lf = lf < 1 ? 1 : (lf > nc - 1 ? nc - 1 : lf);
+                        tilt = s_slopes[lf] == s_slopes[lf - 1] ? s_slopes[lf - 1]
+                                                                  : s_slopes[lf - 1] + (place - lf) * (s_slopes[lf] - s_slopes[lf - 1]);
+                    }
+                } else {
+                    slope = qn;                                             // the tilt report fails -> both NaN (:250-251)
+                }
+            }
+        }
+        out[2 * blockIdx.x] = slope;
+        out[2 * blockIdx.x + 1] = tilt;
+    }
 }
 
 // ---- _measureFormants statistics: F1, B1, F2, B2 linearly interpolated at every pulse ------------------------
@@ -1774,6 +1958,21 @@ int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips
     ProfScope prof("mshds_pulses", s, 0.0, 0.0);
     hipLaunchKernelGGL(pulses_kernel, dim3(n_clips), dim3(64), 0, s, wav, (const ClipInfo*)pitch_clip_info, sel_freq,
                        pitch_dt, pitch_ceiling, pulses, max_pulses, n_pulses);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+int rsaf_mshds_ltas_slope_tilt(const float* wav, const void* clip_info, int n_clips, const double* pulses,
+                               int max_pulses, const int* n_pulses, double shortest_period, double longest_period,
+                               double max_period_factor, double* out, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && max_pulses >= 0, "bad clip/pulse count");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && clip_info && pulses && n_pulses && out, "NULL pointer");
+    RSAF_CHECK_ARG(longest_period * 16000.0 + 2.0 <= LTAS_MAXN, "longest period does not fit the LDS staging");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("mshds_ltas", s, 0.0, 0.0);
+    hipLaunchKernelGGL(ltas_kernel, dim3(n_clips), dim3(256), 0, s, wav, (const ClipInfo*)clip_info, pulses, max_pulses,
+                       n_pulses, shortest_period, longest_period, max_period_factor, out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -34,7 +34,7 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                            # src/mshds_extractor.py:397-404
-BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
+BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 CLIP_INFO = np.dtype([("sample_off", "<i8"), ("frame_off", "<i8"), ("t1", "<f8"),
                       ("n_samples", "<i4"), ("n_frames", "<i4")])
@@ -327,17 +327,43 @@ class MshdsEngine:
         # To Pitch (cc) with parselmouth's defaults (:320) and the pulses (:321)
         p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=frame_shift, floor=floor, ceiling=ceiling,
                        periods=1.0, is_cc=True, refine_depth=70, stream=stream)
-        max_pulses = int(max(lengths) * DX * ceiling * 1.5) + 16
-        pulses = torch.empty(n * max_pulses, dtype=torch.float64, device=dev)
-        npul = torch.zeros(n, dtype=torch.int32, device=dev)
-        _lib.check(lib.rsaf_mshds_pulses(_lib.ptr(wav), _lib.ptr(p["ci_dev"]), n, _lib.ptr(p["sel_freq"]), p["geom"].dt,
-                                         p["geom"].ceiling, _lib.ptr(pulses), max_pulses, _lib.ptr(npul),
-                                         _lib.stream_ptr(stream)), "rsaf_mshds_pulses")
+        pulses, npul, max_pulses = self.pulses(wav, lengths, p, stream)
         _lib.check(lib.rsaf_mshds_formant_stats(_lib.ptr(frames), _lib.ptr(ci_d), n, frame_shift, _lib.ptr(pulses),
                                                 max_pulses, _lib.ptr(npul), _lib.ptr(out), _lib.stream_ptr(stream)),
                    "rsaf_mshds_formant_stats")
         self._last_formants = {"frames": frames, "ci": ci, "pulses": pulses, "n_pulses": npul, "max_pulses": max_pulses,
                                "y10": y10, "ri": ri, "pitch": p}
+        return out[:n]
+
+    def pulses(self, wav, lengths, pitch, stream=None):
+        """Sound & Pitch: To PointProcess (cc): pulse times per clip in ascending order -> (pulses, n_pulses, max_pulses)."""
+        import torch
+        n = len(lengths)
+        ceiling = pitch["geom"].ceiling
+        max_pulses = int(max(lengths) * DX * ceiling * 1.5) + 16
+        pulses = torch.empty(max(n, 1) * max_pulses, dtype=torch.float64, device=self.device)
+        npul = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        if n:
+            _lib.check(_lib.load().rsaf_mshds_pulses(_lib.ptr(wav), _lib.ptr(pitch["ci_dev"]), n, _lib.ptr(pitch["sel_freq"]),
+                                                     pitch["geom"].dt, ceiling, _lib.ptr(pulses), max_pulses,
+                                                     _lib.ptr(npul), _lib.stream_ptr(stream)), "rsaf_mshds_pulses")
+        return pulses, npul, max_pulses
+
+    def slope_tilt(self, wav, sample_offs, lengths, gpeak, floor, ceiling, stream=None):
+        """_extract_Slope_Tilt (src/mshds_extractor.py:227-251) -> float64 [n, 2] = (Spectral_Slope, Spectral_Tilt).
+        "To Ltas (pitch-corrected)" finds its own pulses: To Pitch (ac) with the standard settings and the
+        automatic time step 0.75 / floor, then the cc pulse train."""
+        import torch
+        n = len(lengths)
+        out = torch.full((max(n, 1), 2), float("nan"), dtype=torch.float64, device=self.device)
+        if n == 0:
+            return out[:0]
+        p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.0, floor=floor, ceiling=ceiling, stream=stream)
+        pulses, npul, max_pulses = self.pulses(wav, lengths, p, stream)
+        _lib.check(_lib.load().rsaf_mshds_ltas_slope_tilt(_lib.ptr(wav), _lib.ptr(p["ci_dev"]), n, _lib.ptr(pulses),
+                                                          max_pulses, _lib.ptr(npul), 0.0001, 0.02, 1.3, _lib.ptr(out),
+                                                          _lib.stream_ptr(stream)), "rsaf_mshds_ltas_slope_tilt")
+        self._last_ltas = {"pitch": p, "pulses": pulses, "n_pulses": npul, "max_pulses": max_pulses}
         return out[:n]
 
     def hnr_mean(self, pitch_cc, stream=None):
@@ -402,6 +428,7 @@ class MshdsEngine:
             out[idx, 7] = inten["stats"][:, 0]
             out[idx, 8] = inten["stats"][:, 1]
             out[idx, 9] = hnr
+            out[idx, 10:12] = self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                      # :433
             out[idx, 21:25] = sm["stats"]
         return out, ranges
 

@@ -166,9 +166,37 @@ def test_formants_resampler_pulses_and_statistics(eng):
         p = mo.pitch_cc(c, 0.005, 100.0, 1.0, 15, 0.03, 0.45, 0.01, 0.35, 0.14, 500.0)
         pts = mo.point_process_cc(c.astype(np.float64), p)
         assert npul[i] == len(pts)                                               # integer-exact pulse count
-        assert np.abs(np.sort(pul[i, :npul[i]]) - pts).max() < 1e-9
+        assert np.abs(pul[i, :npul[i]] - pts).max() < 1e-9                       # ascending time, like a PointProcess
         ref = np.array(mo.measure_formants(c, 100, 500))
         assert np.abs(got[i].cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-6, (got[i], ref)
+
+
+def test_ltas_slope_and_tilt(eng):
+    """_extract_Slope_Tilt (:227-251): AC pitch with the automatic time step, cc pulses, one-period spectra
+    binned into 100 Hz bands, "Get slope" and the robust (Theil) tilt."""
+    import torch
+    clips = [synth.synth_clip(180, 2.0), synth.synth_clip(181, 1.3), np.zeros(4000, np.float32),
+             synth.synth_clip(182, 0.05)]                                         # silence / too short: NaN, NaN
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    for floor, ceil in ((60.0, 250.0), (100.0, 500.0)):
+        got = eng.slope_tilt(wav, offs, lens, gp, floor, ceil).cpu().numpy()
+        torch.cuda.synchronize()
+        L = eng._last_ltas
+        pul = L["pulses"].cpu().numpy().reshape(len(clips), L["max_pulses"])
+        npul = L["n_pulses"].cpu().numpy()
+        for i, c in enumerate(clips):
+            p = mo.pitch_ac(c, 0.0, floor, pitch_ceiling=ceil)
+            pts = mo.point_process_cc(c.astype(np.float64), p)
+            assert npul[i] == len(pts)
+            if len(pts):
+                assert np.abs(pul[i, :npul[i]] - pts).max() < 1e-9
+            ref = np.array(mo.extract_slope_tilt(c, floor, ceil))
+            assert np.array_equal(np.isnan(got[i]), np.isnan(ref)), (i, got[i], ref)
+            if not np.isnan(ref).any():
+                assert abs(got[i, 0] - ref[0]) <= 1e-7 * abs(ref[0]) + 1e-9, (got[i], ref)
+                assert abs(got[i, 1] - ref[1]) <= 1e-6 * abs(ref[1]) + 1e-12, (got[i], ref)
+    assert not np.isnan(got[0]).any() and np.isnan(got[2]).all()
 
 
 def test_extract_packed_matches_oracle_and_uses_both_speaker_ranges(eng):
