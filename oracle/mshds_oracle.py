@@ -12,7 +12,7 @@ cross-correlation pitch, path finder, HNR) and the Praat manual pages "Sound: To
 
 Built so far (the rest of the 25 features is NaN, as in ``csrc/mshds.hip``):
   a2 ``_speechrate``, a9 ``_measureFormants``, a3 ``_pitch_values``, a4 ``_extract_pitch``, a5 ``_extract_intensity``, a6 ``_extract_harmonicity``,
-  a10 ``_extract_Spectral_Moments``, a7 ``_extract_Slope_Tilt``.
+  a10 ``_extract_Spectral_Moments``, a7 ``_extract_Slope_Tilt``, a8 ``_extract_CPP``.
 Arithmetic: float64 on the float32 samples (Praat computes in double).
 """
 from __future__ import annotations
@@ -30,7 +30,7 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                          # src/mshds_extractor.py:397-404
-BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
+BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 
 # ---- Sampled helpers (Praat: x1 = 0.5 dx for a Sound read from file) ----------------------------
@@ -1256,6 +1256,186 @@ def extract_slope_tilt(x, floor, ceiling):
     return slope, tilt
 
 
+# ---- Cepstral peak prominence of the voiced stretches  (src/mshds_extractor.py:253-301) ------------------
+CPP_FS = 10000.0            # To PowerCepstrogram: 2 * maximum frequency 5000 Hz
+CPP_DEPTH = 50              # Sound_resample precision used by Sound_to_PowerCepstrogram
+CPP_PITCH_FLOOR = 60.0
+CPP_DT = 0.002
+CPP_PREEMPH_FROM = 50.0
+
+
+def vuv_intervals(pulses, xmin, xmax, max_period=0.02, mean_period=0.1):
+    """PointProcess: To TextGrid (vuv): the voiced intervals [(tmin, tmax)].  A voiced stretch is a run of
+    pulses less than max_period apart, widened by half the mean period on both sides, never before the end
+    of the previous stretch nor beyond the sound."""
+    out = []
+    half = 0.5 * mean_period
+    begin_voiceless = xmin
+    i, n = 0, len(pulses)
+    while i < n:
+        end_voiceless = pulses[i] - half
+        if end_voiceless <= begin_voiceless:
+            end_voiceless = begin_voiceless
+        begin_voiced = end_voiceless
+        j = i + 1
+        while j < n and not (pulses[j] - pulses[j - 1] > max_period):
+            j += 1
+        j -= 1
+        end_voiced = min(pulses[j] + half, xmax)
+        out.append((begin_voiced, end_voiced))
+        begin_voiceless = end_voiced
+        i = j + 1
+    return out
+
+
+def resample_windowed_sinc(seg, x1_seg, duration, fs_out, depth):
+    """Sound_resample of a sound with n = len(seg) samples at 16 kHz whose first sample lies at x1_seg and whose
+    domain is [0, duration]: Praat's brick-wall low-pass + sinc interpolation folded into one raised-cosine
+    windowed sinc with the cut-off at the new Nyquist (the free choice documented at ``resample_10k``)."""
+    n = len(seg)
+    m = int(np.floor(duration * fs_out + 0.5))
+    dxo = 1.0 / fs_out
+    x1o = 0.5 * (duration - (m - 1) * dxo)
+    ratio = fs_out / FS
+    out = np.empty(max(m, 0))
+    k = np.arange(-depth, depth + 1)
+    for i0 in range(0, m, 4096):
+        idx = np.arange(i0, min(m, i0 + 4096))
+        pos = (x1o + idx * dxo - x1_seg) / DX
+        base = np.floor(pos).astype(np.int64)
+        j = base[:, None] + k[None, :]
+        d = pos[:, None] - j
+        w = ratio * np.sinc(ratio * d) * (0.5 + 0.5 * np.cos(np.pi * d / (depth + 1.0)))
+        w = np.where(np.abs(d) <= depth + 1.0, w, 0.0)
+        ok = (j >= 0) & (j < n)
+        out[idx] = np.sum(np.where(ok, seg[np.clip(j, 0, n - 1)] * w, 0.0), axis=1)
+    return out, x1o, dxo
+
+
+def power_cepstrogram(seg, x1_seg, duration):
+    """Sound: To PowerCepstrogram (60 Hz, 2 ms, 5 kHz, pre-emphasis from 50 Hz) of an extracted part with
+    domain [0, duration]: resample to 10 kHz, pre-emphasise, 0.1 s Gaussian-windowed frames (the window shrinks
+    to the physical duration of a shorter sound), power spectrum -> ln -> inverse FFT -> squared.
+    Returns z [nq, n_frames] (quefrency step 1e-4 s)."""
+    n_in = len(seg)
+    window = min(2.0 * 3.0 / CPP_PITCH_FLOOR, DX * n_in)
+    y, x1o, dxo = resample_windowed_sinc(seg, x1_seg, duration, CPP_FS, CPP_DEPTH)
+    a = np.exp(-2.0 * np.pi * CPP_PREEMPH_FROM * dxo)
+    y = np.concatenate([y[:1], y[1:] - a * y[:-1]])
+    my_duration = DX * n_in                                        # Sampled_shortTermAnalysis on the 16 kHz part
+    nf = int(np.floor((my_duration - window) / CPP_DT)) + 1
+    mid = x1_seg - 0.5 * DX + 0.5 * my_duration
+    t1 = mid - 0.5 * nf * CPP_DT + 0.5 * CPP_DT
+    nx = int(np.floor(window * CPP_FS + 0.5))
+    nfft = 2
+    while nfft < nx:
+        nfft *= 2
+    nq = nfft // 2 + 1
+    i = np.arange(1, nx + 1)
+    imid, edge = 0.5 * (nx + 1), np.exp(-12.0)
+    win = (np.exp(-48.0 * (i - imid) ** 2 / (nx + 1) ** 2) - edge) / (1.0 - edge)
+    z = np.empty((nq, nf))
+    sdx = 1.0 / (dxo * nfft)
+    m = len(y)
+    for f in range(nf):
+        t = t1 + f * CPP_DT
+        idx0 = int(np.floor((t - 0.5 * window - x1o) / dxo + 0.5))          # Sampled_xToNearestIndex, 0-based
+        j = idx0 + np.arange(nx)
+        fr = np.where((j >= 0) & (j < m), y[np.clip(j, 0, m - 1)], 0.0)
+        fr = (fr - fr.mean()) * win
+        spec = np.fft.rfft(fr, nfft) * dxo
+        logp = np.log(spec.real ** 2 + spec.imag ** 2 + 1e-300)
+        c = np.fft.irfft(logp, nfft) * nfft * sdx                             # unnormalised Hermitian sum times df
+        z[:, f] = c[:nq] ** 2
+    return z
+
+
+def _moving_average(v, window):
+    """VECsmoothByMovingAverage: [i - w/2, i + w/2] (one less on the right for an even w), clipped."""
+    n = len(v)
+    out = np.empty(n)
+    for i in range(n):
+        lo, hi = i - window // 2, i + window // 2
+        if window % 2 == 0:
+            hi -= 1
+        lo, hi = max(lo, 0), min(hi, n - 1)
+        out[i] = np.sum(v[lo:hi + 1]) / (hi - lo + 1)
+    return out
+
+
+def cpps(z, dq=1e-4, time_window=0.01, quef_window=0.001, pitch_floor=60.0, pitch_ceiling=330.0):
+    """PowerCepstrogram: Get CPPS ("no", 0.01, 0.001, 60, 330, 0.05, parabolic, 0.001, 0, Straight, Robust):
+    moving averages over time and quefrency, then per frame the parabolic peak (dB) in [1/330, 1/60] s minus
+    the robust (Theil, incomplete) straight trend over the whole quefrency range (an end of 0 resets the
+    range), averaged over the frames."""
+    nq, nf = z.shape
+    zs = z.copy()
+    nt = int(np.floor(time_window / CPP_DT))
+    if nt > 1:
+        for q in range(nq):
+            zs[q] = _moving_average(zs[q], nt)
+    nqb = int(np.floor(quef_window / dq))
+    if nqb > 1:
+        for f in range(nf):
+            zs[:, f] = _moving_average(zs[:, f], nqb)
+    quef = np.arange(nq) * dq
+    imin = int(np.ceil((1.0 / pitch_ceiling) / dq))                 # 0-based Sampled_getWindowSamples
+    imax = min(int(np.floor((1.0 / pitch_floor) / dq)), nq - 1)
+    vals = []
+    for f in range(nf):
+        db = 10.0 * np.log10(zs[:, f] + 1e-30)
+        # trend line: Theil's incomplete method, slope then the median of the residual offsets
+        nc = nq // 2
+        n2 = nc + 1 if nq % 2 == 1 else nc
+        slopes = np.sort((db[n2:n2 + nc] - db[:nc]) / (quef[n2:n2 + nc] - quef[:nc]))
+        slope = quantile_sorted(slopes, 0.5)
+        icpt = quantile_sorted(np.sort(db - slope * quef), 0.5)
+        # Vector_getMaximumAndX with parabolic interpolation
+        if imax < imin:
+            return np.nan
+        peak, xq = db[imin], float(imin)
+        if db[imax] > peak:
+            peak, xq = db[imax], float(imax)
+        lo, hi = max(imin, 1), min(imax, nq - 2)
+        for i in range(lo, hi + 1):
+            if db[i] > db[i - 1] and db[i] >= db[i + 1]:
+                dy = 0.5 * (db[i + 1] - db[i - 1])
+                d2y = 2.0 * db[i] - db[i - 1] - db[i + 1]
+                loc = db[i] + 0.5 * dy * dy / d2y
+                if loc > peak:
+                    peak, xq = loc, i + dy / d2y
+        qpeak = min(max(xq * dq, 1.0 / pitch_ceiling), 1.0 / pitch_floor)
+        vals.append(peak - (slope * qpeak + icpt))
+    return float(np.mean(vals)) if vals else np.nan
+
+
+def extract_cpp(x, floor, ceiling, frame_shift=0.005):
+    """_extract_CPP (:253-301): mean CPPS over the voiced intervals whose CPPS exceeds 4 dB."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    p = pitch_ac(x, frame_shift, floor, voicing_threshold=0.3, pitch_ceiling=ceiling)      # :270
+    pulses = point_process_cc(x, p)                                                          # :271
+    vals = []
+    for (tmin, tmax) in vuv_intervals(pulses, 0.0, n * DX):                                  # :272
+        tmin, tmax = float(f"{tmin:.6f}"), float(f"{tmax:.6f}")                              # Down to Table, 6 decimals
+        if tmin >= tmax:
+            continue
+        ix1 = int(np.ceil((tmin - 0.5 * DX) / DX))
+        ix2 = int(np.floor((tmax - 0.5 * DX) / DX))
+        if ix2 < ix1:
+            return np.nan                                        # extract_part raises outside the inner try -> NaN (:299-300)
+        seg = np.zeros(ix2 - ix1 + 1)
+        a, b = max(ix1, 0), min(ix2, n - 1)
+        if b >= a:
+            seg[a - ix1:b - ix1 + 1] = x[a:b + 1]
+        x1_seg = 0.5 * DX + ix1 * DX - tmin
+        z = power_cepstrogram(seg, x1_seg, tmax - tmin)
+        v = cpps(z)
+        if not np.isnan(v) and v > 4:
+            vals.append(v)
+    return float(np.mean(vals)) if vals else np.nan
+
+
 def extract(x):
     """One clip -> 25 features in the reference's column order (unbuilt helpers give NaN)."""
     x = np.asarray(x, dtype=np.float64)
@@ -1267,6 +1447,7 @@ def extract(x):
     out[7], out[8] = extract_intensity(x, floor, 0.005)                              # :431
     out[9] = extract_harmonicity(x, floor, ceiling, 0.005)                           # :432
     out[10], out[11] = extract_slope_tilt(x, floor, ceiling)                         # :433
+    out[12] = extract_cpp(x, floor, ceiling, 0.005)                                  # :434
     out[13:21] = measure_formants(x, floor, ceiling, 0.005)                          # :441
     out[21:25] = extract_spectral_moments(x, floor, ceiling, 0.025, 0.005, p)        # :446
     return out, (floor, ceiling)

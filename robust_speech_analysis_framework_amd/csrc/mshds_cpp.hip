@@ -1,0 +1,501 @@
+// Cepstral peak prominence of the voiced stretches (MSHDS a8) for gfx950.
+//
+// Replaces, for a packed batch of clips resident in HBM, the Praat calls of src/mshds_extractor.py:270-297:
+//   PointProcess "To TextGrid (vuv)" 0.02 0.1 -> "Down to Table" (6 decimals) -> Sound.extract_part ->
+//   "To PowerCepstrogram" 60 0.002 5000 50 -> "Get CPPS" no 0.01 0.001 60 330 0.05 parabolic 0.001 0 Straight Robust
+//   -> mean of the per-interval values above 4 dB.
+// Five kernels: segment table (one wave per clip), resampler to 10 kHz (one thread per output sample),
+// power cepstrum per frame (two 1024-point fp64 FFTs in LDS), smoothed CPP per frame (moving averages,
+// two bitonic sorts for Theil's line, parabolic peak), reduction per interval and clip.
+// The arithmetic is fp64 and nothing is contracted to FMA where Praat's rounding decides an integer.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "rsaf_common.h"
+
+#pragma clang fp contract(off)
+
+namespace rsaf {
+namespace mshds_cpp {
+
+constexpr double DXS = 1.0 / 16000.0;
+constexpr double PI = 3.14159265358979323846;
+constexpr double FS_OUT = 10000.0;
+constexpr double DXO = 1.0 / FS_OUT;
+constexpr int DEPTH = 50;                 // Sound_resample precision of Sound_to_PowerCepstrogram
+constexpr double DT = 0.002;              // cepstrogram time step
+constexpr double DQ = 1.0e-4;             // quefrency step = 1 / FS_OUT
+constexpr int NFFT_MAX = 1024;            // 0.1 s window at 10 kHz = 1000 samples
+constexpr int NQ_MAX = NFFT_MAX / 2 + 1;  // 513
+constexpr int SEG_DOUBLES = 12;
+
+struct ClipInfo {      // same 32-byte rows as csrc/mshds.hip
+    int64_t sample_off;
+    int64_t frame_off;
+    double t1;
+    int n_samples;
+    int n_frames;
+};
+
+// one voiced interval (all fields double so that the table is one plain array)
+struct Seg {
+    double ix1, m_in, m_out, res_off, frame_off, nf, x1_seg, x1o, window, t1, nx, nfft;
+};
+static_assert(sizeof(Seg) == SEG_DOUBLES * sizeof(double), "Seg layout");
+
+__device__ __forceinline__ double round6(double t) { return rint(t * 1.0e6) / 1.0e6; }   // "%.6f" and back
+
+// ---- 1. voiced intervals -> segment table -----------------------------------------------------------------
+// hdr[clip] = {n_seg, fail, total_frames, total_resampled}
+__global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict__ ci, const double* __restrict__ pulses,
+                                                      int max_pulses, const int* __restrict__ n_pulses, double max_period,
+                                                      double mean_period, double pitch_floor, Seg* __restrict__ segs,
+                                                      int max_seg, int cap_res, int cap_frames, int* __restrict__ hdr) {
+    const ClipInfo c = ci[blockIdx.x];
+    const int lane = threadIdx.x;
+    const double* t = pulses + (int64_t)blockIdx.x * max_pulses;
+    const int np_ = n_pulses[blockIdx.x];
+    Seg* out = segs + (int64_t)blockIdx.x * max_seg;
+    const double xmax = c.n_samples * DXS, half = 0.5 * mean_period;
+    int nseg = 0, fail = 0;
+    int64_t res_off = 0, frame_off = 0;
+    double begin_voiceless = 0.0;
+    int cur_start = 0;
+    // every lane keeps the same (uniform) state; lane 0 writes
+    auto emit = [&](int first, int last) {
+        double end_voiceless = t[first] - half;
+        if (end_voiceless <= begin_voiceless) end_voiceless = begin_voiceless;
+        const double begin_voiced = end_voiceless;
+        double end_voiced = t[last] + half;
+        if (end_voiced > xmax) end_voiced = xmax;
+        begin_voiceless = end_voiced;
+        const double tmin = round6(begin_voiced), tmax = round6(end_voiced);
+        if (tmin >= tmax) return;                                            // :284
+        const int64_t ix1 = (int64_t)ceil((tmin - 0.5 * DXS) / DXS), ix2 = (int64_t)floor((tmax - 0.5 * DXS) / DXS);
+        const double dur = tmax - tmin;
+        const int64_t m_out = (int64_t)floor(dur * FS_OUT + 0.5);
+        if (ix2 < ix1 || m_out < 1) { fail = 1; return; }                    // Praat raises outside the inner try -> NaN
+        const int64_t m_in = ix2 - ix1 + 1;
+        double window = 2.0 * 3.0 / pitch_floor;
+        const double my_duration = DXS * (double)m_in;
+        if (window > my_duration) window = my_duration;
+        const int64_t nf = (int64_t)floor((my_duration - window) / DT) + 1;
+        const double x1_seg = 0.5 * DXS + (double)ix1 * DXS - tmin;
+        const double mid = x1_seg - 0.5 * DXS + 0.5 * my_duration;
+        const double t1 = mid - 0.5 * (double)nf * DT + 0.5 * DT;
+        const int64_t nx = (int64_t)floor(window * FS_OUT + 0.5);
+        int nfft = 2;
+        while (nfft < nx) nfft *= 2;
+        if (nseg >= max_seg || res_off + m_out > cap_res || frame_off + nf > cap_frames || nx > NFFT_MAX || nx < 1 || nf < 1) {
+            fail = 1;
+            return;
+        }
+        if (lane == 0) {
+            Seg s;
+            s.ix1 = (double)ix1; s.m_in = (double)m_in; s.m_out = (double)m_out; s.res_off = (double)res_off;
+            s.frame_off = (double)frame_off; s.nf = (double)nf; s.x1_seg = x1_seg;
+            s.x1o = 0.5 * (dur - (double)(m_out - 1) * DXO);
+            s.window = window; s.t1 = t1; s.nx = (double)nx; s.nfft = (double)nfft;
+            out[nseg] = s;
+        }
+        ++nseg;
+        res_off += m_out;
+        frame_off += nf;
+    };
+    for (int base = 0; base < np_; base += 64) {
+        const int i = base + lane;
+        const bool brk = i >= 1 && i < np_ && (t[i] - t[i - 1] > max_period);
+        unsigned long long m = __ballot(brk);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            emit(cur_start, base + b - 1);
+            cur_start = base + b;
+        }
+    }
+    if (np_ > 0) emit(cur_start, np_ - 1);
+    if (lane == 0) {
+        hdr[4 * blockIdx.x + 0] = nseg;
+        hdr[4 * blockIdx.x + 1] = fail;
+        hdr[4 * blockIdx.x + 2] = (int)frame_off;
+        hdr[4 * blockIdx.x + 3] = (int)res_off;
+    }
+}
+
+// index of the segment that owns element g of a prefix-summed range (offset field `off`, length field `len`)
+template <int OFF, int LEN>
+__device__ __forceinline__ int find_seg(const Seg* __restrict__ s, int nseg, int g) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)reinterpret_cast<const double*>(s + mid)[OFF] <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// ---- 2. 16 kHz -> 10 kHz of every interval ----------------------------------------------------------------
+// raised-cosine windowed sinc of half-width DEPTH + 1 input samples with the cut-off at the new Nyquist (the
+// free choice documented in oracle/mshds_oracle.py: Praat filters with a whole-sound FFT first).  The two
+// trigonometric factors advance by fixed angles per tap and are rotated instead of evaluated.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                       const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                       int cap_res, double* __restrict__ res) {
+    const int clip = blockIdx.y;
+    const int nseg = hdr[4 * clip], total = hdr[4 * clip + 3];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total || nseg <= 0) return;
+    const Seg* S = segs + (int64_t)clip * max_seg;
+    const Seg s = S[find_seg<3, 2>(S, nseg, g)];
+    const ClipInfo c = ci[clip];
+    const float* x = wav + c.sample_off;
+    const int i = g - (int)s.res_off;
+    const double pos = (s.x1o + (double)i * DXO - s.x1_seg) / DXS;       // real index into the extracted part
+    const double base = floor(pos);
+    const double frac = pos - base;                                         // in [0, 1)
+    const int64_t j0 = (int64_t)s.ix1 + (int64_t)base - DEPTH;            // clip sample of tap k = -DEPTH
+    const int m_in = (int)s.m_in;
+    const int64_t part_lo = (int64_t)s.ix1, part_hi = part_lo + m_in - 1;
+    const double ratio = FS_OUT / 16000.0;
+    // tap k = -DEPTH .. DEPTH: d = frac - k ; start at d0 = frac + DEPTH and step -1
+    const double d0 = frac + (double)DEPTH;
+    double ss, sc, ws, wc;
+    sincos(PI * ratio * d0, &ss, &sc);                  // sin/cos(pi ratio d)
+    sincos(PI * d0 / (DEPTH + 1.0), &ws, &wc);          // sin/cos(pi d / (DEPTH + 1))
+    double rs, rc, vs, vc;
+    sincos(PI * ratio, &rs, &rc);
+    sincos(PI / (DEPTH + 1.0), &vs, &vc);
+    double acc = 0.0;
+    for (int k = 0; k <= 2 * DEPTH; ++k) {
+        const double d = d0 - (double)k;
+        const int64_t j = j0 + k;
+        double w = d == 0.0 ? ratio : ss / (PI * d);
+        w *= 0.5 + 0.5 * wc;
+        const bool ok = j >= part_lo && j <= part_hi && j >= 0 && j < c.n_samples && fabs(d) <= DEPTH + 1.0;
+        if (ok) acc += (double)x[j] * w;
+        // rotate both angles by one tap backwards
+        const double s2 = ss * rc - sc * rs, c2 = sc * rc + ss * rs;
+        ss = s2; sc = c2;
+        const double w2 = ws * vc - wc * vs, u2 = wc * vc + ws * vs;
+        ws = w2; wc = u2;
+    }
+    res[(int64_t)clip * cap_res + g] = acc;
+}
+
+// ---- 3. power cepstrum of every frame ----------------------------------------------------------------------
+// in-place radix-2 FFT of n complex values that were stored in bit-reversed order (tw[k] = exp(-2 pi i k / 1024))
+__device__ void fft_inplace(double2* a, int n, int log2n, const double2* __restrict__ tw, int tid) {
+    for (int st = 1; st <= log2n; ++st) {
+        const int half = 1 << (st - 1);
+        const int tstep = NFFT_MAX >> st;
+        for (int b = tid; b < (n >> 1); b += 256) {
+            const int grp = b >> (st - 1), p = b & (half - 1);
+            const int i0 = (grp << st) + p, i1 = i0 + half;
+            const double2 w = tw[p * tstep];
+            const double2 u = a[i0], v = a[i1];
+            const double tr = v.x * w.x - v.y * w.y, ti = v.x * w.y + v.y * w.x;
+            a[i0] = make_double2(u.x + tr, u.y + ti);
+            a[i1] = make_double2(u.x - tr, u.y - ti);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int bitrev(int i, int log2n) { return (int)(__brev((unsigned)i) >> (32 - log2n)); }
+
+__global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                       const double* __restrict__ res, int cap_res, int cap_frames,
+                                                       const double* __restrict__ win1000, const double2* __restrict__ tw,
+                                                       double preemph, double* __restrict__ ceps) {
+    __shared__ double2 a[NFFT_MAX];
+    __shared__ double s_red[4];
+    const int clip = blockIdx.y, f = blockIdx.x;
+    const int nseg = hdr[4 * clip];
+    if (nseg <= 0 || f >= hdr[4 * clip + 2]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const Seg* S = segs + (int64_t)clip * max_seg;
+    const Seg s = S[find_seg<4, 5>(S, nseg, f)];
+    const int fl = f - (int)s.frame_off;
+    const int nx = (int)s.nx, nfft = (int)s.nfft, m_out = (int)s.m_out;
+    int log2n = 0;
+    while ((1 << log2n) < nfft) ++log2n;
+    const double* y = res + (int64_t)clip * cap_res + (int64_t)s.res_off;
+    const double t = s.t1 + (double)fl * DT;
+    const int64_t idx0 = (int64_t)floor((t - 0.5 * s.window - s.x1o) / DXO + 0.5);   // Sampled_xToNearestIndex, 0-based
+    // gather with the pre-emphasis y[j] - a y[j-1] (the first sample of the sound is kept), frame mean
+    double loc[4];
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = tid + 256 * r;
+        double v = 0.0;
+        if (i < nx) {
+            const int64_t j = idx0 + i;
+            if (j >= 0 && j < m_out) v = j >= 1 ? y[j] - preemph * y[j - 1] : y[j];
+        }
+        loc[r] = v;
+        sum += v;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) s_red[wv] = sum;
+    __syncthreads();
+    const double mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (double)nx;
+    const double imid = 0.5 * (nx + 1), edge = exp(-12.0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = tid + 256 * r;
+        if (i < nfft) {
+            double v = 0.0;
+            if (i < nx) {
+                double w;
+                if (nx == 1000) w = win1000[i];
+                else {
+                    const double d = (double)(i + 1) - imid;
+                    w = (exp(-48.0 * (d * d) / (double)((nx + 1) * (nx + 1))) - edge) / (1.0 - edge);
+                }
+                v = (loc[r] - mean) * w;
+            }
+            a[bitrev(i, log2n)] = make_double2(v, 0.0);
+        }
+    }
+    __syncthreads();
+    fft_inplace(a, nfft, log2n, tw, tid);
+    // ln power of the bins 0..nfft/2 (spectrum scaled by the sample period), mirrored to a real even sequence
+    const int nq = nfft / 2 + 1;
+    double lp[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int k = tid + 256 * r;
+        lp[r] = 0.0;
+        if (k < nq) {
+            const double re = a[k].x * DXO, im = a[k].y * DXO;
+            lp[r] = log(re * re + im * im + 1e-300);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int k = tid + 256 * r;
+        if (k < nq) {
+            a[bitrev(k, log2n)] = make_double2(lp[r], 0.0);
+            if (k > 0 && k < nfft / 2) a[bitrev(nfft - k, log2n)] = make_double2(lp[r], 0.0);
+        }
+    }
+    __syncthreads();
+    fft_inplace(a, nfft, log2n, tw, tid);
+    const double sdx = 1.0 / (DXO * (double)nfft);
+    double* o = ceps + ((int64_t)clip * cap_frames + f) * NQ_MAX;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int k = tid + 256 * r;
+        if (k < nq) { const double cv = a[k].x * sdx; o[k] = cv * cv; }
+    }
+}
+
+// ---- 4. smoothed cepstral peak prominence of every frame --------------------------------------------------
+// ascending bitonic sort of n (power of two) doubles in LDS by 256 threads
+__device__ void bitonic_sort(double* v, int n, int tid) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const double x = v[i], y = v[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { v[i] = y; v[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ double quantile_half(const double* a, int n) {     // Praat NUMquantile(sorted, 0.5)
+    if (n < 1) return 0.0;
+    if (n == 1) return a[0];
+    const double place = 0.5 * n + 0.5;
+    int left = (int)floor(place);
+    left = left < 1 ? 1 : (left > n - 1 ? n - 1 : left);
+    if (a[left] == a[left - 1]) return a[left - 1];
+    return a[left - 1] + (place - left) * (a[left] - a[left - 1]);
+}
+
+__global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                        const double* __restrict__ ceps, int cap_frames, int n_time,
+                                                        int n_quef, double pitch_floor, double pitch_ceiling,
+                                                        double* __restrict__ cpp_out) {
+    __shared__ double zt[NQ_MAX + 3], db[NQ_MAX + 3], srt[NFFT_MAX];
+    __shared__ double s_val[4];
+    __shared__ int s_ord[4];
+    __shared__ double s_xq[4];
+    const int clip = blockIdx.y, f = blockIdx.x;
+    const int nseg = hdr[4 * clip];
+    if (nseg <= 0 || f >= hdr[4 * clip + 2]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const Seg* S = segs + (int64_t)clip * max_seg;
+    const Seg s = S[find_seg<4, 5>(S, nseg, f)];
+    const int fl = f - (int)s.frame_off, nf = (int)s.nf, nfft = (int)s.nfft, nq = nfft / 2 + 1;
+    const double* Z = ceps + ((int64_t)clip * cap_frames + (int64_t)s.frame_off) * NQ_MAX;   // frames of this interval
+    // moving average over time (VECsmoothByMovingAverage: [i - w/2, i + w/2], one less on the right for even w)
+    int lo = fl, hi = fl;
+    if (n_time > 1) {
+        lo = fl - n_time / 2;
+        hi = fl + n_time / 2 - ((n_time & 1) == 0 ? 1 : 0);
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > nf - 1 ? nf - 1 : hi;
+    }
+    for (int q = tid; q < nq; q += 256) {
+        double v = 0.0;
+        for (int j = lo; j <= hi; ++j) v += Z[(int64_t)j * NQ_MAX + q];
+        zt[q] = n_time > 1 ? v / (double)(hi - lo + 1) : v;
+    }
+    __syncthreads();
+    // moving average over quefrency, then dB
+    for (int q = tid; q < nq; q += 256) {
+        double v = zt[q];
+        if (n_quef > 1) {
+            int a = q - n_quef / 2, b = q + n_quef / 2 - ((n_quef & 1) == 0 ? 1 : 0);
+            a = a < 0 ? 0 : a;
+            b = b > nq - 1 ? nq - 1 : b;
+            v = 0.0;
+            for (int j = a; j <= b; ++j) v += zt[j];
+            v /= (double)(b - a + 1);
+        }
+        db[q] = 10.0 * log10(v + 1e-30);
+    }
+    __syncthreads();
+    // Theil's incomplete method over all nq points: slope = median of the nc half-distance slopes ...
+    const int nc = nq / 2, n2 = (nq & 1) ? nc + 1 : nc;
+    int p2 = 1;
+    while (p2 < nc) p2 <<= 1;
+    for (int i = tid; i < p2; i += 256)
+        srt[i] = i < nc ? (db[n2 + i] - db[i]) / ((double)(n2 + i) * DQ - (double)i * DQ) : INFINITY;
+    __syncthreads();
+    bitonic_sort(srt, p2, tid);
+    const double slope = quantile_half(srt, nc);
+    __syncthreads();
+    // ... intercept = median of the residual offsets
+    p2 = 1;
+    while (p2 < nq) p2 <<= 1;
+    for (int i = tid; i < p2; i += 256) srt[i] = i < nq ? db[i] - slope * ((double)i * DQ) : INFINITY;
+    __syncthreads();
+    bitonic_sort(srt, p2, tid);
+    const double icpt = quantile_half(srt, nq);
+    // Vector_getMaximumAndX (parabolic) over [1/ceiling, 1/floor]: end points first, then the local maxima in
+    // ascending order, a later candidate wins only if strictly greater -> (value, order) reduction
+    const double qlo = 1.0 / pitch_ceiling, qhi = 1.0 / pitch_floor;
+    int imin = (int)ceil(qlo / DQ), imax = (int)floor(qhi / DQ);
+    imax = imax > nq - 1 ? nq - 1 : imax;
+    double best = -INFINITY, bx = 0.0;
+    int bord = 0x7fffffff;
+    if (imax >= imin) {
+        if (tid == 0) { best = db[imin]; bx = (double)imin; bord = 0; }
+        if (tid == 1 && db[imax] > db[imin]) { best = db[imax]; bx = (double)imax; bord = 1; }
+        const int a = imin < 1 ? 1 : imin, b = imax > nq - 2 ? nq - 2 : imax;
+        for (int i = a + tid; i <= b; i += 256) {
+            if (db[i] > db[i - 1] && db[i] >= db[i + 1]) {
+                const double dy = 0.5 * (db[i + 1] - db[i - 1]), d2y = 2.0 * db[i] - db[i - 1] - db[i + 1];
+                const double v = db[i] + 0.5 * dy * dy / d2y;
+                if (v > best) { best = v; bx = (double)i + dy / d2y; bord = 2 + i; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(best, o, 64), ox = __shfl_xor(bx, o, 64);
+        const int oo = __shfl_xor(bord, o, 64);
+        if (ov > best || (ov == best && oo < bord)) { best = ov; bx = ox; bord = oo; }
+    }
+    if (lane == 0) { s_val[wv] = best; s_xq[wv] = bx; s_ord[wv] = bord; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > best || (s_val[w] == best && s_ord[w] < bord)) { best = s_val[w]; bx = s_xq[w]; bord = s_ord[w]; }
+        double out = __longlong_as_double(0x7ff8000000000000LL);
+        if (imax >= imin) {
+            double qpeak = bx * DQ;
+            qpeak = qpeak < qlo ? qlo : (qpeak > qhi ? qhi : qpeak);
+            out = best - (slope * qpeak + icpt);
+        }
+        cpp_out[(int64_t)clip * cap_frames + f] = out;
+    }
+}
+
+// ---- 5. CPPS per interval, mean of the values above 4 dB per clip -----------------------------------------
+__global__ __launch_bounds__(256) void reduce_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                     const double* __restrict__ cpp_frames, int cap_frames, double threshold,
+                                                     double* __restrict__ out) {
+    __shared__ double s_red[4];
+    const int clip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nseg = hdr[4 * clip], fail = hdr[4 * clip + 1];
+    const Seg* S = segs + (int64_t)clip * max_seg;
+    const double* F = cpp_frames + (int64_t)clip * cap_frames;
+    double total = 0.0;
+    int kept = 0;
+    for (int k = 0; k < nseg; ++k) {
+        const int off = (int)S[k].frame_off, nf = (int)S[k].nf;
+        double v = 0.0;
+        for (int i = tid; i < nf; i += 256) v += F[off + i];
+        v = wave_sum_f64(v);
+        __syncthreads();
+        if (lane == 0) s_red[wv] = v;
+        __syncthreads();
+        const double cpps = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (double)nf;
+        if (cpps == cpps && cpps > threshold) { total += cpps; ++kept; }        // :293
+    }
+    if (tid == 0) out[clip] = (kept > 0 && !fail) ? total / (double)kept : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+}  // namespace mshds_cpp
+}  // namespace rsaf
+
+using namespace rsaf;
+using namespace rsaf::mshds_cpp;
+
+extern "C" {
+
+int rsaf_mshds_cpp_seg_doubles(void) { return SEG_DOUBLES; }
+
+int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const double* pulses, int max_pulses,
+                   const int* n_pulses, const double* window1000, const double* twiddle1024, int max_seg, int cap_res,
+                   int cap_frames, void* seg_table, int* hdr, double* resampled, double* cepstrogram, double* cpp_frames,
+                   double* out, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_pulses >= 0, "bad clip/pulse count");
+    if (n_clips == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && clip_info && pulses && n_pulses && window1000 && twiddle1024 && seg_table && hdr && resampled &&
+                   cepstrogram && cpp_frames && out, "NULL pointer");
+    RSAF_CHECK_ARG(max_seg >= 1 && cap_res >= 1 && cap_frames >= 1 && cap_frames <= 65535 * 32, "bad capacities");
+    hipStream_t s = (hipStream_t)stream;
+    const ClipInfo* ci = (const ClipInfo*)clip_info;
+    Seg* segs = (Seg*)seg_table;
+    {
+        ProfScope prof("mshds_cpp_segments", s, 0.0, 0.0);
+        hipLaunchKernelGGL(segments_kernel, dim3(n_clips), dim3(64), 0, s, ci, pulses, max_pulses, n_pulses, 0.02, 0.1, 60.0,
+                           segs, max_seg, cap_res, cap_frames, hdr);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    {
+        ProfScope prof("mshds_cpp_resample", s, 0.0, 0.0);
+        hipLaunchKernelGGL(resample_kernel, dim3((cap_res + 255) / 256, n_clips), dim3(256), 0, s, wav, ci, segs, max_seg, hdr,
+                           cap_res, resampled);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    {
+        ProfScope prof("mshds_cpp_cepstrum", s, 0.0, 0.0);
+        hipLaunchKernelGGL(cepstrum_kernel, dim3(cap_frames, n_clips), dim3(256), 0, s, segs, max_seg, hdr, resampled, cap_res,
+                           cap_frames, window1000, (const double2*)twiddle1024, exp(-2.0 * PI * 50.0 * DXO), cepstrogram);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    {
+        ProfScope prof("mshds_cpp_frames", s, 0.0, 0.0);
+        hipLaunchKernelGGL(cpp_frame_kernel, dim3(cap_frames, n_clips), dim3(256), 0, s, segs, max_seg, hdr, cepstrogram,
+                           cap_frames, (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0, cpp_frames);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(reduce_kernel, dim3(n_clips), dim3(256), 0, s, segs, max_seg, hdr, cpp_frames, cap_frames, 4.0, out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+}  // extern "C"

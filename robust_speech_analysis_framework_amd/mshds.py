@@ -34,7 +34,7 @@ FEATURE_NAMES = [
     "mean_F2_Loc", "std_F2_Loc", "mean_B2_Loc", "std_B2_Loc",
     "Spectral_Gravity", "Spectral_Std_Dev", "Spectral_Skewness", "Spectral_Kurtosis",
 ]                                                            # src/mshds_extractor.py:397-404
-BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
+BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 CLIP_INFO = np.dtype([("sample_off", "<i8"), ("frame_off", "<i8"), ("t1", "<f8"),
                       ("n_samples", "<i4"), ("n_frames", "<i4")])
@@ -366,6 +366,56 @@ class MshdsEngine:
         self._last_ltas = {"pitch": p, "pulses": pulses, "n_pulses": npul, "max_pulses": max_pulses}
         return out[:n]
 
+    CPP_CHUNK = 48          # clips per launch group: the cepstrogram workspace is ~68 MB per 30 s clip
+
+    def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None):
+        """_extract_CPP (src/mshds_extractor.py:253-301) -> float64 [n] mean CPPS of the voiced intervals."""
+        import torch
+        lib = _lib.load()
+        n = len(lengths)
+        dev = self.device
+        out = torch.full((max(n, 1),), float("nan"), dtype=torch.float64, device=dev)
+        if n == 0:
+            return out[:0]
+        p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=frame_shift, floor=floor, ceiling=ceiling,
+                       voicing_threshold=0.3, stream=stream)                                             # :270
+        pulses, npul, max_pulses = self.pulses(wav, lengths, p, stream)                                  # :271
+
+        def build_win():
+            i = np.arange(1, 1001)
+            imid, edge = 0.5 * 1001, math.exp(-12.0)
+            return ((np.exp(-48.0 * (i - imid) ** 2 / 1001 ** 2) - edge) / (1.0 - edge),)
+
+        def build_tw():
+            k = np.arange(512)
+            return (np.stack([np.cos(2.0 * np.pi * k / 1024.0), -np.sin(2.0 * np.pi * k / 1024.0)], axis=1).reshape(-1),)
+        (win,) = self._table(("cpp_window", 1000), build_win)
+        (tw,) = self._table(("cpp_twiddle", 1024), build_tw)
+        dur = max(lengths) * DX
+        max_seg = int(dur / 0.02) + 2
+        cap_res = int(dur * 10000.0) + max_seg + 16
+        cap_frames = int(dur / 0.002) + max_seg
+        segd = int(lib.rsaf_mshds_cpp_seg_doubles())
+        ci_all = p["ci"]
+        for c0 in range(0, n, self.CPP_CHUNK):
+            c1 = min(n, c0 + self.CPP_CHUNK)
+            m = c1 - c0
+            ci_d = _dev(ci_all[c0:c1], dev)
+            segs = torch.empty(m * max_seg * segd, dtype=torch.float64, device=dev)
+            hdr = torch.zeros(m * 4, dtype=torch.int32, device=dev)
+            res = torch.empty(m * cap_res, dtype=torch.float64, device=dev)
+            ceps = torch.empty(m * cap_frames * 513, dtype=torch.float64, device=dev)
+            cppf = torch.empty(m * cap_frames, dtype=torch.float64, device=dev)
+            _lib.check(lib.rsaf_mshds_cpp(_lib.ptr(wav), _lib.ptr(ci_d), m, _lib.c_void_p_off(pulses, c0 * max_pulses),
+                                          max_pulses, _lib.c_void_p_off(npul, c0), _lib.ptr(win), _lib.ptr(tw), max_seg,
+                                          cap_res, cap_frames, _lib.ptr(segs), _lib.ptr(hdr), _lib.ptr(res), _lib.ptr(ceps),
+                                          _lib.ptr(cppf), _lib.c_void_p_off(out, c0), _lib.stream_ptr(stream)),
+                       "rsaf_mshds_cpp")
+            self._last_cpp = {"segs": segs, "hdr": hdr, "res": res, "ceps": ceps, "cpp_frames": cppf, "max_seg": max_seg,
+                              "cap_res": cap_res, "cap_frames": cap_frames, "seg_doubles": segd, "pulses": pulses,
+                              "n_pulses": npul, "max_pulses": max_pulses, "chunk": (c0, c1)}
+        return out[:n]
+
     def hnr_mean(self, pitch_cc, stream=None):
         import torch
         n = len(pitch_cc["ci"])
@@ -429,6 +479,7 @@ class MshdsEngine:
             out[idx, 8] = inten["stats"][:, 1]
             out[idx, 9] = hnr
             out[idx, 10:12] = self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                      # :433
+            out[idx, 12] = self.cpp(wav, so, ln, gp, floor, ceiling, 0.005, stream)                          # :434
             out[idx, 21:25] = sm["stats"]
         return out, ranges
 

@@ -124,7 +124,7 @@ class Pipeline:
     def describe(self, clips, seconds):
         parts = []
         if "mshds" in self.stages:
-            parts.append("MSHDS Praat-style 24/25 features (speech rate, pitch, intensity, HNR, LTAS slope/tilt, formants, spectral moments; fp64)")
+            parts.append("MSHDS Praat-style 25/25 features (speech rate, pitch, intensity, HNR, LTAS slope/tilt, CPPS, formants, spectral moments; fp64)")
         if "smile" in self.stages:
             parts.append("openSMILE-style 32/38 LLD + 912 functionals")
         if "w2v2" in self.stages:

@@ -199,6 +199,60 @@ def test_ltas_slope_and_tilt(eng):
     assert not np.isnan(got[0]).any() and np.isnan(got[2]).all()
 
 
+def test_cpp_voiced_intervals_cepstrogram_and_cpps(eng):
+    """_extract_CPP (:253-301): vuv intervals (6-decimal times), 10 kHz resampling, power cepstrum per frame,
+    smoothed CPP per frame, mean of the per-interval CPPS above 4 dB."""
+    import torch
+    clips = [synth.synth_clip(190, 1.6), synth.synth_clip(191, 1.1), np.zeros(4000, np.float32)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    got = eng.cpp(wav, offs, lens, gp, 100.0, 500.0).cpu().numpy()
+    torch.cuda.synchronize()
+    L = eng._last_cpp
+    sd = L["seg_doubles"]
+    segs = L["segs"].cpu().numpy().reshape(len(clips), L["max_seg"], sd)
+    hdr = L["hdr"].cpu().numpy().reshape(len(clips), 4)
+    res = L["res"].cpu().numpy().reshape(len(clips), L["cap_res"])
+    ceps = L["ceps"].cpu().numpy().reshape(len(clips), L["cap_frames"], 513)
+    cppf = L["cpp_frames"].cpu().numpy().reshape(len(clips), L["cap_frames"])
+    for i, c in enumerate(clips):
+        x = c.astype(np.float64)
+        p = mo.pitch_ac(x, 0.005, 100.0, voicing_threshold=0.3, pitch_ceiling=500.0)
+        pul = mo.point_process_cc(x, p)
+        iv = [(float(f"{a:.6f}"), float(f"{b:.6f}")) for a, b in mo.vuv_intervals(pul, 0.0, len(x) * mo.DX)]
+        iv = [(a, b) for a, b in iv if a < b]
+        assert hdr[i, 0] == len(iv) and hdr[i, 1] == 0                               # interval count is exact
+        ref_vals = []
+        for k, (tmin, tmax) in enumerate(iv):
+            ix1 = int(np.ceil((tmin - 0.5 * mo.DX) / mo.DX))
+            ix2 = int(np.floor((tmax - 0.5 * mo.DX) / mo.DX))
+            seg = np.zeros(ix2 - ix1 + 1)
+            a, b = max(ix1, 0), min(ix2, len(x) - 1)
+            seg[a - ix1:b - ix1 + 1] = x[a:b + 1]
+            x1_seg = 0.5 * mo.DX + ix1 * mo.DX - tmin
+            S = segs[i, k]
+            assert int(S[0]) == ix1 and int(S[1]) == len(seg)                         # integers exact
+            y, x1o, _ = mo.resample_windowed_sinc(seg, x1_seg, tmax - tmin, mo.CPP_FS, mo.CPP_DEPTH)
+            assert int(S[2]) == len(y) and abs(S[7] - x1o) < 1e-15
+            r0 = int(S[3])
+            assert np.abs(res[i, r0:r0 + len(y)] - y).max() < 1e-9 * max(1.0, np.abs(y).max())
+            z = mo.power_cepstrogram(seg, x1_seg, tmax - tmin)
+            f0, nf = int(S[4]), int(S[5])
+            assert nf == z.shape[1] and int(S[11]) // 2 + 1 == z.shape[0]
+            g = ceps[i, f0:f0 + nf, :z.shape[0]].T
+            assert np.abs(g - z).max() <= 1e-7 * np.abs(z).max()
+            v = mo.cpps(z)
+            assert abs(cppf[i, f0:f0 + nf].mean() - v) <= 1e-6 * abs(v)
+            if v > 4:
+                ref_vals.append(v)
+        ref = np.mean(ref_vals) if ref_vals else np.nan
+        assert np.isnan(got[i]) == np.isnan(ref)
+        if not np.isnan(ref):
+            assert abs(got[i] - ref) <= 1e-6 * abs(ref), (got[i], ref)
+            assert abs(ref - mo.extract_cpp(c, 100.0, 500.0)) < 1e-12
+    assert not np.isnan(got[0]) and np.isnan(got[2])
+
+
 def test_extract_packed_matches_oracle_and_uses_both_speaker_ranges(eng):
     import torch
     ids = [140, 141, 142, 143, 144, 145]
