@@ -226,6 +226,18 @@ int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const v
                                 int nbins, double time_step, double freq_step, double* moments,
                                 double* stats_out, rsaf_stream_t stream);
 
+/* ---- sample-rate conversion in front of the extractors ---------------------------------- */
+/* torchaudio.transforms.Resample(orig, new) with its defaults (sinc_interp_hann, lowpass_filter_width 6, rolloff
+ * 0.99): out[i * n_phase + p] = sum_k taps[p][k] * in[i * orig + tap_start[p] + k] (zero outside the input), with
+ * orig/new already divided by their gcd, n_phase = new, n_out = ceil(new * n_in / orig).  The host builds the
+ * taps (resample.sinc_hann_taps).  Replaces src/foundation_model_extractor.py:93-94. */
+int rsaf_resample_sinc_hann(const float* in, int64_t n_in, const float* taps, const int* tap_start, int n_phase, int orig,
+                            int taps_per_phase, float* out, int64_t n_out, rsaf_stream_t stream);
+/* Praat Sound.resample(fs_out, precision) as one windowed sinc; n_out = round(n_in / fs_in * fs_out).
+ * Replaces snd.resample(16000, 50), src/mshds_extractor.py:419. */
+int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_out, int precision, float* out,
+                        int64_t n_out, rsaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

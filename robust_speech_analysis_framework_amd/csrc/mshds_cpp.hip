@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     for (int k = 0; k <= 2 * DEPTH; ++k) {
         const double d = d0 - (double)k;
         const int64_t j = j0 + k;
-        double w = d == 0.0 ? ratio : ss / (PI * d);
+        // the tap next to the position takes sin() directly (the rotated value's ~1e-15 absolute error would be
+        // blown up by the division by a tiny d)
+        const double sn = (k == DEPTH || k == DEPTH + 1) ? sin(PI * ratio * d) : ss;
+        double w = d == 0.0 ? ratio : sn / (PI * d);
         w *= 0.5 + 0.5 * wc;
         const bool ok = j >= part_lo && j <= part_hi && j >= 0 && j < c.n_samples && fabs(d) <= DEPTH + 1.0;
         if (ok) acc += (double)x[j] * w;

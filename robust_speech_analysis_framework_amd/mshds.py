@@ -497,7 +497,7 @@ def get_engine(device="cuda"):
 def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True, batch_files=32):
     """Drop-in for ``src/mshds_extractor.py:379-459``: one row per input row, in input order,
     columns ``filename`` + the 25 feature names; a file that cannot be processed gives a NaN row
-    (``:450-457``).  Columns whose kernels are not built yet are NaN."""
+    (``:450-457``).  Files at another sample rate are converted to 16 kHz on the device first."""
     import pandas as pd
     import torch
     eng = get_engine()
@@ -510,8 +510,9 @@ def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True,
             filename = os.path.basename(pth)
             try:
                 x, fs = read_wav_mono(pth)
-                if fs != SAMPLE_RATE:
-                    raise ValueError(f"sample rate {fs} Hz: resampling is not built yet (16 kHz input only)")
+                if fs != SAMPLE_RATE:                                         # :418-419 snd.resample(16000, 50)
+                    from .resample import resample_praat
+                    x = resample_praat(x, fs, SAMPLE_RATE, 50, device=eng.device).cpu().numpy()
                 if len(x) == 0:
                     raise ValueError("empty file")
                 clips.append(x)

@@ -48,7 +48,9 @@ class Pipeline:
         # MSHDS is fp64-VALU work, Wav2Vec2/CNN-LSTM is MFMA work: different pipes of the same CUs.  With
         # `overlap` the two run on separate HIP streams so the dispatcher co-schedules their workgroups.
         self.overlap = overlap and "mshds" in self.stages and "w2v2" in self.stages
-        self._aux = torch.cuda.Stream(device=device) if self.overlap else None
+        import os
+        prio = int(os.environ.get("RSAF_AUX_PRIORITY", "0"))      # experiment knob: -1 = high priority for the MSHDS stream
+        self._aux = torch.cuda.Stream(device=device, priority=prio) if self.overlap else None
         self._pool = None
         if self.overlap:
             # the main stream's launch queue back-pressures its host thread (thousands of launches per

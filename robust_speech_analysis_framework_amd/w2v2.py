@@ -205,8 +205,10 @@ def extract_wav2vec2_sequences(input_df, model_name="facebook/wav2vec2-base-960h
                         print(f"INFO: Skipping very short file '{filename}'.")
                     continue
                 mono = x.mean(axis=0, dtype=np.float32) if x.shape[0] > 1 else x[0]
-                if fs != SAMPLE_RATE:
-                    raise ValueError(f"sample rate {fs} Hz: resampling is not built yet (16 kHz input only)")
+                if fs != SAMPLE_RATE:                                         # :92-94 torchaudio Resample defaults
+                    from .resample import resample_sinc_hann
+                    mono = resample_sinc_hann(np.ascontiguousarray(mono, dtype=np.float32), fs, SAMPLE_RATE,
+                                              device=eng.device).cpu().numpy()
                 clips.append(np.ascontiguousarray(mono, dtype=np.float32))
                 names.append(filename)
             except Exception as e:
