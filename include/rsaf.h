@@ -190,9 +190,12 @@ int rsaf_mshds_resample10k(const float* wav, const void* resample_info, int n_cl
 int rsaf_mshds_formants(const double* y10, const void* resample_info, const void* clip_info, int n_clips,
                         int max_frames, const double* window, int nsamp_window, double time_step, double dx_out,
                         double preemph_factor, void* frames_out, rsaf_stream_t stream);
-int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips, const double* sel_freq,
-                      double pitch_dt, double pitch_ceiling, double* pulses, int max_pulses, int* n_pulses,
-                      rsaf_stream_t stream);
+/* pulses[clip][max_pulses] in ascending time, n_pulses[clip]; workspace sized by
+ * rsaf_mshds_pulses_workspace_bytes (stretch table and per-stretch pulse slots). */
+int64_t rsaf_mshds_pulses_workspace_bytes(int n_clips, int max_frames, double pitch_dt, double pitch_ceiling);
+int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips, int max_frames, const double* sel_freq,
+                      double pitch_dt, double pitch_ceiling, void* workspace, int64_t workspace_bytes, double* pulses,
+                      int max_pulses, int* n_pulses, rsaf_stream_t stream);
 /* Ltas (pitch-corrected) 0-5000 Hz in 100 Hz bands from the time-sorted pulses of rsaf_mshds_pulses, then
  * "Get slope" (50-1000 vs 1000-4000 Hz, dB) and the slope of the robust line fit over 100-5000 Hz:
  * out[clip][2] = {Spectral_Slope, Spectral_Tilt}, NaN where Praat raises.

@@ -1503,40 +1503,100 @@ __device__ double find_extremum_wave(const float* __restrict__ x, int n, double 
     return 0.5 * DXS + ((double)imin + ie - 1.0) * DXS;
 }
 
-__global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ pci,
-                                                    const double* __restrict__ sel_freq, double pdt, double ceiling,
-                                                    double* __restrict__ pulses, int max_pulses, int* __restrict__ n_pulses) {
-    __shared__ float ps1[PULSE_LDS], ps2[PULSE_LDS];
+// ---- Sound & Pitch: To PointProcess (cc) -------------------------------------------------------------------
+// Praat walks the voiced stretches one after the other; inside a stretch the pulses are found one by one (each
+// search starts at the previous pulse), but the stretches only interact through `added_right` (the last pulse
+// added while walking right), which merely vetoes left-going pulses of later stretches.  So: (1) one wave per
+// clip lists the stretches, (2) one wave per stretch walks it and records its pulses with their veto margins,
+// (3) one wave per clip applies the vetoes in order and writes the pulses in ascending time.
+struct Stretch { int il, irr, off, pad; };      // frame range, first slot of the stretch in the per-clip scratch
+
+__device__ __forceinline__ bool voiced_at(const double* f, int nF, double ceiling, int i) {
+    return i >= 0 && i < nF && f[i] > 0.0 && f[i] < ceiling;
+}
+
+__global__ __launch_bounds__(64) void pulse_stretches_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ pci,
+                                                             const double* __restrict__ sel_freq, double pdt, double ceiling,
+                                                             Stretch* __restrict__ st, int max_st, int* __restrict__ n_st,
+                                                             double* __restrict__ abs_peak) {
     const ClipInfo c = pci[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, nF = c.n_frames;
+    {   // Vector_getAbsoluteExtremum of the whole sound (no mean subtraction, unlike the pitch analysis)
+        const float* x = wav + c.sample_off;
+        double gp = 0.0;
+        for (int i = lane; i < c.n_samples; i += 64) gp = fmax(gp, fabs((double)x[i]));
+        gp = wave_max_f64(gp);
+        if (lane == 0) abs_peak[blockIdx.x] = gp;
+    }
+    const double* f = sel_freq + c.frame_off;
+    Stretch* S = st + (int64_t)blockIdx.x * max_st;
+    int count = 0;
+    for (int base = 0; base < nF; base += 64) {
+        const int i = base + lane;
+        const bool v = voiced_at(f, nF, ceiling, i);
+        const bool start = v && !voiced_at(f, nF, ceiling, i - 1), end = v && !voiced_at(f, nF, ceiling, i + 1);
+        const unsigned long long ms = __ballot(start), me = __ballot(end);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (start) { const int k = count + __popcll(ms & below); if (k < max_st) S[k].il = i; }
+        if (end) {
+            // the stretch that ends here is the last one started at or before this frame
+            const int k = count + __popcll(ms & (below | (1ull << lane))) - 1;
+            if (k >= 0 && k < max_st) S[k].irr = i;
+        }
+        count += __popcll(ms);
+    }
+    count = count < max_st ? count : max_st;
+    __threadfence_block();
+    // scratch slots: a stretch of n frames holds at most n*pdt*ceiling/0.8 + 3 pulses on either side
+    int run = 0;
+    for (int base = 0; base < count; base += 64) {
+        const int k = base + lane;
+        int cap = 0;
+        if (k < count) cap = (int)((double)(S[k].irr - S[k].il + 1) * pdt * ceiling * 1.25) + 4;
+        int inc = cap;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
+        if (k < count) { S[k].off = run + inc - cap; S[k].pad = cap; }
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) n_st[blockIdx.x] = count;
+}
+
+// scratch per clip: left[slot] = (time, veto margin 0.8/f0) in walking order (entry 0 = the middle pulse),
+// right[slot] = time; counts[stretch] = (n_left, n_right)
+__global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ pci,
+                                                         const double* __restrict__ sel_freq, double pdt, double ceiling,
+                                                         const double* __restrict__ abs_peak, const Stretch* __restrict__ st,
+                                                         int max_st, const int* __restrict__ n_st, double2* __restrict__ left,
+                                                         double* __restrict__ right, int cap_slots, int2* __restrict__ counts) {
+    __shared__ float s_ps[4][2][PULSE_LDS];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int clip = blockIdx.y, k = blockIdx.x * 4 + wv;
+    if (k >= n_st[clip]) return;
+    float* ps1 = s_ps[wv][0];
+    float* ps2 = s_ps[wv][1];
+    const ClipInfo c = pci[clip];
     const float* x = wav + c.sample_off;
     const int n = c.n_samples, nF = c.n_frames;
     const double* f = sel_freq + c.frame_off;
-    double* pts = pulses + (int64_t)blockIdx.x * max_pulses;
+    const Stretch S = st[(int64_t)clip * max_st + k];
+    double2* L = left + (int64_t)clip * cap_slots + S.off;
+    double* R = right + (int64_t)clip * cap_slots + S.off;
+    const int cap = S.pad;
     const double duration = n * DXS;
-    double gp = 0.0;
-    for (int i = lane; i < n; i += 64) gp = fmax(gp, fabs((double)x[i]));
-    gp = wave_max_f64(gp);
-    int np_ = 0;
-    double t = 0.0, added_right = -1e308;
-    for (int guard = 0; guard < nF + 2; ++guard) {
-        int64_t il = (int64_t)ceil((t - c.t1) / pdt);
-        il = il < 0 ? 0 : il;
-        while (il < nF && !(f[il] > 0.0 && f[il] < ceiling)) ++il;
-        if (il >= nF) break;
-        int64_t irr = il;
-        while (irr < nF && (f[irr] > 0.0 && f[irr] < ceiling)) ++irr;
-        --irr;
-        double tleft = c.t1 + il * pdt - 0.5 * pdt, tright = c.t1 + irr * pdt + 0.5 * pdt;
-        if (tleft >= duration - 0.5 * pdt) break;
-        tleft = tleft < 0.0 ? 0.0 : tleft;
-        tright = tright > duration ? duration : tright;
-        const double tmid = 0.5 * (tleft + tright);
-        const double f0mid = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmid);
-        if (!(f0mid == f0mid)) { t = tright; continue; }
+    const double gp = abs_peak[clip];
+    int nl = 0, nr = 0;
+    double tleft = c.t1 + S.il * pdt - 0.5 * pdt, tright = c.t1 + S.irr * pdt + 0.5 * pdt;
+    bool skip = tleft >= duration - 0.5 * pdt;               // Praat stops here; every later stretch starts even later
+    tleft = tleft < 0.0 ? 0.0 : tleft;
+    tright = tright > duration ? duration : tright;
+    const double tmid = 0.5 * (tleft + tright);
+    const double f0mid = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmid);
+    if (!(f0mid == f0mid)) skip = true;
+    if (!skip) {
         double tmax = find_extremum_wave(x, n, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid, lane);
-        const int first = np_;
-        if (np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
+        if (lane == 0) L[0] = make_double2(tmax, 0.0);
+        nl = 1;
         const double tsave = tmax;
         for (int g2 = 0; g2 < 200000; ++g2) {                      // to the left
             const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
@@ -1546,19 +1606,11 @@ __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wa
             tmax = tout;
             if (corr == -1.0) tmax -= 1.0 / f0;
             if (tmax < tleft) {
-                if (corr > 0.7 && peak > 0.023333 * gp && tmax - added_right > 0.8 / f0 && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
+                if (corr > 0.7 && peak > 0.023333 * gp && nl < cap) { if (lane == 0) L[nl] = make_double2(tmax, 0.8 / f0); ++nl; }
                 break;
             }
-            if (corr > 0.3 && (peak == 0.0 || peak > 0.01 * gp) && tmax - added_right > 0.8 / f0 && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; }
+            if (corr > 0.3 && (peak == 0.0 || peak > 0.01 * gp) && nl < cap) { if (lane == 0) L[nl] = make_double2(tmax, 0.8 / f0); ++nl; }
         }
-        // the block [first .. np_) holds the middle pulse followed by the left-going pulses in descending time:
-        // reverse it so that the clip's pulses come out in ascending time like a Praat PointProcess
-        __threadfence_block();
-        for (int i = first + lane, j = np_ - 1 - lane; i < j; i += 64, j -= 64) {
-            const double a = pts[i], b = pts[j];
-            pts[i] = b; pts[j] = a;
-        }
-        __threadfence_block();
         tmax = tsave;
         for (int g2 = 0; g2 < 200000; ++g2) {                      // to the right
             const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
@@ -1568,14 +1620,51 @@ __global__ __launch_bounds__(64) void pulses_kernel(const float* __restrict__ wa
             tmax = tout;
             if (corr == -1.0) tmax += 1.0 / f0;
             if (tmax > tright) {
-                if (corr > 0.7 && peak > 0.023333 * gp && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; added_right = tmax; }
+                if (corr > 0.7 && peak > 0.023333 * gp && nr < cap) { if (lane == 0) R[nr] = tmax; ++nr; }
                 break;
             }
-            if (corr > 0.3 && (peak == 0.0 || peak > 0.01 * gp) && np_ < max_pulses) { if (lane == 0) pts[np_] = tmax; ++np_; added_right = tmax; }
+            if (corr > 0.3 && (peak == 0.0 || peak > 0.01 * gp) && nr < cap) { if (lane == 0) R[nr] = tmax; ++nr; }
         }
-        t = tright;
     }
-    if (lane == 0) n_pulses[blockIdx.x] = np_;
+    if (lane == 0) counts[(int64_t)clip * max_st + k] = make_int2(nl, nr);
+}
+
+__global__ __launch_bounds__(64) void pulse_merge_kernel(const Stretch* __restrict__ st, int max_st, const int* __restrict__ n_st,
+                                                         const double2* __restrict__ left, const double* __restrict__ right,
+                                                         int cap_slots, const int2* __restrict__ counts,
+                                                         double* __restrict__ pulses, int max_pulses, int* __restrict__ n_pulses) {
+    const int clip = blockIdx.x, lane = threadIdx.x;
+    const int ns = n_st[clip];
+    double* pts = pulses + (int64_t)clip * max_pulses;
+    int np_ = 0;
+    double added_right = -1e308;
+    for (int k = 0; k < ns; ++k) {
+        const Stretch S = st[(int64_t)clip * max_st + k];
+        const int2 cn = counts[(int64_t)clip * max_st + k];
+        const double2* L = left + (int64_t)clip * cap_slots + S.off;
+        const double* R = right + (int64_t)clip * cap_slots + S.off;
+        if (cn.x <= 0) continue;
+        // left-going pulses in ascending time = walking order reversed; entry 0 (the middle pulse) is never vetoed
+        for (int base = cn.x - 1; base >= 1; base -= 64) {
+            const int i = base - lane;
+            bool keep = false;
+            double t = 0.0;
+            if (i >= 1) { const double2 e = L[i]; t = e.x; keep = t - added_right > e.y; }
+            const unsigned long long m = __ballot(keep);
+            const int pos = np_ + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep && pos < max_pulses) pts[pos] = t;
+            np_ += __popcll(m);
+        }
+        if (np_ < max_pulses && lane == 0) pts[np_] = L[0].x;
+        ++np_;
+        for (int base = 0; base < cn.y; base += 64) {
+            const int i = base + lane;
+            if (i < cn.y && np_ + i < max_pulses) pts[np_ + i] = R[i];
+        }
+        if (cn.y > 0) added_right = R[cn.y - 1];
+        np_ += cn.y;
+    }
+    if (lane == 0) n_pulses[clip] = np_ < max_pulses ? np_ : max_pulses;
 }
 
 // ---- Ltas (pitch-corrected) -> "Get slope" and robust tilt (src/mshds_extractor.py:227-251) ---------------
@@ -1949,15 +2038,50 @@ int rsaf_mshds_formants(const double* y10, const void* resample_info, const void
     return RSAF_OK;
 }
 
-int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips, const double* sel_freq, double pitch_dt,
-                      double pitch_ceiling, double* pulses, int max_pulses, int* n_pulses, rsaf_stream_t stream) {
-    RSAF_CHECK_ARG(n_clips >= 0 && max_pulses >= 1, "bad argument");
+// scratch of rsaf_mshds_pulses: stretch table + per-stretch counts + left (time, margin) + right (time) slots
+static void pulses_layout(int n_clips, int max_frames, int max_samples, double pitch_dt, double ceiling, int* max_st,
+                          int* cap_slots, int64_t* total) {
+    *max_st = max_frames / 2 + 2;
+    *cap_slots = (int)((double)max_frames * pitch_dt * ceiling * 1.25) + 4 * *max_st + 16;
+    (void)max_samples;
+    *total = (int64_t)n_clips * ((int64_t)*max_st * (sizeof(Stretch) + sizeof(int2)) + sizeof(int) * 2 + sizeof(double) +
+                                 (int64_t)*cap_slots * (sizeof(double2) + sizeof(double))) + 256;
+}
+
+int64_t rsaf_mshds_pulses_workspace_bytes(int n_clips, int max_frames, double pitch_dt, double pitch_ceiling) {
+    int ms, cs;
+    int64_t total;
+    pulses_layout(n_clips, max_frames, 0, pitch_dt, pitch_ceiling, &ms, &cs, &total);
+    return total;
+}
+
+int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips, int max_frames, const double* sel_freq,
+                      double pitch_dt, double pitch_ceiling, void* workspace, int64_t workspace_bytes, double* pulses,
+                      int max_pulses, int* n_pulses, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_pulses >= 1 && max_frames >= 0, "bad argument");
     if (n_clips == 0) return RSAF_OK;
-    RSAF_CHECK_ARG(wav && pitch_clip_info && sel_freq && pulses && n_pulses, "NULL pointer");
+    RSAF_CHECK_ARG(wav && pitch_clip_info && sel_freq && workspace && pulses && n_pulses, "NULL pointer");
+    int max_st, cap_slots;
+    int64_t need;
+    pulses_layout(n_clips, max_frames, 0, pitch_dt, pitch_ceiling, &max_st, &cap_slots, &need);
+    RSAF_CHECK_ARG(workspace_bytes >= need, "workspace too small (rsaf_mshds_pulses_workspace_bytes)");
+    char* w = (char*)workspace;
+    double2* left = (double2*)w;              w += (int64_t)n_clips * cap_slots * sizeof(double2);
+    double* right = (double*)w;               w += (int64_t)n_clips * cap_slots * sizeof(double);
+    double* abs_peak = (double*)w;            w += (int64_t)n_clips * sizeof(double);
+    Stretch* st = (Stretch*)w;                w += (int64_t)n_clips * max_st * sizeof(Stretch);
+    int2* counts = (int2*)w;                  w += (int64_t)n_clips * max_st * sizeof(int2);
+    int* n_st = (int*)w;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("mshds_pulses", s, 0.0, 0.0);
-    hipLaunchKernelGGL(pulses_kernel, dim3(n_clips), dim3(64), 0, s, wav, (const ClipInfo*)pitch_clip_info, sel_freq,
-                       pitch_dt, pitch_ceiling, pulses, max_pulses, n_pulses);
+    hipLaunchKernelGGL(pulse_stretches_kernel, dim3(n_clips), dim3(64), 0, s, wav, (const ClipInfo*)pitch_clip_info, sel_freq,
+                       pitch_dt, pitch_ceiling, st, max_st, n_st, abs_peak);
+    RSAF_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pulse_walk_kernel, dim3((max_st + 3) / 4, n_clips), dim3(256), 0, s, wav, (const ClipInfo*)pitch_clip_info,
+                       sel_freq, pitch_dt, pitch_ceiling, abs_peak, st, max_st, n_st, left, right, cap_slots, counts);
+    RSAF_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pulse_merge_kernel, dim3(n_clips), dim3(64), 0, s, st, max_st, n_st, left, right, cap_slots, counts, pulses,
+                       max_pulses, n_pulses);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -344,9 +344,13 @@ class MshdsEngine:
         pulses = torch.empty(max(n, 1) * max_pulses, dtype=torch.float64, device=self.device)
         npul = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
         if n:
-            _lib.check(_lib.load().rsaf_mshds_pulses(_lib.ptr(wav), _lib.ptr(pitch["ci_dev"]), n, _lib.ptr(pitch["sel_freq"]),
-                                                     pitch["geom"].dt, ceiling, _lib.ptr(pulses), max_pulses,
-                                                     _lib.ptr(npul), _lib.stream_ptr(stream)), "rsaf_mshds_pulses")
+            lib = _lib.load()
+            mx = int(pitch["max_frames"])
+            need = int(lib.rsaf_mshds_pulses_workspace_bytes(n, mx, pitch["geom"].dt, ceiling))
+            ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+            _lib.check(lib.rsaf_mshds_pulses(_lib.ptr(wav), _lib.ptr(pitch["ci_dev"]), n, mx, _lib.ptr(pitch["sel_freq"]),
+                                             pitch["geom"].dt, ceiling, _lib.ptr(ws), need, _lib.ptr(pulses), max_pulses,
+                                             _lib.ptr(npul), _lib.stream_ptr(stream)), "rsaf_mshds_pulses")
         return pulses, npul, max_pulses
 
     def slope_tilt(self, wav, sample_offs, lengths, gpeak, floor, ceiling, stream=None):
