@@ -826,7 +826,7 @@ __global__ __launch_bounds__(64) void hnr_stats_kernel(const double* __restrict_
 }
 
 // ---- Gaussian-window spectrogram slice + spectral moments, gated by pitch definedness ----------------------
-// one workgroup per frame; direct DFT of the windowed frame for bins 0..nbins-1 (bin width 1/(dx*nfft))
+// one workgroup per frame; fp64 radix-2 FFT (in LDS) of the zero-padded windowed frame, bins 0..nbins-1 (bin width 1/(dx*nfft))
 __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                            const ClipInfo* __restrict__ pitch_ci, const double* __restrict__ sel_freq,
                                                            double pitch_dt, double ceiling, const double* __restrict__ win,
@@ -834,8 +834,8 @@ __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restri
                                                            int nbins, double tstep, double fstep,
                                                            double* __restrict__ mom /* [frames][5]: ok, cog, sd, skew, kurt */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* seg = reinterpret_cast<double*>(smem_raw);          // nsamp
-    double* pw = seg + ((nsamp + 1) & ~1);                       // nbins
+    double2* a = reinterpret_cast<double2*>(smem_raw);          // nfft complex values of the FFT
+    double* pw = reinterpret_cast<double*>(a + nfft);            // nbins
     __shared__ double s_red[8][4];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
@@ -861,28 +861,34 @@ __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restri
     }
     const float* x = wav + c.sample_off;
     const int64_t start = low_index(t) + 1 - half;
-    for (int j = tid; j < nsamp; j += blockDim.x) {
-        int64_t i = start + j;
-        i = i < 0 ? 0 : (i > c.n_samples - 1 ? c.n_samples - 1 : i);
-        seg[j] = (double)x[i] * win[j];
+    // windowed frame, zero-padded to nfft, stored bit-reversed for the in-place radix-2 FFT
+    const int nthr = blockDim.x;
+    int log2n = 0;
+    while ((1 << log2n) < nfft) ++log2n;
+    for (int j = tid; j < nfft; j += nthr) {
+        double v = 0.0;
+        if (j < nsamp) {
+            int64_t i = start + j;
+            i = i < 0 ? 0 : (i > c.n_samples - 1 ? c.n_samples - 1 : i);
+            v = (double)x[i] * win[j];
+        }
+        a[(int)(__brev((unsigned)j) >> (32 - log2n))] = make_double2(v, 0.0);
     }
     __syncthreads();
-    // direct DFT of the nsamp-sample frame, one bin per thread; the twiddle of bin k advances by a
-    // fixed rotation exp(-2 pi i k / nfft) per sample (seg[j] is an LDS broadcast read)
-    const int nthr = blockDim.x;
-    for (int k = tid; k < nbins; k += nthr) {
-        const double2 step = tw[k & (nfft - 1)];
-        double wr_ = 1.0, wi_ = 0.0, re = 0.0, im = 0.0;
-        for (int j = 0; j < nsamp; ++j) {
-            const double v = seg[j];
-            re += v * wr_;
-            im += v * wi_;
-            const double t2 = wr_ * step.x - wi_ * step.y;
-            wi_ = wr_ * step.y + wi_ * step.x;
-            wr_ = t2;
+    for (int st = 1; st <= log2n; ++st) {
+        const int half_ = 1 << (st - 1), tstep_ = nfft >> st;
+        for (int b = tid; b < (nfft >> 1); b += nthr) {
+            const int grp = b >> (st - 1), p = b & (half_ - 1);
+            const int i0 = (grp << st) + p, i1 = i0 + half_;
+            const double2 w = tw[p * tstep_];
+            const double2 u = a[i0], v = a[i1];
+            const double tr = v.x * w.x - v.y * w.y, ti = v.x * w.y + v.y * w.x;
+            a[i0] = make_double2(u.x + tr, u.y + ti);
+            a[i1] = make_double2(u.x - tr, u.y - ti);
         }
-        pw[k] = re * re + im * im;
+        __syncthreads();
     }
+    for (int k = tid; k < nbins; k += nthr) pw[k] = a[k].x * a[k].x + a[k].y * a[k].y;
     __syncthreads();
     double s0 = 0, s1 = 0;
     for (int k = tid; k < nbins; k += nthr) { s0 += pw[k]; s1 += pw[k] * (k * fstep); }
@@ -2132,11 +2138,12 @@ int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const v
                    "NULL pointer");
     RSAF_CHECK_ARG(nfft > 0 && (nfft & (nfft - 1)) == 0 && nbins > 0 && nbins <= nfft / 2 + 1, "bad FFT geometry");
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)(((nsamp_window + 1) & ~1) + nbins) * sizeof(double);
+    RSAF_CHECK_ARG(nfft >= 2 && (nfft & (nfft - 1)) == 0 && nfft >= nsamp_window && nbins <= nfft / 2 + 1, "nfft must be a power of two >= window");
+    const size_t lds = (size_t)(2 * nfft + nbins) * sizeof(double);
     RSAF_CHECK_ARG(lds <= 60 * 1024, "spectrogram window too long");
     if (max_frames > 0) {
         ProfScope prof("mshds_spec_moments", s, 0.0, 0.0);
-        const int threads = std::min(512, ((nbins + 63) / 64) * 64);
+        const int threads = nfft >= 1024 ? 512 : 256;
         hipLaunchKernelGGL(spec_moments_kernel, dim3(max_frames, n_clips), dim3(threads), lds, s, wav,
                            (const ClipInfo*)clip_info, (const ClipInfo*)pitch_clip_info, sel_freq, pitch_dt, ceiling,
                            window, (const double2*)twiddle, nsamp_window, nsamp_window / 2, nfft, nbins, time_step,
