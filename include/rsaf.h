@@ -168,6 +168,15 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
                      const double* window, const double* window_r, const double* params_host,
                      void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
                      double* stats_out, rsaf_stream_t stream);
+/* The same analysis for two voicing thresholds at once (src/mshds_extractor.py:178 and :270 differ in nothing
+ * else): one frame kernel computes the correlation and refines the union of the two candidate lists, the path
+ * finder runs per threshold.  The *2 outputs have the shapes of their first-threshold counterparts. */
+int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
+                          const double* window, const double* window_r, const double* params_host,
+                          void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
+                          double* stats_out, double voicing_threshold2, void* frame_out2, unsigned char* psi2,
+                          int* end_state2, double* sel_freq2, double* sel_strength2, double* stats_out2,
+                          rsaf_stream_t stream);
 /* _speechrate (src/mshds_extractor.py:11-125) from the 50 Hz / 16 ms intensity contour (rsaf_mshds_intensity)
  * and the 4-candidate pitch pass of :104.  out[clip][5] = Speaking_Rate, Articulation_Rate,
  * Phonation_Ratio, Pause_Rate, Mean_Pause_Dur.  workspace: n_clips * workspace_doubles(max_frames). */

@@ -44,6 +44,7 @@ struct PitchParams {
     double refine_margin;   // > 0: only candidates within this margin of the best first-pass strength are refined
     int nsamp_window, half_window, nsamp_period, half_period, min_lag, max_lag, brent_ixmax, max_cand;
     int refine_depth, is_cc;
+    double voicing_thr2;    // >= 0: also emit the candidate lists for this (lower) voicing threshold into out2
     int debug_stop;         // profiling aid (env RSAF_PITCH_STOP): leave the frame kernel after phase k; 0 = run all
 };
 
@@ -349,7 +350,7 @@ __device__ void refine_candidates(const RefineArgs& A, int tid) {
 __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                           const double* __restrict__ gpeak, const double* __restrict__ win,
                                                           const double* __restrict__ wr, const PitchParams P,
-                                                          FrameOut* __restrict__ out) {
+                                                          FrameOut* __restrict__ out, FrameOut* __restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
@@ -373,8 +374,12 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     double* s_cloc = s_cs + MAXC;                   // [MAXC]
     int* s_maxlag = reinterpret_cast<int*>(s_cloc + MAXC);   // [MAX_MAXIMA]
     int* s_place = s_maxlag + MAX_MAXIMA;           // [MAXC]
-    int* s_cnt = s_place + MAXC;                    // [0] = nmax, [1] = ncand
-    double* s_part = reinterpret_cast<double*>(s_cnt + 4);   // [4][256 * NT] partial correlations of the four waves
+    int* s_place2 = s_place + MAXC;                 // [MAXC]  second (lower-threshold) list
+    int* s_cnt = s_place2 + MAXC;                   // [0] = nmax, [1] = ncand, [2] = ncand2, [3] = missing
+    double* s_cf2 = reinterpret_cast<double*>(s_cnt + 4);   // [MAXC]
+    double* s_cs2 = s_cf2 + MAXC;                   // [MAXC]
+    double* s_cloc2 = s_cs2 + MAXC;                 // [MAXC]
+    double* s_part = s_cloc2 + MAXC;   // [4][256 * NT] partial correlations of the four waves
     double* xs = s_part;                                     // skewed copy of seg[0, nw) until the partials are written
 #define s_nmax s_cnt[0]
 #define s_ncand s_cnt[1]
@@ -533,6 +538,8 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     if (tid == 0) s_nmax = 0;
     __syncthreads();
     // ---- local maxima in ascending lag order (wave 0, ballot + prefix) ----
+    const bool dual = out2 != nullptr && P.voicing_thr2 >= 0.0;
+    const double thr_low = dual && P.voicing_thr2 < P.voicing_thr ? P.voicing_thr2 : P.voicing_thr;
     const int lag_lo = P.min_lag > 2 ? P.min_lag : 2;
     int lag_hi = P.max_lag - 1;
     if (lag_hi > P.brent_ixmax - 1) lag_hi = P.brent_ixmax - 1;
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
             bool ok = false;
             if (l <= lag_hi) {
                 const double v = r[RC + l];
-                ok = (v > 0.5 * P.voicing_thr) && (v > r[RC + l - 1]) && (v >= r[RC + l + 1]);
+                ok = (v > 0.5 * thr_low) && (v > r[RC + l - 1]) && (v >= r[RC + l + 1]);
             }
             const unsigned long long m = __ballot(ok);
             const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
@@ -571,11 +578,14 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     }
     __syncthreads();
     RSAF_PITCH_DBG_STOP(4)
-    // ---- candidate list with replacement of the weakest (thread 0, sequential as in Praat) ----
-    if (tid == 0) {
+    // ---- candidate list with replacement of the weakest (one thread per list, sequential as in Praat) ----
+    // The maxima were collected for the lower of the two voicing thresholds; each list takes the maxima whose
+    // correlation exceeds half its own threshold, in ascending lag order.
+    auto build_list = [&](double vthr, double* cf, double* cs, double* cloc, int* place_lag, int* ncand_out) {
         int nc = 1;
-        s_cf[0] = 0.0; s_cs[0] = 0.0; s_place[0] = 0;
+        cf[0] = 0.0; cs[0] = 0.0; place_lag[0] = 0;
         for (int m = 0; m < nmax; ++m) {
+            if (!(r[RC + s_maxlag[m]] > 0.5 * vthr)) continue;
             int place;
             if (nc < P.max_cand) {
                 place = nc++;
@@ -583,17 +593,19 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
                 double weakest = 2.0;
                 place = 0;
                 for (int z = 1; z < P.max_cand; ++z) {
-                    const double loc = s_cloc[z];
+                    const double loc = cloc[z];
                     if (loc < weakest) { weakest = loc; place = z; }
                 }
                 if (s_mloc[m] <= weakest) place = 0;
             }
-            if (place) { s_cf[place] = s_mfreq[m]; s_cs[place] = s_mstr[m]; s_cloc[place] = s_mloc[m]; s_place[place] = s_maxlag[m]; }
+            if (place) { cf[place] = s_mfreq[m]; cs[place] = s_mstr[m]; cloc[place] = s_mloc[m]; place_lag[place] = s_maxlag[m]; }
         }
-        s_ncand = nc;
-    }
+        *ncand_out = nc;
+    };
+    if (tid == 0) build_list(P.voicing_thr, s_cf, s_cs, s_cloc, s_place, &s_cnt[1]);
+    if (tid == 64 && dual) build_list(P.voicing_thr2, s_cf2, s_cs2, s_cloc2, s_place2, &s_cnt[2]);
     __syncthreads();
-    const int ncand = s_ncand;
+    const int ncand = s_cnt[1];
     RSAF_PITCH_DBG_STOP(5)
     // ---- refine every kept candidate: maximise the sinc-interpolated correlation (16 at a time) ----
     // With every path cost zero (harmonicity pass) the path finder picks the strongest candidate of each
@@ -601,15 +613,54 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     // is left unrefined (the depth-30 and refined strengths differ by far less than the margin).
     // Lanes per candidate follow the candidate count (uniform per frame): few candidates (the usual AC case)
     // get a whole wave each, a full list gets 16 lanes each, so one or two rounds cover every frame.
-    {
-        const int nref = ncand - 1;
+    auto refine_list = [&](int nc, const int* place_lag, double* cf, double* cs) {
+        const int nref = nc - 1;
         const int span = P.refine_depth < 2 * L ? P.refine_depth : 2 * L;    // longest half kernel
-        RefineArgs A{r, RN, RC, P.refine_depth, nz_lo, nz_hi, ncand, P.refine_margin, s_place, s_cf, s_cs};
+        RefineArgs A{r, RN, RC, P.refine_depth, nz_lo, nz_hi, nc, P.refine_margin, place_lag, cf, cs};
         if (nref <= 4) { if (span >= 6 * 64) refine_candidates<64, true>(A, tid); else refine_candidates<64, false>(A, tid); }
         else if (nref <= 8) { if (span >= 6 * 32) refine_candidates<32, true>(A, tid); else refine_candidates<32, false>(A, tid); }
         else { if (span >= 6 * 16) refine_candidates<16, true>(A, tid); else refine_candidates<16, false>(A, tid); }
+        __syncthreads();
+    };
+    if (!dual) {
+        refine_list(ncand, s_place, s_cf, s_cs);
+    } else {
+        // refine the lower-threshold list (normally a superset), copy the shared candidates by lag, and only
+        // when a candidate of the primary list is missing from it (both lists overflowed) refine that list too
+        const int ncand2 = s_cnt[2];
+        const bool low_is_second = P.voicing_thr2 < P.voicing_thr;
+        int* pl_a = low_is_second ? s_place2 : s_place;   double* cf_a = low_is_second ? s_cf2 : s_cf;   double* cs_a = low_is_second ? s_cs2 : s_cs;
+        int* pl_b = low_is_second ? s_place : s_place2;   double* cf_b = low_is_second ? s_cf : s_cf2;   double* cs_b = low_is_second ? s_cs : s_cs2;
+        const int nc_a = low_is_second ? ncand2 : ncand, nc_b = low_is_second ? ncand : ncand2;
+        refine_list(nc_a, pl_a, cf_a, cs_a);
+        if (tid == 0) s_cnt[3] = 0;
+        __syncthreads();
+        if (tid >= 1 && tid < nc_b) {
+            int hit = 0;
+            for (int z = 1; z < nc_a; ++z) if (pl_a[z] == pl_b[tid]) hit = z;
+            if (hit) { cf_b[tid] = cf_a[hit]; cs_b[tid] = cs_a[hit]; } else atomicAdd(&s_cnt[3], 1);
+        }
+        __syncthreads();
+        if (s_cnt[3] > 0) {
+            // restore the first estimates of the list (entries copied above hold refined values) and refine it whole
+            if (tid >= 1 && tid < nc_b) {
+                for (int m = 0; m < nmax; ++m) if (s_maxlag[m] == pl_b[tid]) { cf_b[tid] = s_mfreq[m]; cs_b[tid] = s_mstr[m]; }
+            }
+            __syncthreads();
+            refine_list(nc_b, pl_b, cf_b, cs_b);
+        }
+        if (tid == 0) {
+            FrameOut* o2 = out2 + c.frame_off + f;
+            o2->intensity = intensity;
+            o2->ncand = gp > 0.0 ? (double)ncand2 : 1.0;
+        }
+        if (tid < MAXC) {
+            FrameOut* o2 = out2 + c.frame_off + f;
+            const bool on = tid < ncand2 && gp > 0.0;
+            o2->freq[tid] = on ? s_cf2[tid] : 0.0;
+            o2->strength[tid] = on ? s_cs2[tid] : 0.0;
+        }
     }
-    __syncthreads();
     if (tid == 0) {
         o->intensity = intensity;
         o->ncand = gp > 0.0 ? (double)ncand : 1.0;
@@ -1928,14 +1979,20 @@ int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, i
     return RSAF_OK;
 }
 
-int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
-                     const double* window, const double* window_r, const double* params_host /* 17 doubles */,
-                     void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
-                     rsaf_stream_t stream) {
+// second_*: optional outputs of the same analysis with another voicing threshold (h2_voicing_thr >= 0): the frame
+// kernel shares the correlation and the refinement, the path finder runs once per threshold
+static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
+                      const double* window, const double* window_r, const double* params_host, void* frame_out,
+                      unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
+                      double voicing_thr2, void* frame_out2, unsigned char* psi2, int* end_state2, double* sel_freq2,
+                      double* sel_strength2, double* stats_out2, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_frames >= 0, "bad clip/frame count");
     if (n_clips == 0) return RSAF_OK;
     RSAF_CHECK_ARG(wav && clip_info && gpeak && params_host && frame_out && psi && end_state && sel_freq &&
                    sel_strength && stats_out, "NULL pointer");
+    const bool dual = voicing_thr2 >= 0.0;
+    RSAF_CHECK_ARG(!dual || (frame_out2 && psi2 && end_state2 && sel_freq2 && sel_strength2 && stats_out2),
+                   "NULL pointer (second threshold outputs)");
     const double* h = params_host;
     PitchParams P;
     P.dt = h[0]; P.min_pitch = h[1]; P.ceiling = h[2]; P.voicing_thr = h[3]; P.octave_cost = h[4];
@@ -1943,6 +2000,7 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
     P.nsamp_window = (int)h[8]; P.nsamp_period = (int)h[9]; P.min_lag = (int)h[10]; P.max_lag = (int)h[11];
     P.brent_ixmax = (int)h[12]; P.max_cand = (int)h[13]; P.refine_depth = (int)h[14]; P.is_cc = (int)h[15];
     P.dt_window = h[16];
+    P.voicing_thr2 = dual ? voicing_thr2 : -1.0;
     { const char* e = getenv("RSAF_PITCH_STOP"); P.debug_stop = e ? atoi(e) : 0; }
     P.refine_margin = 0.0;   // lazy refinement is off: it changed a few frames' selection (parity first)
     P.half_window = P.nsamp_window / 2;
@@ -1952,8 +2010,8 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
     RSAF_CHECK_ARG(P.is_cc || (window && window_r), "AC needs the window tables");
     RSAF_CHECK_ARG((P.is_cc ? P.max_lag : P.brent_ixmax) <= 1023, "more than 1023 lags (pitch floor below ~16 Hz) is not supported");
     const int seg_len = P.is_cc ? P.nsamp_window + P.max_lag + 1 : P.nsamp_window;
-    const size_t lds = (size_t)(((seg_len + 1) & ~1) + ((2 * P.brent_ixmax + 2) & ~1) + 8 + 3 * MAX_MAXIMA + 3 * MAXC) *
-                           sizeof(double) + (size_t)(MAX_MAXIMA + MAXC + 4) * sizeof(int) +
+    const size_t lds = (size_t)(((seg_len + 1) & ~1) + ((2 * P.brent_ixmax + 2) & ~1) + 8 + 3 * MAX_MAXIMA + 6 * MAXC) *
+                           sizeof(double) + (size_t)(MAX_MAXIMA + 2 * MAXC + 4) * sizeof(int) +
                        (size_t)pitch_part_doubles(P.nsamp_window, P.is_cc ? P.max_lag : P.brent_ixmax) * sizeof(double) +
                        (P.is_cc ? (size_t)(seg_len + 2) * sizeof(double) : 0);
     RSAF_CHECK_ARG(lds <= 150 * 1024, "analysis window too long for LDS");
@@ -1964,23 +2022,49 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
     if (max_frames > 0) {
         ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s, 0.0, 0.0);
         hipLaunchKernelGGL(pitch_frame_kernel, dim3(max_frames, n_clips), dim3(256), lds, s, wav,
-                           (const ClipInfo*)clip_info, gpeak, window, window_r, P, (FrameOut*)frame_out);
+                           (const ClipInfo*)clip_info, gpeak, window, window_r, P, (FrameOut*)frame_out,
+                           dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr);
         RSAF_CHECK_HIP(hipGetLastError());
     }
-    {
-        ProfScope prof("mshds_pitch_path", s, 0.0, 0.0);
-        hipLaunchKernelGGL(path_kernel, dim3(n_clips), dim3(64), 0, s, (const FrameOut*)frame_out,
-                           (const ClipInfo*)clip_info, P.dt, silence_thr, P.voicing_thr, P.octave_cost, octave_jump, vuv,
-                           P.ceiling, psi, end_state);
-        RSAF_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(backtrack_kernel, dim3(n_clips), dim3(256), 0, s, (const FrameOut*)frame_out,
-                           (const ClipInfo*)clip_info, psi, end_state, sel_freq, sel_strength);
+    for (int pass = 0; pass < (dual ? 2 : 1); ++pass) {
+        const FrameOut* fo = (const FrameOut*)(pass ? frame_out2 : frame_out);
+        unsigned char* ps = pass ? psi2 : psi;
+        int* es = pass ? end_state2 : end_state;
+        double* sf = pass ? sel_freq2 : sel_freq;
+        double* ss = pass ? sel_strength2 : sel_strength;
+        const double vt = pass ? voicing_thr2 : P.voicing_thr;
+        {
+            ProfScope prof("mshds_pitch_path", s, 0.0, 0.0);
+            hipLaunchKernelGGL(path_kernel, dim3(n_clips), dim3(64), 0, s, fo, (const ClipInfo*)clip_info, P.dt, silence_thr,
+                               vt, P.octave_cost, octave_jump, vuv, P.ceiling, ps, es);
+            RSAF_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(backtrack_kernel, dim3(n_clips), dim3(256), 0, s, fo, (const ClipInfo*)clip_info, ps, es, sf, ss);
+            RSAF_CHECK_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(pitch_stats_kernel, dim3(n_clips), dim3(64), 0, s, sf, (const ClipInfo*)clip_info, P.ceiling,
+                           pass ? stats_out2 : stats_out);
         RSAF_CHECK_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(pitch_stats_kernel, dim3(n_clips), dim3(64), 0, s, sel_freq, (const ClipInfo*)clip_info, P.ceiling,
-                       stats_out);
-    RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
+}
+
+int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
+                     const double* window, const double* window_r, const double* params_host /* 17 doubles */,
+                     void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
+                     rsaf_stream_t stream) {
+    return pitch_impl(wav, clip_info, n_clips, max_frames, gpeak, window, window_r, params_host, frame_out, psi, end_state,
+                      sel_freq, sel_strength, stats_out, -1.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
+                          const double* window, const double* window_r, const double* params_host /* 17 doubles */,
+                          void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
+                          double* stats_out, double voicing_threshold2, void* frame_out2, unsigned char* psi2, int* end_state2,
+                          double* sel_freq2, double* sel_strength2, double* stats_out2, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(voicing_threshold2 >= 0.0, "second voicing threshold must be >= 0");
+    return pitch_impl(wav, clip_info, n_clips, max_frames, gpeak, window, window_r, params_host, frame_out, psi, end_state,
+                      sel_freq, sel_strength, stats_out, voicing_threshold2, frame_out2, psi2, end_state2, sel_freq2,
+                      sel_strength2, stats_out2, stream);
 }
 
 int64_t rsaf_mshds_speechrate_workspace_doubles(int max_frames) { return 3 * ((int64_t)max_frames + 2) + 2 * SR_MAX_PEAKS; }

@@ -130,7 +130,10 @@ class MshdsEngine:
     # ---- one pitch analysis over a set of clips ----
     def pitch(self, wav, sample_offs, lengths, gpeak, *, time_step, floor, ceiling, max_candidates=15,
               silence_threshold=0.03, voicing_threshold=0.45, octave_cost=0.01, octave_jump_cost=0.35,
-              voiced_unvoiced_cost=0.14, periods=3.0, is_cc=False, refine_depth=70, stream=None):
+              voiced_unvoiced_cost=0.14, periods=3.0, is_cc=False, refine_depth=70, voicing_threshold2=None,
+              stream=None):
+        """One Sound: To Pitch (ac/cc) analysis.  ``voicing_threshold2``: also return (key ``second``) the same
+        analysis with that voicing threshold; the frame kernel's correlation and refinement are shared."""
         import torch
         lib = _lib.load()
         g = _PitchGeom(time_step, floor, ceiling, periods, is_cc)
@@ -150,17 +153,40 @@ class MshdsEngine:
                                    octave_jump_cost, voiced_unvoiced_cost, g.nsamp_window, g.nsamp_period, g.min_lag,
                                    g.max_lag, g.brent_ixmax, max_candidates, refine_depth, 1 if is_cc else 0,
                                    g.dt_window)
+        second = None
+        if voicing_threshold2 is not None:
+            second = {"geom": g, "ci": ci, "ci_dev": ci_d, "total_frames": total, "max_frames": mx,
+                      "frame_out": torch.empty(tf * self.fo_doubles, dtype=torch.float64, device=dev),
+                      "psi": torch.empty(tf * 16, dtype=torch.uint8, device=dev),
+                      "end_state": torch.empty(max(n, 1), dtype=torch.int32, device=dev),
+                      "sel_freq": torch.zeros(tf, dtype=torch.float64, device=dev),
+                      "sel_strength": torch.zeros(tf, dtype=torch.float64, device=dev),
+                      "stats": torch.empty((max(n, 1), 8), dtype=torch.float64, device=dev)}
+        wp = _lib.ptr(win) if win is not None else None
+        wrp = _lib.ptr(wr) if wr is not None else None
         if n and g.half_window >= 2:
-            _lib.check(lib.rsaf_mshds_pitch(
-                _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak),
-                _lib.ptr(win) if win is not None else None, _lib.ptr(wr) if wr is not None else None, params,
-                _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
-                _lib.ptr(stats), _lib.stream_ptr(stream)), "rsaf_mshds_pitch")
+            if second is None:
+                _lib.check(lib.rsaf_mshds_pitch(
+                    _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak), wp, wrp, params,
+                    _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
+                    _lib.ptr(stats), _lib.stream_ptr(stream)), "rsaf_mshds_pitch")
+            else:
+                _lib.check(lib.rsaf_mshds_pitch_dual(
+                    _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak), wp, wrp, params,
+                    _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
+                    _lib.ptr(stats), float(voicing_threshold2), _lib.ptr(second["frame_out"]), _lib.ptr(second["psi"]),
+                    _lib.ptr(second["end_state"]), _lib.ptr(second["sel_freq"]), _lib.ptr(second["sel_strength"]),
+                    _lib.ptr(second["stats"]), _lib.stream_ptr(stream)), "rsaf_mshds_pitch_dual")
         else:
             stats.fill_(float("nan"))
             stats[:, 0] = 0
+            if second is not None:
+                second["stats"].fill_(float("nan"))
+                second["stats"][:, 0] = 0
+        if second is not None:
+            second["stats"] = second["stats"][:n]
         return {"geom": g, "ci": ci, "ci_dev": ci_d, "sel_freq": sel_f, "sel_strength": sel_s, "stats": stats[:n],
-                "frame_out": frame_out, "total_frames": total, "max_frames": mx}
+                "frame_out": frame_out, "total_frames": total, "max_frames": mx, "second": second}
 
     def intensity(self, wav, sample_offs, lengths, minimum_pitch, time_step, subtract_mean=True, stream=None):
         import torch
@@ -372,7 +398,7 @@ class MshdsEngine:
 
     CPP_CHUNK = 48          # clips per launch group: the cepstrogram workspace is ~68 MB per 30 s clip
 
-    def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None):
+    def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None, pitch=None):
         """_extract_CPP (src/mshds_extractor.py:253-301) -> float64 [n] mean CPPS of the voiced intervals."""
         import torch
         lib = _lib.load()
@@ -381,8 +407,8 @@ class MshdsEngine:
         out = torch.full((max(n, 1),), float("nan"), dtype=torch.float64, device=dev)
         if n == 0:
             return out[:0]
-        p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=frame_shift, floor=floor, ceiling=ceiling,
-                       voicing_threshold=0.3, stream=stream)                                             # :270
+        p = pitch if pitch is not None else self.pitch(wav, sample_offs, lengths, gpeak, time_step=frame_shift, floor=floor,
+                                                       ceiling=ceiling, voicing_threshold=0.3, stream=stream)   # :270
         pulses, npul, max_pulses = self.pulses(wav, lengths, p, stream)                                  # :271
 
         def build_win():
@@ -469,7 +495,9 @@ class MshdsEngine:
             idx = torch.tensor(ids, dtype=torch.long, device=self.device)
             gp = gpeak[idx].contiguous()
             floor, ceiling = float(rng[0]), float(rng[1])
-            p = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=ceiling, stream=stream)   # :178 == :355
+            # :178 == :355, and :270 (voicing threshold 0.3, everything else equal) from the same frame kernel
+            p = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=ceiling, voicing_threshold2=0.3,
+                           stream=stream)
             inten = self.intensity(wav, so, ln, floor, 0.005, True, stream)                                  # :198
             cc = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=0.5 / DX, max_candidates=15,
                             silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
@@ -483,7 +511,7 @@ class MshdsEngine:
             out[idx, 8] = inten["stats"][:, 1]
             out[idx, 9] = hnr
             out[idx, 10:12] = self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                      # :433
-            out[idx, 12] = self.cpp(wav, so, ln, gp, floor, ceiling, 0.005, stream)                          # :434
+            out[idx, 12] = self.cpp(wav, so, ln, gp, floor, ceiling, 0.005, stream, pitch=p["second"])         # :434
             out[idx, 21:25] = sm["stats"]
         return out, ranges
 

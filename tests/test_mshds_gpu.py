@@ -70,6 +70,33 @@ def test_pitch_ac_track_matches_oracle(eng, floor, ceil):
         assert st[i, 4] == len(p.voiced_values())
 
 
+def test_pitch_dual_threshold_equals_two_separate_passes(eng):
+    """:178 and :270 differ only in the voicing threshold: the dual launch must reproduce both standalone passes
+    (candidate lists, selected track, statistics), including frames where a list overflows (max_candidates 4)."""
+    import torch
+    clips = [synth.synth_clip(112, 1.5), synth.synth_clip(113, 1.2)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    for kw in (dict(floor=75.0, ceiling=500.0), dict(floor=60.0, ceiling=250.0, max_candidates=4)):
+        a = eng.pitch(wav, offs, lens, gp, time_step=0.005, voicing_threshold=0.45, **kw)
+        b = eng.pitch(wav, offs, lens, gp, time_step=0.005, voicing_threshold=0.3, **kw)
+        d = eng.pitch(wav, offs, lens, gp, time_step=0.005, voicing_threshold=0.45, voicing_threshold2=0.3, **kw)
+        torch.cuda.synchronize()
+        for single, dual in ((a, d), (b, d["second"])):
+            fs, fd = single["frame_out"].cpu().numpy(), dual["frame_out"].cpu().numpy()
+            assert np.array_equal(fs == 0, fd == 0)
+            assert np.abs(fs - fd).max() <= 1e-9 * np.abs(fs).max()               # group size changes the sum order only
+            ss, sd = single["sel_freq"].cpu().numpy(), dual["sel_freq"].cpu().numpy()
+            assert np.array_equal(ss > 0, sd > 0) and np.abs(ss - sd).max() <= 1e-9 * ss.max()
+            assert np.allclose(single["stats"].cpu().numpy(), dual["stats"].cpu().numpy(), rtol=1e-9, equal_nan=True)
+    for i, c in enumerate(clips):                                                     # and the oracle at 0.3
+        p = mo.pitch_ac(c, 0.005, 75.0, voicing_threshold=0.3, pitch_ceiling=500.0)
+        d = eng.pitch(wav, offs, lens, gp, time_step=0.005, floor=75.0, ceiling=500.0, voicing_threshold2=0.3)["second"]
+        ci = d["ci"][i]
+        got = d["sel_freq"].cpu().numpy()[ci["frame_off"]:ci["frame_off"] + ci["n_frames"]]
+        assert np.array_equal(got > 0, p.frequency() > 0) and _rel(got, p.frequency()) < 1e-7
+
+
 def test_pitch_ac_few_candidates_replacement_rule(eng):
     """The 4-candidate pass of _speechrate (:104): more maxima than slots -> weakest is replaced."""
     import torch
