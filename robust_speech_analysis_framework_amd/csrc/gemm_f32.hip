@@ -9,7 +9,8 @@
 // k-group lanes 0-31 supply k = 0..3 and lanes 32-63 k = 4..7, for A and B alike, so every product
 // still pairs equal k.  The next k-tile is prefetched into registers while the current one is
 // multiplied.  Workgroup ids are remapped so that the 8 XCDs each own a contiguous range of tiles
-// (tiles sharing an A row-panel hit the same L2).
+// (tiles sharing an A row-panel hit the same L2).  The plain NT shapes with K % 32 == 0 (all Wav2Vec2 layers)
+// take the LDS-DMA variant further down (global_load_lds, swizzled unpadded image): +2.5-6 % on those shapes.
 #include <cstdlib>
 
 #include "gemm_f32.h"
@@ -272,6 +273,182 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void gemm_f32_kernel(const GemmPar
     }
 }
 
+
+// ---- LDS-DMA variant for the plain NT shapes (B[N,K], K % 32 == 0, no padded taps) --------------------------
+// Same 128 x 128 x 32 tile and MFMA schedule, but the k-tiles go HBM -> LDS directly
+// (global_load_lds_dwordx4: no staging registers, no ds_write).  One wave-instruction writes 1 KiB of LDS
+// linearly (lane l -> base + 16 l), so the image is unpadded [row][8 chunks of 16 B]; the bank spread comes from
+// an XOR swizzle chunk ^ ((row >> 1) & 7) applied to the per-lane SOURCE address and again to the fragment
+// reads (16 consecutive rows of one chunk column then cover all 64 banks).  Tile kt+1 is issued before the
+// multiply of tile kt into the other image; vmcnt(0) + barrier at the end of the k-step orders it for the reads.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_glds_kernel(const GemmParams p) {
+    constexpr int BK = 32, WM = 64, WN = 64, TM = 2, TN = 2, WAVES_N = BN / WN;
+    constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
+    constexpr int A_INS = BM / 8 / 4, B_INS = BN / 8 / 4;      // 1-KiB wave-instructions per wave per k-tile
+    extern __shared__ __attribute__((aligned(1024))) float smem_dyn[];
+    float* smem = smem_dyn;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_n * tiles_m;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = wg / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int in_grp = wg - grp * per_group;
+    const int m0 = (first_m + in_grp % gsz) * BM;
+    const int n0 = (in_grp / gsz) * BN;
+
+    const int z = blockIdx.y;
+    const int z1 = z / p.nz2, z2 = z - z1 * p.nz2;
+    const float* __restrict__ A = p.A + z1 * p.sA1 + z2 * p.sA2;
+    const float* __restrict__ B = p.B + z1 * p.sB1 + z2 * p.sB2;
+    float* __restrict__ C = p.C + z1 * p.sC1 + z2 * p.sC2;
+    const float* __restrict__ R = p.R ? p.R + z1 * p.sR1 + z2 * p.sR2 : nullptr;
+    const float* __restrict__ bias = p.bias ? p.bias + z2 * p.sBias2 : nullptr;
+
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // per-lane source pointers of this wave's DMA instructions (rows past the end re-read the last row: their
+    // products land in accumulator rows / columns that are never stored)
+    const float* asrc[A_INS];
+    const float* bsrc[B_INS];
+    const int prow = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int i = 0; i < A_INS; ++i) {
+        const int row = 8 * (wave * A_INS + i) + prow;
+        const int gm = m0 + row;
+        asrc[i] = A + (int64_t)(gm < p.M ? gm : p.M - 1) * p.lda + 4 * (pc ^ ((row >> 1) & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < B_INS; ++i) {
+        const int row = 8 * (wave * B_INS + i) + prow;
+        const int gn = n0 + row;
+        bsrc[i] = B + (int64_t)(gn < p.N ? gn : p.N - 1) * p.ldb + 4 * (pc ^ ((row >> 1) & 7));
+    }
+    const int nk = p.K / BK;
+
+#define RSAF_DMA(KT, ST)                                                                                     \
+    do {                                                                                                     \
+        float* stage_ = smem + (ST) * STAGE;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < A_INS; ++i)                                                    \
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(asrc[i] + (KT) * BK),                            \
+                                             (lds_void_ptr)(stage_ + (wave * A_INS + i) * 256), 16, 0, 0);   \
+        _Pragma("unroll") for (int i = 0; i < B_INS; ++i)                                                    \
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(bsrc[i] + (KT) * BK),                            \
+                                             (lds_void_ptr)(stage_ + A_FLOATS + (wave * B_INS + i) * 256), 16, 0, 0); \
+    } while (0)
+
+    RSAF_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fsw = (l31 >> 1) & 7;               // swizzle of this lane's fragment rows (tile bases are multiples of 32)
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) RSAF_DMA(kt + 1, (kt + 1) & 1);
+        const float* a_img = smem + (kt & 1) * STAGE;
+        const float* b_img = a_img + A_FLOATS;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float af[TM][4], bf[TN][4];
+            const int ch = ((2 * g + h) ^ fsw) * 4;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const float4 v = *reinterpret_cast<const float4*>(&a_img[(wm0 + mt * 32 + l31) * BK + ch]);
+                af[mt][0] = v.x; af[mt][1] = v.y; af[mt][2] = v.z; af[mt][3] = v.w;
+            }
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const float4 v = *reinterpret_cast<const float4*>(&b_img[(wn0 + nt * 32 + l31) * BK + ch]);
+                bf[nt][0] = v.x; bf[nt][1] = v.y; bf[nt][2] = v.z; bf[nt][3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j],
+                                                                           acc[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef RSAF_DMA
+
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int gn = n0 + wn0 + nt * 32 + l31;
+        const int n_ok = gn < p.N;
+        const int gnc = n_ok ? gn : 0;
+        const float bv = bias ? bias[gnc] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int gm_base = m0 + wm0 + mt * 32 + 4 * h;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float rv[8];
+                if (R) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = half * 8 + q;
+                        const int gm = gm_base + (e & 3) + 8 * (e >> 2);
+                        rv[q] = R[(int64_t)(gm < p.M ? gm : 0) * p.ldr + gnc];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rv[q] = 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = half * 8 + q;
+                    const int gm = gm_base + (e & 3) + 8 * (e >> 2);
+                    const float v = act_apply(p.alpha * acc[mt][nt][e] + bv + rv[q], p.act);
+                    if (n_ok & (gm < p.M)) C[(int64_t)gm * p.ldc + gn] = v;
+                }
+            }
+        }
+    }
+}
+
+static int launch_glds(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 128, BN = 128;
+    const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    const int lds = 2 * (BM + BN) * 32 * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f32_glds_kernel<BM, BN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN>), dim3((unsigned)tiles, (unsigned)p.nz), dim3(256), lds, s, p);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
@@ -305,6 +482,8 @@ int launch_gemm_f32(const GemmParams& p, hipStream_t stream, const char* tag) {
     RSAF_CHECK_ARG(!p.R || p.ldr > 0, "residual needs ldr");
     const double flops = 2.0 * p.M * (double)p.N * p.K * p.nz;
     ProfScope prof(tag ? tag : "gemm_f32", stream, flops, 0.0);
+    static const int glds = [] { const char* e = getenv("RSAF_GEMM_GLDS"); return e ? atoi(e) : 1; }();   // 0: register-staged kernel everywhere
+    if (glds && !p.b_kn && p.a_pad_k == 0 && p.K % 32 == 0 && p.K >= 32 && p.N > 64) return launch_glds(p, stream);
     if (p.N <= 32) return launch_cfg<128, 32, 32, 32>(p, stream);
     if (p.N <= 64) return launch_cfg<128, 64, 64, 32>(p, stream);
     return launch_cfg<128, 128, 64, 64>(p, stream);
