@@ -710,14 +710,17 @@ __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ f
     double cur = nd.delta, prev_logf = nd.logf;
     int prev_vl = nd.vl, prev_valid = nd.valid;
     if (lane < MAXC) P[lane] = 0;
+    auto clampn = [](double nc) { const int v = (int)nc; return v < 0 ? 0 : (v > MAXC ? MAXC : v); };
+    int prev_n = __builtin_amdgcn_readfirstlane(clampn(F[0].ncand));
     for (int f = 1; f < nF; ++f) {
         const PathIn in2 = load(f + 1);
+        const int cur_n = __builtin_amdgcn_readfirstlane(clampn(in1.nc));
         nd = derive(in1);
         in1 = in2;
         double best = -INFINITY;
         int place = 0;
-#pragma unroll
-        for (int c1 = 0; c1 < MAXC; ++c1) {
+        // only the previous frame's candidates can be predecessors (their count is wave-uniform)
+        for (int c1 = 0; c1 < prev_n; ++c1) {
             const double pc = readlane_f64(cur, c1);
             const double pl = readlane_f64(prev_logf, c1);
             const int pv = __builtin_amdgcn_readlane(prev_vl, c1);
@@ -730,6 +733,7 @@ __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ f
         if (lane < MAXC) P[(int64_t)f * MAXC + lane] = (unsigned char)place;
         cur = best;
         prev_logf = nd.logf; prev_vl = nd.vl; prev_valid = nd.valid;
+        prev_n = cur_n;
     }
     // best end state: first maximum
     double bv = lane < MAXC ? cur : -INFINITY;

@@ -378,13 +378,26 @@ __global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ 
     bitonic_sort(srt, p2, tid);
     const double slope = quantile_half(srt, nc);
     __syncthreads();
-    // ... intercept = median of the residual offsets
+    // ... intercept = median of the residual offsets.  nq = 2^k + 1 (the usual 513): sort the first 2^k values
+    // and place the last one by comparison, which halves the network; NUMquantile(0.5) of an odd count is the
+    // middle order statistic.
+    double icpt;
     p2 = 1;
     while (p2 < nq) p2 <<= 1;
-    for (int i = tid; i < p2; i += 256) srt[i] = i < nq ? db[i] - slope * ((double)i * DQ) : INFINITY;
-    __syncthreads();
-    bitonic_sort(srt, p2, tid);
-    const double icpt = quantile_half(srt, nq);
+    if (nq == (p2 >> 1) + 1 && nq >= 3) {
+        const int hn = p2 >> 1;                                  // nq - 1
+        for (int i = tid; i < hn; i += 256) srt[i] = db[i] - slope * ((double)i * DQ);
+        __syncthreads();
+        bitonic_sort(srt, hn, tid);
+        const double e = db[nq - 1] - slope * ((double)(nq - 1) * DQ);
+        const double lo_v = srt[hn / 2 - 1], hi_v = srt[hn / 2];  // the middle of the union is the median of (lo, e, hi)
+        icpt = e <= lo_v ? lo_v : (e >= hi_v ? hi_v : e);
+    } else {
+        for (int i = tid; i < p2; i += 256) srt[i] = i < nq ? db[i] - slope * ((double)i * DQ) : INFINITY;
+        __syncthreads();
+        bitonic_sort(srt, p2, tid);
+        icpt = quantile_half(srt, nq);
+    }
     // Vector_getMaximumAndX (parabolic) over [1/ceiling, 1/floor]: end points first, then the local maxima in
     // ascending order, a later candidate wins only if strictly greater -> (value, order) reduction
     const double qlo = 1.0 / pitch_ceiling, qhi = 1.0 / pitch_floor;
