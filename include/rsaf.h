@@ -250,6 +250,18 @@ int rsaf_resample_sinc_hann(const float* in, int64_t n_in, const float* taps, co
 int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_out, int precision, float* out,
                         int64_t n_out, rsaf_stream_t stream);
 
+/* ---- session aggregation and batch assembly behind the extractors ---------------------- */
+/* out[seg][col][2] = {mean, sample standard deviation (n-1)} over the rows row_index[seg_off[seg] .. seg_off[seg+1])
+ * of rows[.][ld], NaN skipped, NaN when fewer than 1 / 2 values remain.
+ * Replaces merged_df.groupby('unique_participant_id').agg(['mean', 'std']), src/utils.py:49. */
+int rsaf_segment_mean_std(const double* rows, int64_t ld, const int* row_index, const int* seg_off, int n_seg, int width,
+                          double* out, rsaf_stream_t stream);
+/* dst[r][0..width) = src[src_row[r]][0..width), zeros where src_row[r] < 0.
+ * Replaces np.vstack(participant_sequences), src/utils.py:96, and the zero padding of collate_fn,
+ * src/dl_cv_strategies.py:81-84. */
+int rsaf_gather_rows_f32(const float* src, int64_t ld_src, const int64_t* src_row, int64_t n_rows, int width, float* dst,
+                         int64_t ld_dst, rsaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
