@@ -194,7 +194,14 @@ def extract_opensmile_features(input_df, opensmile_exe_path, config_file_path,
             try:
                 x, fs = read_wav_mono(pth)
                 if fs != SAMPLE_RATE:
-                    raise ValueError(f"sample rate {fs} Hz: only 16 kHz input is supported")
+                    # SMILExtract analyses at the file's own rate (frame sizes in seconds); that is not built.
+                    # Opt-in approximation: convert to 16 kHz on the device and run the 16 kHz chain.
+                    if os.environ.get("RSAF_SMILE_RESAMPLE", "0") != "1":
+                        raise ValueError(f"sample rate {fs} Hz: only 16 kHz input is supported "
+                                         "(set RSAF_SMILE_RESAMPLE=1 to convert to 16 kHz first; results then "
+                                         "differ from a native-rate analysis)")
+                    from .resample import resample_sinc_hann
+                    x = resample_sinc_hann(x, fs, SAMPLE_RATE).cpu().numpy()
                 if n_frames(len(x)) == 0:
                     raise ValueError("shorter than one 25 ms frame")
                 clips.append(x)
