@@ -1,0 +1,46 @@
+"""the notebooks cache extractor outputs with DataFrame.to_csv(index=False), pickle.dump of
+dict[str, ndarray float32] and torch.save of a dict holding a state_dict (notebooks 01/03).  The drop-ins return
+the same Python types with the same column / key names, so the notebooks' own read/write calls keep working;
+this pins that contract on the CPU (no kernels involved)."""
+import io
+import pickle
+
+import numpy as np
+import pandas as pd
+
+
+def test_feature_tables_round_trip_through_csv():
+    from robust_speech_analysis_framework_amd.mshds import FEATURE_NAMES
+    from robust_speech_analysis_framework_amd.smile import feature_names
+    rng = np.random.Generator(np.random.PCG64(1))
+    for names, filename_first in ((FEATURE_NAMES, True), (feature_names(), False)):
+        vals = rng.standard_normal((3, len(names)))
+        vals[1, 2] = np.nan                                            # failed helper -> NaN cell -> empty CSV field
+        df = pd.DataFrame(vals, columns=names)
+        df.insert(0 if filename_first else len(names), "filename", ["a.wav", "b.wav", "c.wav"])
+        buf = io.StringIO()
+        df.to_csv(buf, index=False)                                    # notebooks/01: full_reading_data.to_csv(..., index=False)
+        back = pd.read_csv(io.StringIO(buf.getvalue()))
+        assert list(back.columns) == list(df.columns)
+        assert np.allclose(back[names].to_numpy(), vals, rtol=1e-14, atol=0, equal_nan=True)   # pandas fast float parser: <= 1 ulp
+    assert len(FEATURE_NAMES) == 25 and len(feature_names()) == 912
+
+
+def test_sequence_dict_round_trips_through_pickle():
+    seqs = {"clip_a.wav": np.arange(12, dtype=np.float32).reshape(4, 3), "clip_b.wav": np.zeros((0, 3), np.float32)}
+    back = pickle.loads(pickle.dumps(seqs))                            # notebooks/03: pickle.dump(interview_clip_sequences, f)
+    assert list(back) == list(seqs) and all(back[k].dtype == np.float32 and np.array_equal(back[k], seqs[k]) for k in seqs)
+
+
+def test_checkpoint_dict_round_trips_through_torch_save(tmp_path):
+    import torch
+    from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+    torch.manual_seed(0)
+    m = CNNLSTM(cnn_out_channels=32, lstm_hidden_dim=64)
+    path = tmp_path / "final_tuned_cnn_lstm_reading.pt"
+    torch.save({"model_state_dict": m.state_dict(), "train_loss_history": [0.7, 0.6], "val_loss_history": [0.71, 0.65]}, path)
+    saved = torch.load(path, map_location=torch.device("cpu"), weights_only=True)
+    m2 = CNNLSTM(cnn_out_channels=32, lstm_hidden_dim=64)
+    m2.load_state_dict(saved["model_state_dict"])                     # the reference's keys
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert saved["val_loss_history"] == [0.71, 0.65]
