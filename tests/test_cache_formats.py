@@ -22,7 +22,7 @@ def test_feature_tables_round_trip_through_csv():
         df.to_csv(buf, index=False)                                    # notebooks/01: full_reading_data.to_csv(..., index=False)
         back = pd.read_csv(io.StringIO(buf.getvalue()))
         assert list(back.columns) == list(df.columns)
-        assert np.allclose(back[names].to_numpy(), vals, rtol=1e-14, atol=0, equal_nan=True)   # pandas fast float parser: <= 1 ulp
+        assert np.allclose(back[names].to_numpy(), vals, rtol=1e-12, atol=0, equal_nan=True)   # pandas default float parser is not round-trip exact
     assert len(FEATURE_NAMES) == 25 and len(feature_names()) == 912
 
 
