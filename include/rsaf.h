@@ -163,11 +163,14 @@ int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, i
  *   voiced_unvoiced_cost, nsamp_window, nsamp_period, min_lag, max_lag, brent_ixmax, max_candidates,
  *   refine_depth, is_cc, dt_window}.  sel_freq / sel_strength: the path finder's choice per frame.
  * stats_out[clip][8] = {n(f != 0), mean, population sd, mean after |z| <= 2, n voiced, mean Hz,
- *   sd in semitones (n-1), n after filter}. */
+ *   sd in semitones (n-1), n after filter}.
+ * sinc_cheb (may be NULL): [2 * refine_depth][16] Chebyshev coefficients on frac in [0, 1] of the sinc-interpolation
+ *   weights of tap offsets -(depth-1) .. depth (mshds.sinc_cheb_table); with it the Brent refinement evaluates a
+ *   16-term polynomial per step instead of the 2*depth-term sum whenever no candidate's depth is clipped. */
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
                      const double* window, const double* window_r, const double* params_host,
                      void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
-                     double* stats_out, rsaf_stream_t stream);
+                     double* stats_out, const double* sinc_cheb, rsaf_stream_t stream);
 /* The same analysis for two voicing thresholds at once (src/mshds_extractor.py:178 and :270 differ in nothing
  * else): one frame kernel computes the correlation and refines the union of the two candidate lists, the path
  * finder runs per threshold.  The *2 outputs have the shapes of their first-threshold counterparts. */
@@ -176,7 +179,7 @@ int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, 
                           void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
                           double* stats_out, double voicing_threshold2, void* frame_out2, unsigned char* psi2,
                           int* end_state2, double* sel_freq2, double* sel_strength2, double* stats_out2,
-                          rsaf_stream_t stream);
+                          const double* sinc_cheb, rsaf_stream_t stream);
 /* _speechrate (src/mshds_extractor.py:11-125) from the 50 Hz / 16 ms intensity contour (rsaf_mshds_intensity)
  * and the 4-candidate pitch pass of :104.  out[clip][5] = Speaking_Rate, Articulation_Rate,
  * Phonation_Ratio, Pause_Rate, Mean_Pause_Dur.  workspace: n_clips * workspace_doubles(max_frames). */

@@ -46,9 +46,9 @@ SIGNATURES = {
     "rsaf_mshds_frameout_doubles": (_I, []),
     "rsaf_mshds_clip_peak": (_I, [_P, _P, _I, _P, _P]),
     "rsaf_mshds_intensity": (_I, [_P, _P, _I, _I, _P, _I, C.c_double, _I, _P, _P, _P]),
-    "rsaf_mshds_pitch": (_I, [_P, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_double), _P, _P, _P, _P, _P, _P, _P]),
+    "rsaf_mshds_pitch": (_I, [_P, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_double), _P, _P, _P, _P, _P, _P, _P, _P]),
     "rsaf_mshds_pitch_dual": (_I, [_P, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_double), _P, _P, _P, _P, _P, _P,
-                                   C.c_double, _P, _P, _P, _P, _P, _P, _P]),
+                                   C.c_double, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rsaf_mshds_speechrate_workspace_doubles": (_L, [_I]),
     "rsaf_mshds_speechrate": (_I, [_P, _P, _I, _I, C.c_double, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
     "rsaf_mshds_resample10k": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P]),

@@ -323,6 +323,74 @@ __device__ __forceinline__ double4_t corr_tile(const double* __restrict__ seg, c
     return c0 + c1;
 }
 
+// ---- sinc interpolation as a polynomial in the fractional position -----------------------------------------
+// Between two samples the depth-d interpolation is S(b + frac) = sum_o W_o(frac) y[b + o], o = -(d-1) .. d, and
+// every weight W_o is a smooth function of frac in [0, 1] alone (as long as the depth is not clipped by the
+// array ends).  With the degree-15 Chebyshev coefficients of the weights tabulated once on the host
+// (cheb[o + d - 1][j]), the 16 coefficients of S on a cell cost one pass over the taps, after which every Brent
+// evaluation is a 16-term Clenshaw recurrence instead of 2d reciprocal-and-cosine terms.  The fit error
+// (< 1e-12) is below the rounding of the direct formula near integer positions.
+constexpr int NCH = 16;
+
+__device__ __forceinline__ double cheb_eval(const double* __restrict__ c, double frac) {
+    const double t = 2.0 * frac - 1.0, t2 = 2.0 * t;
+    double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int j = NCH - 1; j >= 1; --j) { const double b0 = c[j] + t2 * b1 - b2; b2 = b1; b1 = b0; }
+    return c[0] + t * b1 - b2;
+}
+
+// Praat NUMimproveMaximum (sinc) on the two cells around the 0-based integer position x0; P = [2][NCH] coefficients
+// (cell 0 = [x0-1, x0], cell 1 = [x0, x0+1]).  One lane per candidate; the loop runs while any lane is active.
+__device__ void improve_max_cheb(const double* __restrict__ Pc, int x0, bool live, double& xm, double& ym) {
+    const double SQRT_EPS = 1.4901161193847656e-08, TOL3 = 1e-10 / 3.0;
+    const double ix1 = (double)x0 + 1.0;                    // 1-based like Praat
+    auto f = [&](double v1) {                               // v1: 1-based position in [ix1-1, ix1+1]
+        double fl = floor(v1);
+        double cell = fl - (ix1 - 1.0);
+        cell = cell < 0.0 ? 0.0 : (cell > 1.0 ? 1.0 : cell);
+        const double frac = v1 - (ix1 - 1.0 + cell);
+        return -cheb_eval(Pc + (int)cell * NCH, frac);
+    };
+    double a = ix1 - 1.0, b = ix1 + 1.0;
+    double v = a + GOLD * (b - a);
+    double fv = f(v);
+    double x = v, w = v, fx = fv, fw = fv;
+    bool active = live;
+    for (int it = 0; it < 60; ++it) {
+        const double rng = b - a, mid = 0.5 * (a + b);
+        const double tol_act = SQRT_EPS * fabs(x) + TOL3;
+        if (fabs(x - mid) + 0.5 * rng <= 2.0 * tol_act) active = false;
+        if (!__any(active)) break;
+        double step = GOLD * (x < mid ? b - x : a - x);
+        if (fabs(x - w) >= tol_act) {
+            const double t = (x - w) * (fx - fv);
+            double q = (x - v) * (fx - fw);
+            double p = (x - v) * q - (x - w) * t;
+            q = 2.0 * (q - t);
+            if (q > 0.0) p = -p; else q = -q;
+            if (fabs(p) < fabs(step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
+                step = p / q;
+        }
+        if (fabs(step) < tol_act) step = step > 0.0 ? tol_act : -tol_act;
+        const double tt = x + step;
+        const double ft = f(tt);
+        if (active) {
+            if (ft <= fx) {
+                if (tt < x) b = x; else a = x;
+                v = w; w = x; x = tt;
+                fv = fw; fw = fx; fx = ft;
+            } else {
+                if (tt < x) a = tt; else b = tt;
+                if (ft <= fw || w == x) { v = w; w = tt; fv = fw; fw = ft; }
+                else if (ft <= fv || v == x || v == w) { v = tt; fv = ft; }
+            }
+        }
+    }
+    xm = x - 1.0;
+    ym = -fx;
+}
+
 struct RefineArgs {
     const double* r; int RN, RC, depth, nz_lo, nz_hi, ncand; double margin;
     const int* place; double* cf; double* cs;
@@ -350,7 +418,8 @@ __device__ void refine_candidates(const RefineArgs& A, int tid) {
 __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                           const double* __restrict__ gpeak, const double* __restrict__ win,
                                                           const double* __restrict__ wr, const PitchParams P,
-                                                          FrameOut* __restrict__ out, FrameOut* __restrict__ out2) {
+                                                          FrameOut* __restrict__ out, FrameOut* __restrict__ out2,
+                                                          const double* __restrict__ cheb) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
@@ -614,6 +683,74 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     // Lanes per candidate follow the candidate count (uniform per frame): few candidates (the usual AC case)
     // get a whole wave each, a full list gets 16 lanes each, so one or two rounds cover every frame.
     auto refine_list = [&](int nc, const int* place_lag, double* cf, double* cs) {
+        if (cheb != nullptr) {
+            // Chebyshev coefficients of both cells of every candidate.  Wave w takes candidates w, w+4, ... (<= 4);
+            // lane = (tap residue mod 4, coefficient j): one table load feeds the wave's 8 accumulators, the four
+            // tap residues are folded with two cross-lane adds, and no partial sums cross waves.
+            double* s_P = s_part;                                    // [MAXC][2][NCH], the partial sums are dead by now
+            const int d = P.refine_depth;
+            const int chunk = lane >> 4, j = lane & 15;
+            int bq[4];
+            int bmin = 0x7fffffff, bmax = -0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 1 + wv + 4 * q;
+                const bool on = k < nc;
+                bq[q] = place_lag[on ? k : 1] + RC - 1;              // 0-based left sample of cell 0 (cell 1: + 1)
+                if (on) { bmin = bq[q] < bmin ? bq[q] : bmin; bmax = bq[q] > bmax ? bq[q] : bmax; }
+            }
+            if (1 + wv < nc) {
+                // r is zero outside [nz_lo, nz_hi]: taps that reach no candidate's non-zero range are skipped
+                int o_lo = nz_lo - (bmax + 1), o_hi = nz_hi - bmin;
+                o_lo = o_lo < -(d - 1) ? -(d - 1) : o_lo;
+                o_hi = o_hi > d ? d : o_hi;
+                double acc[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+                // eight table loads (L2-resident, ~500 cycles each) are issued together before they are consumed
+                const double* ctab = cheb + (int64_t)(d - 1) * NCH + j;
+                int o = o_lo + chunk;
+                for (; o + 28 <= o_hi; o += 32) {
+                    double cw[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cw[u] = ctab[(int64_t)(o + 4 * u) * NCH];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[q][0] += cw[u] * r[bq[q] + o + 4 * u];
+                            acc[q][1] += cw[u] * r[bq[q] + 1 + o + 4 * u];
+                        }
+                }
+                for (; o <= o_hi; o += 4) {
+                    const double cw = ctab[(int64_t)o * NCH];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[q][0] += cw * r[bq[q] + o];
+                        acc[q][1] += cw * r[bq[q] + 1 + o];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int cell = 0; cell < 2; ++cell) {
+                        double v = acc[q][cell];
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        const int k = 1 + wv + 4 * q;
+                        if (chunk == 0 && k < nc) s_P[(k * 2 + cell) * NCH + j] = v;
+                    }
+            }
+            __syncthreads();
+            if (tid < 64) {                                          // nc <= 16: one lane per candidate
+                const int k = 1 + tid;
+                const bool live = k < nc;
+                double xm, ym;
+                improve_max_cheb(s_P + (live ? k : 1) * 2 * NCH, place_lag[live ? k : 1] + RC, live, xm, ym);
+                if (ym > 1.0) ym = 1.0 / ym;
+                if (live) { cf[k] = 1.0 / DXS / (xm - RC); cs[k] = ym; }
+            }
+            __syncthreads();
+            return;
+        }
         const int nref = nc - 1;
         const int span = P.refine_depth < 2 * L ? P.refine_depth : 2 * L;    // longest half kernel
         RefineArgs A{r, RN, RC, P.refine_depth, nz_lo, nz_hi, nc, P.refine_margin, place_lag, cf, cs};
@@ -1989,7 +2126,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                       const double* window, const double* window_r, const double* params_host, void* frame_out,
                       unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
                       double voicing_thr2, void* frame_out2, unsigned char* psi2, int* end_state2, double* sel_freq2,
-                      double* sel_strength2, double* stats_out2, rsaf_stream_t stream) {
+                      double* sel_strength2, double* stats_out2, const double* sinc_cheb, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_frames >= 0, "bad clip/frame count");
     if (n_clips == 0) return RSAF_OK;
     RSAF_CHECK_ARG(wav && clip_info && gpeak && params_host && frame_out && psi && end_state && sel_freq &&
@@ -2023,11 +2160,20 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     if (lds > 48 * 1024)
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds));
+    // the Chebyshev form needs the full depth on both sides of every cell a candidate can use
+    const double* cheb = sinc_cheb;
+    {
+        const int lag_lo = P.min_lag > 2 ? P.min_lag : 2;
+        int lag_hi = P.max_lag - 1;
+        if (lag_hi > P.brent_ixmax - 1) lag_hi = P.brent_ixmax - 1;
+        const bool unclipped = P.brent_ixmax + lag_lo - 1 >= P.refine_depth && lag_hi + 2 + P.refine_depth <= P.brent_ixmax;
+        if (!unclipped || getenv("RSAF_PITCH_NO_CHEB")) cheb = nullptr;
+    }
     if (max_frames > 0) {
         ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s, 0.0, 0.0);
         hipLaunchKernelGGL(pitch_frame_kernel, dim3(max_frames, n_clips), dim3(256), lds, s, wav,
                            (const ClipInfo*)clip_info, gpeak, window, window_r, P, (FrameOut*)frame_out,
-                           dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr);
+                           dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     for (int pass = 0; pass < (dual ? 2 : 1); ++pass) {
@@ -2055,20 +2201,22 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
                      const double* window, const double* window_r, const double* params_host /* 17 doubles */,
                      void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
-                     rsaf_stream_t stream) {
+                     const double* sinc_cheb, rsaf_stream_t stream) {
     return pitch_impl(wav, clip_info, n_clips, max_frames, gpeak, window, window_r, params_host, frame_out, psi, end_state,
-                      sel_freq, sel_strength, stats_out, -1.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                      sel_freq, sel_strength, stats_out, -1.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sinc_cheb,
+                      stream);
 }
 
 int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
                           const double* window, const double* window_r, const double* params_host /* 17 doubles */,
                           void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
                           double* stats_out, double voicing_threshold2, void* frame_out2, unsigned char* psi2, int* end_state2,
-                          double* sel_freq2, double* sel_strength2, double* stats_out2, rsaf_stream_t stream) {
+                          double* sel_freq2, double* sel_strength2, double* stats_out2, const double* sinc_cheb,
+                          rsaf_stream_t stream) {
     RSAF_CHECK_ARG(voicing_threshold2 >= 0.0, "second voicing threshold must be >= 0");
     return pitch_impl(wav, clip_info, n_clips, max_frames, gpeak, window, window_r, params_host, frame_out, psi, end_state,
                       sel_freq, sel_strength, stats_out, voicing_threshold2, frame_out2, psi2, end_state2, sel_freq2,
-                      sel_strength2, stats_out2, stream);
+                      sel_strength2, stats_out2, sinc_cheb, stream);
 }
 
 int64_t rsaf_mshds_speechrate_workspace_doubles(int max_frames) { return 3 * ((int64_t)max_frames + 2) + 2 * SR_MAX_PEAKS; }

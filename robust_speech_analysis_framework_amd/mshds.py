@@ -74,6 +74,29 @@ def _dev(arr, device):
         torch.from_numpy(a).to(device)
 
 
+def sinc_cheb_table(depth: int, ncoef: int = 16):
+    """Chebyshev coefficients (on frac in [0, 1]) of the weights of Praat's depth-``depth`` sinc interpolation:
+    S(b + frac) = sum_o W_o(frac) y[b + o], o = -(depth-1) .. depth.  float64 [2 * depth, ncoef], row o + depth - 1.
+    Evaluated at the ``ncoef`` Chebyshev nodes and transformed exactly (DCT); the fit error is < 1e-12."""
+    d = int(depth)
+    n = np.arange(ncoef)
+    nodes = np.cos(np.pi * (n + 0.5) / ncoef)
+    frac = ((nodes + 1.0) / 2.0)[:, None]
+    hs = 0.5 * np.sin(np.pi * frac)
+    kk = np.arange(d)[None, :]
+    sign = np.where(kk % 2 == 0, 1.0, -1.0)
+    a_l = np.pi * (frac + kk)
+    w_l = hs * sign / a_l * (1.0 + np.cos(a_l / (d + frac)))
+    a_r = np.pi * (1.0 - frac + kk)
+    w_r = hs * sign / a_r * (1.0 + np.cos(a_r / (d + 1.0 - frac)))
+    w = np.concatenate([w_l[:, ::-1], w_r], axis=1)                     # [ncoef nodes, 2d taps]
+    j = np.arange(ncoef)[:, None]
+    t = np.cos(np.pi * j * (n[None, :] + 0.5) / ncoef)
+    c = (2.0 / ncoef) * (t @ w)
+    c[0] *= 0.5
+    return np.ascontiguousarray(c.T)
+
+
 class _PitchGeom:
     """Window geometry of Sound: To Pitch (ac/cc) for one parameter set (Boersma 1993)."""
 
@@ -164,19 +187,21 @@ class MshdsEngine:
                       "stats": torch.empty((max(n, 1), 8), dtype=torch.float64, device=dev)}
         wp = _lib.ptr(win) if win is not None else None
         wrp = _lib.ptr(wr) if wr is not None else None
+        (cheb,) = self._table(("sinc_cheb", int(refine_depth)), lambda: (sinc_cheb_table(int(refine_depth)).reshape(-1),))
+        chp = _lib.ptr(cheb)
         if n and g.half_window >= 2:
             if second is None:
                 _lib.check(lib.rsaf_mshds_pitch(
                     _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak), wp, wrp, params,
                     _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
-                    _lib.ptr(stats), _lib.stream_ptr(stream)), "rsaf_mshds_pitch")
+                    _lib.ptr(stats), chp, _lib.stream_ptr(stream)), "rsaf_mshds_pitch")
             else:
                 _lib.check(lib.rsaf_mshds_pitch_dual(
                     _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak), wp, wrp, params,
                     _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
                     _lib.ptr(stats), float(voicing_threshold2), _lib.ptr(second["frame_out"]), _lib.ptr(second["psi"]),
                     _lib.ptr(second["end_state"]), _lib.ptr(second["sel_freq"]), _lib.ptr(second["sel_strength"]),
-                    _lib.ptr(second["stats"]), _lib.stream_ptr(stream)), "rsaf_mshds_pitch_dual")
+                    _lib.ptr(second["stats"]), chp, _lib.stream_ptr(stream)), "rsaf_mshds_pitch_dual")
         else:
             stats.fill_(float("nan"))
             stats[:, 0] = 0

@@ -125,3 +125,24 @@ def test_resampler_preserves_in_band_tone():
 
 def test_feature_order_matches_reference():
     assert len(mo.FEATURE_NAMES) == 25 and mo.FEATURE_NAMES[5] == "mean_F0" and mo.FEATURE_NAMES[-1] == "Spectral_Kurtosis"
+
+
+def test_sinc_cheb_table_reproduces_the_direct_interpolation():
+    """The product's Chebyshev form of the sinc-interpolation weights (used by the pitch kernel's Brent refinement)
+    against the oracle's direct Praat formula, for both depths the extractor uses."""
+    from numpy.polynomial import chebyshev as Ch
+    from robust_speech_analysis_framework_amd.mshds import sinc_cheb_table
+    rng = np.random.Generator(np.random.PCG64(9))
+    for depth, n in ((70, 400), (700, 2001)):
+        tab = sinc_cheb_table(depth)                                   # [2 depth, 16]
+        assert tab.shape == (2 * depth, 16)
+        y = rng.standard_normal(n)
+        b = rng.integers(depth + 2, n - depth - 3, size=40)            # left sample of the cell, depth unclipped
+        frac = rng.uniform(1e-3, 1.0 - 1e-3, size=40)
+        ref = mo.interpolate_sinc(np.tile(y, (40, 1)), b + frac, depth)
+        got = np.empty(40)
+        for i in range(40):
+            taps = y[b[i] - (depth - 1):b[i] + depth + 1]              # offsets -(depth-1) .. depth
+            coef = tab.T @ taps                                        # 16 Chebyshev coefficients of S on the cell
+            got[i] = Ch.chebval(2.0 * frac[i] - 1.0, coef)
+        assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
