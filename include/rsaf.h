@@ -242,6 +242,11 @@ int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const v
                                 double* stats_out, rsaf_stream_t stream);
 
 /* ---- sample-rate conversion in front of the extractors ---------------------------------- */
+/* Interleaved little-endian integer PCM (1 = unsigned 8 bit, 2, 3, 4 bytes per sample) -> float32 in [-1, 1),
+ * channel mean in float32.  Replaces torchaudio.load + waveform.mean(dim=0), src/foundation_model_extractor.py:87-91
+ * (and the mono conversion of parselmouth.Sound / cWaveSource monoMixdown). */
+int rsaf_pcm_to_mono_f32(const void* pcm, int sample_width, int n_channels, int64_t n_frames, float* out,
+                         rsaf_stream_t stream);
 /* torchaudio.transforms.Resample(orig, new) with its defaults (sinc_interp_hann, lowpass_filter_width 6, rolloff
  * 0.99): out[i * n_phase + p] = sum_k taps[p][k] * in[i * orig + tap_start[p] + k] (zero outside the input), with
  * orig/new already divided by their gcd, n_phase = new, n_out = ceil(new * n_in / orig).  The host builds the

@@ -29,7 +29,6 @@ constexpr double PI = 3.14159265358979323846;
 constexpr int MAXC = 16;            // candidate slots per frame (max_candidates <= 15)
 constexpr int MAX_MAXIMA = 96;      // local maxima considered per frame (in ascending lag order)
 constexpr double GOLD = 0.38196601125010515180;   // (3 - sqrt 5) / 2
-constexpr int N_GOLDEN = 32;
 
 struct ClipInfo {       // one entry per clip of a launch (host-built)
     int64_t sample_off;
@@ -1733,7 +1732,7 @@ __global__ __launch_bounds__(64) void pulse_stretches_kernel(const float* __rest
         const int i = base + lane;
         const bool v = voiced_at(f, nF, ceiling, i);
         const bool start = v && !voiced_at(f, nF, ceiling, i - 1), end = v && !voiced_at(f, nF, ceiling, i + 1);
-        const unsigned long long ms = __ballot(start), me = __ballot(end);
+        const unsigned long long ms = __ballot(start);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (start) { const int k = count + __popcll(ms & below); if (k < max_st) S[k].il = i; }
         if (end) {

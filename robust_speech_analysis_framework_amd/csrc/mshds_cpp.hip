@@ -124,8 +124,8 @@ __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict
     }
 }
 
-// index of the segment that owns element g of a prefix-summed range (offset field `off`, length field `len`)
-template <int OFF, int LEN>
+// index of the segment that owns element g of a prefix-summed range (OFF = index of the offset field in Seg)
+template <int OFF>
 __device__ __forceinline__ int find_seg(const Seg* __restrict__ s, int nseg, int g) {
     int lo = 0, hi = nseg - 1;
     while (lo < hi) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= total || nseg <= 0) return;
     const Seg* S = segs + (int64_t)clip * max_seg;
-    const Seg s = S[find_seg<3, 2>(S, nseg, g)];
+    const Seg s = S[find_seg<3>(S, nseg, g)];
     const ClipInfo c = ci[clip];
     const float* x = wav + c.sample_off;
     const int i = g - (int)s.res_off;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ s
     if (nseg <= 0 || f >= hdr[4 * clip + 2]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Seg* S = segs + (int64_t)clip * max_seg;
-    const Seg s = S[find_seg<4, 5>(S, nseg, f)];
+    const Seg s = S[find_seg<4>(S, nseg, f)];
     const int fl = f - (int)s.frame_off;
     const int nx = (int)s.nx, nfft = (int)s.nfft, m_out = (int)s.m_out;
     int log2n = 0;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ 
     if (nseg <= 0 || f >= hdr[4 * clip + 2]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Seg* S = segs + (int64_t)clip * max_seg;
-    const Seg s = S[find_seg<4, 5>(S, nseg, f)];
+    const Seg s = S[find_seg<4>(S, nseg, f)];
     const int fl = f - (int)s.frame_off, nf = (int)s.nf, nfft = (int)s.nfft, nq = nfft / 2 + 1;
     const double* Z = ceps + ((int64_t)clip * cap_frames + (int64_t)s.frame_off) * NQ_MAX;   // frames of this interval
     // moving average over time (VECsmoothByMovingAverage: [i - w/2, i + w/2], one less on the right for even w)

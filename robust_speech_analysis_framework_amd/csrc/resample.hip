@@ -108,3 +108,52 @@ int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_o
 }
 
 }  // extern "C"
+
+// ---- PCM decode + mono mix-down (the first step of SURVEY.md §8f rank 1) --------------------------------------
+// Interleaved little-endian integer PCM of 1, 2, 3 or 4 bytes per sample -> float32 in [-1, 1) per channel
+// (8-bit is unsigned, as in WAV), then the channel mean in channel order, float32 arithmetic: the same numbers
+// as torchaudio.load(...).mean(dim=0) (src/foundation_model_extractor.py:87-91) and wavio.read_wav_mono.
+namespace rsaf {
+namespace resample {
+
+__global__ __launch_bounds__(256) void pcm_to_mono_kernel(const unsigned char* __restrict__ pcm, int width, int n_ch,
+                                                          int64_t n_frames, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_frames) return;
+    const unsigned char* p = pcm + i * n_ch * width;
+    float acc = 0.0f;
+    for (int c = 0; c < n_ch; ++c, p += width) {
+        float v;
+        if (width == 2) {
+            v = (float)(short)(p[0] | (p[1] << 8)) / 32768.0f;
+        } else if (width == 1) {
+            v = ((float)p[0] - 128.0f) / 128.0f;
+        } else if (width == 3) {
+            int s = p[0] | (p[1] << 8) | (p[2] << 16);
+            s = s >= (1 << 23) ? s - (1 << 24) : s;
+            v = (float)((double)s / 8388608.0);
+        } else {
+            const int s = (int)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+            v = (float)((double)s / 2147483648.0);
+        }
+        acc = c == 0 ? v : acc + v;
+    }
+    out[i] = n_ch > 1 ? acc / (float)n_ch : acc;
+}
+
+}  // namespace resample
+}  // namespace rsaf
+
+extern "C" int rsaf_pcm_to_mono_f32(const void* pcm, int sample_width, int n_channels, int64_t n_frames, float* out,
+                                    rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(sample_width >= 1 && sample_width <= 4 && n_channels >= 1 && n_frames >= 0, "bad PCM geometry");
+    if (n_frames == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(pcm && out, "NULL pointer");
+    RSAF_CHECK_ARG((n_frames + 255) / 256 <= 0x7fffffffLL, "too many frames for one launch");
+    hipStream_t s = (hipStream_t)stream;
+    rsaf::ProfScope prof("pcm_to_mono", s, 0.0, (double)n_frames * (n_channels * sample_width + 4));
+    hipLaunchKernelGGL(rsaf::resample::pcm_to_mono_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned char*)pcm, sample_width, n_channels, n_frames, out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}

@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .wavio import read_wav_mono
+from .wavio import read_wav_mono_device
 
 FS = 16000.0
 DX = 1.0 / FS
@@ -566,11 +566,11 @@ def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True,
         for j, pth in enumerate(batch):
             filename = os.path.basename(pth)
             try:
-                x, fs = read_wav_mono(pth)
+                x, fs, n_in = read_wav_mono_device(pth, device=eng.device)     # :415-416 Sound(path), convert_to_mono
                 if fs != SAMPLE_RATE:                                         # :418-419 snd.resample(16000, 50)
                     from .resample import resample_praat
-                    x = resample_praat(x, fs, SAMPLE_RATE, 50, device=eng.device).cpu().numpy()
-                if len(x) == 0:
+                    x = resample_praat(x, fs, SAMPLE_RATE, 50, device=eng.device)
+                if int(x.numel()) == 0:
                     raise ValueError("empty file")
                 clips.append(x)
                 ok_idx.append(j)
@@ -579,10 +579,10 @@ def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True,
                     print(f"ERROR processing file '{filename}': {e}. Appending NaNs.")
         feats = np.full((len(batch), 25), np.nan)
         if clips:
-            lengths = [len(c) for c in clips]
+            lengths = [int(c.numel()) for c in clips]
             offs = np.zeros(len(clips) + 1, dtype=np.int64)
             offs[1:] = np.cumsum(lengths)
-            wav = torch.from_numpy(np.concatenate(clips)).to(eng.device)
+            wav = torch.cat(clips) if len(clips) > 1 else clips[0].contiguous()
             vals, _ = eng.extract_packed(wav, offs[:-1], lengths)
             torch.cuda.synchronize()
             feats[ok_idx] = vals.cpu().numpy()

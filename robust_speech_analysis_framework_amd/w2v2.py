@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 from .w2v2_config import SAMPLE_RATE, W2V2Config, chunk_plan, load_local_model, random_state_dict
-from .wavio import read_wav
+from .wavio import read_wav_mono_device
 
 _KERNELS = (10, 3, 3, 3, 3, 2, 2)
 
@@ -199,27 +199,25 @@ def extract_wav2vec2_sequences(input_df, model_name="facebook/wav2vec2-base-960h
         for pth in paths[b0:b0 + batch_files]:
             filename = os.path.basename(pth)
             try:
-                x, fs = read_wav(pth)
-                if x.shape[1] < int(SAMPLE_RATE * 0.5):                       # :88 (pre-resample count)
+                mono, fs, n_in = read_wav_mono_device(pth, device=eng.device)   # :87,91 decode + channel mean on the device
+                if n_in < int(SAMPLE_RATE * 0.5):                             # :88 (pre-resample count)
                     if verbose:
                         print(f"INFO: Skipping very short file '{filename}'.")
                     continue
-                mono = x.mean(axis=0, dtype=np.float32) if x.shape[0] > 1 else x[0]
                 if fs != SAMPLE_RATE:                                         # :92-94 torchaudio Resample defaults
                     from .resample import resample_sinc_hann
-                    mono = resample_sinc_hann(np.ascontiguousarray(mono, dtype=np.float32), fs, SAMPLE_RATE,
-                                              device=eng.device).cpu().numpy()
-                clips.append(np.ascontiguousarray(mono, dtype=np.float32))
+                    mono = resample_sinc_hann(mono, fs, SAMPLE_RATE, device=eng.device)
+                clips.append(mono)
                 names.append(filename)
             except Exception as e:
                 if verbose:
                     print(f"FATAL ERROR processing file '{filename}': {e}. Skipping.")
         if not clips:
             continue
-        lengths = [len(c) for c in clips]
+        lengths = [int(c.numel()) for c in clips]
         offs = np.zeros(len(clips) + 1, dtype=np.int64)
         offs[1:] = np.cumsum(lengths)
-        wav = torch.from_numpy(np.concatenate(clips)).to(eng.device)
+        wav = torch.cat(clips) if len(clips) > 1 else clips[0].contiguous()
         out, frame_off = eng.extract_packed(wav, offs[:-1], lengths, chunk_seconds, overlap_seconds)
         torch.cuda.synchronize()
         host = out.cpu().numpy()

@@ -49,3 +49,30 @@ def read_wav_mono(path: str):
     else:
         x = x[0]
     return np.ascontiguousarray(x, dtype=np.float32), fs
+
+
+def read_wav_raw(path: str):
+    """Return (raw interleaved PCM bytes, n_channels, sample_width, sample_rate, n_frames) without decoding."""
+    with wave.open(path, "rb") as w:
+        nch, width, fs, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if width not in (1, 2, 3, 4):
+        raise UnsupportedAudio(f"{path}: unsupported sample width {width}")
+    n = len(raw) // (nch * width)
+    return raw, int(nch), int(width), int(fs), int(n)
+
+
+def read_wav_mono_device(path: str, device="cuda", stream=None):
+    """PCM decode and mono mix-down on the device: (torch float32 [n] on ``device``, sample_rate, n_frames).
+    Bit-identical to ``read_wav_mono`` (same float32 operations in the same order)."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    _lib.require_gpu()
+    raw, nch, width, fs, n = read_wav_raw(path)
+    out = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+    if n:
+        buf = torch.frombuffer(bytearray(raw[:n * nch * width]), dtype=torch.uint8).to(out.device)
+        _lib.check(lib.rsaf_pcm_to_mono_f32(_lib.ptr(buf), width, nch, n, _lib.ptr(out), _lib.stream_ptr(stream)),
+                   "rsaf_pcm_to_mono_f32")
+    return out[:n], fs, n

@@ -58,3 +58,28 @@ def test_mshds_dropin_accepts_44k1_files(rsaf_lib, tmp_path):
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     ok = ~np.isnan(ref)
     assert (np.abs(got[ok] - ref[ok]) <= 1e-4 * np.maximum(np.abs(ref[ok]), 1e-3)).all(), (got, ref)
+
+
+@pytest.mark.parametrize("width,nch", [(2, 1), (2, 2), (1, 2), (3, 1), (4, 3)])
+def test_pcm_decode_and_mixdown_on_device_is_bit_identical_to_the_host_reader(rsaf_lib, tmp_path, width, nch):
+    import wave
+    from robust_speech_analysis_framework_amd.wavio import read_wav_mono, read_wav_mono_device
+    rng = np.random.Generator(np.random.PCG64(7 + width + nch))
+    n = 4097
+    if width == 1:
+        raw = rng.integers(0, 256, size=(n, nch), dtype=np.uint8).tobytes()
+    elif width == 2:
+        raw = rng.integers(-32768, 32768, size=(n, nch), dtype=np.int16).astype("<i2").tobytes()
+    elif width == 3:
+        v = rng.integers(-(1 << 23), 1 << 23, size=(n, nch), dtype=np.int32)
+        b = np.stack([(v & 0xFF), ((v >> 8) & 0xFF), ((v >> 16) & 0xFF)], axis=-1).astype(np.uint8)
+        raw = b.tobytes()
+    else:
+        raw = rng.integers(-(1 << 31), 1 << 31, size=(n, nch), dtype=np.int64).astype("<i4").tobytes()
+    path = str(tmp_path / f"pcm{width}_{nch}.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(nch); w.setsampwidth(width); w.setframerate(22050); w.writeframes(raw)
+    host, fs = read_wav_mono(path)
+    dev, fs2, nfr = read_wav_mono_device(path)
+    assert fs == fs2 == 22050 and nfr == n == len(host)
+    assert np.array_equal(dev.cpu().numpy(), host)                      # same float32 operations in the same order
