@@ -86,19 +86,19 @@ def cpu_baseline(stages, seconds, sample_clips):
     n = sample_clips or 1
     log(f"cpu_baseline: {n} clip(s) on {cores} thread(s)")
     clips = [synth.synth_clip(900000 + k, seconds) for k in range(n)]
-    parts, total = {}, 0.0
+    parts, total, ref = {}, 0.0, {"clip0": clips[0]}
     if "smile" in stages:
         from oracle import smile_oracle
         t0 = time.perf_counter()
-        for c in clips:
-            smile_oracle.extract(c)
+        ref["smile"] = [smile_oracle.extract(c) for c in clips][0]
         parts["smile"] = time.perf_counter() - t0
         log(f"cpu_baseline smile {parts['smile']:.2f} s")
     if "mshds" in stages:
         from oracle import mshds_oracle
         sub = clips[0][:int(16000 * min(seconds, 5.0))]          # bounded: 5 s of one clip (Python oracle)
         t0 = time.perf_counter()
-        mshds_oracle.extract(sub)
+        ref["mshds"], _ = mshds_oracle.extract(sub)
+        ref["mshds_input"] = sub
         dt_m = time.perf_counter() - t0
         parts["mshds"] = dt_m * (n * seconds) / (len(sub) / 16000.0)   # scaled to the sample's audio-seconds
         log(f"cpu_baseline mshds {dt_m:.2f} s for {len(sub) / 16000.0:g} audio-s (scaled to {parts['mshds']:.1f} s)")
@@ -120,7 +120,7 @@ def cpu_baseline(stages, seconds, sample_clips):
         sdm = {k: v.numpy() for k, v in CNNLSTM().state_dict().items()}
         x = cnnlstm_oracle.collate_zero_pad(seqs)
         t0 = time.perf_counter()
-        cnnlstm_oracle.forward_torch(sdm, x, "silu")
+        ref["logits"] = np.asarray(cnnlstm_oracle.forward_torch(sdm, x, "silu"))[0]
         parts["cnnlstm"] = time.perf_counter() - t0
     total = sum(parts.values())
     cpu_model = ""
@@ -132,13 +132,53 @@ def cpu_baseline(stages, seconds, sample_clips):
     except OSError:
         pass
     model_stages = [s for s in stages if s in ("w2v2", "cnnlstm")]
-    return {"value": round(n * seconds / total, 2), "unit": "audio-s/s", "cores": cores if model_stages else 1,
+    return ref, {"value": round(n * seconds / total, 2), "unit": "audio-s/s", "cores": cores if model_stages else 1,
             "kind": "port",
             "sample": f"{n} x {seconds:g} s clips through stages {stages}: oracle/ (numpy float64 DSP on 1 core, "
                       f"MSHDS timed on 5 s and scaled linearly; torch-CPU float32 models on {cores} threads, "
                       f"batch-1 windows like the reference)",
             "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
             "seconds_per_stage": {k: round(v, 3) for k, v in parts.items()}}
+
+
+def parity_vs_cpu(pipe, ref, stages, dev):
+    """BASELINE.json's second half of the metric ("feature max-abs-err vs CPU"): the HIP path on the very clip the
+    cpu_baseline leg just pushed through oracle/ (the oracle is the checker here, as in tests/ and smoke()).
+    rel = |gpu - cpu| / max(|cpu|, 1e-3 * max|cpu| of the stage's vector); NaN patterns must coincide."""
+    import numpy as np
+    import torch
+    out = {}
+    clip = torch.from_numpy(np.ascontiguousarray(ref["clip0"])).to(dev)[None, :]
+    row = pipe.run(clip)[0].double().cpu().numpy()
+    torch.cuda.synchronize()
+    col = 0
+
+    def cmp(name, got, want):
+        got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        both = ~np.isnan(got) & ~np.isnan(want)
+        d = np.abs(got[both] - want[both])
+        scale = np.maximum(np.abs(want[both]), 1e-3 * np.abs(want[both]).max()) if both.any() else np.ones(0)
+        own = d / np.maximum(np.abs(want[both]), 1e-30)                 # per column, no floor (harsh on ~0 columns)
+        out[name] = {"columns": int(got.size), "compared": int(both.sum()),
+                     "nan_pattern_equal": bool(np.array_equal(np.isnan(got), np.isnan(want))),
+                     "max_abs_err": float(d.max()) if d.size else None,
+                     "max_rel_err": float((d / scale).max()) if d.size else None,
+                     "median_rel_err_per_column": float(np.median(own)) if d.size else None,
+                     "columns_within_1e-4_per_column_rel": int((own <= 1e-4).sum()) if d.size else 0}
+    if "mshds" in stages:
+        if "mshds" in ref:                                   # the oracle ran on a 5 s excerpt: run the HIP path on the same
+            sub = torch.from_numpy(np.ascontiguousarray(ref["mshds_input"])).to(dev)
+            got, _ = pipe.mshds.extract_packed(sub, [0], [int(sub.numel())])
+            torch.cuda.synchronize()
+            cmp("mshds_25_features_5s_excerpt", got[0].cpu().numpy(), ref["mshds"])
+        col += 25
+    if "smile" in stages:
+        if "smile" in ref:
+            cmp("opensmile_912_functionals_30s", row[col:col + 912], ref["smile"])
+        col += 912
+    if "cnnlstm" in stages and "logits" in ref:
+        cmp("wav2vec2_to_cnnlstm_logits_30s", row[col:col + 2], ref["logits"])
+    return out
 
 
 def main():
@@ -240,13 +280,14 @@ def main():
                        "stages": [s for s in stages], "sharding": f"clips/{world} ranks, all_gather of result rows"},
             "roofline": roof,
             "checks": {"finite": True, "duplicate_clips_bit_identical": dup_ok,
-                       "note": "parity vs the CPU oracle is asserted by tests/ (-m gpu) and smoke(), not in the timed run"},
+                       "note": "parity vs the CPU oracle is asserted by tests/ (-m gpu) and smoke(); parity_vs_cpu below reports it for the cpu_baseline sample, outside the timed run"},
             "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 and v["ms"] > 0 else {})}
                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(stages, args.seconds, args.cpu_sample_clips)
+            ref, line["cpu_baseline"] = cpu_baseline(stages, args.seconds, args.cpu_sample_clips)
+            line["parity_vs_cpu"] = parity_vs_cpu(pipe, ref, stages, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
