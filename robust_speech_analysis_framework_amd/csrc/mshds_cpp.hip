@@ -45,7 +45,19 @@ struct Seg {
 };
 static_assert(sizeof(Seg) == SEG_DOUBLES * sizeof(double), "Seg layout");
 
-__device__ __forceinline__ double round6(double t) { return rint(t * 1.0e6) / 1.0e6; }   // "%.6f" and back
+// "%.6f" and back ("Down to Table" prints the interval times with 6 decimals, the reference parses them again).
+// printf rounds the exact binary value; interval ends clipped to the sound's end are multiples of 62.5 us, i.e.
+// sit within one ulp of a decimal tie, so the product t * 1e6 must not be rounded before the decision: the FMA
+// recovers its rounding error exactly.
+__device__ __forceinline__ double round6(double t) {
+    const double p = t * 1.0e6;
+    const double e = fma(t, 1.0e6, -p);                  // t * 1e6 == p + e exactly
+    double q = floor(p);
+    double f = (p - q) + e;                              // fractional part of the exact product
+    if (f < 0.0) { q -= 1.0; f += 1.0; }
+    const bool up = f > 0.5 || (f == 0.5 && fmod(q, 2.0) != 0.0);
+    return (up ? q + 1.0 : q) / 1.0e6;
+}
 
 // ---- 1. voiced intervals -> segment table -----------------------------------------------------------------
 // hdr[clip] = {n_seg, fail, total_frames, total_resampled}
