@@ -206,8 +206,10 @@ def lld(x: np.ndarray) -> np.ndarray:
     out[35] = np.sum(P * sharpness_weights()[None, :], axis=1) / safe
     pk = np.zeros(nf)
     mid = mag[:, 1:-1]
-    ismax = (mid > mag[:, :-2]) & (mid > mag[:, 2:])
-    pk = np.sum(np.where(ismax, mid - 0.5 * (mag[:, :-2] + mag[:, 2:]), 0.0), axis=1)
+    # excess of every bin over the mean of its two neighbours, clipped at zero: at a spectral peak this is the
+    # peak's prominence; unlike a "bin is a strict local maximum" test it is continuous in the magnitudes, so
+    # float32 and float64 runs cannot disagree on a decision
+    pk = np.sum(np.maximum(mid - 0.5 * (mag[:, :-2] + mag[:, 2:]), 0.0), axis=1)
     msum = np.sum(mag, axis=1)
     out[36] = pk / np.where(msum > 0, msum, 1.0)                 # harmonicity proxy (free choice)
     out[37] = np.exp(np.mean(np.log(np.maximum(P, 1e-30)), axis=1)) / np.maximum(tot / NBINS, 1e-30)

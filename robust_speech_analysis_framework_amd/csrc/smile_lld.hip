@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void smile_lld_kernel(const float* __restrict_
             s_lg += logf(fmaxf(p, 1e-30f));
             if (b >= 1) {
                 const float ml = M[b - 1], mr = M[b + 1];
-                s_pk += (m > ml && m > mr) ? (m - 0.5f * (ml + mr)) : 0.f;
+                s_pk += fmaxf(m - 0.5f * (ml + mr), 0.f);   // prominence over the neighbours' mean (continuous)
             }
         }
         if (lane == 0) {

@@ -9,7 +9,7 @@ from robust_speech_analysis_framework_amd.mshds import MshdsEngine, FEATURE_NAME
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 rng = np.random.Generator(np.random.PCG64(first))
-clips = [synth.synth_clip(first + k, float(rng.uniform(1.2, 3.5))) for k in range(count)]
+clips = [synth.synth_clip(first + k, float(rng.uniform(float(os.environ.get("FUZZ_MIN_S", "1.2")), float(os.environ.get("FUZZ_MAX_S", "3.5"))))) for k in range(count)]
 lens = [len(c) for c in clips]
 offs = np.concatenate([[0], np.cumsum(lens)])[:-1]
 wav = torch.from_numpy(np.concatenate(clips)).cuda()
