@@ -1,7 +1,7 @@
 """One-off edge-input sweep of the MSHDS HIP path against the oracle: degenerate signals must give the same NaN
 pattern / values and must never fault (tool; the fixed edge cases live in tests/)."""
 import os, sys, time, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import mshds_oracle as mo
 from robust_speech_analysis_framework_amd import synth

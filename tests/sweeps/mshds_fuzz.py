@@ -1,6 +1,6 @@
 """One-off randomized parity sweep of the MSHDS HIP path against the CPU oracle (tool; tests/ holds the fixed cases)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import mshds_oracle as mo
 from robust_speech_analysis_framework_amd import synth

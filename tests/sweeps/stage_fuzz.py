@@ -1,7 +1,7 @@
 """One-off randomized parity sweeps of the openSMILE-chain and Wav2Vec2 -> CNN-LSTM HIP paths against the CPU
 oracles on random clip lengths (tool; tests/ holds the fixed cases and the tolerances reused here)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import smile_oracle as so, w2v2_oracle, cnnlstm_oracle
 from robust_speech_analysis_framework_amd import smile, synth
