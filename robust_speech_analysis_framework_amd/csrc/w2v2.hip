@@ -14,6 +14,7 @@
 // conv0 (Cin = 1) + GroupNorm + GELU is recomputed in two passes (stats, apply) instead of
 // materialising the un-normalised 15 999 x 512 activation; LayerNorm / softmax are one wave per row.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "gemm_f32.h"
@@ -261,6 +262,140 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// ---- fused attention for windows of at most 256 frames (every Wav2Vec2 window: T <= 249) -------------------
+// One workgroup = 128 queries of one (window, head); wave = 32 queries.  Exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//   S^T = K Q^T : keys are the MFMA rows, queries the columns, so a lane holds ONE query's scores for 16 keys per
+//                 tile: the softmax over keys is in-lane plus one exchange with lane ^ 32, and the probabilities
+//                 already sit in the register layout the next MFMA wants as its A operand (row = lane & 31 =
+//                 query, k slot = lane >> 5): register e of key tile kt pairs keys a_e and a_e + 4, and the V
+//                 fragment simply reads those two keys.  No score or probability ever goes to memory
+//                 (the three-launch path wrote and re-read 762 MB per layer and 256 windows).
+//   K and V are staged through one 35 KB LDS buffer in blocks of 128 keys (K rows padded to 68 floats so the
+//   float4 fragment reads are conflict-free); all 256 scores of a query stay in registers, so the softmax is the
+//   plain two-pass form, not an online rescaling.
+using af32x16 = __attribute__((ext_vector_type(16))) float;
+
+__global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
+                                                            int NH, int Hd, float scale) {
+    constexpr int HD = 64, KB = 128, KS = HD + 4;
+    __shared__ __attribute__((aligned(16))) float kv[KB * KS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int win = blockIdx.x / NH, head = blockIdx.x - win * NH;
+    const int64_t ld = 3 * (int64_t)Hd;
+    const float* base = qkv + (int64_t)win * T * ld + (int64_t)head * HD;      // q of this window and head
+    const int q0 = blockIdx.y * 128 + wv * 32;
+    const int nblk = (T + KB - 1) / KB;                                         // 1 or 2 key blocks
+
+    // Q fragments: lane (query l31, half h) holds d = 8g + 4h + j  (the pairing both MFMA operands use)
+    float4 qf[8];
+    {
+        const int q = q0 + l31 < T ? q0 + l31 : T - 1;
+        const float* qp = base + (int64_t)q * ld + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const float4*>(qp + 8 * g);
+    }
+    af32x16 sc[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
+
+    auto stage = [&](const float* src0, int key0, int stride) {                 // 128 keys x 64 floats -> LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 4, c4 = idx & 15;
+            const int key = key0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (key < T) v = *reinterpret_cast<const float4*>(src0 + (int64_t)key * ld + 4 * c4);
+            *reinterpret_cast<float4*>(&kv[r * stride + 4 * c4]) = v;
+        }
+    };
+
+    // ---- scores ----
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b < nblk) {
+            __syncthreads();
+            stage(base + Hd, KB * b, KS);
+            __syncthreads();
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int kt = 4 * b + t4;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float4 kf = *reinterpret_cast<const float4*>(&kv[(32 * t4 + l31) * KS + 8 * g + 4 * h]);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g].x, sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g].y, sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g].z, sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g].w, sc[kt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- softmax over the keys of this lane's query: key = 32 kt + (e & 3) + 8 (e >> 2) + 4 h ----
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = key < T ? sc[kt][e] * scale : -INFINITY;
+            sc[kt][e] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float ev = expf(sc[kt][e] - m);                               // exp(-inf) = 0 for the padded keys
+            sc[kt][e] = ev;
+            sum += ev;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[kt][e] *= inv;
+
+    // ---- O = P V ----
+    af32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.0f; o1[e] = 0.0f; }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b < nblk) {
+            __syncthreads();
+            stage(base + 2 * Hd, KB * b, HD);
+            __syncthreads();
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int kt = 4 * b + t4;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;   // within the staged block
+                    const float v0 = kv[key * HD + l31], v1 = kv[key * HD + 32 + l31];
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], v0, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], v1, o1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C layout: column = lane & 31 (d), row = (e & 3) + 8 (e >> 2) + 4 h (query within the wave's 32)
+    float* op = out + (int64_t)win * T * Hd + (int64_t)head * HD;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (q < T) {
+            op[(int64_t)q * Hd + l31] = o0[e];
+            op[(int64_t)q * Hd + 32 + l31] = o1[e];
+        }
+    }
+}
+
 // ---- row softmax in place, one wave per row of length T (row stride Tp, pad columns zeroed) ---------
 // Tp <= 256 (every Wav2Vec2 window: T <= 249): the row lives in one float4 per lane, one load + one store
 template <bool SMALL>
@@ -499,6 +634,14 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             rc = launch_gemm_f32(p, s, "w2v2_gemm");
             if (rc) return rc;
         }
+        static const bool fused_attn = [] { const char* e = getenv("RSAF_W2V2_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
+        if (fused_attn && hd == 64 && Tt <= 256) {
+            // 2 x 2 T^2 hd flops per (chunk, head)
+            ProfScope prof("w2v2_attn_fused", s, 4.0 * (double)n * c.NH * (double)Tt * Tt * hd, 0.0);
+            hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256), 0, s,
+                               ws + W.qkv, ws + W.att, Tt, c.NH, Hd, scale);
+            RSAF_CHECK_HIP(hipGetLastError());
+        } else {
         {   // S = scale * Q K^T per (chunk, head)
             GemmParams p = gemm_params_plain(ws + W.qkv, ws + W.qkv + Hd, ws + W.S, Tt, Tt, hd, 3 * Hd, 3 * Hd, W.Tp);
             p.nz = n * c.NH; p.nz2 = c.NH;
@@ -527,6 +670,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             p.sC1 = (int64_t)Tt * Hd; p.sC2 = hd;
             rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
+        }
         }
         {   // y = attn Wo^T + bo + x ; x = LN(y)
             GemmParams p = gemm_params_plain(ws + W.att, Wt + lo.wo, ws + W.y, (int)rows, Hd, Hd, Hd, Hd, Hd);
