@@ -1162,8 +1162,8 @@ constexpr int SR_MAX_PEAKS = 4096;
 __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict__ db_all, const ClipInfo* __restrict__ ci,
                                                         double dt, const double* __restrict__ sel_freq,
                                                         const ClipInfo* __restrict__ pci, double pitch_dt, double ceiling,
-                                                        double* __restrict__ work, int64_t work_stride,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ work, int64_t work_stride, int max_frames,
+                                                        int peak_cap, int in_global, double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const ClipInfo c = ci[blockIdx.x];
     const int n = c.n_frames, lane = threadIdx.x;
@@ -1173,9 +1173,11 @@ __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict
         if (lane < 5) o[lane] = qn;
         return;
     }
-    double* y = reinterpret_cast<double*>(smem_raw);          // [n] intensity contour
+    // contours that do not fit the LDS (clips beyond ~2 minutes) live in the per-clip global scratch instead
+    double* gscr = work + (int64_t)blockIdx.x * work_stride + 3 * ((int64_t)max_frames + 2) + 2 * (int64_t)peak_cap;
+    double* y = in_global ? gscr : reinterpret_cast<double*>(smem_raw);      // [n] intensity contour
     double* srt = y + ((n + 1) & ~1);                          // [n] sorted copy, later peak positions
-    int* pk = reinterpret_cast<int*>(srt + ((n + 1) & ~1));    // [SR_MAX_PEAKS] local-maximum indices
+    int* pk = reinterpret_cast<int*>(srt + ((n + 1) & ~1));    // [peak_cap] local-maximum indices
     const double* src = db_all + c.frame_off;
     for (int i = lane; i < n; i += 64) y[i] = src[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1223,10 +1225,10 @@ __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict
         if (i < n - 1) ok = y[i] > y[i - 1] && y[i] >= y[i + 1];
         const unsigned long long m = __ballot(ok);
         const int pos = npk + __popcll(m & ((1ull << lane) - 1ull));
-        if (ok && pos < SR_MAX_PEAKS) pk[pos] = i;
+        if (ok && pos < peak_cap) pk[pos] = i;
         npk += __popcll(m);
     }
-    if (npk > SR_MAX_PEAKS) npk = SR_MAX_PEAKS;
+    if (npk > peak_cap) npk = peak_cap;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1250,7 +1252,7 @@ __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict
     double* ivb = iva + (n + 2);                               // interval ends
     double* ivl = ivb + (n + 2);                               // 1 = sounding, 0 = silent
     double* tpk = ivl + (n + 2);                               // kept peak times
-    double* vpk = tpk + SR_MAX_PEAKS;                          // kept peak values
+    double* vpk = tpk + peak_cap;                              // kept peak values
     const double duration = c.n_samples * DXS;
     int niv = 0;
     {
@@ -2218,7 +2220,18 @@ int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, 
                       sel_strength2, stats_out2, sinc_cheb, stream);
 }
 
-int64_t rsaf_mshds_speechrate_workspace_doubles(int max_frames) { return 3 * ((int64_t)max_frames + 2) + 2 * SR_MAX_PEAKS; }
+// peaks of an n-frame contour: at most n/2; the LDS form keeps SR_MAX_PEAKS of them (a smooth 16 ms contour of at most
+// ~8 500 frames has far fewer), the global-memory form of long clips sizes the lists exactly
+static int sr_peak_cap(int max_frames, bool in_global) { return in_global ? max_frames / 2 + 2 : SR_MAX_PEAKS; }
+static bool sr_in_global(int max_frames) {
+    return (size_t)2 * ((max_frames + 1) & ~1) * sizeof(double) + SR_MAX_PEAKS * sizeof(int) > 150 * 1024;
+}
+
+int64_t rsaf_mshds_speechrate_workspace_doubles(int max_frames) {
+    const bool g = sr_in_global(max_frames);
+    const int64_t cap = sr_peak_cap(max_frames, g);
+    return 3 * ((int64_t)max_frames + 2) + 2 * cap + (g ? 2 * ((int64_t)max_frames + 2) + cap / 2 + 2 : 0);
+}
 
 int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int n_clips, int max_frames,
                           double intensity_dt, const double* sel_freq, const void* pitch_clip_info, double pitch_dt,
@@ -2226,8 +2239,9 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
     RSAF_CHECK_ARG(n_clips >= 0 && max_frames >= 0, "bad clip/frame count");
     if (n_clips == 0) return RSAF_OK;
     RSAF_CHECK_ARG(intensity_db && clip_info && sel_freq && pitch_clip_info && workspace && out, "NULL pointer");
-    const size_t lds = (size_t)2 * ((max_frames + 1) & ~1) * sizeof(double) + SR_MAX_PEAKS * sizeof(int);
-    RSAF_CHECK_ARG(lds <= 150 * 1024, "clip too long for the speech-rate kernel (intensity contour must fit LDS)");
+    const bool in_global = sr_in_global(max_frames);
+    const int peak_cap = sr_peak_cap(max_frames, in_global);
+    const size_t lds = in_global ? 0 : (size_t)2 * ((max_frames + 1) & ~1) * sizeof(double) + SR_MAX_PEAKS * sizeof(int);
     hipStream_t s = (hipStream_t)stream;
     if (lds > 48 * 1024)
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)speechrate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2235,7 +2249,7 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
     ProfScope prof("mshds_speechrate", s, 0.0, 0.0);
     hipLaunchKernelGGL(speechrate_kernel, dim3(n_clips), dim3(64), lds, s, intensity_db, (const ClipInfo*)clip_info,
                        intensity_dt, sel_freq, (const ClipInfo*)pitch_clip_info, pitch_dt, pitch_ceiling, workspace,
-                       rsaf_mshds_speechrate_workspace_doubles(max_frames), out);
+                       rsaf_mshds_speechrate_workspace_doubles(max_frames), max_frames, peak_cap, in_global ? 1 : 0, out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -421,7 +421,7 @@ class MshdsEngine:
         self._last_ltas = {"pitch": p, "pulses": pulses, "n_pulses": npul, "max_pulses": max_pulses}
         return out[:n]
 
-    CPP_CHUNK = 48          # clips per launch group: the cepstrogram workspace is ~68 MB per 30 s clip
+    CPP_CHUNK = 48          # most clips per launch group (the cepstrogram workspace is ~68 MB per 30 s clip)
 
     def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None, pitch=None):
         """_extract_CPP (src/mshds_extractor.py:253-301) -> float64 [n] mean CPPS of the voiced intervals."""
@@ -452,8 +452,10 @@ class MshdsEngine:
         cap_frames = int(dur / 0.002) + max_seg
         segd = int(lib.rsaf_mshds_cpp_seg_doubles())
         ci_all = p["ci"]
-        for c0 in range(0, n, self.CPP_CHUNK):
-            c1 = min(n, c0 + self.CPP_CHUNK)
+        # clips per launch group: bound the cepstrogram workspace (cap_frames x 513 doubles per clip) to ~3 GB
+        chunk = max(1, min(self.CPP_CHUNK, int(3.0e9 // (cap_frames * 513 * 8))))
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
             m = c1 - c0
             ci_d = _dev(ci_all[c0:c1], dev)
             segs = torch.empty(m * max_seg * segd, dtype=torch.float64, device=dev)
