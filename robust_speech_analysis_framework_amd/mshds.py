@@ -585,9 +585,23 @@ def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True,
             offs = np.zeros(len(clips) + 1, dtype=np.int64)
             offs[1:] = np.cumsum(lengths)
             wav = torch.cat(clips) if len(clips) > 1 else clips[0].contiguous()
-            vals, _ = eng.extract_packed(wav, offs[:-1], lengths)
-            torch.cuda.synchronize()
-            feats[ok_idx] = vals.cpu().numpy()
+            try:
+                vals, _ = eng.extract_packed(wav, offs[:-1], lengths)
+                torch.cuda.synchronize()
+                feats[ok_idx] = vals.cpu().numpy()
+            except _lib.RsafError as e:
+                # a clip the kernels reject must not take its batch mates down: redo the batch clip by clip and give
+                # only the offending files the reference's per-file NaN row (:450-457)
+                if verbose:
+                    print(f"WARNING: batch of {len(clips)} files failed ({e}); retrying file by file.")
+                for j, c in zip(ok_idx, clips):
+                    try:
+                        v1, _ = eng.extract_packed(c.contiguous(), [0], [int(c.numel())])
+                        torch.cuda.synchronize()
+                        feats[j] = v1.cpu().numpy()[0]
+                    except _lib.RsafError as e1:
+                        if verbose:
+                            print(f"ERROR processing file '{os.path.basename(batch[j])}': {e1}. Appending NaNs.")
         for j, pth in enumerate(batch):
             d = {"filename": os.path.basename(pth)}
             d.update({nme: feats[j, k] for k, nme in enumerate(FEATURE_NAMES)})
