@@ -1,17 +1,21 @@
 // Praat-style analyses behind the MSHDS features, float64 kernels for gfx950.
 //
-// Replaces the parselmouth/Praat calls of src/mshds_extractor.py for the helpers built so far:
-//   _pitch_values (:127-162), _extract_pitch (:164-183), _extract_intensity (:185-205),
-//   _extract_harmonicity (:207-225), _extract_Spectral_Moments (:340-376).
-// Algorithms: Boersma (1993) autocorrelation / cross-correlation pitch with sinc-interpolated
-// candidates and the Viterbi path finder; Praat's intensity (Kaiser-weighted mean square) and
-// Gaussian-window spectrogram + spectral moments.  Semantics = oracle/mshds_oracle.py (parity
-// unpinned: Praat itself is not available).  Praat computes in double, so do these kernels
-// (MI355X: 78 TFLOP/s fp64 vector); discrete decisions (voicing, path) then agree with the oracle.
+// Replaces the parselmouth/Praat calls of src/mshds_extractor.py (all ten helpers; the cepstral part lives in
+// mshds_cpp.hip):
+//   _speechrate (:11-125), _pitch_values (:127-162), _extract_pitch (:164-183), _extract_intensity (:185-205),
+//   _extract_harmonicity (:207-225), _extract_Slope_Tilt (:227-251), _measureFormants (:303-338),
+//   _extract_Spectral_Moments (:340-376).
+// Algorithms: Boersma (1993) autocorrelation / cross-correlation pitch with sinc-interpolated candidates and the
+// Viterbi path finder; Praat's intensity (Kaiser-weighted mean square), Gaussian-window spectrogram + spectral
+// moments, cc pulse walker, pitch-corrected Ltas, Burg formants, de Jong & Wempe syllable nuclei.  Semantics =
+// oracle/mshds_oracle.py (parity unpinned: Praat itself is not available).  Praat computes in double, so do these
+// kernels (MI355X: 78 TFLOP/s fp64, vector and matrix alike); discrete decisions (voicing, path) then agree with
+// the oracle.
 //
-// Mapping: one 256-thread workgroup per analysis frame for the correlation kernels (frame staged in
-// LDS, 4 lags per thread in registers, candidates refined by wave-cooperative sinc sums), one wave
-// per frame for intensity, one wave per clip for the path finder and the per-clip statistics.
+// Mapping: one 256-thread workgroup per analysis frame for the pitch kernel (frame staged in LDS, correlation on
+// v_mfma_f64_16x16x4_f64, candidates refined by Brent's method on a Chebyshev form of the sinc interpolation or,
+// where the depth is clipped, on wave-cooperative sinc sums), one wave per frame for intensity, one wave per clip
+// for the path finder and the per-clip statistics, one wave per voiced stretch for the pulse walker.
 #include <algorithm>
 
 #include "rsaf_common.h"
