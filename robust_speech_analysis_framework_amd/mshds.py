@@ -6,10 +6,9 @@ run as float64 HIP kernels (``csrc/mshds.hip``); the host only builds the frame 
 ``Sampled_shortTermAnalysis`` arithmetic), the window tables, and routes each clip to the
 speaker-adapted pitch range that ``_pitch_values`` chooses (``:127-162``).
 
-Built so far: the five speech-rate/pausing columns, mean_F0, stdev_F0_Semitone, mean_dB,
-range_ratio_dB, HNR_dB, the eight F1/B1/F2/B2 statistics, Spectral_Gravity, Spectral_Std_Dev,
-Spectral_Skewness, Spectral_Kurtosis.  The 3 other columns are NaN until their kernels exist (LTAS
-slope/tilt, CPPS): there is no CPU fallback.
+All 25 columns are computed on the device (``csrc/mshds.hip``, ``csrc/mshds_cpp.hip``); there is no CPU
+fallback.  A helper that fails in the reference gives NaN for its columns there (``except: return nan``);
+the kernels reproduce those cases (too-short clips, no voiced frames, no periods) as NaN as well.
 """
 from __future__ import annotations
 

@@ -134,7 +134,7 @@ class Pipeline:
         if "cnnlstm" in self.stages:
             parts.append("CNN-LSTM-attn forward (C=H=128) on the Wav2Vec2 sequences")
         return (f"{' -> '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU; "
-                "columns whose kernels are not built yet are NaN (DESIGN.md)")
+                "the six openSMILE pitch / voice-quality LLDs that are not built are NaN (DESIGN.md)")
 
 
 def roofline(prof, pipe, clips, seconds, steps, hbm_peak_gbs, mfma_peak_tflops):
