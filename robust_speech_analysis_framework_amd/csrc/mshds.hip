@@ -2175,7 +2175,20 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         if (!unclipped || getenv("RSAF_PITCH_NO_CHEB")) cheb = nullptr;
     }
     if (max_frames > 0) {
-        ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s, 0.0, 0.0);
+        // matrix-pipe work of the correlation phase (v_mfma_f64_16x16x4: 1 024 MAC each), counted for equal-length
+        // clips (an upper bound for ragged batches); the refinement's VALU work is not counted
+        double mfma_per_frame = 0.0;
+        {
+            const int Lc = P.is_cc ? P.max_lag : P.brent_ixmax, NTc = (Lc + 256) / 256;
+            for (int tile = 0; tile < NTc; ++tile) {
+                int j_hi = P.nsamp_window + 240 + 256 * tile;
+                j_hi = j_hi < seg_len ? j_hi : seg_len;
+                const int j_lo = 256 * tile;
+                if (j_hi > j_lo) mfma_per_frame += (double)((j_hi - j_lo + 3) / 4);
+            }
+        }
+        ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s,
+                       2048.0 * mfma_per_frame * (double)max_frames * (double)n_clips, 0.0);
         hipLaunchKernelGGL(pitch_frame_kernel, dim3(max_frames, n_clips), dim3(256), lds, s, wav,
                            (const ClipInfo*)clip_info, gpeak, window, window_r, P, (FrameOut*)frame_out,
                            dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb);
