@@ -166,11 +166,16 @@ int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, i
  *   sd in semitones (n-1), n after filter}.
  * sinc_cheb (may be NULL): [2 * refine_depth][16] Chebyshev coefficients on frac in [0, 1] of the sinc-interpolation
  *   weights of tap offsets -(depth-1) .. depth (mshds.sinc_cheb_table); with it the Brent refinement evaluates a
- *   16-term polynomial per step instead of the 2*depth-term sum whenever no candidate's depth is clipped. */
+ *   16-term polynomial per step instead of the 2*depth-term sum whenever no candidate's depth is clipped.
+ * workspace: the per-frame correlation rows between the correlation kernel (one workgroup per frame, fp64 MFMA)
+ *   and the candidate kernel (one wave per frame); at least rsaf_mshds_pitch_workspace_bytes_per_clip bytes, the
+ *   clips are processed in groups of floor(workspace_bytes / that). */
+int64_t rsaf_mshds_pitch_workspace_bytes_per_clip(int max_frames, const double* params_host);
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
                      const double* window, const double* window_r, const double* params_host,
                      void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
-                     double* stats_out, const double* sinc_cheb, rsaf_stream_t stream);
+                     double* stats_out, const double* sinc_cheb, void* workspace, int64_t workspace_bytes,
+                     rsaf_stream_t stream);
 /* The same analysis for two voicing thresholds at once (src/mshds_extractor.py:178 and :270 differ in nothing
  * else): one frame kernel computes the correlation and refines the union of the two candidate lists, the path
  * finder runs per threshold.  The *2 outputs have the shapes of their first-threshold counterparts. */
@@ -179,7 +184,7 @@ int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, 
                           void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
                           double* stats_out, double voicing_threshold2, void* frame_out2, unsigned char* psi2,
                           int* end_state2, double* sel_freq2, double* sel_strength2, double* stats_out2,
-                          const double* sinc_cheb, rsaf_stream_t stream);
+                          const double* sinc_cheb, void* workspace, int64_t workspace_bytes, rsaf_stream_t stream);
 /* _speechrate (src/mshds_extractor.py:11-125) from the 50 Hz / 16 ms intensity contour (rsaf_mshds_intensity)
  * and the 4-candidate pitch pass of :104.  out[clip][5] = Speaking_Rate, Articulation_Rate,
  * Phonation_Ratio, Pause_Rate, Mean_Pause_Dur.  workspace: n_clips * workspace_doubles(max_frames). */

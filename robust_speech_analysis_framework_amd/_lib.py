@@ -46,9 +46,10 @@ SIGNATURES = {
     "rsaf_mshds_frameout_doubles": (_I, []),
     "rsaf_mshds_clip_peak": (_I, [_P, _P, _I, _P, _P]),
     "rsaf_mshds_intensity": (_I, [_P, _P, _I, _I, _P, _I, C.c_double, _I, _P, _P, _P]),
-    "rsaf_mshds_pitch": (_I, [_P, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_double), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rsaf_mshds_pitch_workspace_bytes_per_clip": (_L, [_I, C.POINTER(C.c_double)]),
+    "rsaf_mshds_pitch": (_I, [_P, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_double), _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "rsaf_mshds_pitch_dual": (_I, [_P, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_double), _P, _P, _P, _P, _P, _P,
-                                   C.c_double, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                   C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "rsaf_mshds_speechrate_workspace_doubles": (_L, [_I]),
     "rsaf_mshds_speechrate": (_I, [_P, _P, _I, _I, C.c_double, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
     "rsaf_mshds_resample10k": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P]),

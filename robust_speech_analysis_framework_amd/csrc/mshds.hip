@@ -291,39 +291,64 @@ struct FrameOut {     // per frame, written contiguously: intensity, ncand, freq
 typedef double double4_t __attribute__((ext_vector_type(4)));
 // doubles of the region shared by the skewed window copy and the per-wave partial correlations
 __host__ __device__ inline int pitch_part_doubles(int nw, int L) {
-    const int a = 4 * 256 * ((L + 256) / 256), b = nw + (nw >> 4) + 2;
-    return (a > b ? a : b + (b & 1));
+    const int a = 4 * 256 * ((L + 256) / 256), b = 16 * 160;       // partial sums | residue rows (XR_DOUBLES)
+    (void)nw;
+    return a > b ? a : b;
 }
 
-// One wave's share [s0, s1) of the k steps of one 256-lag tile.  Four steps per trip with all eight operand
-// loads issued ahead of the four MFMAs, two accumulators so consecutive MFMAs do not depend on each other.
-// Operand indices: A reads seg[y0 + 4 s] (zero at and beyond seg_len), B reads window sample x0 + 4 s
-// (zero outside [0, nw)) from the skewed copy.  Loads are unconditional from clamped addresses.
-__device__ __forceinline__ double4_t corr_tile(const double* __restrict__ seg, const double* __restrict__ xs, int seg_len,
-                                               int nw, int y0, int x0, int s0, int s1) {
-    double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
-    auto ld_a = [&](int st) {
-        const int yi = y0 + 4 * st;
-        const double v = seg[yi < seg_len ? yi : seg_len - 1];
-        return yi < seg_len ? v : 0.0;
-    };
-    auto ld_b = [&](int st) {
-        const int xi = x0 + 4 * st;
-        const int xc = xi < 0 ? 0 : (xi < nw ? xi : nw - 1);
-        const double v = xs[xc + (xc >> 4)];
-        return (xi >= 0 && xi < nw) ? v : 0.0;
-    };
-    int st = s0;
-    for (; st + 4 <= s1; st += 4) {
-        const double a0 = ld_a(st), a1 = ld_a(st + 1), a2 = ld_a(st + 2), a3 = ld_a(st + 3);
-        const double b0 = ld_b(st), b1 = ld_b(st + 1), b2 = ld_b(st + 2), b3 = ld_b(st + 3);
+// ---- correlation inner loops ----
+// On gfx950 the fp64 MFMA runs at the vector fp64 rate and shares its issue with every other VALU instruction of
+// the SIMD, so the loop must be MFMA and LDS reads only: no clamps, no selects, no address arithmetic.
+//  * seg is followed by SEG_PAD zeros, so the A operand seg[y0 + 16 t + 4 p] needs no bound check.
+//  * the window samples xm[i] (zero outside [0, nw)) are stored by residue: XR[i mod 16][i div 16 + XR_Q0].  A row
+//    of 16 lanes needs xm[4 s + kq - 16 nn] = XR[4 p + kq][t - nn + XR_Q0] (s = 4 t + p): 16 consecutive doubles
+//    (conflict-free), the four phases p differ by a compile-time offset and t advances the address by 8 bytes.
+// One group = 4 k-steps (p = 0..3); a wave takes whole groups.
+constexpr int SEG_PAD = 64;
+constexpr int XR_ROW = 160;          // doubles per residue row: nw / 16 + 50 <= 160  (nw <= 1760 samples)
+constexpr int XR_Q0 = 32;            // quotient offset: i >= -512
+constexpr int XR_DOUBLES = 16 * XR_ROW;
+
+__device__ __forceinline__ double4_t corr_groups(const double* __restrict__ ap, const double* __restrict__ bp, int t0, int t1) {
+    double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0;
+    ap += 16 * t0;
+    bp += t0;
+    for (int t = t0; t < t1; ++t) {
+        const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+        const double b0 = bp[0], b1 = bp[4 * XR_ROW], b2 = bp[8 * XR_ROW], b3 = bp[12 * XR_ROW];
         c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
         c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, c1, 0, 0, 0);
+        ap += 16;
+        bp += 1;
     }
-    for (; st < s1; ++st) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_a(st), ld_b(st), c0, 0, 0, 0);
     return c0 + c1;
+}
+
+// two 256-lag tiles at once: same B operand, A moved by 256 samples (six LDS reads... eight MFMAs per group)
+__device__ __forceinline__ void corr_groups_pair(const double* __restrict__ ap, const double* __restrict__ bp, int t0, int t1,
+                                                 double4_t& out0, double4_t& out1) {
+    double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, d0 = c0, d1 = c0;
+    ap += 16 * t0;
+    bp += t0;
+    for (int t = t0; t < t1; ++t) {
+        const double b0 = bp[0], b1 = bp[4 * XR_ROW], b2 = bp[8 * XR_ROW], b3 = bp[12 * XR_ROW];
+        const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+        const double e0 = ap[256], e1 = ap[260], e2 = ap[264], e3 = ap[268];
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, b0, d0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, b1, d1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c0, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2, b2, d0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, c1, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3, b3, d1, 0, 0, 0);
+        ap += 16;
+        bp += 1;
+    }
+    out0 = c0 + c1;
+    out1 = d0 + d1;
 }
 
 // ---- sinc interpolation as a polynomial in the fractional position -----------------------------------------
@@ -402,12 +427,12 @@ struct RefineArgs {
 // With every path cost zero (harmonicity pass) a candidate far below the best first-pass strength could
 // be left unrefined (margin > 0); that is off by default because it moved a few frames' selection.
 template <int G, bool RECUR>
-__device__ void refine_candidates(const RefineArgs& A, int tid) {
+__device__ void refine_candidates(const RefineArgs& A, int tid, int nthreads) {
     const int lane = tid & 63, lg = lane & (G - 1), gidx = (tid >> 6) * (64 / G) + lane / G;
     double best_first = 0.0;
     for (int k = 1; k < A.ncand; ++k) best_first = fmax(best_first, A.cs[k]);
     __syncthreads();
-    for (int kb = 1; kb < A.ncand; kb += 256 / G) {
+    for (int kb = 1; kb < A.ncand; kb += nthreads / G) {
         const int k = kb + gidx;
         const bool live = k < A.ncand && (A.margin <= 0.0 || A.cs[k < A.ncand ? k : 1] >= best_first - A.margin);
         double xm, ym;
@@ -418,11 +443,14 @@ __device__ void refine_candidates(const RefineArgs& A, int tid) {
     }
 }
 
-__global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
-                                                          const double* __restrict__ gpeak, const double* __restrict__ win,
-                                                          const double* __restrict__ wr, const PitchParams P,
-                                                          FrameOut* __restrict__ out, FrameOut* __restrict__ out2,
-                                                          const double* __restrict__ cheb) {
+// Kernel 1 of 2: one 256-thread workgroup per frame computes the normalised correlation r[0..L] (and the frame's
+// relative intensity) into a global row; kernel 2 (one wave per frame) turns rows into candidates.  The split keeps
+// the four-wave matrix-pipe phase free of the single-wave phases (maxima, candidate lists, Brent refinement),
+// during which three of the four waves used to sit at barriers (PMC: waves parked 49 % of their cycles).
+__global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                         const double* __restrict__ gpeak, const double* __restrict__ win,
+                                                         const double* __restrict__ wr, const PitchParams P,
+                                                         double* __restrict__ rbuf, int rstride, int max_frames) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
@@ -430,39 +458,14 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nw = P.nsamp_window, L = P.is_cc ? P.max_lag : P.brent_ixmax;
     const int seg_len = P.is_cc ? nw + P.max_lag + 1 : nw;
-    const int RC = P.brent_ixmax;                   // centre index of r
-    const int RN = 2 * P.brent_ixmax + 1;
     const int part_doubles = pitch_part_doubles(nw, L);
     // all LDS lives in the dynamic region (keeps every double 8-byte aligned, guide G17)
     double* seg = reinterpret_cast<double*>(smem_raw);
-    double* r = seg + ((seg_len + 1) & ~1);
-    double* s_red = r + ((RN + 1) & ~1);            // [4]
+    double* s_red = seg + ((seg_len + SEG_PAD + 1) & ~1);   // [4]   (seg is followed by SEG_PAD zeros)
     double* s_val = s_red + 4;                      // [4]
-    double* s_mfreq = s_val + 4;                    // [MAX_MAXIMA]
-    double* s_mstr = s_mfreq + MAX_MAXIMA;          // [MAX_MAXIMA]
-    double* s_mloc = s_mstr + MAX_MAXIMA;           // [MAX_MAXIMA] strength - octave cost (Praat's "local strength")
-    double* s_cf = s_mloc + MAX_MAXIMA;             // [MAXC]
-    double* s_cs = s_cf + MAXC;                     // [MAXC]
-    double* s_cloc = s_cs + MAXC;                   // [MAXC]
-    int* s_maxlag = reinterpret_cast<int*>(s_cloc + MAXC);   // [MAX_MAXIMA]
-    int* s_place = s_maxlag + MAX_MAXIMA;           // [MAXC]
-    int* s_place2 = s_place + MAXC;                 // [MAXC]  second (lower-threshold) list
-    int* s_cnt = s_place2 + MAXC;                   // [0] = nmax, [1] = ncand, [2] = ncand2, [3] = missing
-    double* s_cf2 = reinterpret_cast<double*>(s_cnt + 4);   // [MAXC]
-    double* s_cs2 = s_cf2 + MAXC;                   // [MAXC]
-    double* s_cloc2 = s_cs2 + MAXC;                 // [MAXC]
-    double* s_part = s_cloc2 + MAXC;   // [4][256 * NT] partial correlations of the four waves
-    double* xs = s_part;                                     // skewed copy of seg[0, nw) until the partials are written
-#define s_nmax s_cnt[0]
-#define s_ncand s_cnt[1]
-
-    FrameOut* o = out + c.frame_off + f;
-#define RSAF_PITCH_DBG_STOP(k)                                                                       \
-    if (P.debug_stop == (k)) {                                                                       \
-        if (tid == 0) { o->intensity = 0.0; o->ncand = 1.0; }                                        \
-        if (tid < MAXC) { o->freq[tid] = 0.0; o->strength[tid] = 0.0; }                              \
-        return;                                                                                      \
-    }
+    double* s_part = s_val + 4;                     // [4][256 * NT] partial correlations of the four waves
+    double* xr = s_part;                            // [16][XR_ROW] window samples by residue until the partials are written
+    double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
     const float* x = wav + c.sample_off;
     const int n = c.n_samples;
     const double t = c.t1 + f * P.dt;
@@ -505,11 +508,15 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
             seg[j] = i < n ? ((double)x[i < 0 ? 0 : i] - local_mean) : 0.0;
         }
     }
-    for (int j = tid; j < RN; j += 256) r[j] = 0.0;
     __syncthreads();
     // local peak over half a longest period around the window centre
     {
-        for (int j = tid; j < nw; j += 256) xs[j + (j >> 4)] = seg[j];
+        if (tid < SEG_PAD) seg[seg_len + tid] = 0.0;
+        for (int j = tid; j < XR_DOUBLES; j += 256) {          // xm[i], i = 16 (q - XR_Q0) + rho, zero outside [0, nw)
+            const int rho = j / XR_ROW, q = j - rho * XR_ROW;
+            const int i = 16 * (q - XR_Q0) + rho;
+            xr[j] = (i >= 0 && i < nw) ? seg[i] : 0.0;
+        }
         int a = P.half_window - P.half_period, b = P.half_window + P.half_period;
         a = a < 0 ? 0 : a;
         b = b > nw ? nw : b;
@@ -523,12 +530,12 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     const double gp = gpeak[blockIdx.y];
     const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
 
-    RSAF_PITCH_DBG_STOP(1)
+    if (P.debug_stop == 1) return;
     // ---- correlation on the fp64 matrix pipe ----
     // R[m + 16 n + 256 tile] = sum_j' seg[j' + m] * xm[j' - 16 n - 256 tile], xm = seg restricted to [0, nw):
     // a 16 x 16 tile of lags per v_mfma_f64_16x16x4_f64 with j' as the k dimension (A[m][k] = seg[j'+m] is read
-    // straight from `seg`; B[k][n] has a lane stride of 16 samples and is read from the copy `xs`, skewed by
-    // one element per 16 so that the 16 lanes of a row hit 16 different bank pairs).  The four waves split j'.
+    // straight from the zero-padded `seg`; B[k][n] has a lane stride of 16 samples and is read from the residue
+    // rows `xr`, see corr_groups).  The four waves split j'.
     // D layout (probed by tools/mfma_f64_layout.hip): lane l, register v -> row l/16 + 4 v, column l%16.
     const int NT = (L + 256) / 256;                      // 256-lag tiles covering lags 0..L  (<= 4)
     const int pstride = 256 * NT;
@@ -536,18 +543,31 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
         const int kq = lane >> 4, nn = lane & 15;
         double4_t acc[4];
 #pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
-            acc[tile] = double4_t{0.0, 0.0, 0.0, 0.0};
-            if (tile < NT) {
-                const int j_lo = 256 * tile;
-                int j_hi = nw + 240 + 256 * tile;
-                j_hi = j_hi < seg_len ? j_hi : seg_len;
-                const int steps = j_hi > j_lo ? (j_hi - j_lo + 3) / 4 : 0;
-                const int s0 = steps * wv / 4, s1 = steps * (wv + 1) / 4;
-                acc[tile] = corr_tile(seg, xs, seg_len, nw, j_lo + kq + nn, kq - 16 * nn, s0, s1);
+        for (int tile = 0; tile < 4; ++tile) acc[tile] = double4_t{0.0, 0.0, 0.0, 0.0};
+        auto tile_groups = [&](int tile) {                // groups of 4 k-steps; the zero padding absorbs the round-up
+            int j_hi = nw + 240 + 256 * tile;
+            j_hi = j_hi < seg_len ? j_hi : seg_len;
+            const int j_lo = 256 * tile;
+            return j_hi > j_lo ? (j_hi - j_lo + 15) / 16 : 0;
+        };
+        const double* ap = seg + kq + nn;                                  // A: seg[kq + nn + 16 t + 4 p (+ 256 tile)]
+        const double* bp = xr + kq * XR_ROW + (XR_Q0 - nn);                // B: XR[4 p + kq][t - nn + XR_Q0]
+        if (NT == 2) {
+            // groups [0, g1) exist in both tiles (shared B operand), [g1, g0) in tile 0 only
+            const int g0 = tile_groups(0), g1 = tile_groups(1) < g0 ? tile_groups(1) : g0;
+            corr_groups_pair(ap, bp, g1 * wv / 4, g1 * (wv + 1) / 4, acc[0], acc[1]);
+            const int rest = g0 - g1;
+            acc[0] = acc[0] + corr_groups(ap, bp, g1 + rest * wv / 4, g1 + rest * (wv + 1) / 4);
+        } else {
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile) {
+                if (tile < NT) {
+                    const int g = tile_groups(tile);
+                    acc[tile] = corr_groups(ap + 256 * tile, bp, g * wv / 4, g * (wv + 1) / 4);
+                }
             }
         }
-        __syncthreads();                                  // every wave is done with xs (it aliases s_part)
+        __syncthreads();                                  // every wave is done with xr (it aliases s_part)
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             if (tile < NT) {
@@ -558,26 +578,19 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int l = tid; l <= L; l += 256) {
+    auto raw = [&](int l) {                             // the four waves' partial sums in wave order
         double v = 0.0;
         for (int q = 0; q < 4; ++q) v += s_part[q * pstride + l];
-        r[RC + l] = v;                                   // raw sums for now
-    }
-    __syncthreads();
-    RSAF_PITCH_DBG_STOP(2)
-    // ---- normalise ----
+        return v;
+    };
+    if (P.debug_stop == 2) return;
+    // ---- normalise into the global row ----
+    if (tid == 0) { rb[0] = 1.0; rb[L + 1] = intensity; }
     if (!P.is_cc) {
-        const double r0 = r[RC];
-        __syncthreads();
-        for (int l = 1 + tid; l <= L; l += 256) {
-            const double v = r0 > 0.0 ? r[RC + l] / (r0 * wr[l]) : 0.0;
-            r[RC + l] = v;
-            r[RC - l] = v;
-        }
-        if (tid == 0) r[RC] = 1.0;
+        const double r0 = raw(0);
+        for (int l = 1 + tid; l <= L; l += 256) rb[l] = r0 > 0.0 ? raw(l) / (r0 * wr[l]) : 0.0;
     } else {
-        const double sumx2 = r[RC];
-        __syncthreads();
+        const double sumx2 = raw(0);
         // sumy2(lag) = sum_{j=lag}^{lag+nw-1} seg[j]^2 = csq[lag+nw] - csq[lag] with the exclusive prefix sums
         // csq[j] = sum_{i<j} seg[i]^2 (block scan; the O(L*nw) direct loop was a quarter of this kernel)
         double* csq = s_part + part_doubles;                 // [seg_len + 1]
@@ -601,11 +614,61 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
         for (int l = 1 + tid; l <= L; l += 256) {
             const double sy = csq[l + nw] - csq[l];
             const double den = sumx2 * sy;
-            const double v = (l <= loc_max_lag && den > 0.0) ? r[RC + l] / sqrt(den) : 0.0;
-            r[RC + l] = v;
-            r[RC - l] = v;
+            rb[l] = (l <= loc_max_lag && den > 0.0) ? raw(l) / sqrt(den) : 0.0;
         }
-        if (tid == 0) r[RC] = 1.0;
+    }
+}
+
+// Kernel 2 of 2: one wave per frame.  Reads the frame's normalised correlation row, finds the local maxima,
+// estimates them (parabola + sinc 30), builds the candidate list(s) with Praat's replacement rule and refines
+// every kept candidate with Brent's method.  All phases are single-wave, so nothing waits at a workgroup barrier
+// and ~10 frames are resident per CU.
+constexpr int CT = 64;          // threads of the candidate kernel
+__global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restrict__ ci, const double* __restrict__ gpeak,
+                                                        const PitchParams P, const double* __restrict__ rbuf, int rstride,
+                                                        int max_frames, FrameOut* __restrict__ out,
+                                                        FrameOut* __restrict__ out2, const double* __restrict__ cheb) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const ClipInfo c = ci[blockIdx.y];
+    const int f = blockIdx.x;
+    if (f >= c.n_frames) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = 0;
+    const int L = P.is_cc ? P.max_lag : P.brent_ixmax;
+    const int RC = P.brent_ixmax;                   // centre index of r
+    const int RN = 2 * P.brent_ixmax + 1;
+    double* r = reinterpret_cast<double*>(smem_raw);
+    double* s_mfreq = r + ((RN + 1) & ~1);          // [MAX_MAXIMA]
+    double* s_mstr = s_mfreq + MAX_MAXIMA;          // [MAX_MAXIMA]
+    double* s_mloc = s_mstr + MAX_MAXIMA;           // [MAX_MAXIMA] strength - octave cost (Praat's "local strength")
+    double* s_cf = s_mloc + MAX_MAXIMA;             // [MAXC]
+    double* s_cs = s_cf + MAXC;                     // [MAXC]
+    double* s_cloc = s_cs + MAXC;                   // [MAXC]
+    int* s_maxlag = reinterpret_cast<int*>(s_cloc + MAXC);   // [MAX_MAXIMA]
+    int* s_place = s_maxlag + MAX_MAXIMA;           // [MAXC]
+    int* s_place2 = s_place + MAXC;                 // [MAXC]  second (lower-threshold) list
+    int* s_cnt = s_place2 + MAXC;                   // [0] = nmax, [1] = ncand, [2] = ncand2, [3] = missing
+    double* s_cf2 = reinterpret_cast<double*>(s_cnt + 4);   // [MAXC]
+    double* s_cs2 = s_cf2 + MAXC;                   // [MAXC]
+    double* s_cloc2 = s_cs2 + MAXC;                 // [MAXC]
+    double* s_part = s_cloc2 + MAXC;                // [MAXC][2][NCH] Chebyshev coefficients of the candidates' cells
+#define s_nmax s_cnt[0]
+#define s_ncand s_cnt[1]
+
+    FrameOut* o = out + c.frame_off + f;
+#define RSAF_PITCH_DBG_STOP(k)                                                                       \
+    if (P.debug_stop == (k)) {                                                                       \
+        if (tid == 0) { o->intensity = 0.0; o->ncand = 1.0; }                                        \
+        if (tid < MAXC) { o->freq[tid] = 0.0; o->strength[tid] = 0.0; }                              \
+        return;                                                                                      \
+    }
+    RSAF_PITCH_DBG_STOP(1)
+    RSAF_PITCH_DBG_STOP(2)
+    const double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;
+    const double intensity = rb[L + 1];
+    const double gp = gpeak[blockIdx.y];
+    for (int j = tid; j < RN; j += CT) {
+        const int l = j >= RC ? j - RC : RC - j;
+        r[j] = l <= L ? rb[l] : 0.0;
     }
     if (tid == 0) s_nmax = 0;
     __syncthreads();
@@ -636,8 +699,8 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
     const int nmax = s_nmax;
     const int nz_lo = RC - L, nz_hi = RC + L;
     // ---- first estimate of every maximum: parabolic position, sinc(30) strength (16 maxima per round) ----
-    const int l16 = lane & 15, gidx = wv * 4 + (lane >> 4);
-    for (int mb = 0; mb < nmax; mb += 16) {
+    const int l16 = lane & 15, gidx = lane >> 4;
+    for (int mb = 0; mb < nmax; mb += CT / 16) {
         const int m = mb + gidx;
         const bool live = m < nmax;
         const int l = s_maxlag[live ? m : 0];
@@ -675,7 +738,7 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
         *ncand_out = nc;
     };
     if (tid == 0) build_list(P.voicing_thr, s_cf, s_cs, s_cloc, s_place, &s_cnt[1]);
-    if (tid == 64 && dual) build_list(P.voicing_thr2, s_cf2, s_cs2, s_cloc2, s_place2, &s_cnt[2]);
+    if (tid == 32 && dual) build_list(P.voicing_thr2, s_cf2, s_cs2, s_cloc2, s_place2, &s_cnt[2]);
     __syncthreads();
     const int ncand = s_cnt[1];
     RSAF_PITCH_DBG_STOP(5)
@@ -693,16 +756,17 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
             double* s_P = s_part;                                    // [MAXC][2][NCH], the partial sums are dead by now
             const int d = P.refine_depth;
             const int chunk = lane >> 4, j = lane & 15;
+            for (int wq = 0; wq < 4; ++wq) {                         // the single wave takes the four candidate slots in turn
             int bq[4];
             int bmin = 0x7fffffff, bmax = -0x7fffffff;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int k = 1 + wv + 4 * q;
+                const int k = 1 + wq + 4 * q;
                 const bool on = k < nc;
                 bq[q] = place_lag[on ? k : 1] + RC - 1;              // 0-based left sample of cell 0 (cell 1: + 1)
                 if (on) { bmin = bq[q] < bmin ? bq[q] : bmin; bmax = bq[q] > bmax ? bq[q] : bmax; }
             }
-            if (1 + wv < nc) {
+            if (1 + wq < nc) {
                 // r is zero outside [nz_lo, nz_hi]: taps that reach no candidate's non-zero range are skipped
                 int o_lo = nz_lo - (bmax + 1), o_hi = nz_hi - bmin;
                 o_lo = o_lo < -(d - 1) ? -(d - 1) : o_lo;
@@ -738,9 +802,10 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
                         double v = acc[q][cell];
                         v += __shfl_xor(v, 16, 64);
                         v += __shfl_xor(v, 32, 64);
-                        const int k = 1 + wv + 4 * q;
+                        const int k = 1 + wq + 4 * q;
                         if (chunk == 0 && k < nc) s_P[(k * 2 + cell) * NCH + j] = v;
                     }
+            }
             }
             __syncthreads();
             if (tid < 64) {                                          // nc <= 16: one lane per candidate
@@ -757,9 +822,9 @@ __global__ __launch_bounds__(256) void pitch_frame_kernel(const float* __restric
         const int nref = nc - 1;
         const int span = P.refine_depth < 2 * L ? P.refine_depth : 2 * L;    // longest half kernel
         RefineArgs A{r, RN, RC, P.refine_depth, nz_lo, nz_hi, nc, P.refine_margin, place_lag, cf, cs};
-        if (nref <= 4) { if (span >= 6 * 64) refine_candidates<64, true>(A, tid); else refine_candidates<64, false>(A, tid); }
-        else if (nref <= 8) { if (span >= 6 * 32) refine_candidates<32, true>(A, tid); else refine_candidates<32, false>(A, tid); }
-        else { if (span >= 6 * 16) refine_candidates<16, true>(A, tid); else refine_candidates<16, false>(A, tid); }
+        if (nref <= 4) { if (span >= 6 * 64) refine_candidates<64, true>(A, tid, CT); else refine_candidates<64, false>(A, tid, CT); }
+        else if (nref <= 8) { if (span >= 6 * 32) refine_candidates<32, true>(A, tid, CT); else refine_candidates<32, false>(A, tid, CT); }
+        else { if (span >= 6 * 16) refine_candidates<16, true>(A, tid, CT); else refine_candidates<16, false>(A, tid, CT); }
         __syncthreads();
     };
     if (!dual) {
@@ -2131,7 +2196,8 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                       const double* window, const double* window_r, const double* params_host, void* frame_out,
                       unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
                       double voicing_thr2, void* frame_out2, unsigned char* psi2, int* end_state2, double* sel_freq2,
-                      double* sel_strength2, double* stats_out2, const double* sinc_cheb, rsaf_stream_t stream) {
+                      double* sel_strength2, double* stats_out2, const double* sinc_cheb, void* workspace,
+                      int64_t workspace_bytes, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_frames >= 0, "bad clip/frame count");
     if (n_clips == 0) return RSAF_OK;
     RSAF_CHECK_ARG(wav && clip_info && gpeak && params_host && frame_out && psi && end_state && sel_freq &&
@@ -2156,15 +2222,27 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     RSAF_CHECK_ARG(P.is_cc || (window && window_r), "AC needs the window tables");
     RSAF_CHECK_ARG((P.is_cc ? P.max_lag : P.brent_ixmax) <= 1023, "more than 1023 lags (pitch floor below ~16 Hz) is not supported");
     const int seg_len = P.is_cc ? P.nsamp_window + P.max_lag + 1 : P.nsamp_window;
-    const size_t lds = (size_t)(((seg_len + 1) & ~1) + ((2 * P.brent_ixmax + 2) & ~1) + 8 + 3 * MAX_MAXIMA + 6 * MAXC) *
-                           sizeof(double) + (size_t)(MAX_MAXIMA + 2 * MAXC + 4) * sizeof(int) +
-                       (size_t)pitch_part_doubles(P.nsamp_window, P.is_cc ? P.max_lag : P.brent_ixmax) * sizeof(double) +
-                       (P.is_cc ? (size_t)(seg_len + 2) * sizeof(double) : 0);
-    RSAF_CHECK_ARG(lds <= 150 * 1024, "analysis window too long for LDS");
+    const int Lr = P.is_cc ? P.max_lag : P.brent_ixmax;
+    const int rstride = Lr + 2;                                    // r[0..L] + the frame's relative intensity
+    RSAF_CHECK_ARG(P.nsamp_window / 16 + 50 <= XR_ROW, "analysis window longer than 1 760 samples (pitch floor below ~28 Hz) is not supported");
+    const size_t lds_corr = (size_t)(((seg_len + SEG_PAD + 1) & ~1) + 8) * sizeof(double) +
+                            (size_t)pitch_part_doubles(P.nsamp_window, Lr) * sizeof(double) +
+                            (P.is_cc ? (size_t)(seg_len + 2) * sizeof(double) : 0);
+    const size_t lds_cand = (size_t)(((2 * P.brent_ixmax + 2) & ~1) + 3 * MAX_MAXIMA + 6 * MAXC + MAXC * 2 * NCH) * sizeof(double) +
+                            (size_t)(MAX_MAXIMA + 2 * MAXC + 4) * sizeof(int);
+    RSAF_CHECK_ARG(lds_corr <= 150 * 1024 && lds_cand <= 150 * 1024, "analysis window too long for LDS");
+    // the correlation rows of a group of clips live in the caller's workspace between the two kernels
+    const int64_t row_bytes_per_clip = (int64_t)max_frames * rstride * (int64_t)sizeof(double);
+    RSAF_CHECK_ARG(max_frames == 0 || (workspace && workspace_bytes >= row_bytes_per_clip),
+                   "workspace too small (rsaf_mshds_pitch_workspace_bytes)");
+    const int group = max_frames == 0 ? n_clips : (int)std::min<int64_t>(n_clips, workspace_bytes / std::max<int64_t>(row_bytes_per_clip, 1));
     hipStream_t s = (hipStream_t)stream;
-    if (lds > 48 * 1024)
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
+    if (lds_corr > 48 * 1024)
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_corr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_corr));
+    if (lds_cand > 48 * 1024)
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_cand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_cand));
     // the Chebyshev form needs the full depth on both sides of every cell a candidate can use
     const double* cheb = sinc_cheb;
     {
@@ -2189,10 +2267,17 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         }
         ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s,
                        2048.0 * mfma_per_frame * (double)max_frames * (double)n_clips, 0.0);
-        hipLaunchKernelGGL(pitch_frame_kernel, dim3(max_frames, n_clips), dim3(256), lds, s, wav,
-                           (const ClipInfo*)clip_info, gpeak, window, window_r, P, (FrameOut*)frame_out,
-                           dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb);
-        RSAF_CHECK_HIP(hipGetLastError());
+        for (int c0 = 0; c0 < n_clips; c0 += group) {
+            const int nc = std::min(group, n_clips - c0);
+            const ClipInfo* cig = (const ClipInfo*)clip_info + c0;
+            hipLaunchKernelGGL(pitch_corr_kernel, dim3(max_frames, nc), dim3(256), lds_corr, s, wav, cig, gpeak + c0, window,
+                               window_r, P, (double*)workspace, rstride, max_frames);
+            RSAF_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(pitch_cand_kernel, dim3(max_frames, nc), dim3(CT), lds_cand, s, cig, gpeak + c0, P,
+                               (const double*)workspace, rstride, max_frames, (FrameOut*)frame_out,
+                               dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb);
+            RSAF_CHECK_HIP(hipGetLastError());
+        }
     }
     for (int pass = 0; pass < (dual ? 2 : 1); ++pass) {
         const FrameOut* fo = (const FrameOut*)(pass ? frame_out2 : frame_out);
@@ -2216,13 +2301,21 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     return RSAF_OK;
 }
 
+// bytes of correlation rows per clip (max_frames rows of max_lag + 2 doubles); the analysis runs the clips in groups of
+// floor(workspace_bytes / this), so any multiple >= 1 works and n_clips multiples avoid the grouping
+int64_t rsaf_mshds_pitch_workspace_bytes_per_clip(int max_frames, const double* params_host /* 17 doubles */) {
+    if (!params_host || max_frames < 0) return -1;
+    const int Lr = (int)params_host[15] ? (int)params_host[11] : (int)params_host[12];
+    return (int64_t)max_frames * (Lr + 2) * (int64_t)sizeof(double);
+}
+
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
                      const double* window, const double* window_r, const double* params_host /* 17 doubles */,
                      void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
-                     const double* sinc_cheb, rsaf_stream_t stream) {
+                     const double* sinc_cheb, void* workspace, int64_t workspace_bytes, rsaf_stream_t stream) {
     return pitch_impl(wav, clip_info, n_clips, max_frames, gpeak, window, window_r, params_host, frame_out, psi, end_state,
                       sel_freq, sel_strength, stats_out, -1.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sinc_cheb,
-                      stream);
+                      workspace, workspace_bytes, stream);
 }
 
 int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
@@ -2230,11 +2323,11 @@ int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, 
                           void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
                           double* stats_out, double voicing_threshold2, void* frame_out2, unsigned char* psi2, int* end_state2,
                           double* sel_freq2, double* sel_strength2, double* stats_out2, const double* sinc_cheb,
-                          rsaf_stream_t stream) {
+                          void* workspace, int64_t workspace_bytes, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(voicing_threshold2 >= 0.0, "second voicing threshold must be >= 0");
     return pitch_impl(wav, clip_info, n_clips, max_frames, gpeak, window, window_r, params_host, frame_out, psi, end_state,
                       sel_freq, sel_strength, stats_out, voicing_threshold2, frame_out2, psi2, end_state2, sel_freq2,
-                      sel_strength2, stats_out2, sinc_cheb, stream);
+                      sel_strength2, stats_out2, sinc_cheb, workspace, workspace_bytes, stream);
 }
 
 // peaks of an n-frame contour: at most n/2; the LDS form keeps SR_MAX_PEAKS of them (a smooth 16 ms contour of at most

@@ -188,19 +188,23 @@ class MshdsEngine:
         wrp = _lib.ptr(wr) if wr is not None else None
         (cheb,) = self._table(("sinc_cheb", int(refine_depth)), lambda: (sinc_cheb_table(int(refine_depth)).reshape(-1),))
         chp = _lib.ptr(cheb)
+        # correlation rows between the two pitch kernels: all clips at once if that stays below ~4 GB, else in groups
+        per_clip = int(lib.rsaf_mshds_pitch_workspace_bytes_per_clip(mx, params)) if n else 0
+        ws_bytes = max(per_clip * max(1, min(n, int(4.0e9 // max(per_clip, 1)))), 8)
+        ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=dev)
         if n and g.half_window >= 2:
             if second is None:
                 _lib.check(lib.rsaf_mshds_pitch(
                     _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak), wp, wrp, params,
                     _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
-                    _lib.ptr(stats), chp, _lib.stream_ptr(stream)), "rsaf_mshds_pitch")
+                    _lib.ptr(stats), chp, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(stream)), "rsaf_mshds_pitch")
             else:
                 _lib.check(lib.rsaf_mshds_pitch_dual(
                     _lib.ptr(wav), _lib.ptr(ci_d), n, mx, _lib.ptr(gpeak), wp, wrp, params,
                     _lib.ptr(frame_out), _lib.ptr(psi), _lib.ptr(end_state), _lib.ptr(sel_f), _lib.ptr(sel_s),
                     _lib.ptr(stats), float(voicing_threshold2), _lib.ptr(second["frame_out"]), _lib.ptr(second["psi"]),
                     _lib.ptr(second["end_state"]), _lib.ptr(second["sel_freq"]), _lib.ptr(second["sel_strength"]),
-                    _lib.ptr(second["stats"]), chp, _lib.stream_ptr(stream)), "rsaf_mshds_pitch_dual")
+                    _lib.ptr(second["stats"]), chp, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(stream)), "rsaf_mshds_pitch_dual")
         else:
             stats.fill_(float("nan"))
             stats[:, 0] = 0
