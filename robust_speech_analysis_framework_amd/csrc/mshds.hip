@@ -289,6 +289,19 @@ struct FrameOut {     // per frame, written contiguously: intensity, ncand, freq
 };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// stored half-width of the candidate kernel's correlation array (see pitch_cand_kernel)
+// [lo, hi] = the lags the candidate kernel can touch: the candidates' lags widened by the interpolation depth, never
+// beyond 2 L + 2 (zeros past the non-zero range |lag| <= L that a tap loop may still multiply) nor the array itself
+__host__ __device__ inline void pitch_r_range(int rc, int L, int min_lag, int max_lag, int depth, int* lo, int* hi) {
+    const int w = 2 * L + 2, span = w < rc ? w : rc;
+    const int lag_lo = min_lag > 2 ? min_lag : 2;
+    int lag_hi = max_lag - 1;
+    if (lag_hi > rc - 1) lag_hi = rc - 1;
+    const int d = depth > 30 ? depth : 30;
+    int a = lag_lo - d - 3, b = lag_hi + d + 3;
+    *lo = a < -span ? -span : a;
+    *hi = b > span ? span : b;
+}
 // doubles of the region shared by the skewed window copy and the per-wave partial correlations
 __host__ __device__ inline int pitch_part_doubles(int nw, int L) {
     const int a = 4 * 256 * ((L + 256) / 256), b = 16 * 160;       // partial sums | residue rows (XR_DOUBLES)
@@ -636,8 +649,14 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     const int L = P.is_cc ? P.max_lag : P.brent_ixmax;
     const int RC = P.brent_ixmax;                   // centre index of r
     const int RN = 2 * P.brent_ixmax + 1;
-    double* r = reinterpret_cast<double*>(smem_raw);
-    double* s_mfreq = r + ((RN + 1) & ~1);          // [MAX_MAXIMA]
+    // r is Praat's symmetric array of 2 ixmax + 1 lags, but only |lag| <= L is non-zero and nothing reads beyond
+    // the candidates' lags widened by the interpolation depth (and never past 2 L + 1): only that range is stored,
+    // through a base pointer shifted so that the indices stay Praat's
+    int r_lo, r_hi;
+    pitch_r_range(RC, L, P.min_lag, P.max_lag, P.refine_depth, &r_lo, &r_hi);
+    double* r_store = reinterpret_cast<double*>(smem_raw);
+    double* r = r_store - (RC + r_lo);
+    double* s_mfreq = r_store + ((r_hi - r_lo + 2) & ~1);   // [MAX_MAXIMA]
     double* s_mstr = s_mfreq + MAX_MAXIMA;          // [MAX_MAXIMA]
     double* s_mloc = s_mstr + MAX_MAXIMA;           // [MAX_MAXIMA] strength - octave cost (Praat's "local strength")
     double* s_cf = s_mloc + MAX_MAXIMA;             // [MAXC]
@@ -666,7 +685,7 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     const double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;
     const double intensity = rb[L + 1];
     const double gp = gpeak[blockIdx.y];
-    for (int j = tid; j < RN; j += CT) {
+    for (int j = RC + r_lo + tid; j <= RC + r_hi; j += CT) {
         const int l = j >= RC ? j - RC : RC - j;
         r[j] = l <= L ? rb[l] : 0.0;
     }
@@ -2228,7 +2247,9 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     const size_t lds_corr = (size_t)(((seg_len + SEG_PAD + 1) & ~1) + 8) * sizeof(double) +
                             (size_t)pitch_part_doubles(P.nsamp_window, Lr) * sizeof(double) +
                             (P.is_cc ? (size_t)(seg_len + 2) * sizeof(double) : 0);
-    const size_t lds_cand = (size_t)(((2 * P.brent_ixmax + 2) & ~1) + 3 * MAX_MAXIMA + 6 * MAXC + MAXC * 2 * NCH) * sizeof(double) +
+    int r_lo_h, r_hi_h;
+    pitch_r_range(P.brent_ixmax, Lr, P.min_lag, P.max_lag, P.refine_depth, &r_lo_h, &r_hi_h);
+    const size_t lds_cand = (size_t)(((r_hi_h - r_lo_h + 2) & ~1) + 3 * MAX_MAXIMA + 6 * MAXC + MAXC * 2 * NCH) * sizeof(double) +
                             (size_t)(MAX_MAXIMA + 2 * MAXC + 4) * sizeof(int);
     RSAF_CHECK_ARG(lds_corr <= 150 * 1024 && lds_cand <= 150 * 1024, "analysis window too long for LDS");
     // the correlation rows of a group of clips live in the caller's workspace between the two kernels
