@@ -190,7 +190,7 @@ class MshdsEngine:
         chp = _lib.ptr(cheb)
         # correlation rows between the two pitch kernels: all clips at once if that stays below ~4 GB, else in groups
         per_clip = int(lib.rsaf_mshds_pitch_workspace_bytes_per_clip(mx, params)) if n else 0
-        ws_bytes = max(per_clip * max(1, min(n, int(4.0e9 // max(per_clip, 1)))), 8)
+        ws_bytes = max(per_clip * max(1, min(n, int(self.pitch_ws_cap_bytes // max(per_clip, 1)))), 8)
         ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=dev)
         if n and g.half_window >= 2:
             if second is None:
@@ -424,6 +424,7 @@ class MshdsEngine:
         self._last_ltas = {"pitch": p, "pulses": pulses, "n_pulses": npul, "max_pulses": max_pulses}
         return out[:n]
 
+    pitch_ws_cap_bytes = 4.0e9   # cap of the correlation-row workspace between the two pitch kernels (clips run in groups)
     CPP_CHUNK = 48          # most clips per launch group (the cepstrogram workspace is ~68 MB per 30 s clip)
 
     def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None, pitch=None):

@@ -97,6 +97,27 @@ def test_pitch_dual_threshold_equals_two_separate_passes(eng):
         assert np.array_equal(got > 0, p.frequency() > 0) and _rel(got, p.frequency()) < 1e-7
 
 
+def test_pitch_in_clip_groups_equals_one_launch(eng):
+    """The correlation rows live in a caller workspace; when it holds fewer clips than the batch, the two pitch kernels
+    run group by group.  Results must not depend on the grouping (ragged batch, groups of one clip)."""
+    import torch
+    clips = [synth.synth_clip(114, 1.0), synth.synth_clip(115, 0.6), synth.synth_clip(116, 1.3)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    kw = dict(time_step=0.005, floor=75.0, ceiling=500.0, voicing_threshold2=0.3)
+    a = eng.pitch(wav, offs, lens, gp, **kw)
+    cap = eng.pitch_ws_cap_bytes
+    try:
+        eng.pitch_ws_cap_bytes = 1.0                                  # -> exactly one clip per group
+        b = eng.pitch(wav, offs, lens, gp, **kw)
+    finally:
+        eng.pitch_ws_cap_bytes = cap
+    torch.cuda.synchronize()
+    for x, y in ((a, b), (a["second"], b["second"])):
+        assert torch.equal(x["frame_out"], y["frame_out"]) and torch.equal(x["sel_freq"], y["sel_freq"])
+        assert torch.equal(torch.nan_to_num(x["stats"]), torch.nan_to_num(y["stats"]))
+
+
 def test_pitch_ac_few_candidates_replacement_rule(eng):
     """The 4-candidate pass of _speechrate (:104): more maxima than slots -> weakest is replaced."""
     import torch
