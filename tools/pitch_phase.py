@@ -27,6 +27,14 @@ cfgs = {
                       voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0, voiced_unvoiced_cost=0.0,
                       periods=4.5, is_cc=True, refine_depth=700),
     "cc_pulses_75_500": dict(time_step=0.005, floor=75.0, ceiling=500.0, periods=1.0, is_cc=True, refine_depth=70),
+    "cc_hnr_60": dict(time_step=0.005, floor=60.0, ceiling=8000.0, max_candidates=15, silence_threshold=0.1,
+                      voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0, voiced_unvoiced_cost=0.0,
+                      periods=4.5, is_cc=True, refine_depth=700),
+    "cc_hnr_100": dict(time_step=0.005, floor=100.0, ceiling=8000.0, max_candidates=15, silence_threshold=0.1,
+                       voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0, voiced_unvoiced_cost=0.0,
+                       periods=4.5, is_cc=True, refine_depth=700),
+    "ac_60_250_dual": dict(time_step=0.005, floor=60.0, ceiling=250.0, voicing_threshold2=0.3),
+    "ac_100_500_dual": dict(time_step=0.005, floor=100.0, ceiling=500.0, voicing_threshold2=0.3),
 }
 res = {}
 for name, kw in cfgs.items():
