@@ -270,15 +270,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 //                 query, k slot = lane >> 5): register e of key tile kt pairs keys a_e and a_e + 4, and the V
 //                 fragment simply reads those two keys.  No score or probability ever goes to memory
 //                 (the three-launch path wrote and re-read 762 MB per layer and 256 windows).
-//   K and V are staged through one 35 KB LDS buffer in blocks of 128 keys (K rows padded to 68 floats so the
-//   float4 fragment reads are conflict-free); all 256 scores of a query stay in registers, so the softmax is the
-//   plain two-pass form, not an online rescaling.
+//   K and V are staged in blocks of 128 keys by LDS-DMA (global_load_lds, two 32 KB buffers, the next block in
+//   flight during the multiply; K chunks XOR-swizzled on the source address so the float4 fragment reads are
+//   conflict-free); all 256 scores of a query stay in registers, so the softmax is the plain two-pass form, not an
+//   online rescaling.
 using af32x16 = __attribute__((ext_vector_type(16))) float;
+
+typedef __attribute__((address_space(3))) void* attn_lds_ptr;
+typedef const __attribute__((address_space(1))) void* attn_glb_ptr;
 
 __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
                                                             int NH, int Hd, float scale) {
-    constexpr int HD = 64, KB = 128, KS = HD + 4;
-    __shared__ __attribute__((aligned(16))) float kv[KB * KS];
+    constexpr int HD = 64, KB = 128, TILE = KB * HD;                            // one staged block: 32 KB
+    extern __shared__ __attribute__((aligned(1024))) float kvbuf[];             // two blocks
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int win = blockIdx.x / NH, head = blockIdx.x - win * NH;
@@ -301,38 +305,54 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
 
-    auto stage = [&](const float* src0, int key0, int stride) {                 // 128 keys x 64 floats -> LDS
+    // LDS-DMA staging of a 128-key block: one wave-instruction writes 4 rows of 256 B linearly; for K the 16-byte
+    // chunk c of row r is fetched into slot c ^ (r & 15) (swizzle on the source address) so that the float4 fragment
+    // reads of 16 consecutive rows hit 16 different chunk slots; V is read row-contiguously and stays unswizzled.
+    // Rows past the window re-read the last row (their scores are masked / their probabilities are zero).
+    auto stage = [&](const float* src0, int key0, float* dst, bool swz) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, r = idx >> 4, c4 = idx & 15;
-            const int key = key0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (key < T) v = *reinterpret_cast<const float4*>(src0 + (int64_t)key * ld + 4 * c4);
-            *reinterpret_cast<float4*>(&kv[r * stride + 4 * c4]) = v;
+            const int ins = wv * 8 + i;                                         // 32 wave-instructions per block
+            const int r = 4 * ins + (lane >> 4), pc = lane & 15;
+            const int key = key0 + r < T ? key0 + r : T - 1;
+            const int c = swz ? (pc ^ (r & 15)) : pc;
+            __builtin_amdgcn_global_load_lds((attn_glb_ptr)(src0 + (int64_t)key * ld + 4 * c),
+                                             (attn_lds_ptr)(dst + ins * 256), 16, 0, 0);
         }
     };
+    auto drain = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    float* buf0 = kvbuf;
+    float* buf1 = kvbuf + TILE;
 
-    // ---- scores ----
+    // ---- scores: block b of K lives in buf[b]; the next block (K1, then V0) is in flight during the multiply ----
+    stage(base + Hd, 0, buf0, true);
+    drain();
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b < nblk) {
-            __syncthreads();
-            stage(base + Hd, KB * b, KS);
-            __syncthreads();
+            float* cur = b == 0 ? buf0 : buf1;
+            if (b + 1 < nblk) stage(base + Hd, KB * (b + 1), buf1, true);      // K1 -> buf1 while K0 is multiplied
+            else stage(base + 2 * Hd, 0, b == 0 ? buf1 : buf0, false);        // last K block: V0 -> the other buffer
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const int kt = 4 * b + t4;
+                const int row = 32 * t4 + l31;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    const float4 kf = *reinterpret_cast<const float4*>(&kv[(32 * t4 + l31) * KS + 8 * g + 4 * h]);
+                    const float4 kf = *reinterpret_cast<const float4*>(&cur[row * HD + 4 * ((2 * g + h) ^ (row & 15))]);
                     sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g].x, sc[kt], 0, 0, 0);
                     sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g].y, sc[kt], 0, 0, 0);
                     sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g].z, sc[kt], 0, 0, 0);
                     sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g].w, sc[kt], 0, 0, 0);
                 }
             }
+            drain();
         }
     }
+    // V0 now sits in buf1 (one key block) or buf0 (two key blocks)
     // ---- softmax over the keys of this lane's query: key = 32 kt + (e & 3) + 8 (e >> 2) + 4 h ----
     float m = -INFINITY;
 #pragma unroll
@@ -368,20 +388,22 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b < nblk) {
-            __syncthreads();
-            stage(base + 2 * Hd, KB * b, HD);
-            __syncthreads();
+            // V block b: V0 is where the score phase left it, V1 goes to the other buffer while V0 is multiplied
+            float* v0buf = nblk == 1 ? buf1 : buf0;
+            float* cur = b == 0 ? v0buf : (v0buf == buf0 ? buf1 : buf0);
+            if (b == 0 && nblk > 1) stage(base + 2 * Hd, KB, v0buf == buf0 ? buf1 : buf0, false);
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const int kt = 4 * b + t4;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;   // within the staged block
-                    const float v0 = kv[key * HD + l31], v1 = kv[key * HD + 32 + l31];
+                    const float v0 = cur[key * HD + l31], v1 = cur[key * HD + 32 + l31];
                     o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], v0, o0, 0, 0, 0);
                     o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], v1, o1, 0, 0, 0);
                 }
             }
+            if (b == 0 && nblk > 1) drain();
         }
     }
     // C layout: column = lane & 31 (d), row = (e & 3) + 8 (e >> 2) + 4 h (query within the wave's 32)
@@ -638,8 +660,14 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         if (fused_attn && hd == 64 && Tt <= 256) {
             // 2 x 2 T^2 hd flops per (chunk, head)
             ProfScope prof("w2v2_attn_fused", s, 4.0 * (double)n * c.NH * (double)Tt * Tt * hd, 0.0);
-            hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256), 0, s,
-                               ws + W.qkv, ws + W.att, Tt, c.NH, Hd, scale);
+            static bool attn_attr = false;
+            if (!attn_attr) {
+                RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   2 * 128 * 64 * (int)sizeof(float)));
+                attn_attr = true;
+            }
+            hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256),
+                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, ws + W.att, Tt, c.NH, Hd, scale);
             RSAF_CHECK_HIP(hipGetLastError());
         } else {
         {   // S = scale * Q K^T per (chunk, head)
