@@ -60,3 +60,10 @@ def synth_state_dict(input_dim, C, H, seed, num_classes=2, layers=2):
 def synth_input(B, T, D, seed):
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.standard_normal((B, T, D)).astype(np.float32)
+
+
+def sample_tensor(a, cap=512):
+    """Fixture-sized view of a tensor: (evenly spaced samples of the flattened array, sum, sum of squares)."""
+    f = np.asarray(a, dtype=np.float64).reshape(-1)
+    idx = np.linspace(0, f.size - 1, min(cap, f.size)).astype(np.int64)
+    return np.concatenate([f[idx], [f.sum(), (f * f).sum()]])
