@@ -114,6 +114,40 @@ int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channe
                          int num_classes, int lstm_layers, int act, const float* weights,
                          void* workspace, int64_t workspace_bytes, float* logits, rsaf_stream_t stream);
 
+/* ---- CNN-LSTM training step: forward in training mode + backward -------------------------------------
+ * Replaces `out = model(seq)` under model.train() and the model part of `loss.backward()` in the reference's
+ * training loops (src/dl_cv_strategies.py:118-125,241-243; module: src/models.py:64-76,161-193): BatchNorm1d on
+ * batch statistics (biased variance over B*T rows; zero-padded frames count), dropout by caller-supplied masks
+ * (float32 0 or 1/(1-p), NULL = no dropout): mask_block1 [B][T][C], mask_block2 [B][T/2][C],
+ * mask_lstm_host = HOST array of lstm_layers-1 DEVICE pointers [B][T/2][2H] (or NULL), mask_fc [B][2H].
+ * `params` / `grads`: float32 device blobs, segment offsets (floats) from rsaf_cnnlstm_train_param_offsets in
+ * this order (conv kernels tap-major [Cout][tap][Cin]; g/be = BatchNorm weight/bias; b_l = b_ih + b_hh, both
+ * directions stacked [fwd 4H | reverse 4H], gate order i,f,g,o):
+ *   w1 b1 g1 be1  wsc bsc gsc besc  w2 b2 g2 be2  w3 b3 g3 be3  w4 b4 g4 be4  {wih_l b_l whh_l} x layers
+ *   watt batt wfc bfc                                  (the four shortcut entries are -1 when input_dim == channels)
+ * The gradient of b_l is the gradient of both b_ih and b_hh.
+ * `saved` (rsaf_cnnlstm_train_saved_floats) carries the activations from forward to backward; `scratch`
+ * (rsaf_cnnlstm_train_scratch_floats) may be reused between calls.  bn_stats_out (optional, device): [5][3][C]
+ * mean / biased variance / rstd of bn1, shortcut BN, bn2 of block 1 and bn1, bn2 of block 2, for the caller's
+ * running-statistics update.  backward consumes `saved` (the gates are overwritten): one backward per forward. */
+int64_t rsaf_cnnlstm_train_param_floats(int input_dim, int channels, int hidden, int num_classes, int lstm_layers);
+int rsaf_cnnlstm_train_param_offsets(int input_dim, int channels, int hidden, int num_classes, int lstm_layers,
+                                     int64_t* offsets_host, int cap, int* n_host);
+int64_t rsaf_cnnlstm_train_saved_floats(int B, int T, int input_dim, int channels, int hidden, int lstm_layers);
+int64_t rsaf_cnnlstm_train_scratch_floats(int B, int T, int input_dim, int channels, int hidden, int lstm_layers);
+int rsaf_cnnlstm_train_forward(const float* x, int B, int T, int input_dim, int channels, int hidden,
+                               int num_classes, int lstm_layers, int act, const float* params,
+                               const float* mask_block1, const float* mask_block2,
+                               const float* const* mask_lstm_host, const float* mask_fc, float* saved,
+                               int64_t saved_floats, float* scratch, int64_t scratch_floats, float* logits,
+                               float* bn_stats_out, rsaf_stream_t stream);
+int rsaf_cnnlstm_train_backward(const float* x, int B, int T, int input_dim, int channels, int hidden,
+                                int num_classes, int lstm_layers, int act, const float* params,
+                                const float* mask_block1, const float* mask_block2,
+                                const float* const* mask_lstm_host, const float* mask_fc, float* saved,
+                                int64_t saved_floats, float* scratch, int64_t scratch_floats,
+                                const float* dlogits, float* grads, rsaf_stream_t stream);
+
 /* ---- Wav2Vec2 frame embeddings for a batch of equal-length chunks -----------------------------------
  * Replaces, per chunk, `processor(chunk).input_values` + `Wav2Vec2Model(...)(input_values)
  * .last_hidden_state` (src/foundation_model_extractor.py:113-116; third-party transformers

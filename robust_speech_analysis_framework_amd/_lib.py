@@ -43,6 +43,12 @@ SIGNATURES = {
     "rsaf_cnnlstm_weight_offsets": (_I, [_I, _I, _I, _I, _I, C.POINTER(_L), _I, C.POINTER(_I)]),
     "rsaf_cnnlstm_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "rsaf_cnnlstm_forward": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _P]),
+    "rsaf_cnnlstm_train_param_floats": (_L, [_I, _I, _I, _I, _I]),
+    "rsaf_cnnlstm_train_param_offsets": (_I, [_I, _I, _I, _I, _I, C.POINTER(_L), _I, C.POINTER(_I)]),
+    "rsaf_cnnlstm_train_saved_floats": (_L, [_I, _I, _I, _I, _I, _I]),
+    "rsaf_cnnlstm_train_scratch_floats": (_L, [_I, _I, _I, _I, _I, _I]),
+    "rsaf_cnnlstm_train_forward": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P]),
+    "rsaf_cnnlstm_train_backward": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P]),
     "rsaf_mshds_frameout_doubles": (_I, []),
     "rsaf_mshds_clip_peak": (_I, [_P, _P, _I, _P, _P]),
     "rsaf_mshds_intensity": (_I, [_P, _P, _I, _I, _P, _I, C.c_double, _I, _P, _P, _P]),

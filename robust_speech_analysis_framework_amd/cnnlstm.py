@@ -7,9 +7,12 @@ parameters live in ordinary ``torch.nn`` containers; ``forward`` does not call t
 it folds BatchNorm into the convolutions, packs everything into one device blob and runs
 ``rsaf_cnnlstm_forward`` (fp32 MFMA GEMMs + persistent LSTM kernel).
 
-Training (autograd through the HIP kernels) is outside the hot path of this build (SURVEY.md §8f
-rank 3): ``forward`` raises in training mode or for CPU tensors instead of silently using a
-PyTorch fallback.
+Training: in ``model.train()`` mode ``forward`` runs ``rsaf_cnnlstm_train_forward``
+(BatchNorm on batch statistics, dropout masks drawn from torch's device RNG, running statistics updated as
+``nn.BatchNorm1d`` does) inside a ``torch.autograd.Function`` whose backward is ``rsaf_cnnlstm_train_backward``:
+``loss.backward()`` fills ``.grad`` of the ordinary parameters, so the reference's loops
+(``src/dl_cv_strategies.py:118-125,241-243``) and ``torch.optim.Adam(model.parameters())`` work unchanged.
+``forward`` raises for CPU tensors instead of silently using a PyTorch fallback.
 """
 from __future__ import annotations
 
@@ -147,6 +150,157 @@ def cnnlstm_forward_packed(x, blob, dims, act, workspace=None, stream=None):
     return logits, workspace
 
 
+def train_param_offsets(dims):
+    lib = _lib.load()
+    buf = (C.c_int64 * 48)()
+    n = C.c_int(0)
+    a = (dims["input_dim"], dims["channels"], dims["hidden"], dims["num_classes"], dims["layers"])
+    _lib.check(lib.rsaf_cnnlstm_train_param_offsets(*a, buf, 48, C.byref(n)), "rsaf_cnnlstm_train_param_offsets")
+    return [int(buf[i]) for i in range(n.value)], int(lib.rsaf_cnnlstm_train_param_floats(*a))
+
+
+def _train_segments(model):
+    """Blob segments in the order of ``rsaf_cnnlstm_train_param_offsets`` (include/rsaf.h): a list of
+    ``(offset, n_floats, pack() -> flat tensor, [(parameter, unpack(grad segment) -> grad of that parameter)])``."""
+    d = model.dims
+    offs, total = train_param_offsets(d)
+    it = iter(offs)
+    H, L = d["hidden"], d["layers"]
+    segs = []
+
+    def plain(prm):
+        segs.append((next(it), prm.numel(), (lambda q=prm: q.reshape(-1)), [(prm, lambda g, q=prm: g.view(q.shape))]))
+
+    def conv(cv, bn):
+        cout, cin, k = cv.weight.shape                          # stored tap-major [Cout][k][Cin]
+        segs.append((next(it), cv.weight.numel(), (lambda w=cv.weight: w.permute(0, 2, 1).reshape(-1)),
+                     [(cv.weight, lambda g, a=cout, b=k, c=cin: g.view(a, b, c).permute(0, 2, 1))]))
+        for prm in (cv.bias, bn.weight, bn.bias):
+            plain(prm)
+
+    r1, r2 = model.res_block1, model.res_block2
+    conv(r1.conv1, r1.bn1)
+    if len(r1.shortcut) > 0:
+        conv(r1.shortcut[0], r1.shortcut[1])
+    else:
+        for _ in range(4):
+            next(it)
+    conv(r1.conv2, r1.bn2)
+    conv(r2.conv1, r2.bn1)
+    conv(r2.conv2, r2.bn2)
+    for l in range(L):
+        g = lambda n: getattr(model.lstm, n)                                         # noqa: E731
+        wf, wr = g(f"weight_ih_l{l}"), g(f"weight_ih_l{l}_reverse")
+        segs.append((next(it), 2 * wf.numel(), (lambda a=wf, b=wr: torch.cat([a, b], 0).reshape(-1)),
+                     [(wf, lambda gr: gr.view(8 * H, -1)[:4 * H]), (wr, lambda gr: gr.view(8 * H, -1)[4 * H:])]))
+        bs = [g(f"bias_ih_l{l}"), g(f"bias_hh_l{l}"), g(f"bias_ih_l{l}_reverse"), g(f"bias_hh_l{l}_reverse")]
+        segs.append((next(it), 8 * H, (lambda b=bs: torch.cat([b[0] + b[1], b[2] + b[3]])),
+                     [(bs[0], lambda gr: gr[:4 * H]), (bs[1], lambda gr: gr[:4 * H]),
+                      (bs[2], lambda gr: gr[4 * H:]), (bs[3], lambda gr: gr[4 * H:])]))
+        hf, hr = g(f"weight_hh_l{l}"), g(f"weight_hh_l{l}_reverse")
+        segs.append((next(it), 2 * hf.numel(), (lambda a=hf, b=hr: torch.stack([a, b]).reshape(-1)),
+                     [(hf, lambda gr: gr.view(2, 4 * H, H)[0]), (hr, lambda gr: gr.view(2, 4 * H, H)[1])]))
+    aw = model.attention_pooling.attention_weights
+    for prm in (aw.weight, aw.bias, model.fc.weight, model.fc.bias):
+        plain(prm)
+    return segs, total
+
+
+def _bn_modules(model):
+    r1, r2 = model.res_block1, model.res_block2
+    return [r1.bn1, r1.shortcut[1] if len(r1.shortcut) > 0 else None, r1.bn2, r2.bn1, r2.bn2]
+
+
+def draw_masks(model, B, T, device):
+    """Dropout keep masks of one training step (float32 0 or 1/(1-p); None where p == 0), from torch's device RNG."""
+    d = model.dims
+    Tp = T // 2
+
+    def mk(shape, p):
+        if p <= 0.0:
+            return None
+        if p >= 1.0:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        return (torch.rand(shape, device=device) >= p).to(torch.float32) / (1.0 - p)
+
+    p_l = float(model.lstm.dropout)
+    return {"res_block1": mk((B, T, d["channels"]), float(model.res_block1.dropout.p)),
+            "res_block2": mk((B, Tp, d["channels"]), float(model.res_block2.dropout.p)),
+            "lstm": [mk((B, Tp, 2 * d["hidden"]), p_l) for _ in range(d["layers"] - 1)],
+            "fc": mk((B, 2 * d["hidden"]), float(model.dropout.p))}
+
+
+class _TrainStep(torch.autograd.Function):
+    """logits = CNNLSTM(x) in training mode; backward fills the parameter gradients (none for x)."""
+
+    @staticmethod
+    def forward(ctx, x, model, masks, *params):
+        lib = _lib.load()
+        d = model.dims
+        B, T, D = x.shape
+        segs, total = _train_segments(model)
+        blob = torch.zeros(total, dtype=torch.float32, device=x.device)
+        with torch.no_grad():
+            for off, n, pack, _ in segs:
+                blob[off:off + n] = pack()
+        a = (B, T, D, d["channels"], d["hidden"], d["layers"])
+        n_saved, n_scr = int(lib.rsaf_cnnlstm_train_saved_floats(*a)), int(lib.rsaf_cnnlstm_train_scratch_floats(*a))
+        if n_saved < 0 or n_scr < 0:
+            raise ValueError("sequence length must be >= 2")
+        saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
+        if model._train_scratch is None or model._train_scratch.numel() < n_scr or model._train_scratch.device != x.device:
+            model._train_scratch = torch.empty(n_scr, dtype=torch.float32, device=x.device)
+        scratch = model._train_scratch
+        logits = torch.empty((B, d["num_classes"]), dtype=torch.float32, device=x.device)
+        stats = torch.empty((5, 3, d["channels"]), dtype=torch.float32, device=x.device)
+        lm = masks["lstm"]
+        lstm_ptrs = (C.c_void_p * max(len(lm), 1))(*[(_lib.ptr(m) if m is not None else None) for m in lm]) if lm else None
+        ctx.call = (x, B, T, D, d["channels"], d["hidden"], d["num_classes"], d["layers"], _ACT_CODE[model.activation_name])
+        ctx.bufs = (blob, masks, lstm_ptrs, saved, scratch)
+        ctx.segs = segs
+        ctx.params = params
+        ctx.model = model
+        optr = lambda t: _lib.ptr(t) if t is not None else None                      # noqa: E731
+        _lib.check(lib.rsaf_cnnlstm_train_forward(
+            _lib.ptr(x), *ctx.call[1:], _lib.ptr(blob), optr(masks["res_block1"]), optr(masks["res_block2"]), lstm_ptrs,
+            optr(masks["fc"]), _lib.ptr(saved), n_saved, _lib.ptr(scratch), scratch.numel(), _lib.ptr(logits),
+            _lib.ptr(stats), _lib.stream_ptr(None)), "rsaf_cnnlstm_train_forward")
+        # running statistics, as nn.BatchNorm1d in training mode (momentum, unbiased variance)
+        with torch.no_grad():
+            for i, (bn, n) in enumerate(zip(_bn_modules(model), (B * T, B * T, B * T, B * (T // 2), B * (T // 2)))):
+                if bn is None or not bn.track_running_stats or bn.running_mean is None:
+                    continue
+                bn.num_batches_tracked += 1
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - m).add_(stats[i, 0], alpha=m)
+                bn.running_var.mul_(1 - m).add_(stats[i, 1], alpha=m * (n / (n - 1.0) if n > 1 else 1.0))
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _lib.load()
+        if ctx.bufs is None:
+            raise RuntimeError("CNNLSTM training step: backward can run once per forward (the saved activations are consumed)")
+        blob, masks, lstm_ptrs, saved, scratch = ctx.bufs
+        x = ctx.call[0]
+        if scratch is not ctx.model._train_scratch:
+            scratch = torch.empty_like(scratch)
+        grads = torch.zeros_like(blob)
+        dl = dlogits.to(torch.float32).contiguous()
+        optr = lambda t: _lib.ptr(t) if t is not None else None                      # noqa: E731
+        _lib.check(lib.rsaf_cnnlstm_train_backward(
+            _lib.ptr(x), *ctx.call[1:], _lib.ptr(blob), optr(masks["res_block1"]), optr(masks["res_block2"]), lstm_ptrs,
+            optr(masks["fc"]), _lib.ptr(saved), saved.numel(), _lib.ptr(scratch), scratch.numel(), _lib.ptr(dl),
+            _lib.ptr(grads), _lib.stream_ptr(None)), "rsaf_cnnlstm_train_backward")
+        ctx.bufs = None
+        by_param = {id(prm): (off, n, unpack) for off, n, _, outs in ctx.segs for prm, unpack in outs}
+        out = []
+        for prm in ctx.params:
+            off, n, unpack = by_param[id(prm)]
+            out.append(unpack(grads[off:off + n]).reshape(prm.shape).contiguous())
+        return (None, None, None, *out)
+
+
 class CNNLSTM(nn.Module):
     """Drop-in for ``src/models.py:109-193`` (constructor signature and state_dict keys identical)."""
 
@@ -168,6 +322,8 @@ class CNNLSTM(nn.Module):
         self._packed = None
         self._packed_key = None
         self._workspace = None
+        self._train_scratch = None
+        self.forced_masks = None            # tests: explicit dropout masks for the next training-mode forward
 
     def _weights_key(self, device):
         return (str(device),) + tuple((p.data_ptr(), p._version) for p in
@@ -182,13 +338,19 @@ class CNNLSTM(nn.Module):
         return self._packed
 
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError(
-                "CNNLSTM.forward on the MI355X path is inference-only (call .eval()); training/backward "
-                "is outside this build's hot path and there is no PyTorch fallback")
         if not x.is_cuda:
             raise _lib.RsafError("CNNLSTM.forward needs a HIP (cuda) tensor: there is no CPU fallback")
         x = x.to(torch.float32)
+        if self.training:
+            if x.dim() != 3 or x.shape[2] != self.dims["input_dim"]:
+                raise ValueError(f"expected input [B, T, {self.dims['input_dim']}], got {tuple(x.shape)}")
+            if x.shape[0] * (x.shape[1] // 2) <= 1:
+                # nn.BatchNorm1d in training mode (res_block2 sees B * (T // 2) values per channel)
+                raise ValueError("Expected more than 1 value per channel when training")
+            x = x.contiguous()
+            masks = self.forced_masks if self.forced_masks is not None else draw_masks(self, x.shape[0], x.shape[1], x.device)
+            params = [p for _, _, _, outs in _train_segments(self)[0] for p, _ in outs]
+            return _TrainStep.apply(x.detach(), self, masks, *params)
         blob = self.packed_weights(x.device)
         with torch.no_grad():
             logits, self._workspace = cnnlstm_forward_packed(x, blob, self.dims, self.activation_name,

@@ -19,6 +19,7 @@
 // register index), h_t goes to LDS (double-buffered, one barrier per step) and to HBM.
 #include <algorithm>
 
+#include "cnnlstm_kernels.h"
 #include "gemm_f32.h"
 
 namespace rsaf {
@@ -89,10 +90,12 @@ __global__ __launch_bounds__(256) void pool2_kernel(const float4* __restrict__ x
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---- persistent bidirectional LSTM recurrence ------------------------------------------------------
-template <int H>
-__global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* __restrict__ xproj,
-                                                               const float* __restrict__ whh,
-                                                               float* __restrict__ hout, int B, int T) {
+// SAVE (training): the post-activation gates overwrite the input projection in place (the lane that read an element
+// is the lane that rewrites it, one step after the read of the next step was issued) and the cell state is kept.
+template <int H, bool SAVE>
+__global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* xproj, const float* __restrict__ whh,
+                                                               float* __restrict__ hout, float* gates_save,
+                                                               float* __restrict__ c_save, int B, int T) {
     constexpr int LDH = H + 4;
     constexpr int KG = H / 16;                   // k-groups of 16 (4 MFMA k-steps each)
     __shared__ __attribute__((aligned(16))) float hbuf[2][16][LDH];
@@ -176,6 +179,11 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* __re
             const float hv = og * tanhf(cst[r]);
             hbuf[cur ^ 1][q * 4 + r][unit] = hv;
             if (brow[r]) hout[hoff[r] + (int64_t)t * 2 * H] = hv;
+            if (SAVE && brow[r]) {
+                float* gs = gates_save + xoff[r] + (int64_t)t * 8 * H;
+                gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+                c_save[hoff[r] + (int64_t)t * 2 * H] = cst[r];
+            }
         }
         __syncthreads();
         cur ^= 1;
@@ -240,6 +248,28 @@ __global__ __launch_bounds__(256) void attnpool_fc_kernel(const float* __restric
             s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x] +
             bfc[threadIdx.x];
 }
+
+}  // namespace cnnlstm
+
+int launch_lstm_rec(const float* xproj, const float* whh, float* hout, float* gates_save, float* c_save, int B, int T,
+                    int H, hipStream_t s) {
+    using namespace cnnlstm;
+    RSAF_CHECK_ARG(H == 64 || H == 128, "lstm_hidden_dim must be 64 or 128");
+    RSAF_CHECK_ARG((gates_save == nullptr) == (c_save == nullptr), "gates_save and c_save go together");
+    ProfScope prof("lstm_recurrent", s, 2.0 * B * T * 2.0 * 4 * H * H, 0.0);
+    dim3 grid((B + 15) / 16, 2);
+    if (gates_save) {
+        if (H == 128) hipLaunchKernelGGL((lstm_rec_kernel<128, true>), grid, dim3(512), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
+        else hipLaunchKernelGGL((lstm_rec_kernel<64, true>), grid, dim3(256), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
+    } else {
+        if (H == 128) hipLaunchKernelGGL((lstm_rec_kernel<128, false>), grid, dim3(512), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
+        else hipLaunchKernelGGL((lstm_rec_kernel<64, false>), grid, dim3(256), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
+    }
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+namespace cnnlstm {
 
 static int conv3(const float* x, const float* wk, const float* bias, const float* R, int64_t ldr, int64_t sR,
                  float* y, int B, int T, int Cin, int Cout, int act, hipStream_t s) {
@@ -359,15 +389,8 @@ int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channe
         p.bias = W + L.bih[l];
         rc = launch_gemm_f32(p, s, "lstm_inproj_gemm");
         if (rc) return rc;
-        {
-            ProfScope prof("lstm_recurrent", s, 2.0 * B * Tp * 2.0 * 4 * H * H, 0.0);
-            dim3 grid((B + 15) / 16, 2);
-            if (H == 128)
-                hipLaunchKernelGGL(lstm_rec_kernel<128>, grid, dim3(512), 0, s, xproj, W + L.whh[l], lout, B, Tp);
-            else
-                hipLaunchKernelGGL(lstm_rec_kernel<64>, grid, dim3(256), 0, s, xproj, W + L.whh[l], lout, B, Tp);
-            RSAF_CHECK_HIP(hipGetLastError());
-        }
+        rc = launch_lstm_rec(xproj, W + L.whh[l], lout, nullptr, nullptr, B, Tp, H, s);
+        if (rc) return rc;
         lin = lout; in = 2 * H;
         lout = (lout == seq0) ? seq1 : seq0;
     }

@@ -1,0 +1,203 @@
+"""CNN-LSTM training step on the HIP path (rsaf_cnnlstm_train_forward/backward through the CNNLSTM drop-in) against
+the training oracle and the vectors captured from the reference module.
+
+Tolerance: 1e-4 relative to the largest magnitude of each tensor (the north-star float tolerance); the HIP path is
+float32 end to end, the oracle float64."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from weights import sample_tensor, synth_input, synth_state_dict  # noqa: E402
+
+from oracle import cnnlstm_train_oracle as to
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+ZERO_GRAD = ("conv1.bias", "conv2.bias", "shortcut.0.bias", "attention_weights.bias")    # mathematically zero
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "cnnlstm_train_*.npz")))
+
+
+def build(D, C, H, seed, act, p_rate=0.0, p_block=0.0):
+    import torch
+    from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+    m = CNNLSTM(input_dim=D, cnn_out_channels=C, lstm_hidden_dim=H, activation_fn=act, dropout_rate=p_rate)
+    sd = synth_state_dict(D, C, H, seed)
+    full = m.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(v)
+    m.load_state_dict(full)
+    m.res_block1.dropout.p = p_block
+    m.res_block2.dropout.p = p_block
+    return m.to("cuda").train(), sd
+
+
+def device_masks(mk):
+    import torch
+    t = lambda a: torch.from_numpy(a).to("cuda")                                  # noqa: E731
+    lst = [t(mk[k]) for k in sorted(k for k in mk if k.startswith("lstm"))]
+    return {"res_block1": t(mk["res_block1"]), "res_block2": t(mk["res_block2"]), "lstm": lst, "fc": t(mk["fc"])}
+
+
+def step(m, x, labels):
+    import torch
+    m.zero_grad()
+    out = m(torch.from_numpy(x).to("cuda"))
+    loss = torch.nn.CrossEntropyLoss()(out, torch.from_numpy(np.asarray(labels)).to("cuda"))
+    loss.backward()
+    torch.cuda.synchronize()
+    return out.detach().cpu().numpy(), loss.item(), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+
+
+def check_grads(got, want, scale_floor=1e-7):
+    worst = ("", 0.0)
+    for k, g in want.items():
+        a = got[k].astype(np.float64)
+        assert a.shape == g.shape, k
+        if k.endswith(ZERO_GRAD):
+            # rounding noise on both sides; bound it by the scale of the neighbouring weight gradient
+            assert np.abs(a).max() < 1e-3 * max(np.abs(want[k.replace("bias", "weight")]).max(), 1e-6), (k, np.abs(a).max())
+            continue
+        err = np.abs(a - g).max() / max(np.abs(g).max(), scale_floor)
+        if err > worst[1]:
+            worst = (k, err)
+        assert err < RTOL, (k, err)
+    return worst
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[14:-4] for p in GOLDEN])
+def test_step_matches_reference_vectors(path):
+    z = np.load(path)
+    D, C, H, B, T, seed = [int(v) for v in z["meta"]]
+    act = str(z["act"])
+    m, sd = build(D, C, H, seed, act)
+    x = synth_input(B, T, D, seed + 1000)
+    logits, loss, grads = step(m, x, z["labels"])
+    assert np.abs(logits - z["logits"]).max() < RTOL * max(np.abs(z["logits"]).max(), 1.0)
+    assert abs(loss - float(z["loss"])) < RTOL
+    for k, g in grads.items():
+        ref = z["grad/" + k]
+        if k.endswith(ZERO_GRAD):
+            continue
+        got = sample_tensor(g)
+        err = np.abs(got[:-2] - ref[:-2]).max() / max(np.abs(ref[:-2]).max(), 1e-7)
+        assert err < RTOL, (k, err)
+        assert abs(got[-1] - ref[-1]) <= 4 * RTOL * max(abs(ref[-1]), 1e-12), (k, "sum of squares")
+    # BatchNorm buffers after the step
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            ref = z["after/" + k]
+            got = sample_tensor(v.cpu().numpy())
+            assert np.abs(got[:-2] - ref[:-2]).max() < RTOL * max(np.abs(ref[:-2]).max(), 1e-3), k
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 1
+
+
+CASES = [
+    # D, C, H, act, B, T, seed, p_block, p_rate
+    (16, 32, 64, "silu", 3, 21, 301, 0.2, 0.5),          # odd T, all dropouts
+    (24, 64, 128, "gelu", 2, 40, 302, 0.2, 0.3),
+    (32, 32, 64, "gelu", 5, 18, 303, 0.5, 0.0),          # identity shortcut in block 1
+    (768, 128, 128, "silu", 4, 64, 304, 0.2, 0.5),       # reference defaults
+    (16, 32, 128, "silu", 19, 12, 305, 0.0, 0.5),        # more than one 16-row recurrence workgroup
+    (768, 32, 64, "silu", 2, 700, 306, 0.2, 0.5),        # rows > one split of the weight-gradient GEMM
+    (16, 32, 64, "silu", 2, 4, 307, 0.0, 0.0),           # tiny: 4 values per channel in block 2 (with 2 the BN gradient is identically 0)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"d{c[0]}_c{c[1]}_h{c[2]}_{c[3]}_b{c[4]}_t{c[5]}" for c in CASES])
+def test_step_matches_oracle_with_dropout_masks(case):
+    D, C, H, act, B, T, seed, p_block, p_rate = case
+    m, sd = build(D, C, H, seed, act, p_rate, p_block)
+    x = synth_input(B, T, D, seed + 1000)
+    labels = np.random.Generator(np.random.PCG64(seed + 2000)).integers(0, 2, B)
+    mk = to.make_masks(B, T, C, H, p_block, p_rate, seed + 3000)
+    m.forced_masks = device_masks(mk)
+    logits, loss, grads = step(m, x, labels)
+    want = to.forward_backward(sd, x, labels, act, masks=mk)
+    assert np.abs(logits - want["logits"]).max() < RTOL * max(np.abs(want["logits"]).max(), 1.0)
+    assert abs(loss - want["loss"]) < RTOL
+    check_grads(grads, want["grads"])
+    new = to.updated_bn_buffers(sd, want["bn_stats"])
+    st = m.state_dict()
+    for k, v in new.items():
+        assert np.abs(st[k].cpu().numpy() - v).max() < RTOL * max(np.abs(v).max(), 1e-3), k
+
+
+def test_adam_loop_follows_oracle():
+    """Three steps of the reference's inner loop (zero_grad / forward / CrossEntropy / backward / Adam.step) with
+    torch.optim.Adam on the drop-in's ordinary parameters, against the oracle's loop."""
+    import torch
+    D, C, H, act, B, T, seed, lr = 16, 32, 64, "silu", 4, 24, 401, 1e-3
+    m, sd = build(D, C, H, seed, act)
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    params = {k: np.asarray(v, np.float64) for k, v in sd.items()}
+    state, losses_o, losses_g = {}, [], []
+    for it in range(3):
+        x = synth_input(B, T, D, seed + 10 + it)
+        labels = np.random.Generator(np.random.PCG64(seed + 20 + it)).integers(0, 2, B)
+        r = to.forward_backward(params, x, labels, act)
+        # the mathematically-zero gradients are rounding noise that Adam would amplify to +-lr: freeze them on both sides
+        g = {k: (np.zeros_like(v) if k.endswith(ZERO_GRAD) else v) for k, v in r["grads"].items()}
+        upd = to.adam_step({k: params[k] for k in g}, g, state, lr)
+        params.update(upd)
+        params.update(to.updated_bn_buffers(params, r["bn_stats"]))
+        losses_o.append(r["loss"])
+        opt.zero_grad()
+        out = m(torch.from_numpy(x).to("cuda"))
+        loss = torch.nn.CrossEntropyLoss()(out, torch.from_numpy(labels).to("cuda"))
+        loss.backward()
+        for k, p in m.named_parameters():
+            if k.endswith(ZERO_GRAD):
+                p.grad.zero_()
+        opt.step()
+        losses_g.append(loss.item())
+    assert np.allclose(losses_g, losses_o, rtol=2e-4, atol=2e-5), (losses_g, losses_o)
+    st = m.state_dict()
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            continue
+        a, b = st[k].cpu().numpy().astype(np.float64), params[k]
+        # after 3 Adam steps every weight moved by <= 3*lr; require agreement to a small fraction of that move
+        assert np.abs(a - b).max() < 0.05 * lr + 1e-4 * np.abs(b).max(), (k, np.abs(a - b).max())
+
+
+def test_eval_after_training_uses_updated_statistics():
+    """model.eval() after a training step folds the UPDATED running statistics (the inference path's weight cache is
+    keyed on parameter versions)."""
+    import torch
+    from oracle import cnnlstm_oracle as co
+    D, C, H, act, B, T, seed = 16, 32, 64, "silu", 3, 20, 501
+    m, sd = build(D, C, H, seed, act)
+    x = synth_input(B, T, D, seed + 1)
+    m.eval()
+    before = m(torch.from_numpy(x).to("cuda")).cpu().numpy()
+    m.train()
+    step(m, x, [0, 1, 0])
+    m.eval()
+    after = m(torch.from_numpy(x).to("cuda")).cpu().numpy()
+    assert np.abs(after - before).max() > 1e-5
+    sd2 = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+    want = co.forward_numpy(sd2, x, act)
+    assert np.abs(after - want).max() < 1e-4 * max(np.abs(want).max(), 1.0)
+
+
+def test_double_backward_is_refused():
+    import torch
+    m, _ = build(16, 32, 64, 601, "silu")
+    out = m(torch.from_numpy(synth_input(2, 8, 16, 602)).to("cuda"))
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError):
+        out.sum().backward()
+
+
+def test_single_value_per_channel_is_refused_like_batchnorm():
+    import torch
+    m, _ = build(16, 32, 64, 701, "silu")
+    with pytest.raises(ValueError):
+        m(torch.from_numpy(synth_input(1, 3, 16, 702)).to("cuda"))          # T // 2 == 1 frame after the pool
