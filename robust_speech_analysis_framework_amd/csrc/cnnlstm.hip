@@ -190,6 +190,105 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* xpro
     }
 }
 
+// ---- the same recurrence for small batches: 4 batch rows per workgroup -------------------------------------
+// With a handful of sequences (the reference trains with batches of 4 and 8, src/dl_cv_strategies.py:234,265) the
+// 16-row tile above wastes 3/4 of its MFMA work and leaves the step time at 16 rows' worth.  Here a workgroup owns 4
+// rows of one direction and uses v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products per instruction): row i
+// of every block is batch row i, the 64 (block, j) columns of wave w are the four gates of hidden units 16w..16w+15
+// (column c = 16*gate + u).  W_hh stays register-resident (H registers per lane: the lane's column over all k), h
+// is broadcast from LDS.  The gate pre-activations of one (row, unit) land in four lanes (one per gate); they are
+// exchanged through a wave-private LDS tile so that lane (q, u) updates cell (row q, unit u).
+template <int H, bool SAVE>
+__global__ __launch_bounds__(H / 16 * 64) void lstm_rec4_kernel(const float* xproj, const float* __restrict__ whh,
+                                                                float* __restrict__ hout, float* gates_save,
+                                                                float* __restrict__ c_save, int B, int T) {
+    constexpr int LDH = H + 4;
+    constexpr int NW = H / 16;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4][LDH];
+    __shared__ float gx[NW][4][80];                 // [wave][row][16*gate + u], row stride 80: conflict-free both ways
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int gq = lane >> 4, u = lane & 15;        // as a column: gate gq of unit u; as a cell owner: row gq of unit u
+    const int dir = blockIdx.y, b0 = blockIdx.x * 4;
+    const int unit = 16 * w + u;
+
+    float breg[H];
+    {
+        const float* wr = whh + (int64_t)dir * 4 * H * H + (int64_t)(gq * H + unit) * H;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(wr + k);
+            breg[k] = v.x; breg[k + 1] = v.y; breg[k + 2] = v.z; breg[k + 3] = v.w;
+        }
+    }
+    for (int i = tid; i < 2 * 4 * LDH; i += NW * 64) (&hbuf[0][0][0])[i] = 0.0f;
+
+    // as a column: input projections of rows 0..3; as a cell owner: outputs of row gq
+    int64_t xoff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int bc = min(b0 + r, B - 1);
+        xoff[r] = (int64_t)bc * T * 8 * H + dir * 4 * H + gq * H + unit;
+    }
+    const bool own = b0 + gq < B;
+    const int bo = min(b0 + gq, B - 1);
+    const int64_t hoff = (int64_t)bo * T * 2 * H + dir * H + unit;
+    const int64_t goff = (int64_t)bo * T * 8 * H + dir * 4 * H + unit;
+    const int arow = lane & 3;                      // A operand: lane 4*blk + i carries batch row i
+    const float ya = gq == 2 ? 2.0f : 1.0f, yb = gq == 2 ? -2.0f : -1.0f, yc = gq == 2 ? -1.0f : 0.0f;
+    float cst = 0.f;
+    float xin[4];
+    {
+        const int t = dir ? T - 1 : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xin[r] = xproj[xoff[r] + (int64_t)t * 8 * H];
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        f32x4 acc[4];
+        acc[0] = f32x4{xin[0], xin[1], xin[2], xin[3]};
+#pragma unroll
+        for (int a = 1; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s + 1 < T) {
+            const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xin[r] = xproj[xoff[r] + (int64_t)tn * 8 * H];
+        }
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&hbuf[cur][arow][k]);
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, breg[k + 0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, breg[k + 1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, breg[k + 2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, breg[k + 3], acc[3], 0, 0, 0);
+        }
+        // gate nonlinearity in the column's lane (one gate type per lane: y = ya / (1 + exp(yb * x)) + yc is the
+        // logistic function for i, f, o and tanh for g), then the 4x4 exchange through the wave's LDS tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pre = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+            gx[w][r][lane] = ya * __builtin_amdgcn_rcpf(1.0f + __expf(yb * pre)) + yc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float ig = gx[w][gq][u], fg = gx[w][gq][16 + u], gg = gx[w][gq][32 + u], og = gx[w][gq][48 + u];
+        cst = fg * cst + ig * gg;
+        const float hv = og * (2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * cst)) - 1.0f);
+        hbuf[cur ^ 1][gq][unit] = hv;
+        if (own) {
+            hout[hoff + (int64_t)t * 2 * H] = hv;
+            if (SAVE) {
+                float* gs = gates_save + goff + (int64_t)t * 8 * H;
+                gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+                c_save[hoff + (int64_t)t * 2 * H] = cst;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // ---- attention pooling (softmax over time) + final Linear -----------------------------------------
 template <int NF>   // features per lane: 2H = 64*NF
 __global__ __launch_bounds__(256) void attnpool_fc_kernel(const float* __restrict__ seq, const float* __restrict__ watt,
@@ -257,14 +356,20 @@ int launch_lstm_rec(const float* xproj, const float* whh, float* hout, float* ga
     RSAF_CHECK_ARG(H == 64 || H == 128, "lstm_hidden_dim must be 64 or 128");
     RSAF_CHECK_ARG((gates_save == nullptr) == (c_save == nullptr), "gates_save and c_save go together");
     ProfScope prof("lstm_recurrent", s, 2.0 * B * T * 2.0 * 4 * H * H, 0.0);
-    dim3 grid((B + 15) / 16, 2);
-    if (gates_save) {
-        if (H == 128) hipLaunchKernelGGL((lstm_rec_kernel<128, true>), grid, dim3(512), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
-        else hipLaunchKernelGGL((lstm_rec_kernel<64, true>), grid, dim3(256), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
+    // 4-row workgroups while they still fit the chip about twice over; the 16-row tile beyond (same pipe time for 4x the rows)
+    static const int small_max = [] { const char* e = getenv("RSAF_LSTM_SMALL_MAX"); return e ? atoi(e) : 1024; }();
+    const bool small = B <= small_max;
+    dim3 grid(small ? (B + 3) / 4 : (B + 15) / 16, 2);
+#define RSAF_LSTM_LAUNCH(KERNEL, HH, SV) \
+    hipLaunchKernelGGL((KERNEL<HH, SV>), grid, dim3(HH / 16 * 64), 0, s, xproj, whh, hout, gates_save, c_save, B, T)
+    if (small) {
+        if (gates_save) { if (H == 128) RSAF_LSTM_LAUNCH(lstm_rec4_kernel, 128, true); else RSAF_LSTM_LAUNCH(lstm_rec4_kernel, 64, true); }
+        else { if (H == 128) RSAF_LSTM_LAUNCH(lstm_rec4_kernel, 128, false); else RSAF_LSTM_LAUNCH(lstm_rec4_kernel, 64, false); }
     } else {
-        if (H == 128) hipLaunchKernelGGL((lstm_rec_kernel<128, false>), grid, dim3(512), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
-        else hipLaunchKernelGGL((lstm_rec_kernel<64, false>), grid, dim3(256), 0, s, xproj, whh, hout, gates_save, c_save, B, T);
+        if (gates_save) { if (H == 128) RSAF_LSTM_LAUNCH(lstm_rec_kernel, 128, true); else RSAF_LSTM_LAUNCH(lstm_rec_kernel, 64, true); }
+        else { if (H == 128) RSAF_LSTM_LAUNCH(lstm_rec_kernel, 128, false); else RSAF_LSTM_LAUNCH(lstm_rec_kernel, 64, false); }
     }
+#undef RSAF_LSTM_LAUNCH
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

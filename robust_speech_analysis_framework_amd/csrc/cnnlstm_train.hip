@@ -625,6 +625,99 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(float* gates, con
     }
 }
 
+// ---- the same backward recurrence for small batches: 4 batch rows per workgroup ---------------------------------------
+// Thread (row, unit) = (tid / H, tid % H) owns one cell: lane-local gate / cell derivatives, dgates to HBM (in place) and
+// to LDS.  dh_rec = dgates . W_hh with v_mfma_f32_4x4x1_16B_f32 (row i of every block = batch row i): wave w contracts
+// the gate rows k in [64w, 64w + 64) against all H units (column c of chain j = unit 64j + c; W_hh slice register-resident,
+// H registers per lane); the H/16 partial products meet in LDS and thread (row, unit) sums them in a fixed order.
+template <int H>
+__global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, const float* __restrict__ cst,
+                                                                const float* __restrict__ dh_out, const float* __restrict__ whh,
+                                                                int B, int T) {
+    constexpr int NW = H / 16;                      // waves; 64 * NW = 4 * H threads
+    constexpr int NCH = H / 64;                     // 64-column chains per wave
+    constexpr int LDG = 4 * H + 4;
+    __shared__ __attribute__((aligned(16))) float dg[4][LDG];
+    __shared__ float part[NW][4][H];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int dir = blockIdx.y, b0 = blockIdx.x * 4;
+    const int row = tid / H, unit = tid % H;
+    const int arow = lane & 3;
+
+    // breg[j][kk] = W_hh[dir][64w + kk][64j + lane]
+    float breg[NCH][64];
+    const float* wd = whh + (int64_t)dir * 4 * H * H + (int64_t)(64 * w) * H;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) breg[j][kk] = wd[(int64_t)kk * H + 64 * j + lane];
+
+    const bool own = b0 + row < B;
+    const int bo = min(b0 + row, B - 1);
+    const int64_t goff = (int64_t)bo * T * 8 * H + dir * 4 * H + unit;
+    const int64_t hoff = (int64_t)bo * T * 2 * H + dir * H + unit;
+    float dcc = 0.f, dh_rec = 0.f;
+    // values of the current step (prefetched)
+    float ig, fg, gg, og, cc, dho;
+    {
+        const int t = dir ? 0 : T - 1;
+        const float* gp = gates + goff + (int64_t)t * 8 * H;
+        ig = gp[0]; fg = gp[H]; gg = gp[2 * H]; og = gp[3 * H];
+        cc = cst[hoff + (int64_t)t * 2 * H];
+        dho = dh_out[hoff + (int64_t)t * 2 * H];
+    }
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s;           // reverse of the forward order
+        const int tprev = dir ? t + 1 : t - 1;       // the step the forward pass ran just before t == the next step here
+        const bool last = s + 1 == T;
+        float nig = 0.f, nfg = 0.f, ngg = 0.f, nog = 0.f, ncc = 0.f, ndho = 0.f;
+        if (!last) {
+            const float* gp = gates + goff + (int64_t)tprev * 8 * H;
+            nig = gp[0]; nfg = gp[H]; ngg = gp[2 * H]; nog = gp[3 * H];
+            ncc = cst[hoff + (int64_t)tprev * 2 * H];
+            ndho = dh_out[hoff + (int64_t)tprev * 2 * H];
+        }
+        const float dh = dho + dh_rec;
+        const float tc = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * cc)) - 1.0f;
+        const float dc = dcc + dh * og * (1.0f - tc * tc);
+        const float d_o = dh * tc * og * (1.0f - og);
+        const float d_i = dc * gg * ig * (1.0f - ig);
+        const float d_f = dc * ncc * fg * (1.0f - fg);           // c of the previous forward step (0 at the first: ncc = 0)
+        const float d_g = dc * ig * (1.0f - gg * gg);
+        dcc = dc * fg;
+        dg[row][unit] = d_i; dg[row][H + unit] = d_f; dg[row][2 * H + unit] = d_g; dg[row][3 * H + unit] = d_o;
+        if (own) {
+            float* go = gates + goff + (int64_t)t * 8 * H;
+            go[0] = d_i; go[H] = d_f; go[2 * H] = d_g; go[3 * H] = d_o;
+        }
+        __syncthreads();
+        f32x4 acc[NCH][2];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kk = 0; kk < 64; kk += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&dg[arow][64 * w + kk]);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, breg[j][kk + 0], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, breg[j][kk + 1], acc[j][1], 0, 0, 0);
+                acc[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, breg[j][kk + 2], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, breg[j][kk + 3], acc[j][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[w][r][64 * j + lane] = acc[j][0][r] + acc[j][1][r];
+        __syncthreads();
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) sum += part[ww][row][unit];
+        dh_rec = sum;
+        ig = nig; fg = nfg; gg = ngg; og = nog; cc = ncc; dho = ndho;
+    }
+}
+
 // ---- host-side helpers ------------------------------------------------------------------------------------------
 static inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 32)); }
 
@@ -968,12 +1061,19 @@ int rsaf_cnnlstm_train_backward(const float* x, int B, int T, int input_dim, int
                                   : ((mask_lstm_host && mask_lstm_host[l - 1]) ? saved + S.hdrop[l - 1] : saved + S.hout[l - 1]);
         {
             ProfScope prof("lstm_bwd_recurrent", s, 2.0 * B * Tp * 2.0 * 4 * H * H, 0.0);
-            dim3 grid((B + 15) / 16, 2);
-            const size_t lds = (size_t)2 * 16 * (4 * H + 4) * sizeof(float);
-            if (H == 128)
-                RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (H == 128) hipLaunchKernelGGL(lstm_bwd_kernel<128>, grid, dim3(512), lds, s, gates, saved + S.cst[l], dcur, P + L.whh[l], B, Tp);
-            else hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(256), lds, s, gates, saved + S.cst[l], dcur, P + L.whh[l], B, Tp);
+            static const int small_max = [] { const char* e = getenv("RSAF_LSTM_SMALL_MAX"); return e ? atoi(e) : 1024; }();
+            if (B <= small_max) {
+                dim3 grid((B + 3) / 4, 2);
+                if (H == 128) hipLaunchKernelGGL(lstm_bwd4_kernel<128>, grid, dim3(512), 0, s, gates, saved + S.cst[l], dcur, P + L.whh[l], B, Tp);
+                else hipLaunchKernelGGL(lstm_bwd4_kernel<64>, grid, dim3(256), 0, s, gates, saved + S.cst[l], dcur, P + L.whh[l], B, Tp);
+            } else {
+                dim3 grid((B + 15) / 16, 2);
+                const size_t lds = (size_t)2 * 16 * (4 * H + 4) * sizeof(float);
+                if (H == 128)
+                    RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (H == 128) hipLaunchKernelGGL(lstm_bwd_kernel<128>, grid, dim3(512), lds, s, gates, saved + S.cst[l], dcur, P + L.whh[l], B, Tp);
+                else hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(256), lds, s, gates, saved + S.cst[l], dcur, P + L.whh[l], B, Tp);
+            }
             RSAF_CHECK_HIP(hipGetLastError());
         }
         // gates now holds dgates (pre-activation gradients) [rows2][8H]

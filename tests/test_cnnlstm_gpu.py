@@ -113,7 +113,9 @@ def test_weights_repacked_after_update_and_errors(rsaf_lib):
     assert np.allclose((b - a).cpu().numpy(), 1.0, atol=1e-5)
     with pytest.raises(ValueError):
         CNNLSTM(activation_fn="relu")
-    with pytest.raises(NotImplementedError):
-        m.train()(x)
+    out = m.train()(x)                       # training mode runs the HIP training step (tests/test_cnnlstm_train_gpu.py)
+    assert out.requires_grad and out.shape == (2, 2)
+    with pytest.raises(_lib.RsafError):
+        m.train()(x.cpu())
     with pytest.raises(_lib.RsafError):
         m.eval()(x.cpu())
