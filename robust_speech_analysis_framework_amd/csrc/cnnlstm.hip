@@ -142,6 +142,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* xpro
 #pragma unroll
             for (int r = 0; r < 4; ++r) xin[gt][r] = xproj[xoff[r] + (int64_t)t * 8 * H + gt * H];
     }
+    vmem_drain();
     __syncthreads();
 
     int cur = 0;
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* xpro
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[gt][r] = xin[gt][r];
-        if (s + 1 < T) {                           // prefetch the next step's input projection
-            const int tn = dir ? t - 1 : t + 1;
+        {                                          // prefetch the next step's input projection (the last step reloads
+            const int tn = s + 1 < T ? (dir ? t - 1 : t + 1) : t;      // its own: the loop body stays branch-free)
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
@@ -178,14 +179,16 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* xpro
             cst[r] = fg * cst[r] + ig * gg;
             const float hv = og * tanhf(cst[r]);
             hbuf[cur ^ 1][q * 4 + r][unit] = hv;
-            if (brow[r]) hout[hoff[r] + (int64_t)t * 2 * H] = hv;
-            if (SAVE && brow[r]) {
+            // rows past B are clamped to row B-1 and replicate it bit for bit: their stores rewrite the same values, and
+            // leaving them unconditional keeps the loop branch-free (exact vmcnt bookkeeping, no store drain per step)
+            hout[hoff[r] + (int64_t)t * 2 * H] = hv;
+            if (SAVE) {
                 float* gs = gates_save + xoff[r] + (int64_t)t * 8 * H;
                 gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
                 c_save[hoff[r] + (int64_t)t * 2 * H] = cst[r];
             }
         }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }
@@ -229,7 +232,6 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec4_kernel(const float* xpr
         const int bc = min(b0 + r, B - 1);
         xoff[r] = (int64_t)bc * T * 8 * H + dir * 4 * H + gq * H + unit;
     }
-    const bool own = b0 + gq < B;
     const int bo = min(b0 + gq, B - 1);
     const int64_t hoff = (int64_t)bo * T * 2 * H + dir * H + unit;
     const int64_t goff = (int64_t)bo * T * 8 * H + dir * 4 * H + unit;
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec4_kernel(const float* xpr
 #pragma unroll
         for (int r = 0; r < 4; ++r) xin[r] = xproj[xoff[r] + (int64_t)t * 8 * H];
     }
+    vmem_drain();
     __syncthreads();
 
     int cur = 0;
@@ -251,18 +254,31 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec4_kernel(const float* xpr
         acc[0] = f32x4{xin[0], xin[1], xin[2], xin[3]};
 #pragma unroll
         for (int a = 1; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (s + 1 < T) {
-            const int tn = dir ? t - 1 : t + 1;
+        {
+            const int tn = s + 1 < T ? (dir ? t - 1 : t + 1) : t;      // branch-free: the last step reloads its own row
 #pragma unroll
             for (int r = 0; r < 4; ++r) xin[r] = xproj[xoff[r] + (int64_t)tn * 8 * H];
         }
+        // h in batches of 8 float4 (32 k), the next batch in flight while this one feeds the matrix pipe
+        float4 ab[2][8];
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&hbuf[cur][arow][k]);
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, breg[k + 0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, breg[k + 1], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, breg[k + 2], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, breg[k + 3], acc[3], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) ab[0][j] = *reinterpret_cast<const float4*>(&hbuf[cur][arow][4 * j]);
+#pragma unroll
+        for (int kb = 0; kb < H / 32; ++kb) {
+            if (kb + 1 < H / 32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    ab[(kb + 1) & 1][j] = *reinterpret_cast<const float4*>(&hbuf[cur][arow][32 * (kb + 1) + 4 * j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 a4 = ab[kb & 1][j];
+                const int k = 32 * kb + 4 * j;
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, breg[k + 0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, breg[k + 1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, breg[k + 2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, breg[k + 3], acc[3], 0, 0, 0);
+            }
         }
         // gate nonlinearity in the column's lane (one gate type per lane: y = ya / (1 + exp(yb * x)) + yc is the
         // logistic function for i, f, o and tanh for g), then the 4x4 exchange through the wave's LDS tile
@@ -276,15 +292,13 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec4_kernel(const float* xpr
         cst = fg * cst + ig * gg;
         const float hv = og * (2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * cst)) - 1.0f);
         hbuf[cur ^ 1][gq][unit] = hv;
-        if (own) {
-            hout[hoff + (int64_t)t * 2 * H] = hv;
-            if (SAVE) {
-                float* gs = gates_save + goff + (int64_t)t * 8 * H;
-                gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
-                c_save[hoff + (int64_t)t * 2 * H] = cst;
-            }
+        hout[hoff + (int64_t)t * 2 * H] = hv;          // rows past B replicate row B-1 (see lstm_rec_kernel)
+        if (SAVE) {
+            float* gs = gates_save + goff + (int64_t)t * 8 * H;
+            gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+            c_save[hoff + (int64_t)t * 2 * H] = cst;
         }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }

@@ -108,7 +108,7 @@ struct WLayout {
     int64_t total;
 };
 
-static const int RED_PARTS = 1024;
+static const int RED_PARTS = 256;
 
 static WLayout make_wlayout(const Dims& d, int B, int T) {
     WLayout W{};
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void colred_partial_kernel(const float* __rest
     if (c < C) {
         float mean = 0.f, rstd = 0.f, gg = 0.f, bb = 0.f;
         if (MODE == 1) { mean = stat[c]; rstd = stat[2 * C + c]; gg = g[c]; bb = be[c]; }
+#pragma unroll 4
         for (int64_t r = r0 + ry; r < r1; r += 4) {
             if (MODE == 0) {
                 const double v = a[r * lda + c];
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256) void colred_final_kernel(const double* __restr
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
     for (int p = 0; p < nparts; ++p) { s0 += partial[((int64_t)p * 2 + 0) * C + c]; s1 += partial[((int64_t)p * 2 + 1) * C + c]; }
     if (FIN == 0) {
         const double mean = s0 / rows;
@@ -388,12 +390,14 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict
 }
 
 // ---- attention pooling, training forward: probabilities and pooled context are kept -----------------------------------
+constexpr int ATT_WAVES = 16;     // one 1024-thread workgroup per sequence: 16 row streams in flight on its CU
+
 template <int NF>   // 2H = 64*NF
-__global__ __launch_bounds__(256) void attnpool_train_kernel(const float* __restrict__ seq, const float* __restrict__ watt,
-                                                             const float* __restrict__ batt, float* __restrict__ prob,
-                                                             float* __restrict__ ctx_out, int T) {
+__global__ __launch_bounds__(ATT_WAVES * 64) void attnpool_train_kernel(const float* __restrict__ seq, const float* __restrict__ watt,
+                                                                        const float* __restrict__ batt, float* __restrict__ prob,
+                                                                        float* __restrict__ ctx_out, int T) {
     constexpr int F = 64 * NF;
-    __shared__ float s_m[4], s_l[4], s_ctx[4][F];
+    __shared__ float s_m[ATT_WAVES], s_l[ATT_WAVES], s_ctx[ATT_WAVES][F];
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* sb = seq + (int64_t)b * T * F;
     float* pb = prob + (int64_t)b * T;
@@ -402,7 +406,8 @@ __global__ __launch_bounds__(256) void attnpool_train_kernel(const float* __rest
     for (int i = 0; i < NF; ++i) wa[i] = watt[lane + 64 * i];
     const float ba = batt[0];
     float m = -INFINITY, l = 0.f;
-    for (int t = w; t < T; t += 4) {
+#pragma unroll 2
+    for (int t = w; t < T; t += ATT_WAVES) {
         float d = 0.f;
 #pragma unroll
         for (int i = 0; i < NF; ++i) d += sb[(int64_t)t * F + lane + 64 * i] * wa[i];
@@ -414,26 +419,33 @@ __global__ __launch_bounds__(256) void attnpool_train_kernel(const float* __rest
     }
     if (lane == 0) { s_m[w] = m; s_l[w] = l; }
     __syncthreads();
-    const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    float M = s_m[0];
+#pragma unroll
+    for (int k = 1; k < ATT_WAVES; ++k) M = fmaxf(M, s_m[k]);
     float Lt = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Lt += s_l[k] > 0.f ? s_l[k] * expf(s_m[k] - M) : 0.f;
+    for (int k = 0; k < ATT_WAVES; ++k) Lt += s_l[k] > 0.f ? s_l[k] * expf(s_m[k] - M) : 0.f;
     float ctx[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) ctx[i] = 0.f;
-    for (int t = w; t < T; t += 4) {
+#pragma unroll 2
+    for (int t = w; t < T; t += ATT_WAVES) {
         // lane 0 of this wave wrote pb[t] in the first pass: read it past the (non-coherent) vector L1
         const float p = expf(__hip_atomic_load(pb + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - M) / Lt;
-        __builtin_amdgcn_s_waitcnt(0);               // every lane has its copy before lane 0 overwrites the score
-        if (lane == 0) pb[t] = p;
 #pragma unroll
         for (int i = 0; i < NF; ++i) ctx[i] += p * sb[(int64_t)t * F + lane + 64 * i];
+        if (lane == 0) pb[t] = p;                    // after this wave's own read of the score (program order, same address)
     }
 #pragma unroll
     for (int i = 0; i < NF; ++i) s_ctx[w][lane + 64 * i] = ctx[i];
     __syncthreads();
     const int f = threadIdx.x;
-    if (f < F) ctx_out[(int64_t)b * F + f] = s_ctx[0][f] + s_ctx[1][f] + s_ctx[2][f] + s_ctx[3][f];
+    if (f < F) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < ATT_WAVES; ++k) a += s_ctx[k][f];
+        ctx_out[(int64_t)b * F + f] = a;
+    }
 }
 
 // logits = (ctx * mask) . wfc^T + bfc
@@ -490,12 +502,12 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const float* __restrict__ d
 // attention pooling backward for one sequence: dh[t][f] = p_t*dctx[f] + ds_t*wa[f], ds_t = p_t*(dp_t - sum_t' p_t' dp_t'),
 // dp_t = dctx . h_t; per-sequence partials of dwatt[f] = sum_t ds_t h_t[f] and dbatt = sum_t ds_t
 template <int NF>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ seq, const float* __restrict__ prob,
-                                                       const float* __restrict__ dctx, const float* __restrict__ watt,
-                                                       float* __restrict__ dp_scratch, float* __restrict__ dseq,
-                                                       float* __restrict__ dwatt_part, float* __restrict__ dbatt_part, int T) {
+__global__ __launch_bounds__(ATT_WAVES * 64) void attn_bwd_kernel(const float* __restrict__ seq, const float* __restrict__ prob,
+                                                                  const float* __restrict__ dctx, const float* __restrict__ watt,
+                                                                  float* __restrict__ dp_scratch, float* __restrict__ dseq,
+                                                                  float* __restrict__ dwatt_part, float* __restrict__ dbatt_part, int T) {
     constexpr int F = 64 * NF;
-    __shared__ float s_dot[4], s_db[4], s_dw[4][F];
+    __shared__ float s_dot[ATT_WAVES], s_db[ATT_WAVES], s_dw[ATT_WAVES][F];
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* sb = seq + (int64_t)b * T * F;
     const float* pb = prob + (int64_t)b * T;
@@ -505,7 +517,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NF; ++i) { dc[i] = dctx[(int64_t)b * F + lane + 64 * i]; wa[i] = watt[lane + 64 * i]; dw[i] = 0.f; }
     float dot = 0.f;
-    for (int t = w; t < T; t += 4) {
+#pragma unroll 2
+    for (int t = w; t < T; t += ATT_WAVES) {
         float d = 0.f;
 #pragma unroll
         for (int i = 0; i < NF; ++i) d += sb[(int64_t)t * F + lane + 64 * i] * dc[i];
@@ -515,9 +528,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     if (lane == 0) s_dot[w] = dot;
     __syncthreads();
-    dot = s_dot[0] + s_dot[1] + s_dot[2] + s_dot[3];
+    dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < ATT_WAVES; ++k) dot += s_dot[k];
     float dbs = 0.f;
-    for (int t = w; t < T; t += 4) {
+#pragma unroll 2
+    for (int t = w; t < T; t += ATT_WAVES) {
         const float p = pb[t];
         const float ds = p * (__hip_atomic_load(dpb + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - dot);   // written by lane 0 above
         dbs += ds;
@@ -533,8 +549,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     if (lane == 0) s_db[w] = dbs;
     __syncthreads();
     const int f = threadIdx.x;
-    if (f < F) dwatt_part[(int64_t)b * F + f] = s_dw[0][f] + s_dw[1][f] + s_dw[2][f] + s_dw[3][f];
-    if (f == 0) dbatt_part[b] = s_db[0] + s_db[1] + s_db[2] + s_db[3];
+    if (f < F) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < ATT_WAVES; ++k) a += s_dw[k][f];
+        dwatt_part[(int64_t)b * F + f] = a;
+    }
+    if (f == 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < ATT_WAVES; ++k) a += s_db[k];
+        dbatt_part[b] = a;
+    }
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -592,7 +618,8 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(float* gates, con
             const float* gp = gates + goff[r] + (int64_t)t * 8 * H;
             const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
             const float c = cst[hoff[r] + (int64_t)t * 2 * H];
-            const float cp = first ? 0.f : cst[hoff[r] + (int64_t)tprev * 2 * H];
+            const float cpl = cst[hoff[r] + (int64_t)(first ? t : tprev) * 2 * H];
+            const float cp = first ? 0.f : cpl;
             const float dh = dh_out[hoff[r] + (int64_t)t * 2 * H] + (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
             const float tc = tanhf(c);
             const float dc = dcc[r] + dh * og * (1.0f - tc * tc);
@@ -604,12 +631,12 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(float* gates, con
             const int row = q * 4 + r;
             dgw[row * LDG + unit] = d_i; dgw[row * LDG + H + unit] = d_f;
             dgw[row * LDG + 2 * H + unit] = d_g; dgw[row * LDG + 3 * H + unit] = d_o;
-            if (brow[r]) {
+            {   // rows past B replicate row B-1 bit for bit (see lstm_rec_kernel): unconditional stores, branch-free loop
                 float* go = gates + goff[r] + (int64_t)t * 8 * H;
                 go[0] = d_i; go[H] = d_f; go[2 * H] = d_g; go[3 * H] = d_o;
             }
         }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
         const float* dgr = dgbuf + cur * 16 * LDG;
 #pragma unroll
@@ -652,7 +679,6 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, co
 #pragma unroll
         for (int kk = 0; kk < 64; ++kk) breg[j][kk] = wd[(int64_t)kk * H + 64 * j + lane];
 
-    const bool own = b0 + row < B;
     const int bo = min(b0 + row, B - 1);
     const int64_t goff = (int64_t)bo * T * 8 * H + dir * 4 * H + unit;
     const int64_t hoff = (int64_t)bo * T * 2 * H + dir * H + unit;
@@ -666,17 +692,18 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, co
         cc = cst[hoff + (int64_t)t * 2 * H];
         dho = dh_out[hoff + (int64_t)t * 2 * H];
     }
+    vmem_drain();
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : T - 1 - s;           // reverse of the forward order
         const int tprev = dir ? t + 1 : t - 1;       // the step the forward pass ran just before t == the next step here
         const bool last = s + 1 == T;
-        float nig = 0.f, nfg = 0.f, ngg = 0.f, nog = 0.f, ncc = 0.f, ndho = 0.f;
-        if (!last) {
-            const float* gp = gates + goff + (int64_t)tprev * 8 * H;
-            nig = gp[0]; nfg = gp[H]; ngg = gp[2 * H]; nog = gp[3 * H];
-            ncc = cst[hoff + (int64_t)tprev * 2 * H];
-            ndho = dh_out[hoff + (int64_t)tprev * 2 * H];
-        }
+        // next step's operands (branch-free: the last step reloads its own and zeroes c_prev)
+        const int tl = last ? t : tprev;
+        const float* gp = gates + goff + (int64_t)tl * 8 * H;
+        const float nig = gp[0], nfg = gp[H], ngg = gp[2 * H], nog = gp[3 * H];
+        const float ncl = cst[hoff + (int64_t)tl * 2 * H];
+        const float ncc = last ? 0.f : ncl;
+        const float ndho = dh_out[hoff + (int64_t)tl * 2 * H];
         const float dh = dho + dh_rec;
         const float tc = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * cc)) - 1.0f;
         const float dc = dcc + dh * og * (1.0f - tc * tc);
@@ -686,17 +713,20 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, co
         const float d_g = dc * ig * (1.0f - gg * gg);
         dcc = dc * fg;
         dg[row][unit] = d_i; dg[row][H + unit] = d_f; dg[row][2 * H + unit] = d_g; dg[row][3 * H + unit] = d_o;
-        if (own) {
+        {
             float* go = gates + goff + (int64_t)t * 8 * H;
             go[0] = d_i; go[H] = d_f; go[2 * H] = d_g; go[3 * H] = d_o;
         }
-        __syncthreads();
+        lds_barrier();
         f32x4 acc[NCH][2];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        float4 ab[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ab[i] = *reinterpret_cast<const float4*>(&dg[arow][64 * w + 4 * i]);
 #pragma unroll
         for (int kk = 0; kk < 64; kk += 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&dg[arow][64 * w + kk]);
+            const float4 a4 = ab[kk / 4];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 acc[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, breg[j][kk + 0], acc[j][0], 0, 0, 0);
@@ -709,7 +739,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, co
         for (int j = 0; j < NCH; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[w][r][64 * j + lane] = acc[j][0][r] + acc[j][1][r];
-        __syncthreads();
+        lds_barrier();
         float sum = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) sum += part[ww][row][unit];
@@ -739,7 +769,7 @@ struct Ctx {
 
 static int bn_stats(const Ctx& c, const float* y, int64_t rows, float* stat) {
     const int C = c.d.C;
-    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(RED_PARTS, rows / 64));
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(RED_PARTS, rows / 128));
     double* partial = reinterpret_cast<double*>(c.ws + c.W.red);
     ProfScope prof("train_bn_reduce", c.s, 0.0, (double)rows * C * 4);
     hipLaunchKernelGGL((colred_partial_kernel<0, 0>), dim3(parts, (C + 63) / 64), dim3(256), 0, c.s, y, (int64_t)C, nullptr, nullptr,
@@ -751,7 +781,7 @@ static int bn_stats(const Ctx& c, const float* y, int64_t rows, float* stat) {
 }
 
 static int colsum(const Ctx& c, const float* a, int64_t lda, int64_t rows, int N, float* out) {
-    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(RED_PARTS, rows / 64));
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(RED_PARTS, rows / 128));
     double* partial = reinterpret_cast<double*>(c.ws + c.W.red);
     ProfScope prof("train_bn_reduce", c.s, 0.0, (double)rows * N * 4);
     hipLaunchKernelGGL((colred_partial_kernel<2, 0>), dim3(parts, (N + 63) / 64), dim3(256), 0, c.s, a, lda, nullptr, nullptr, nullptr,
@@ -766,7 +796,7 @@ static int colsum(const Ctx& c, const float* a, int64_t lda, int64_t rows, int N
 static int bn_backward(const Ctx& c, const float* dout, const float* mask, bool pre, const float* y, const float* stat,
                        const float* g, const float* be, int64_t rows, float* dgamma, float* dbeta, float* dy) {
     const int C = c.d.C;
-    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(RED_PARTS, rows / 64));
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(RED_PARTS, rows / 128));
     double* partial = reinterpret_cast<double*>(c.ws + c.W.red);
     float* sums = c.ws + c.W.small;                      // [2][C] (C <= 1024 fits: small >= 64 + ...)
     {
@@ -987,9 +1017,9 @@ int rsaf_cnnlstm_train_forward(const float* x, int B, int T, int input_dim, int 
     {
         ProfScope prof("train_attnpool", s, 0.0, (double)rows2 * 2 * H * 8);
         if (H == 128)
-            hipLaunchKernelGGL(attnpool_train_kernel<4>, dim3(B), dim3(256), 0, s, lin, P + L.watt, P + L.batt, saved + S.prob, saved + S.ctx, Tp);
+            hipLaunchKernelGGL(attnpool_train_kernel<4>, dim3(B), dim3(ATT_WAVES * 64), 0, s, lin, P + L.watt, P + L.batt, saved + S.prob, saved + S.ctx, Tp);
         else
-            hipLaunchKernelGGL(attnpool_train_kernel<2>, dim3(B), dim3(256), 0, s, lin, P + L.watt, P + L.batt, saved + S.prob, saved + S.ctx, Tp);
+            hipLaunchKernelGGL(attnpool_train_kernel<2>, dim3(B), dim3(ATT_WAVES * 64), 0, s, lin, P + L.watt, P + L.batt, saved + S.prob, saved + S.ctx, Tp);
         hipLaunchKernelGGL(fc_fwd_kernel, dim3(B), dim3(256), 0, s, saved + S.ctx, mask_fc, P + L.wfc, P + L.bfc, logits, 2 * H, d.NC);
         RSAF_CHECK_HIP(hipGetLastError());
     }
@@ -1041,10 +1071,10 @@ int rsaf_cnnlstm_train_backward(const float* x, int B, int T, int input_dim, int
         hipLaunchKernelGGL(fc_bwd_kernel, dim3((F + 255) / 256), dim3(256), 0, s, dlogits, saved + S.ctx, mask_fc, P + L.wfc, G + L.wfc,
                            G + L.bfc, dctx, B, F, d.NC);
         if (H == 128)
-            hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(B), dim3(256), 0, s, seq_top, saved + S.prob, dctx, P + L.watt, dp_scr, dseq,
+            hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(B), dim3(ATT_WAVES * 64), 0, s, seq_top, saved + S.prob, dctx, P + L.watt, dp_scr, dseq,
                                dwatt_part, dbatt_part, Tp);
         else
-            hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(B), dim3(256), 0, s, seq_top, saved + S.prob, dctx, P + L.watt, dp_scr, dseq,
+            hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(B), dim3(ATT_WAVES * 64), 0, s, seq_top, saved + S.prob, dctx, P + L.watt, dp_scr, dseq,
                                dwatt_part, dbatt_part, Tp);
         RSAF_CHECK_HIP(hipGetLastError());
     }

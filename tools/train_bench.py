@@ -18,6 +18,7 @@ from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
 ap = argparse.ArgumentParser()
 ap.add_argument("--torch", action="store_true")
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
 args = ap.parse_args()
 _lib.load()
 
@@ -81,7 +82,7 @@ def run(model, B, T, steps, prof):
     return dt, (_lib.prof_end() if prof else None)
 
 
-for B, T, tag in SHAPES:
+for B, T, tag in (SHAPES if args.only < 0 else [SHAPES[args.only]]):
     m = CNNLSTM().to("cuda").train()
     dt, rec = run(m, B, T, args.steps, True)
     print(f"== {tag}: B={B} T={T}: {dt * 1e3:.1f} ms per step (HIP path)", flush=True)
