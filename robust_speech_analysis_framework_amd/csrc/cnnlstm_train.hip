@@ -653,38 +653,37 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(float* gates, con
 }
 
 // ---- the same backward recurrence for small batches: 4 batch rows per workgroup ---------------------------------------
-// Thread (row, unit) = (tid / H, tid % H) owns one cell: lane-local gate / cell derivatives, dgates to HBM (in place) and
-// to LDS.  dh_rec = dgates . W_hh with v_mfma_f32_4x4x1_16B_f32 (row i of every block = batch row i): wave w contracts
-// the gate rows k in [64w, 64w + 64) against all H units (column c of chain j = unit 64j + c; W_hh slice register-resident,
-// H registers per lane); the H/16 partial products meet in LDS and thread (row, unit) sums them in a fixed order.
+// Wave w owns hidden units 16w..16w+15; lane (q, u) = (lane / 16, lane % 16) owns cell (row q, unit 16w + u): lane-local
+// gate / cell derivatives, dgates to HBM (in place) and to LDS (double-buffered: one LDS-only barrier per step).
+// dh_rec = dgates . W_hh with v_mfma_f32_4x4x1_16B_f32 (row i of every block = batch row i): the 16 blocks of an
+// instruction are 4 gates x 4 groups of 4 units, i.e. lane (g, u) contracts the H rows of gate g against unit u (its
+// W_hh column slice is register-resident, H registers) and a two-step butterfly over the gate lanes completes the sum
+// in a fixed order.  No partial products through LDS.
 template <int H>
 __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, const float* __restrict__ cst,
                                                                 const float* __restrict__ dh_out, const float* __restrict__ whh,
                                                                 int B, int T) {
-    constexpr int NW = H / 16;                      // waves; 64 * NW = 4 * H threads
-    constexpr int NCH = H / 64;                     // 64-column chains per wave
+    constexpr int NW = H / 16;
     constexpr int LDG = 4 * H + 4;
-    __shared__ __attribute__((aligned(16))) float dg[4][LDG];
-    __shared__ float part[NW][4][H];
+    __shared__ __attribute__((aligned(16))) float dg[2][4][LDG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q = lane >> 4, u = lane & 15;
     const int dir = blockIdx.y, b0 = blockIdx.x * 4;
-    const int row = tid / H, unit = tid % H;
+    const int unit = 16 * w + u;
     const int arow = lane & 3;
 
-    // breg[j][kk] = W_hh[dir][64w + kk][64j + lane]
-    float breg[NCH][64];
-    const float* wd = whh + (int64_t)dir * 4 * H * H + (int64_t)(64 * w) * H;
+    // breg[m] = W_hh[dir][q*H + m][unit]   (q as the gate of this lane's blocks)
+    float breg[H];
+    {
+        const float* wd = whh + (int64_t)dir * 4 * H * H + (int64_t)(q * H) * H + unit;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 64; ++kk) breg[j][kk] = wd[(int64_t)kk * H + 64 * j + lane];
-
-    const int bo = min(b0 + row, B - 1);
+        for (int m = 0; m < H; ++m) breg[m] = wd[(int64_t)m * H];
+    }
+    const int bo = min(b0 + q, B - 1);              // rows past B replicate row B-1 bit for bit (see lstm_rec_kernel)
     const int64_t goff = (int64_t)bo * T * 8 * H + dir * 4 * H + unit;
     const int64_t hoff = (int64_t)bo * T * 2 * H + dir * H + unit;
     float dcc = 0.f, dh_rec = 0.f;
-    // values of the current step (prefetched)
-    float ig, fg, gg, og, cc, dho;
+    float ig, fg, gg, og, cc, dho;                  // operands of the current step (prefetched)
     {
         const int t = dir ? 0 : T - 1;
         const float* gp = gates + goff + (int64_t)t * 8 * H;
@@ -693,6 +692,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, co
         dho = dh_out[hoff + (int64_t)t * 2 * H];
     }
     vmem_drain();
+    int cur = 0;
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : T - 1 - s;           // reverse of the forward order
         const int tprev = dir ? t + 1 : t - 1;       // the step the forward pass ran just before t == the next step here
@@ -704,46 +704,58 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, co
         const float ncl = cst[hoff + (int64_t)tl * 2 * H];
         const float ncc = last ? 0.f : ncl;
         const float ndho = dh_out[hoff + (int64_t)tl * 2 * H];
+
         const float dh = dho + dh_rec;
         const float tc = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * cc)) - 1.0f;
         const float dc = dcc + dh * og * (1.0f - tc * tc);
         const float d_o = dh * tc * og * (1.0f - og);
         const float d_i = dc * gg * ig * (1.0f - ig);
-        const float d_f = dc * ncc * fg * (1.0f - fg);           // c of the previous forward step (0 at the first: ncc = 0)
+        const float d_f = dc * ncc * fg * (1.0f - fg);           // c of the previous forward step (0 at the first)
         const float d_g = dc * ig * (1.0f - gg * gg);
         dcc = dc * fg;
-        dg[row][unit] = d_i; dg[row][H + unit] = d_f; dg[row][2 * H + unit] = d_g; dg[row][3 * H + unit] = d_o;
+        float* dgw = &dg[cur][q][0];
+        dgw[unit] = d_i; dgw[H + unit] = d_f; dgw[2 * H + unit] = d_g; dgw[3 * H + unit] = d_o;
         {
             float* go = gates + goff + (int64_t)t * 8 * H;
             go[0] = d_i; go[H] = d_f; go[2 * H] = d_g; go[3 * H] = d_o;
         }
         lds_barrier();
-        f32x4 acc[NCH][2];
+        // A operand: lane 4*blk + i carries batch row i; the block's gate is this lane's q
+        const float* dgr = &dg[cur][arow][q * H];
+        f32x4 acc[4];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        float4 ab[16];
+        for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 ab[2][8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ab[i] = *reinterpret_cast<const float4*>(&dg[arow][64 * w + 4 * i]);
+        for (int j = 0; j < 8; ++j) ab[0][j] = *reinterpret_cast<const float4*>(dgr + 4 * j);
 #pragma unroll
-        for (int kk = 0; kk < 64; kk += 4) {
-            const float4 a4 = ab[kk / 4];
+        for (int kb = 0; kb < H / 32; ++kb) {
+            if (kb + 1 < H / 32) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                acc[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, breg[j][kk + 0], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, breg[j][kk + 1], acc[j][1], 0, 0, 0);
-                acc[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, breg[j][kk + 2], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, breg[j][kk + 3], acc[j][1], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) ab[(kb + 1) & 1][j] = *reinterpret_cast<const float4*>(dgr + 32 * (kb + 1) + 4 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 a4 = ab[kb & 1][j];
+                const int m = 32 * kb + 4 * j;
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, breg[m + 0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, breg[m + 1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, breg[m + 2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, breg[m + 3], acc[3], 0, 0, 0);
             }
         }
+        // lane (g, u), register r: sum over the rows of gate g for (batch row r, unit u).  Butterfly over g; lane (q, u)
+        // keeps batch row q.
+        float pr[4];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[w][r][64 * j + lane] = acc[j][0][r] + acc[j][1][r];
-        lds_barrier();
-        float sum = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) sum += part[ww][row][unit];
-        dh_rec = sum;
+        for (int r = 0; r < 4; ++r) {
+            float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            pr[r] = v;
+        }
+        dh_rec = q == 0 ? pr[0] : q == 1 ? pr[1] : q == 2 ? pr[2] : pr[3];
+        cur ^= 1;
         ig = nig; fg = nfg; gg = ngg; og = nog; cc = ncc; dho = ndho;
     }
 }

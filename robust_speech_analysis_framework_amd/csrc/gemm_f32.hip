@@ -285,10 +285,10 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_f32_glds_kernel(const GemmParams p) {
-    constexpr int BK = 32, WM = 64, WN = 64, TM = 2, TN = 2, WAVES_N = BN / WN;
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 512 / ((BM / 64) * (BN / 64) * 64)) void gemm_f32_glds_kernel(const GemmParams p) {
+    constexpr int BK = 32, WM = 64, WN = 64, TM = 2, TN = 2, WAVES_N = BN / WN, NWAVES = (BM / WM) * WAVES_N;
     constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
-    constexpr int A_INS = BM / 8 / 4, B_INS = BN / 8 / 4;      // 1-KiB wave-instructions per wave per k-tile
+    constexpr int A_INS = BM / 8 / NWAVES, B_INS = BN / 8 / NWAVES;      // 1-KiB wave-instructions per wave per k-tile
     extern __shared__ __attribute__((aligned(1024))) float smem_dyn[];
     float* smem = smem_dyn;
 
@@ -434,8 +434,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_glds_kernel(const GemmParams 
     }
 }
 
-static int launch_glds(const GemmParams& p, hipStream_t s) {
-    constexpr int BM = 128, BN = 128;
+template <int BM, int BN>
+static int launch_glds_cfg(const GemmParams& p, hipStream_t s) {
+    constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
     const int lds = 2 * (BM + BN) * 32 * (int)sizeof(float);
     static bool attr_set = false;
@@ -444,9 +445,16 @@ static int launch_glds(const GemmParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN>), dim3((unsigned)tiles, (unsigned)p.nz), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN>), dim3((unsigned)tiles, (unsigned)p.nz), dim3(THREADS), lds, s, p);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
+}
+
+static int launch_glds(const GemmParams& p, hipStream_t s) {
+    // RSAF_GEMM_TALL=1: 256 x 128 tiles (8 waves, one workgroup per CU, 25 % less global->LDS traffic per FLOP)
+    static const int tall = [] { const char* e = getenv("RSAF_GEMM_TALL"); return e ? atoi(e) : 0; }();
+    if (tall && p.M >= 2048) return launch_glds_cfg<256, 128>(p, s);
+    return launch_glds_cfg<128, 128>(p, s);
 }
 
 template <int BM, int BN, int WM, int WN>
