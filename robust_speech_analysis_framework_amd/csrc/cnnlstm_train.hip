@@ -631,7 +631,9 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(float* gates, con
             const int row = q * 4 + r;
             dgw[row * LDG + unit] = d_i; dgw[row * LDG + H + unit] = d_f;
             dgw[row * LDG + 2 * H + unit] = d_g; dgw[row * LDG + 3 * H + unit] = d_o;
-            {   // rows past B replicate row B-1 bit for bit (see lstm_rec_kernel): unconditional stores, branch-free loop
+            // rows past B are clamped copies of row B-1: they must NOT store here, because this loop reads the gates of
+            // step t row by row and a copy in an earlier register row would overwrite them before the real row reads
+            if (brow[r]) {
                 float* go = gates + goff[r] + (int64_t)t * 8 * H;
                 go[0] = d_i; go[H] = d_f; go[2 * H] = d_g; go[3 * H] = d_o;
             }

@@ -131,9 +131,12 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void gemm_f32_kernel(const GemmPar
     do {                                                                                        \
         const int gk = (KT) * BK + c4 * 4;                                                      \
         const int gkc = (gk < p.K) ? gk : 0;                                                    \
+        /* k past the end (K % 32 != 0): any valid address; with a_pad_k the row base of the first row lies \
+           a_pad_k floats in front of the buffer, so offset 0 would be out of bounds there */    \
+        const int gka = (gk < p.K) ? gk : p.a_pad_k;                                            \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
             const int hit = (alo[i] & (gk < p.a_pad_k)) | (ahi[i] & (gk >= p.K - p.a_pad_k));   \
-            const int off = hit ? p.a_pad_k : gkc;                                              \
+            const int off = hit ? p.a_pad_k : gka;                                              \
             ra[i] = *reinterpret_cast<const float4*>(aptr[i] + off);                            \
         }                                                                                       \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \

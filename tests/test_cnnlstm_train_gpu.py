@@ -201,3 +201,48 @@ def test_single_value_per_channel_is_refused_like_batchnorm():
     m, _ = build(16, 32, 64, 701, "silu")
     with pytest.raises(ValueError):
         m(torch.from_numpy(synth_input(1, 3, 16, 702)).to("cuda"))          # T // 2 == 1 frame after the pool
+
+
+def test_sixteen_row_recurrence_kernels_in_a_subprocess():
+    """Batches above RSAF_LSTM_SMALL_MAX (default 1 024) use the 16-row recurrence tiles in inference, training forward
+    and BPTT.  The switch is read once per process, so a child process with the threshold at 0 runs one training step
+    and one eval forward on them and compares with the oracles itself."""
+    import subprocess
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests/golden")
+from weights import synth_input, synth_state_dict
+from oracle import cnnlstm_train_oracle as to, cnnlstm_oracle as co
+from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+for D, C, H, act, B, T, seed in ((16, 32, 128, "silu", 19, 12, 305), (24, 64, 64, "gelu", 3, 31, 306)):
+    sd = synth_state_dict(D, C, H, seed)
+    m = CNNLSTM(input_dim=D, cnn_out_channels=C, lstm_hidden_dim=H, activation_fn=act, dropout_rate=0.5)
+    full = m.state_dict()
+    full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.load_state_dict(full)
+    m = m.to("cuda")
+    x = synth_input(B, T, D, seed + 1)
+    want_eval = co.forward_numpy(sd, x, act)
+    got_eval = m.eval()(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.abs(got_eval - want_eval).max() < 1e-4 * max(np.abs(want_eval).max(), 1.0), "eval"
+    labels = np.arange(B) % 2
+    mk = to.make_masks(B, T, C, H, 0.2, 0.5, seed + 2)
+    t = lambda a: torch.from_numpy(a).cuda()
+    m.train()
+    m.forced_masks = {"res_block1": t(mk["res_block1"]), "res_block2": t(mk["res_block2"]), "lstm": [t(mk["lstm0"])], "fc": t(mk["fc"])}
+    out = m(t(x))
+    torch.nn.CrossEntropyLoss()(out, t(labels)).backward()
+    want = to.forward_backward(sd, x, labels, act, masks=mk)
+    assert np.abs(out.detach().cpu().numpy() - want["logits"]).max() < 1e-4 * max(np.abs(want["logits"]).max(), 1.0), "train logits"
+    for k, p in m.named_parameters():
+        if k.endswith(("conv1.bias", "conv2.bias", "shortcut.0.bias", "attention_weights.bias")):
+            continue
+        g = want["grads"][k]
+        e = np.abs(p.grad.cpu().numpy() - g).max() / max(np.abs(g).max(), 1e-7)
+        assert e < 1e-4, (k, e)
+print("SIXTEEN_ROW_OK")
+'''
+    env = dict(os.environ, RSAF_LSTM_SMALL_MAX="0")
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SIXTEEN_ROW_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
