@@ -122,13 +122,11 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_rec_kernel(const float* xpro
         }
     for (int i = tid; i < 2 * 16 * LDH; i += H / 16 * 64) (&hbuf[0][0][0])[i] = 0.0f;
 
-    // rows of this lane in the C/D map: q*4 + r; clamp for loads, mask for stores
-    int brow[4];
+    // rows of this lane in the C/D map: q*4 + r, clamped to the last batch row (copies replicate it bit for bit)
     int64_t xoff[4], hoff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = b0 + q * 4 + r;
-        brow[r] = b < B;
         const int bc = b < B ? b : B - 1;
         xoff[r] = (int64_t)bc * T * 8 * H + dir * 4 * H + unit;
         hoff[r] = (int64_t)bc * T * 2 * H + dir * H + unit;

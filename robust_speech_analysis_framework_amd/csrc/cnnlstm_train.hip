@@ -99,7 +99,7 @@ static Split make_split(int64_t rows) {
 
 // scratch (floats) shared by forward and backward
 struct WLayout {
-    int64_t bufA, bufB, bufC, bufD;     // [B*T][max(C, 2H)] activations / gradients
+    int64_t bufA, bufB, bufC;           // [B*T][max(C, 2H)] activations / gradients
     int64_t t1, t2;                     // transposed images [Mmax][kp], [Nmax][kp]
     int64_t part;                       // split-K partial products
     int64_t red;                        // column-reduction partials
@@ -119,7 +119,7 @@ static WLayout make_wlayout(const Dims& d, int B, int T) {
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t s = o; o += pad4(n); return s; };
     const int64_t nb = std::max<int64_t>((int64_t)B * T * d.C, (int64_t)B * Tp * wide);
-    W.bufA = take(nb); W.bufB = take(nb); W.bufC = take(nb); W.bufD = take(nb);
+    W.bufA = take(nb); W.bufB = take(nb); W.bufC = take(nb);
     const int64_t Mmax = std::max<int64_t>(d.C, 8 * d.H);
     const int64_t Nmax = std::max<int64_t>(std::max<int64_t>(3 * d.D, 3 * d.C), 2 * d.H);
     W.t1 = take(Mmax * sp.kp); W.t2 = take(Nmax * sp.kp);
@@ -1069,13 +1069,11 @@ int rsaf_cnnlstm_train_backward(const float* x, int B, int T, int input_dim, int
     float* bufA = scratch + WL.bufA;
     float* bufB = scratch + WL.bufB;
     float* bufC = scratch + WL.bufC;
-    float* bufD = scratch + WL.bufD;
     float* small = scratch + WL.small;
     float* dctx = small + 2 * 1024 + 64;               // after the BN `sums` area
     float* dwatt_part = dctx + (int64_t)B * F;
     float* dbatt_part = dwatt_part + (int64_t)B * F;
     float* dp_scr = dbatt_part + B + 4;
-    (void)bufD;
 
     // ---- classifier + attention pooling ----------------------------------------------------------------------------
     const float* seq_top = saved + S.hout[d.L - 1];
