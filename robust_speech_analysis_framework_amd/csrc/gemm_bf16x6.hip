@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_dma_kernel(const Gemm6DmaP
     constexpr int BM = 128, BN = 128, BK = 16;
     constexpr int PLANE = BM * BK;                       // 2048 bf16 = 4 KiB
     constexpr int STAGE = 6 * PLANE;                     // 24 KiB
-    __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * STAGE];
+    constexpr int NST = 3;                               // stages: DMA runs two k-tiles ahead of the multiply
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -281,11 +282,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_dma_kernel(const Gemm6DmaP
     } while (0)
 
     G6_DMA(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk > 1) G6_DMA(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int st = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) G6_DMA(kt + 1, (kt + 1) & 1);
-        const unsigned short* img = smem + (kt & 1) * STAGE;
+        // stage (st + 2) % 3 was read in iteration kt - 1: every wave is past that iteration's barrier
+        if (kt + 2 < nk) G6_DMA(kt + 2, st >= 1 ? st - 1 : 2);
+        const unsigned short* img = smem + st * STAGE;
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -314,8 +318,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_dma_kernel(const Gemm6DmaP
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][0], c, 0, 0, 0);
                 acc[mt][nt] = c;
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the next k-tile (issued one iteration ago: 6 DMA instructions per wave and k-tile) must have landed
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        st = st == NST - 1 ? 0 : st + 1;
     }
 #undef G6_DMA
 
