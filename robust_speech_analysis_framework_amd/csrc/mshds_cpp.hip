@@ -217,13 +217,24 @@ __device__ void fft_inplace(double2* a, int n, int log2n, const double2* __restr
     }
 }
 
-__device__ __forceinline__ int bitrev(int i, int log2n) { return (int)(__brev((unsigned)i) >> (32 - log2n)); }
+__device__ __forceinline__ int bitrev(int i, int log2n) { return log2n ? (int)(__brev((unsigned)i) >> (32 - log2n)) : 0; }
+
+// Real-input FFT of n = 2m points from an m-point complex FFT of z[j] = x[2j] + i x[2j+1] (already transformed in `a`):
+// X[k] = E + W_n^k O,  E = (Z[k] + conj Z[m-k]) / 2,  O = -i (Z[k] - conj Z[m-k]) / 2,  k = 0..m  (Z[m] = Z[0]).
+__device__ __forceinline__ double2 real_fft_bin(const double2* a, int m, int k, const double2* __restrict__ tw, int twstep) {
+    const double2 zk = a[k == m ? 0 : k], zc = a[k == 0 ? 0 : m - k];
+    const double er = 0.5 * (zk.x + zc.x), ei = 0.5 * (zk.y - zc.y);
+    const double orr = 0.5 * (zk.y + zc.y), oi = -0.5 * (zk.x - zc.x);
+    const double2 w = k == m ? make_double2(-1.0, 0.0) : tw[k * twstep];
+    return make_double2(er + w.x * orr - w.y * oi, ei + w.x * oi + w.y * orr);
+}
 
 __global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
                                                        const double* __restrict__ res, int cap_res, int cap_frames,
                                                        const double* __restrict__ win1000, const double2* __restrict__ tw,
                                                        double preemph, double* __restrict__ ceps) {
-    __shared__ double2 a[NFFT_MAX];
+    __shared__ double2 a[NFFT_MAX / 2];
+    __shared__ double xs[NFFT_MAX + 1];                 // windowed frame, then the ln-power half spectrum
     __shared__ double s_red[4];
     const int clip = blockIdx.y, f = blockIdx.x;
     const int nseg = hdr[4 * clip];
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ s
     const int nx = (int)s.nx, nfft = (int)s.nfft, m_out = (int)s.m_out;
     int log2n = 0;
     while ((1 << log2n) < nfft) ++log2n;
+    const int m = nfft >> 1, log2m = log2n - 1, twstep = NFFT_MAX / nfft;
     const double* y = res + (int64_t)clip * cap_res + (int64_t)s.res_off;
     const double t = s.t1 + (double)fl * DT;
     const int64_t idx0 = (int64_t)floor((t - 0.5 * s.window - s.x1o) / DXO + 0.5);   // Sampled_xToNearestIndex, 0-based
@@ -271,40 +283,33 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ s
                 }
                 v = (loc[r] - mean) * w;
             }
-            a[bitrev(i, log2n)] = make_double2(v, 0.0);
+            xs[i] = v;
         }
     }
     __syncthreads();
-    fft_inplace(a, nfft, log2n, tw, tid);
-    // ln power of the bins 0..nfft/2 (spectrum scaled by the sample period), mirrored to a real even sequence
-    const int nq = nfft / 2 + 1;
-    double lp[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int k = tid + 256 * r;
-        lp[r] = 0.0;
-        if (k < nq) {
-            const double re = a[k].x * DXO, im = a[k].y * DXO;
-            lp[r] = log(re * re + im * im + 1e-300);
-        }
+    // both transforms have real input (the second one even as well): one complex FFT of half the length each
+    for (int j = tid; j < m; j += 256) a[bitrev(j, log2m)] = make_double2(xs[2 * j], xs[2 * j + 1]);
+    __syncthreads();
+    fft_inplace(a, m, log2m, tw, tid);
+    // ln power of the bins 0..nfft/2 (spectrum scaled by the sample period)
+    for (int k = tid; k <= m; k += 256) {
+        const double2 X = real_fft_bin(a, m, k, tw, twstep);
+        const double re = X.x * DXO, im = X.y * DXO;
+        xs[k] = log(re * re + im * im + 1e-300);
     }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int k = tid + 256 * r;
-        if (k < nq) {
-            a[bitrev(k, log2n)] = make_double2(lp[r], 0.0);
-            if (k > 0 && k < nfft / 2) a[bitrev(nfft - k, log2n)] = make_double2(lp[r], 0.0);
-        }
+    // real even sequence e[n] = lp[min(n, nfft - n)]
+    for (int j = tid; j < m; j += 256) {
+        const int n0 = 2 * j, n1 = 2 * j + 1;
+        a[bitrev(j, log2m)] = make_double2(xs[n0 <= m ? n0 : nfft - n0], xs[n1 <= m ? n1 : nfft - n1]);
     }
     __syncthreads();
-    fft_inplace(a, nfft, log2n, tw, tid);
+    fft_inplace(a, m, log2m, tw, tid);
     const double sdx = 1.0 / (DXO * (double)nfft);
     double* o = ceps + ((int64_t)clip * cap_frames + f) * NQ_MAX;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int k = tid + 256 * r;
-        if (k < nq) { const double cv = a[k].x * sdx; o[k] = cv * cv; }
+    for (int k = tid; k <= m; k += 256) {
+        const double cv = real_fft_bin(a, m, k, tw, twstep).x * sdx;
+        o[k] = cv * cv;
     }
 }
 
