@@ -331,6 +331,56 @@ __device__ void bitonic_sort(double* v, int n, int tid) {
     }
 }
 
+// The same sort for n = 256 or 512 with the elements in registers (thread t owns v[t] and, for 512, v[t + 256]): the
+// compare-exchange distances below 64 are wave shuffles, 256 is thread-local, only 64 and 128 go through LDS.
+template <int E>
+__device__ void bitonic_sort_reg(double* v, int tid) {
+    constexpr int N = 256 * E;
+    double x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = v[tid + 256 * e];
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 256) {                                   // E == 2, k == 512: partner in the same thread, ascending
+                if (E == 2) {
+                    const double lo = x[0] < x[E - 1] ? x[0] : x[E - 1], hi = x[0] < x[E - 1] ? x[E - 1] : x[0];
+                    x[0] = lo; x[E - 1] = hi;
+                }
+                continue;
+            }
+            double y[E];
+            if (j >= 64) {
+                __syncthreads();                               // earlier readers of v are done
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[tid + 256 * e] = x[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) y[e] = v[(tid ^ j) + 256 * e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) y[e] = __shfl_xor(x[e], j, 64);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = tid + 256 * e;
+                const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                const double mn = x[e] < y[e] ? x[e] : y[e], mx = x[e] < y[e] ? y[e] : x[e];
+                x[e] = keep_min ? mn : mx;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[tid + 256 * e] = x[e];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void sort_lds(double* v, int n, int tid) {
+    if (n == 512) bitonic_sort_reg<2>(v, tid);
+    else if (n == 256) bitonic_sort_reg<1>(v, tid);
+    else bitonic_sort(v, n, tid);
+}
+
 __device__ double quantile_half(const double* a, int n) {     // Praat NUMquantile(sorted, 0.5)
     if (n < 1) return 0.0;
     if (n == 1) return a[0];
@@ -392,7 +442,7 @@ __global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ 
     for (int i = tid; i < p2; i += 256)
         srt[i] = i < nc ? (db[n2 + i] - db[i]) / ((double)(n2 + i) * DQ - (double)i * DQ) : INFINITY;
     __syncthreads();
-    bitonic_sort(srt, p2, tid);
+    sort_lds(srt, p2, tid);
     const double slope = quantile_half(srt, nc);
     __syncthreads();
     // ... intercept = median of the residual offsets.  nq = 2^k + 1 (the usual 513): sort the first 2^k values
@@ -405,14 +455,14 @@ __global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ 
         const int hn = p2 >> 1;                                  // nq - 1
         for (int i = tid; i < hn; i += 256) srt[i] = db[i] - slope * ((double)i * DQ);
         __syncthreads();
-        bitonic_sort(srt, hn, tid);
+        sort_lds(srt, hn, tid);
         const double e = db[nq - 1] - slope * ((double)(nq - 1) * DQ);
         const double lo_v = srt[hn / 2 - 1], hi_v = srt[hn / 2];  // the middle of the union is the median of (lo, e, hi)
         icpt = e <= lo_v ? lo_v : (e >= hi_v ? hi_v : e);
     } else {
         for (int i = tid; i < p2; i += 256) srt[i] = i < nq ? db[i] - slope * ((double)i * DQ) : INFINITY;
         __syncthreads();
-        bitonic_sort(srt, p2, tid);
+        sort_lds(srt, p2, tid);
         icpt = quantile_half(srt, nq);
     }
     // Vector_getMaximumAndX (parabolic) over [1/ceiling, 1/floor]: end points first, then the local maxima in
