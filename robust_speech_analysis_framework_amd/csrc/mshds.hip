@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(64) void hnr_stats_kernel(const double* __restrict_
 }
 
 // ---- Gaussian-window spectrogram slice + spectral moments, gated by pitch definedness ----------------------
-// one workgroup per frame; fp64 radix-2 FFT (in LDS) of the zero-padded windowed frame, bins 0..nbins-1 (bin width 1/(dx*nfft))
+// one workgroup per frame; fp64 radix-2 FFT (in LDS, half length: real input) of the zero-padded windowed frame, bins 0..nbins-1 (bin width 1/(dx*nfft))
 __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                            const ClipInfo* __restrict__ pitch_ci, const double* __restrict__ sel_freq,
                                                            double pitch_dt, double ceiling, const double* __restrict__ win,
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restri
                                                            double* __restrict__ mom /* [frames][5]: ok, cog, sd, skew, kurt */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double2* a = reinterpret_cast<double2*>(smem_raw);          // nfft complex values of the FFT
-    double* pw = reinterpret_cast<double*>(a + nfft);            // nbins
+    double* pw = reinterpret_cast<double*>(a + nfft / 2);        // nbins (the FFT works on nfft / 2 complex values)
     __shared__ double s_red[8][4];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
@@ -1140,23 +1140,30 @@ __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restri
     }
     const float* x = wav + c.sample_off;
     const int64_t start = low_index(t) + 1 - half;
-    // windowed frame, zero-padded to nfft, stored bit-reversed for the in-place radix-2 FFT
+    // windowed frame, zero-padded to nfft.  Real input: one complex FFT of half the length over z[j] = x[2j] + i x[2j+1]
+    // (stored bit-reversed for the in-place radix-2 passes), then X[k] = E + W^k O with E / O the even / odd parts.
     const int nthr = blockDim.x;
     int log2n = 0;
     while ((1 << log2n) < nfft) ++log2n;
-    for (int j = tid; j < nfft; j += nthr) {
-        double v = 0.0;
-        if (j < nsamp) {
-            int64_t i = start + j;
-            i = i < 0 ? 0 : (i > c.n_samples - 1 ? c.n_samples - 1 : i);
-            v = (double)x[i] * win[j];
+    const int m = nfft >> 1, log2m = log2n - 1;
+    for (int j = tid; j < m; j += nthr) {
+        double v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int jj = 2 * j + e;
+            v[e] = 0.0;
+            if (jj < nsamp) {
+                int64_t i = start + jj;
+                i = i < 0 ? 0 : (i > c.n_samples - 1 ? c.n_samples - 1 : i);
+                v[e] = (double)x[i] * win[jj];
+            }
         }
-        a[(int)(__brev((unsigned)j) >> (32 - log2n))] = make_double2(v, 0.0);
+        a[log2m ? (int)(__brev((unsigned)j) >> (32 - log2m)) : 0] = make_double2(v[0], v[1]);
     }
     __syncthreads();
-    for (int st = 1; st <= log2n; ++st) {
+    for (int st = 1; st <= log2m; ++st) {
         const int half_ = 1 << (st - 1), tstep_ = nfft >> st;
-        for (int b = tid; b < (nfft >> 1); b += nthr) {
+        for (int b = tid; b < (m >> 1); b += nthr) {
             const int grp = b >> (st - 1), p = b & (half_ - 1);
             const int i0 = (grp << st) + p, i1 = i0 + half_;
             const double2 w = tw[p * tstep_];
@@ -1167,7 +1174,14 @@ __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restri
         }
         __syncthreads();
     }
-    for (int k = tid; k < nbins; k += nthr) pw[k] = a[k].x * a[k].x + a[k].y * a[k].y;
+    for (int k = tid; k < nbins; k += nthr) {              // nbins <= nfft / 2 + 1
+        const double2 zk = a[k == m ? 0 : k], zc = a[k == 0 ? 0 : m - k];
+        const double er = 0.5 * (zk.x + zc.x), ei = 0.5 * (zk.y - zc.y);
+        const double orr = 0.5 * (zk.y + zc.y), oi = -0.5 * (zk.x - zc.x);
+        const double2 w = k == m ? make_double2(-1.0, 0.0) : tw[k];
+        const double re = er + w.x * orr - w.y * oi, im = ei + w.x * oi + w.y * orr;
+        pw[k] = re * re + im * im;
+    }
     __syncthreads();
     double s0 = 0, s1 = 0;
     for (int k = tid; k < nbins; k += nthr) { s0 += pw[k]; s1 += pw[k] * (k * fstep); }
@@ -2519,11 +2533,11 @@ int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const v
     RSAF_CHECK_ARG(nfft > 0 && (nfft & (nfft - 1)) == 0 && nbins > 0 && nbins <= nfft / 2 + 1, "bad FFT geometry");
     hipStream_t s = (hipStream_t)stream;
     RSAF_CHECK_ARG(nfft >= 2 && (nfft & (nfft - 1)) == 0 && nfft >= nsamp_window && nbins <= nfft / 2 + 1, "nfft must be a power of two >= window");
-    const size_t lds = (size_t)(2 * nfft + nbins) * sizeof(double);
+    const size_t lds = (size_t)(nfft + nbins) * sizeof(double);
     RSAF_CHECK_ARG(lds <= 60 * 1024, "spectrogram window too long");
     if (max_frames > 0) {
         ProfScope prof("mshds_spec_moments", s, 0.0, 0.0);
-        const int threads = nfft >= 1024 ? 512 : 256;
+        const int threads = nfft >= 2048 ? 512 : 256;      // nfft / 4 butterflies per pass of the half-length FFT
         hipLaunchKernelGGL(spec_moments_kernel, dim3(max_frames, n_clips), dim3(threads), lds, s, wav,
                            (const ClipInfo*)clip_info, (const ClipInfo*)pitch_clip_info, sel_freq, pitch_dt, ceiling,
                            window, (const double2*)twiddle, nsamp_window, nsamp_window / 2, nfft, nbins, time_step,
