@@ -141,6 +141,9 @@ class MshdsEngine:
         self.device = torch.device(device)
         self._tables = {}
         self.fo_doubles = _lib.load().rsaf_mshds_frameout_doubles()
+        import os
+        self.n_streams = int(os.environ.get("RSAF_MSHDS_STREAMS", "2"))     # 1: every analysis on the caller's stream
+        self._aux = None
 
     # ---- cached device tables ----
     def _table(self, key, builder):
@@ -509,10 +512,35 @@ class MshdsEngine:
         sample_offs = [int(v) for v in sample_offs]
         lengths = [int(v) for v in lengths]
         gpeak = self.clip_peaks(wav, sample_offs, lengths, stream)
-        out[:, 0:5] = self.speechrate(wav, sample_offs, lengths, gpeak, stream)                     # :426
+        # Two HIP streams when the caller leaves the stream choice to us: the analyses of a clip are independent once the
+        # speaker range is known, and several of them are latency-bound (path finder, pulse walk, speech-rate scan: one
+        # wave per clip or stretch), so they run beside the correlation-heavy passes instead of in front of them.
+        two = stream is None and self.n_streams > 1
+        main = torch.cuda.current_stream(self.device) if two else None
+        if two and self._aux is None:
+            self._aux = torch.cuda.Stream(device=self.device)
+        aux = self._aux if two else None
+
+        def side(fn):
+            """Run fn() on the auxiliary stream (after everything queued on the main stream so far)."""
+            if not two:
+                return fn()
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                return fn()
+
+        def join(*tensors):
+            if two:
+                main.wait_stream(aux)
+                for t in tensors:
+                    t.record_stream(main)
+
+        sr = side(lambda: self.speechrate(wav, sample_offs, lengths, gpeak, stream))                # :426
         # _pitch_values (:127-162): wide search, outlier-trimmed mean -> speaker range
         wide = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.005, floor=50.0, ceiling=600.0, stream=stream)
         st = wide["stats"].cpu().numpy()                       # one small D2H per batch
+        join(sr)
+        out[:, 0:5] = sr
         ranges = []
         for i in range(n):
             if st[i, 0] == 0 or not st[i, 7] > 0:
@@ -526,24 +554,35 @@ class MshdsEngine:
             idx = torch.tensor(ids, dtype=torch.long, device=self.device)
             gp = gpeak[idx].contiguous()
             floor, ceiling = float(rng[0]), float(rng[1])
+
+            def side_branch():
+                inten = self.intensity(wav, so, ln, floor, 0.005, True, stream)                              # :198
+                cc = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=0.5 / DX, max_candidates=15,
+                                silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
+                                voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700, stream=stream)  # :221
+                hnr = self.hnr_mean(cc, stream)
+                fm = self.formants(wav, so, ln, gp, floor, ceiling, 0.005, stream)                           # :441
+                sl = self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                                # :433
+                return inten["stats"], hnr, fm, sl
+
+            i_stats, hnr, fm, sl = side(side_branch)
             # :178 == :355, and :270 (voicing threshold 0.3, everything else equal) from the same frame kernel
             p = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=ceiling, voicing_threshold2=0.3,
                            stream=stream)
-            inten = self.intensity(wav, so, ln, floor, 0.005, True, stream)                                  # :198
-            cc = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=0.5 / DX, max_candidates=15,
-                            silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
-                            voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700, stream=stream)  # :221
-            hnr = self.hnr_mean(cc, stream)
             sm = self.spectral_moments(wav, so, ln, p, 0.025, 0.005, stream=stream)                          # :356
-            out[idx, 13:21] = self.formants(wav, so, ln, gp, floor, ceiling, 0.005, stream)                  # :441
+            cppv = self.cpp(wav, so, ln, gp, floor, ceiling, 0.005, stream, pitch=p["second"])               # :434
+            join(i_stats, hnr, fm, sl)
             out[idx, 5] = p["stats"][:, 5]
             out[idx, 6] = p["stats"][:, 6]
-            out[idx, 7] = inten["stats"][:, 0]
-            out[idx, 8] = inten["stats"][:, 1]
+            out[idx, 7] = i_stats[:, 0]
+            out[idx, 8] = i_stats[:, 1]
             out[idx, 9] = hnr
-            out[idx, 10:12] = self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                      # :433
-            out[idx, 12] = self.cpp(wav, so, ln, gp, floor, ceiling, 0.005, stream, pitch=p["second"])         # :434
+            out[idx, 10:12] = sl
+            out[idx, 12] = cppv
+            out[idx, 13:21] = fm
             out[idx, 21:25] = sm["stats"]
+            if two:
+                aux.wait_stream(main)        # the next group's side branch must not overtake these reads of gp / idx
         return out, ranges
 
 
