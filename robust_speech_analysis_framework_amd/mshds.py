@@ -518,20 +518,22 @@ class MshdsEngine:
         two = stream is None and self.n_streams > 1
         main = torch.cuda.current_stream(self.device) if two else None
         if two and self._aux is None:
-            self._aux = torch.cuda.Stream(device=self.device)
-        aux = self._aux if two else None
+            self._aux = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        three = two and self.n_streams > 2
 
-        def side(fn):
-            """Run fn() on the auxiliary stream (after everything queued on the main stream so far)."""
+        def side(fn, which=0):
+            """Run fn() on an auxiliary stream (after everything queued on the main stream so far)."""
             if not two:
                 return fn()
+            aux = self._aux[which if three else 0]
             aux.wait_stream(main)
             with torch.cuda.stream(aux):
                 return fn()
 
         def join(*tensors):
             if two:
-                main.wait_stream(aux)
+                for aux in self._aux[:2 if three else 1]:
+                    main.wait_stream(aux)
                 for t in tensors:
                     t.record_stream(main)
 
@@ -555,17 +557,19 @@ class MshdsEngine:
             gp = gpeak[idx].contiguous()
             floor, ceiling = float(rng[0]), float(rng[1])
 
-            def side_branch():
+            def branch_hnr():
                 inten = self.intensity(wav, so, ln, floor, 0.005, True, stream)                              # :198
                 cc = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=0.5 / DX, max_candidates=15,
                                 silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
                                 voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700, stream=stream)  # :221
-                hnr = self.hnr_mean(cc, stream)
-                fm = self.formants(wav, so, ln, gp, floor, ceiling, 0.005, stream)                           # :441
-                sl = self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                                # :433
-                return inten["stats"], hnr, fm, sl
+                return inten["stats"], self.hnr_mean(cc, stream)
 
-            i_stats, hnr, fm, sl = side(side_branch)
+            def branch_pulses():
+                fm = self.formants(wav, so, ln, gp, floor, ceiling, 0.005, stream)                           # :441
+                return fm, self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                          # :433
+
+            i_stats, hnr = side(branch_hnr, 0)
+            fm, sl = side(branch_pulses, 1)
             # :178 == :355, and :270 (voicing threshold 0.3, everything else equal) from the same frame kernel
             p = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=ceiling, voicing_threshold2=0.3,
                            stream=stream)
@@ -581,8 +585,6 @@ class MshdsEngine:
             out[idx, 12] = cppv
             out[idx, 13:21] = fm
             out[idx, 21:25] = sm["stats"]
-            if two:
-                aux.wait_stream(main)        # the next group's side branch must not overtake these reads of gp / idx
         return out, ranges
 
 
