@@ -279,7 +279,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": pipe.describe(args.clips, args.seconds),
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds,
-                       "stages": [s for s in stages], "sharding": f"clips/{world} ranks, all_gather of result rows"},
+                       "stages": [s for s in stages], "sharding": f"clips/{world} ranks, all_gather of result rows",
+                       "w2v2_windows_per_call": args.w2v2_chunks_per_call},
             "roofline": roof,
             "checks": {"finite": True, "duplicate_clips_bit_identical": dup_ok,
                        "note": "parity vs the CPU oracle is asserted by tests/ (-m gpu) and smoke(); parity_vs_cpu below reports it for the cpu_baseline sample, outside the timed run"},
