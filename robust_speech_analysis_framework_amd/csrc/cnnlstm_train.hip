@@ -666,7 +666,8 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd4_kernel(float* gates, co
                                                                 const float* __restrict__ dh_out, const float* __restrict__ whh,
                                                                 int B, int T) {
     constexpr int NW = H / 16;
-    constexpr int LDG = 4 * H + 4;
+    constexpr int LDG = 4 * H + 20;                 // row stride = 20 banks (mod 32): the four rows of a fragment read and the
+                                                    // 16-lane row groups of the cell owners' writes land on distinct banks
     __shared__ __attribute__((aligned(16))) float dg[2][4][LDG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, u = lane & 15;
