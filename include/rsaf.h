@@ -95,22 +95,6 @@ int rsaf_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
                   int nz, int nz2, const int64_t* strides8_host, int a_pad_k, int act, float alpha,
                   int b_kn, rsaf_stream_t stream);
 
-/* ---- EXPERIMENT (opt-in; nothing on the default path calls it): fp32-accurate GEMM on the bf16 matrix pipe ------
- * Same contraction as rsaf_gemm_f32 for the plain case (A [M,K] float32 row-major, B [N,K], K % 32 == 0, no batching,
- * no convolution padding), computed as six bf16 MFMA partial products of three-way bf16 splits of both operands with
- * fp32 accumulation (csrc/gemm_bf16x6.hip): error a few fp32 roundings, matrix pipe 16x faster per MAC.
- * rsaf_split_bf16x3 writes the three planes of a weight matrix ([3][n] bf16 bit patterns) once; B_planes points at
- * plane 0 of a [N][ldb] matrix, planes `plane_stride` elements apart.                                              */
-int rsaf_split_bf16x3(const float* src, int64_t n, uint16_t* planes, rsaf_stream_t stream);
-int rsaf_gemm_f32_bf16x6(const float* A, const uint16_t* B_planes, int64_t plane_stride, float* C,
-                         const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
-                         int64_t ldc, int64_t ldr, int act, float alpha, rsaf_stream_t stream);
-/* both operands pre-split (A_planes: [3][M][lda] bf16, K % 16 == 0): k-tiles by LDS-DMA, no conversion in the kernel */
-int rsaf_gemm_bf16x6_presplit(const uint16_t* A_planes, int64_t a_plane_stride, const uint16_t* B_planes,
-                              int64_t b_plane_stride, float* C, const float* bias, const float* R, int M, int N,
-                              int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int act, float alpha,
-                              rsaf_stream_t stream);
-
 /* ---- CNN-LSTM-with-attention classifier forward ----------------------------------------------------
  * Replaces CNNLSTM.forward (src/models.py:161-193) in eval mode: x[B,T,input_dim] float32 ->
  * logits[B,num_classes].  Zero-padded frames are processed like any other frame (the reference's
@@ -129,6 +113,27 @@ int64_t rsaf_cnnlstm_workspace_bytes(int B, int T, int input_dim, int channels, 
 int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channels, int hidden,
                          int num_classes, int lstm_layers, int act, const float* weights,
                          void* workspace, int64_t workspace_bytes, float* logits, rsaf_stream_t stream);
+/* The same forward with the intermediate tensors the reference's sub-modules return copied out (any pointer may
+ * be NULL): res1_out [B][T][C] = res_block1 output (src/models.py:175, channels-last), res2_out [B][T/2][C] =
+ * res_block2 output (:178), lstm_out [B][T/2][2H] = nn.LSTM output (:184), pooled_out [B][2H] =
+ * AttentionPooling output (:187). */
+int rsaf_cnnlstm_forward_stages(const float* x, int B, int T, int input_dim, int channels, int hidden,
+                                int num_classes, int lstm_layers, int act, const float* weights, void* workspace,
+                                int64_t workspace_bytes, float* logits, float* res1_out, float* res2_out,
+                                float* lstm_out, float* pooled_out, rsaf_stream_t stream);
+/* ResidualBlock.forward (src/models.py:64-76) in eval mode on a channels-last sequence: x [B][T][Cin] ->
+ * y [B][T][Cout] = act(BN2(conv2(act(BN1(conv1(x))))) + shortcut(x)), k = 3 / pad 1 / stride 1.  BatchNorm folded
+ * into tap-major weights ([Cout][tap*Cin + ci]) as in the blob of rsaf_cnnlstm_forward; wsc/bsc = folded
+ * conv1x1+BN shortcut, both NULL for the identity shortcut (Cin == Cout). */
+int64_t rsaf_cnn_resblock_workspace_bytes(int B, int T, int out_channels);
+int rsaf_cnn_resblock_forward(const float* x, int B, int T, int in_channels, int out_channels, int act,
+                              const float* w1, const float* b1, const float* wsc, const float* bsc,
+                              const float* w2, const float* b2, void* workspace, int64_t workspace_bytes,
+                              float* y, rsaf_stream_t stream);
+/* AttentionPooling.forward (src/models.py:94-107): seq [B][T][features] -> pooled [B][features] =
+ * sum_t softmax_t(seq . watt + batt) * seq; features = 128 or 256. */
+int rsaf_attnpool_forward(const float* seq, int B, int T, int features, const float* watt, const float* batt,
+                          float* pooled, rsaf_stream_t stream);
 
 /* ---- CNN-LSTM training step: forward in training mode + backward -------------------------------------
  * Replaces `out = model(seq)` under model.train() and the model part of `loss.backward()` in the reference's

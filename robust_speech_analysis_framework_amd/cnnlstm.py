@@ -55,8 +55,50 @@ class ResidualBlock(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv1d(in_channels, out_channels, kernel_size=1, stride=stride),
                                           nn.BatchNorm1d(out_channels))
 
+        self._packed = None
+        self._packed_key = None
+        self._workspace = None
+
+    def _folded(self, device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._packed is None or self._packed_key != key:
+            parts = list(_fold_conv_bn(self.conv1, self.bn1))
+            parts += list(_fold_conv_bn(self.shortcut[0], self.shortcut[1])) if len(self.shortcut) > 0 else [None, None]
+            parts += list(_fold_conv_bn(self.conv2, self.bn2))
+            self._packed = [None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+                            for a in parts]
+            self._packed_key = key
+        return self._packed
+
     def forward(self, x):
-        raise NotImplementedError("ResidualBlock runs only inside CNNLSTM.forward on the HIP path")
+        """Standalone block (``src/models.py:64-76``): x [B, Cin, T] -> [B, Cout, T], eval mode, on the HIP path
+        (``rsaf_cnn_resblock_forward``; the kernels are channels-last, so the two permutes are real copies here while
+        ``CNNLSTM.forward`` reads its [B, T, D] input in place)."""
+        if not x.is_cuda:
+            raise _lib.RsafError("ResidualBlock.forward needs a HIP (cuda) tensor: there is no CPU fallback")
+        if self.training:
+            raise NotImplementedError("a standalone ResidualBlock runs in eval mode on the HIP path; the training step "
+                                      "(batch statistics, dropout, backward) runs through CNNLSTM")
+        if any(c.stride[0] != 1 or c.kernel_size[0] != k for c, k in ((self.conv1, 3), (self.conv2, 3))):
+            raise NotImplementedError("the HIP block implements kernel_size 3 / stride 1 (all the reference uses)")
+        cin, cout = self.conv1.in_channels, self.conv1.out_channels
+        if x.dim() != 3 or x.shape[1] != cin:
+            raise ValueError(f"expected input [B, {cin}, T], got {tuple(x.shape)}")
+        lib = _lib.load()
+        w1, b1, wsc, bsc, w2, b2 = self._folded(x.device)
+        xt = x.to(torch.float32).permute(0, 2, 1).contiguous()
+        B, T = xt.shape[0], xt.shape[1]
+        need = max(int(lib.rsaf_cnn_resblock_workspace_bytes(B, T, cout)), 16)
+        if self._workspace is None or self._workspace.numel() * 4 < need or self._workspace.device != x.device:
+            self._workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+        y = torch.empty((B, T, cout), dtype=torch.float32, device=x.device)
+        optr = lambda t: _lib.ptr(t) if t is not None else None                      # noqa: E731
+        with torch.no_grad():
+            _lib.check(lib.rsaf_cnn_resblock_forward(
+                _lib.ptr(xt), B, T, cin, cout, _ACT_CODE[self.activation_name], _lib.ptr(w1), _lib.ptr(b1), optr(wsc),
+                optr(bsc), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(self._workspace), self._workspace.numel() * 4,
+                _lib.ptr(y), _lib.stream_ptr(None)), "rsaf_cnn_resblock_forward")
+        return y.permute(0, 2, 1)
 
 
 class AttentionPooling(nn.Module):
@@ -67,7 +109,22 @@ class AttentionPooling(nn.Module):
         self.attention_weights = nn.Linear(input_dim, 1)
 
     def forward(self, lstm_out):
-        raise NotImplementedError("AttentionPooling runs only inside CNNLSTM.forward on the HIP path")
+        """Standalone pooling (``src/models.py:94-107``): [B, T, F] -> [B, F] through ``rsaf_attnpool_forward``."""
+        if not lstm_out.is_cuda:
+            raise _lib.RsafError("AttentionPooling.forward needs a HIP (cuda) tensor: there is no CPU fallback")
+        F_ = self.attention_weights.in_features
+        if lstm_out.dim() != 3 or lstm_out.shape[2] != F_:
+            raise ValueError(f"expected input [B, T, {F_}], got {tuple(lstm_out.shape)}")
+        if F_ not in (128, 256):
+            raise NotImplementedError("the HIP pooling kernel covers 2 * lstm_hidden_dim = 128 or 256")
+        lib = _lib.load()
+        x = lstm_out.detach().to(torch.float32).contiguous()
+        w = self.attention_weights.weight.detach().to(torch.float32).reshape(-1).contiguous()
+        b = self.attention_weights.bias.detach().to(torch.float32).contiguous()
+        out = torch.empty((x.shape[0], F_), dtype=torch.float32, device=x.device)
+        _lib.check(lib.rsaf_attnpool_forward(_lib.ptr(x), x.shape[0], x.shape[1], F_, _lib.ptr(w), _lib.ptr(b),
+                                             _lib.ptr(out), _lib.stream_ptr(None)), "rsaf_attnpool_forward")
+        return out
 
 
 def _f64(t):
@@ -356,6 +413,31 @@ class CNNLSTM(nn.Module):
             logits, self._workspace = cnnlstm_forward_packed(x, blob, self.dims, self.activation_name,
                                                              self._workspace)
         return logits
+
+
+def cnnlstm_forward_stages(model: "CNNLSTM", x):
+    """Eval-mode forward that also returns what the reference's sub-modules return (forward hooks on
+    ``res_block1`` / ``res_block2`` / ``lstm`` / ``attention_pooling`` of ``src/models.py``), channels-last:
+    dict(res1 [B,T,C], res2 [B,T/2,C], lstm [B,T/2,2H], pooled [B,2H], logits [B,NC])."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise _lib.RsafError("cnnlstm_forward_stages needs a HIP (cuda) tensor")
+    d = model.dims
+    x = x.to(torch.float32).contiguous()
+    B, T, D = x.shape
+    blob = model.packed_weights(x.device)
+    need = lib.rsaf_cnnlstm_workspace_bytes(B, T, D, d["channels"], d["hidden"], d["layers"])
+    if need < 0:
+        raise ValueError("sequence length must be >= 2")
+    ws = torch.empty(max(int(need), 16) // 4, dtype=torch.float32, device=x.device)
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)            # noqa: E731
+    out = {"res1": e(B, T, d["channels"]), "res2": e(B, T // 2, d["channels"]), "lstm": e(B, T // 2, 2 * d["hidden"]),
+           "pooled": e(B, 2 * d["hidden"]), "logits": e(B, d["num_classes"])}
+    _lib.check(lib.rsaf_cnnlstm_forward_stages(
+        _lib.ptr(x), B, T, D, d["channels"], d["hidden"], d["num_classes"], d["layers"], _ACT_CODE[model.activation_name],
+        _lib.ptr(blob), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(out["logits"]), _lib.ptr(out["res1"]), _lib.ptr(out["res2"]),
+        _lib.ptr(out["lstm"]), _lib.ptr(out["pooled"]), _lib.stream_ptr(None)), "rsaf_cnnlstm_forward_stages")
+    return out
 
 
 def collate_zero_pad(seqs, device="cuda"):

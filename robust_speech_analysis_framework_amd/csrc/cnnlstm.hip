@@ -306,7 +306,7 @@ template <int NF>   // features per lane: 2H = 64*NF
 __global__ __launch_bounds__(256) void attnpool_fc_kernel(const float* __restrict__ seq, const float* __restrict__ watt,
                                                           const float* __restrict__ batt, const float* __restrict__ wfc,
                                                           const float* __restrict__ bfc, float* __restrict__ logits,
-                                                          int T, int NC) {
+                                                          float* __restrict__ pooled_out, int T, int NC) {
     constexpr int F = 64 * NF;
     __shared__ float s_m[4], s_l[4], s_ctx[4][F], s_red[4][16];
     const int b = blockIdx.x;
@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256) void attnpool_fc_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) pooled += s_ctx[k][f] * expf(s_m[k] - M);
         pooled /= Lt;
+        if (pooled_out) pooled_out[(int64_t)b * F + f] = pooled;
     }
+    if (!wfc) return;                                  // pooling only (AttentionPooling.forward, src/models.py:94-107)
     for (int c = 0; c < NC; ++c) {
         float part = (f < F) ? pooled * wfc[(int64_t)c * F + f] : 0.f;
         part = wave_sum(part);
@@ -439,9 +441,15 @@ int64_t rsaf_cnnlstm_workspace_bytes(int B, int T, int input_dim, int channels, 
     return (3 * conv + xp + 2 * sq) * (int64_t)sizeof(float);
 }
 
-int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channels, int hidden, int num_classes,
-                         int lstm_layers, int act, const float* weights, void* workspace,
-                         int64_t workspace_bytes, float* logits, rsaf_stream_t stream) {
+static int tap_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
+    if (dst) RSAF_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return RSAF_OK;
+}
+
+static int forward_impl(const float* x, int B, int T, int input_dim, int channels, int hidden, int num_classes,
+                        int lstm_layers, int act, const float* weights, void* workspace,
+                        int64_t workspace_bytes, float* logits, float* res1_out, float* res2_out, float* lstm_out,
+                        float* pooled_out, rsaf_stream_t stream) {
     Dims d{input_dim, channels, hidden, num_classes, lstm_layers, act};
     int rc = check_dims(d);
     if (rc != RSAF_OK) return rc;
@@ -481,6 +489,7 @@ int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channe
     }
     rc = conv3(bufA, W + L.w2, W + L.b2, sc, ldsc, (int64_t)T * ldsc, bufC, B, T, C, C, d.act, s);
     if (rc) return rc;
+    if ((rc = tap_copy(res1_out, bufC, (int64_t)B * T * C, s))) return rc;
     // max_pool1d(2) (:177)
     {
         const int64_t n4 = (int64_t)B * Tp * (C / 4);
@@ -495,6 +504,7 @@ int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channe
     if (rc) return rc;
     rc = conv3(bufB, W + L.w4, W + L.b4, bufA, C, (int64_t)Tp * C, bufC, B, Tp, C, C, d.act, s);
     if (rc) return rc;
+    if ((rc = tap_copy(res2_out, bufC, (int64_t)B * Tp * C, s))) return rc;
     // LSTM (:184)
     const float* lin = bufC;
     int in = C;
@@ -511,17 +521,91 @@ int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channe
         lin = lout; in = 2 * H;
         lout = (lout == seq0) ? seq1 : seq0;
     }
+    if ((rc = tap_copy(lstm_out, lin, (int64_t)B * Tp * 2 * H, s))) return rc;
     // attention pooling + fc (:187-191)
     {
         ProfScope prof("attnpool_fc", s, 0.0, (double)B * Tp * 2 * H * 4);
         if (H == 128)
             hipLaunchKernelGGL(attnpool_fc_kernel<4>, dim3(B), dim3(256), 0, s, lin, W + L.watt, W + L.batt,
-                               W + L.wfc, W + L.bfc, logits, Tp, d.NC);
+                               W + L.wfc, W + L.bfc, logits, pooled_out, Tp, d.NC);
         else
             hipLaunchKernelGGL(attnpool_fc_kernel<2>, dim3(B), dim3(256), 0, s, lin, W + L.watt, W + L.batt,
-                               W + L.wfc, W + L.bfc, logits, Tp, d.NC);
+                               W + L.wfc, W + L.bfc, logits, pooled_out, Tp, d.NC);
         RSAF_CHECK_HIP(hipGetLastError());
     }
+    return RSAF_OK;
+}
+
+int rsaf_cnnlstm_forward(const float* x, int B, int T, int input_dim, int channels, int hidden, int num_classes,
+                         int lstm_layers, int act, const float* weights, void* workspace,
+                         int64_t workspace_bytes, float* logits, rsaf_stream_t stream) {
+    return forward_impl(x, B, T, input_dim, channels, hidden, num_classes, lstm_layers, act, weights, workspace,
+                        workspace_bytes, logits, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int rsaf_cnnlstm_forward_stages(const float* x, int B, int T, int input_dim, int channels, int hidden,
+                                int num_classes, int lstm_layers, int act, const float* weights, void* workspace,
+                                int64_t workspace_bytes, float* logits, float* res1_out, float* res2_out,
+                                float* lstm_out, float* pooled_out, rsaf_stream_t stream) {
+    return forward_impl(x, B, T, input_dim, channels, hidden, num_classes, lstm_layers, act, weights, workspace,
+                        workspace_bytes, logits, res1_out, res2_out, lstm_out, pooled_out, stream);
+}
+
+int64_t rsaf_cnn_resblock_workspace_bytes(int B, int T, int out_channels) {
+    if (B <= 0 || T < 1) return -1;
+    return 2 * pad4((int64_t)B * T * out_channels) * (int64_t)sizeof(float);
+}
+
+int rsaf_cnn_resblock_forward(const float* x, int B, int T, int in_channels, int out_channels, int act,
+                              const float* w1, const float* b1, const float* wsc, const float* bsc,
+                              const float* w2, const float* b2, void* workspace, int64_t workspace_bytes,
+                              float* y, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(in_channels > 0 && in_channels % 4 == 0 && out_channels > 0 && out_channels % 4 == 0,
+                   "channel counts must be positive multiples of 4");
+    RSAF_CHECK_ARG(act == ACT_GELU || act == ACT_SILU, "activation must be gelu (1) or silu (2)");
+    RSAF_CHECK_ARG(B >= 0 && B <= 65535, "batch must be in [0, 65535]");
+    if (B == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(T >= 1, "sequence length must be >= 1");
+    RSAF_CHECK_ARG(x && w1 && b1 && w2 && b2 && workspace && y, "NULL pointer");
+    RSAF_CHECK_ARG((wsc != nullptr) == (bsc != nullptr), "shortcut weight and bias come together");
+    RSAF_CHECK_ARG(wsc || in_channels == out_channels, "identity shortcut needs in_channels == out_channels");
+    if (workspace_bytes < rsaf_cnn_resblock_workspace_bytes(B, T, out_channels)) {
+        set_error("rsaf_cnn_resblock_forward: workspace too small");
+        return RSAF_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int D = in_channels, C = out_channels;
+    float* bufA = static_cast<float*>(workspace);
+    float* bufB = bufA + pad4((int64_t)B * T * C);
+    int rc = conv3(x, w1, b1, nullptr, 0, 0, bufA, B, T, D, C, act, s);
+    if (rc) return rc;
+    const float* sc = x;
+    int64_t ldsc = D;
+    if (wsc) {
+        GemmParams p = gemm_params_plain(x, wsc, bufB, T, C, D, D, D, C);
+        p.bias = bsc; p.nz = B; p.sA1 = (int64_t)T * D; p.sC1 = (int64_t)T * C;
+        rc = launch_gemm_f32(p, s, "cnn_conv_gemm");
+        if (rc) return rc;
+        sc = bufB; ldsc = C;
+    }
+    return conv3(bufA, w2, b2, sc, ldsc, (int64_t)T * ldsc, y, B, T, C, C, act, s);
+}
+
+int rsaf_attnpool_forward(const float* seq, int B, int T, int features, const float* watt, const float* batt,
+                          float* pooled, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(features == 128 || features == 256, "features (2 * lstm_hidden_dim) must be 128 or 256");
+    RSAF_CHECK_ARG(B >= 0 && T >= 1, "bad shape");
+    if (B == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(seq && watt && batt && pooled, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("attnpool_fc", s, 0.0, (double)B * T * features * 4);
+    if (features == 256)
+        hipLaunchKernelGGL(attnpool_fc_kernel<4>, dim3(B), dim3(256), 0, s, seq, watt, batt,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, pooled, T, 0);
+    else
+        hipLaunchKernelGGL(attnpool_fc_kernel<2>, dim3(B), dim3(256), 0, s, seq, watt, batt,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, pooled, T, 0);
+    RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }
 

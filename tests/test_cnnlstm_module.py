@@ -49,3 +49,19 @@ def test_unknown_activation(rsaf_lib):
         get_activation_fn("tanh")
     with pytest.raises(ValueError):
         CNNLSTM(activation_fn="tanh")
+
+
+def test_default_init_under_seed_0_equals_the_reference_module():
+    """`torch.manual_seed(0); CNNLSTM()` draws the parameters in the reference's construction order
+    (src/models.py:43-62,141-159): fingerprint of the reference's state_dict captured by make_cnnlstm_c4_golden.py."""
+    import os
+    import numpy as np
+    import torch
+    from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cnnlstm_c4_rows.npz"))
+    torch.manual_seed(0)
+    sd = CNNLSTM().state_dict()
+    names = [k for k in sd if not k.endswith("num_batches_tracked")]
+    assert names == [str(n) for n in z["sd_names"]]
+    fp = np.array([[sd[k].double().sum().item(), (sd[k].double() ** 2).sum().item()] for k in names])
+    assert np.allclose(fp, z["sd_fingerprint"], rtol=1e-12, atol=1e-12)

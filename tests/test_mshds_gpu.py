@@ -342,3 +342,57 @@ def test_dropin_dataframe_contract(eng, tmp_path):
     ok = ~np.isnan(ref)
     assert np.array_equal(np.isnan(row), ~ok)
     assert (np.abs(row[ok] - ref[ok]) <= TOL * np.maximum(np.abs(ref[ok]), 1e-3)).all()
+
+
+def _oracle_extract(args):
+    k, seconds = args
+    from oracle import mshds_oracle
+    from robust_speech_analysis_framework_amd import synth as sy
+    r, rng = mshds_oracle.extract(sy.synth_clip(k, seconds))
+    return r, tuple(rng)
+
+
+def _oracle_pool(jobs):
+    """The numpy restatement takes ~1.4 s per audio-second: run the clips of a config in worker processes
+    (spawned: the test process has initialised the GPU and must not fork)."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    with cf.ProcessPoolExecutor(max_workers=min(8, len(jobs)), mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_oracle_extract, jobs))
+
+
+def _check_rows(got, refs):
+    for i, (ref, _) in enumerate(refs):
+        assert np.array_equal(np.isnan(got[i]), np.isnan(ref)), (i, got[i], ref)
+        ok = ~np.isnan(ref)
+        assert ok.sum() >= 20                                                   # a voiced clip defines the features
+        assert (np.abs(got[i][ok] - ref[ok]) <= TOL * np.maximum(np.abs(ref[ok]), 1e-3)).all(), (i, got[i][ok], ref[ok])
+
+
+def test_config_c1_ten_5s_wav_files_through_the_dropin(eng, tmp_path):
+    """BASELINE config C1: MSHDS 25-feature extract on 10 synthetic 16 kHz 5 s mono WAVs through the reference's entry
+    point (src.mshds_extractor.extract_mshds_features); all 25 columns + NaN pattern against the CPU restatement."""
+    import pandas as pd
+    from src.mshds_extractor import extract_mshds_features
+    from robust_speech_analysis_framework_amd.mshds import FEATURE_NAMES
+    paths = synth.write_synth_corpus(str(tmp_path), 10, 5.0, first=20260000)
+    out = extract_mshds_features(pd.DataFrame({"filepath": paths}), verbose=False)
+    assert list(out.columns) == ["filename"] + FEATURE_NAMES and len(out) == 10
+    assert list(out["filename"]) == [f"synth_{20260000 + k:05d}.wav" for k in range(10)]
+    refs = _oracle_pool([(20260000 + k, 5.0) for k in range(10)])
+    _check_rows(out.iloc[:, 1:].to_numpy(dtype=np.float64), refs)
+
+
+def test_config_c2_mshds_30s_clips_match_oracle(eng):
+    """BASELINE config C2 clip length: full 30 s clips (5 990 pitch frames, ~25 voiced stretches each) through
+    extract_packed in one batch, against the CPU restatement, including the speaker-range decision."""
+    import torch
+    ids = [20260100, 20260101, 20260102]
+    clips = [synth.synth_clip(k, 30.0) for k in ids]
+    wav, offs, lens = _pack(clips)
+    out, ranges = eng.extract_packed(wav, offs, lens)
+    torch.cuda.synchronize()
+    refs = _oracle_pool([(k, 30.0) for k in ids])
+    for i, (_, rng) in enumerate(refs):
+        assert tuple(ranges[i]) == rng
+    _check_rows(out.cpu().numpy(), refs)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "gemm_f32.h"
+#include "rsaf_exp.h"
 
 namespace rsaf {
 

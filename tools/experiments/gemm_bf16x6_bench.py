@@ -1,14 +1,17 @@
-"""EXPERIMENT: speed and accuracy of the bf16x6 split GEMM (csrc/gemm_bf16x6.hip) against the exact-fp32 MFMA GEMM, both
+"""EXPERIMENT: speed and accuracy of the bf16x6 split GEMM (gemm_bf16x6.hip, built by exp_lib.py into librsaf_exp.so) against the exact-fp32 MFMA GEMM, both
 measured against a float64 reference, on the Wav2Vec2 shapes."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import exp_lib
 import torch
 
 from robust_speech_analysis_framework_amd import _lib, ops
 
-lib = _lib.load()
+_lib.load()
+lib = exp_lib.load()
 shapes = [(256 * 249, 2304, 768, "w2v2 qkv"), (256 * 249, 3072, 768, "w2v2 ffn1"), (256 * 249, 768, 3072, "w2v2 ffn2"),
           (256 * 249, 768, 768, "w2v2 out-proj"), (4096, 4096, 4096, "square 4096")]
 torch.manual_seed(0)
