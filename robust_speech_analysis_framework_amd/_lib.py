@@ -34,9 +34,12 @@ SIGNATURES = {
     "rsaf_init_device": (_I, [_I]),
     "rsaf_prof_begin": (_I, []),
     "rsaf_prof_end": (_I, [C.POINTER(ProfRecord), _I, C.POINTER(_I)]),
-    "rsaf_smile_n_frames": (_L, [_L]),
-    "rsaf_smile_lld_batch": (_I, [_P, _P, _P, _I, _L, _L, _P, _P]),
-    "rsaf_smile_functionals": (_I, [_P, _P, _I, _L, _P, _P]),
+    "rsaf_smile_geometry": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "rsaf_smile_n_frames": (_L, [_L, _I]),
+    "rsaf_smile_lld_batch": (_I, [_P, _P, _P, _I, _L, _L, _I, _P, _P, _P, _P]),
+    "rsaf_smile_workspace_bytes": (_L, [_L]),
+    "rsaf_smile_pitch_track": (_I, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P]),
+    "rsaf_smile_functionals": (_I, [_P, _P, _I, _L, _I, _P, _P]),
     "rsaf_gemm_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I,
                            C.POINTER(_L), _I, _I, _F, _I, _P]),
     "rsaf_cnnlstm_weight_floats": (_L, [_I, _I, _I, _I, _I]),

@@ -77,4 +77,15 @@ __device__ __forceinline__ float readlane_f32(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// wave maximum of non-negative values (the zero fill of the DPP shifts is neutral), broadcast to every lane
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+    x = fmaxf(x, dpp_f32<0x111>(x));
+    x = fmaxf(x, dpp_f32<0x112>(x));
+    x = fmaxf(x, dpp_f32<0x114>(x));
+    x = fmaxf(x, dpp_f32<0x118>(x));
+    x = fmaxf(x, dpp_f32<0x142, 0xA>(x));
+    x = fmaxf(x, dpp_f32<0x143, 0xC>(x));
+    return readlane_f32(x, 63);
+}
+
 }  // namespace rsaf

@@ -1,5 +1,5 @@
 // cContourSmoother (sma3) -> cDeltaRegression (W=2) -> cFunctionals (12 statistics over the whole
-// clip) for gfx950: Androids.conf:284-368 of the reference, reached through
+// clip, or over its first window_frames frames: the two readings of Androids.conf:349-356) for gfx950: Androids.conf:284-368 of the reference, reached through
 // src/opensmile_extractor.py:62-87.
 //
 // One wave per (clip, LLD contour).  The contour (<= a few thousand frames, contiguous because the
@@ -87,7 +87,7 @@ __device__ void write_stats(float* __restrict__ o, Ext mx, Ext mn, double mean, 
 __global__ __launch_bounds__(256) void smile_functionals_kernel(const float* __restrict__ lld,
                                                                 const int64_t* __restrict__ frame_off,
                                                                 int n_clips, int64_t total_frames,
-                                                                float* __restrict__ out) {
+                                                                int window_frames, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gw >= (int64_t)n_clips * NLLD) return;   // wave-uniform
@@ -104,19 +104,20 @@ __global__ __launch_bounds__(256) void smile_functionals_kernel(const float* __r
     float* o_s = out + (int64_t)clip * RSAF_SMILE_NFEAT + base + (li - lo) * NFUNC;
     float* o_d = o_s + nlev * NFUNC;
 
-    const bool built = !(li == 14 || li == 15 || (li >= 18 && li <= 21));
-    if (!built || T <= 0) {
+    if (T <= 0) {
         const float qnan = __int_as_float(0x7fc00000);
         if (lane < NFUNC) { o_s[lane] = qnan; o_d[lane] = qnan; }
         return;
     }
     const float* x = lld + (int64_t)li * total_frames + fo;
+    // statistics over the first TW frames of the full-length sma / delta contours (TW = T: the whole clip)
+    const int TW = window_frames > 0 ? min(window_frames, T) : T;
 
     // pass 1: extrema (first occurrence) and sums
     Ext smx{-INFINITY, 0x7fffffff}, smn{INFINITY, 0x7fffffff};
     Ext dmx{-INFINITY, 0x7fffffff}, dmn{INFINITY, 0x7fffffff};
     double ssum = 0.0, dsum = 0.0;
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane; t < TW; t += 64) {
         float s, d;
         sma_delta_at(x, t, T, s, d);
         if (s > smx.v) { smx.v = s; smx.i = t; }
@@ -128,13 +129,13 @@ __global__ __launch_bounds__(256) void smile_functionals_kernel(const float* __r
     }
     smx = wave_argmax(smx); smn = wave_argmin(smn);
     dmx = wave_argmax(dmx); dmn = wave_argmin(dmn);
-    const double smean = wave_sum_f64(ssum) / T;
-    const double dmean = wave_sum_f64(dsum) / T;
+    const double smean = wave_sum_f64(ssum) / TW;
+    const double dmean = wave_sum_f64(dsum) / TW;
 
     // pass 2: central moments and regression cross term
-    const double tm = 0.5 * ((double)T - 1.0);
+    const double tm = 0.5 * ((double)TW - 1.0);
     double s2 = 0, s3 = 0, s4 = 0, sty = 0, d2 = 0, d3 = 0, d4 = 0, dty = 0;
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane; t < TW; t += 64) {
         float s, d;
         sma_delta_at(x, t, T, s, d);
         const double tc = (double)t - tm;
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256) void smile_functionals_kernel(const float* __r
     s2 = wave_sum_f64(s2); s3 = wave_sum_f64(s3); s4 = wave_sum_f64(s4); sty = wave_sum_f64(sty);
     d2 = wave_sum_f64(d2); d3 = wave_sum_f64(d3); d4 = wave_sum_f64(d4); dty = wave_sum_f64(dty);
     if (lane == 0) {
-        write_stats(o_s, smx, smn, smean, s2, s3, s4, sty, T);
-        write_stats(o_d, dmx, dmn, dmean, d2, d3, d4, dty, T);
+        write_stats(o_s, smx, smn, smean, s2, s3, s4, sty, TW);
+        write_stats(o_d, dmx, dmn, dmean, d2, d3, d4, dty, TW);
     }
 }
 
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void smile_functionals_kernel(const float* __r
 using namespace rsaf;
 
 extern "C" int rsaf_smile_functionals(const float* lld, const int64_t* frame_off, int n_clips,
-                                      int64_t total_frames, float* out, rsaf_stream_t stream) {
-    RSAF_CHECK_ARG(n_clips >= 0, "negative n_clips");
+                                      int64_t total_frames, int window_frames, float* out, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_clips >= 0 && window_frames >= 0, "negative n_clips or window_frames");
     if (n_clips == 0) return RSAF_OK;
     RSAF_CHECK_ARG(frame_off && out, "NULL pointer");
     RSAF_CHECK_ARG(lld || total_frames == 0, "NULL lld");
@@ -170,7 +171,7 @@ extern "C" int rsaf_smile_functionals(const float* lld, const int64_t* frame_off
     RSAF_CHECK_ARG(blocks <= 0x7fffffffLL, "too many clips");
     ProfScope prof("smile_functionals", s, 0.0, 0.0);
     hipLaunchKernelGGL(smile::smile_functionals_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lld,
-                       frame_off, n_clips, total_frames, out);
+                       frame_off, n_clips, total_frames, window_frames, out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -1,21 +1,31 @@
-// openSMILE-style low-level descriptors for gfx950 (wave64).
+// openSMILE-style low-level descriptors for gfx950 (wave64), at the file's own sample rate.
 //
-// One fused kernel for Androids.conf:73-139 and :258-280 of the reference
+// One fused kernel for Androids.conf:73-186 and :258-280 of the reference
 // (cFramer -> cVectorPreemphasis -> cWindower -> cTransformFFT -> cFFTmagphase ->
-//  {cMelspec -> cMfcc, cEnergy, cMZcr, cIntensity, cSpectral}); the reference runs that chain by
-// spawning SMILExtract once per file (src/opensmile_extractor.py:62-75).
+//  {cMelspec -> cMfcc, cEnergy, cMZcr, cIntensity, cSpectral, cSpecScale -> cPitchShs}); the reference runs that
+// chain by spawning SMILExtract once per file (src/opensmile_extractor.py:62-75).  The sequential tail of the
+// pitch chain (cPitchSmootherViterbi, cValbasedSelector, cPitchJitter) is csrc/smile_pitch.hip.
 //
-// Mapping: a 256-thread workgroup owns a run of 32 consecutive frames of one clip.  The run's
-// samples (31*160+400, plus one hop of history for the spectral-flux warm-up frame) are staged
-// once in LDS with coalesced loads, so the 2.5x frame overlap never re-reads HBM.  Each wave then
-// walks 8 consecutive frames: packed-real 512-point FFT as a 256-point complex Stockham radix-4
-// FFT (4 stages, 4 points per lane, per-wave LDS ping-pong, twiddles from LDS), magnitudes to LDS,
-// HTK mel bank as 27 segment sums, log + DCT/lifter from LDS, spectral descriptors as wave
-// reductions (DPP).  The 32 built LLD rows are buffered per run in LDS and written contour-major
-// with 128-byte coalesced rows.
+// Mapping.  A wave owns PAIRS of consecutive frames and keeps the two frames in the two halves of packed
+// float2 registers: every elementwise step (pre-emphasis, window, FFT butterflies, spectral descriptors,
+// spline, sub-harmonic summation) is then v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on both frames at once,
+// and every LDS access moves 8 or 16 bytes per lane.  The kernel is VALU-issue bound (profiles/r02), so this is
+// the lever: half the vector instructions per frame.  A workgroup of 8 waves (4 for the 2048-point FFT) shares
+// one LDS copy of the constant tables (twiddles, Hamming, mel weights, spline / octave-scale tables); each wave
+// stages its own samples (the 2.5x frame overlap is served by L2, HBM sees every sample once), and has a
+// private FFT buffer that is reused for the octave-spectrum arrays.  FFT: packed-real N-point transform as an
+// N/2-point complex Stockham radix-4 (+ one radix-2 stage when log2(N/2) is odd), in place in LDS (all reads of a
+// stage precede its writes in program order; a wave is lock-step, so no second buffer is needed).
+// Templated on the FFT length (256 / 512 / 1024 / 2048 <-> 8 / 16 / 22.05-32 / 44.1-48 kHz; frame and hop
+// lengths are run-time).
+//
+// Spectral flux needs the previous frame's magnitudes: inside a pair they are in registers; a wave's first
+// frame takes them from the previous wave's last pair after the workgroup barrier; only wave 0 transforms
+// one extra frame (the last one of the previous run).
 //
 // Semantics are those of oracle/smile_oracle.py (the CPU restatement), parity unpinned.
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -24,436 +34,942 @@
 namespace rsaf {
 namespace smile {
 
-constexpr int FRAME = RSAF_SMILE_FRAME;
-constexpr int HOP = RSAF_SMILE_HOP;
-constexpr int NFFT = 512;
-constexpr int NBINS = 257;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int NLLD = RSAF_SMILE_NLLD;
 constexpr int NMEL = 26;
 constexpr int NMFCC = 12;
-constexpr int NLLD = RSAF_SMILE_NLLD;
+constexpr int NCAND = RSAF_SMILE_NCAND;
+constexpr int NHARM = 15;
+constexpr int CARRY = 6;                 // lanes of carry kept in the blocked tridiagonal solve (0.268^(4*6) ~ 2e-14)
+constexpr int NLOCAL = 32;               // LLD rows this kernel produces (38 minus the six pitch-chain rows)
 constexpr float PREEMPH = 0.97f;
 constexpr float HTK_SCALE = 32767.0f;
 constexpr float MEL_FLOOR = 1.0f;
-constexpr float DF = 16000.0f / NFFT;
 
-constexpr int RUN = 32;                               // frames per workgroup
-constexpr int FPW = RUN / 4;                          // frames per wave
-constexpr int NSAMP = (RUN - 1) * HOP + FRAME + HOP;  // 5520 incl. one hop of history
-
-// ---- constant tables (host-computed in double, uploaded once per device) -----------------
-struct Tables {
-    float ham[FRAME];
-    float2 tw256[256];     // exp(-2 pi i m / 256)
-    float2 tw512[256];     // exp(-2 pi i k / 512)
-    float lo_wt[260];      // HTK lower-channel weight per bin (0 where unused)
-    int seg_start[32];     // bins with lo_chan == c are [seg_start[c], seg_start[c+1]), c = 0..26
-    float dct[NMFCC * NMEL];  // DCT-II rows 1..12 with the lifter folded in
-    float sharp[260];      // bark(f) * g(bark) per bin
-    float ham_sum;
-    float pad[3];
+template <int LOG2N>
+struct Geo {
+    static constexpr int NFFT = 1 << LOG2N;
+    static constexpr int NC = NFFT / 2;              // complex points of the packed-real transform
+    static constexpr int NB = NC + 1;                // magnitude bins
+    static constexpr int PPL = NC / 64;              // bins per lane
+    static constexpr int NBP = NC + 16;              // padded length of the per-bin tables
+    static constexpr int HALF = NC + 8;              // float2 entries of one half of the wave's FFT buffer
+    static constexpr int XF = 4 * HALF;              // floats of the wave's FFT buffer
+    static constexpr int MF = 2 * HALF;              // floats of the wave's magnitude slot
+    static constexpr int WAVES = LOG2N >= 11 ? 4 : 8;
+    static constexpr int PPW = LOG2N <= 9 ? 4 : 2;   // frame pairs per wave
+    static constexpr int RUN = WAVES * PPW * 2;      // frames per workgroup
 };
-static_assert(sizeof(Tables) % 16 == 0, "Tables must be float4-copyable");
+
+// ---- constant tables (host-computed in double, one blob per (device, sample rate)) -------------------
+template <int LOG2N>
+struct __attribute__((aligned(16))) Tables {
+    using G = Geo<LOG2N>;
+    float2 twc[G::NC];                // exp(-2 pi i m / NC)
+    float2 twr[G::NC];                // exp(-2 pi i k / NFFT)
+    float ham[G::NFFT];               // Hamming window, zero beyond the frame
+    float lo_wt[G::NBP];              // HTK lower-channel weight per bin (0 where unused)
+    float sharp[G::NBP];              // bark(f) * g(bark) per bin
+    float tb[G::NBP];                 // octave-scale target i: fractional position inside source interval klo[i]
+    float audw[G::NBP];               // auditory weighting of target i
+    int klo[G::NBP];
+    float sp_g[G::NBP];               // tridiagonal (1, 4, 1) elimination factors, 0 at bin 0
+    float sp_cf[CARRY - 1][64];       // forward / backward carry coefficients of the lane-blocked solve
+    float sp_cb[CARRY - 1][64];
+    float dct[NMFCC * NMEL + 8];      // DCT-II rows 1..12 with the lifter folded in
+    int seg_start[32];                // bins with lower channel c are [seg_start[c], seg_start[c+1]), c = 0..26
+    int shs_shift[16];
+    float shs_w[16];
+    float ham_sum, df, fmin_l2, dl2;
+    float band1_lo, band1_hi, band2_lo, band2_hi;
+    float slope_sf, slope_den, pad0, pad1;
+    int frame, hop, fs, max_seg;
+};
 
 static double mel_d(double f) { return 2595.0 * std::log10(1.0 + f / 700.0); }
 
-static void build_tables(Tables& t) {
+template <int LOG2N>
+static void build_tables(Tables<LOG2N>& t, int fs, int frame, int hop) {
+    using G = Geo<LOG2N>;
     std::memset(&t, 0, sizeof(t));
+    t.fs = fs; t.frame = frame; t.hop = hop;
+    const double df = (double)fs / G::NFFT;
+    t.df = (float)df;
     double hs = 0;
-    for (int i = 0; i < FRAME; ++i) {
-        double w = 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (FRAME - 1));
+    for (int i = 0; i < frame; ++i) {
+        const double w = 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (frame - 1));
         t.ham[i] = (float)w;
         hs += w;
     }
     t.ham_sum = (float)hs;
-    for (int m = 0; m < 256; ++m) {
-        t.tw256[m] = make_float2((float)std::cos(2.0 * M_PI * m / 256), (float)-std::sin(2.0 * M_PI * m / 256));
-        t.tw512[m] = make_float2((float)std::cos(2.0 * M_PI * m / 512), (float)-std::sin(2.0 * M_PI * m / 512));
+    for (int m = 0; m < G::NC; ++m) {
+        t.twc[m] = make_float2((float)std::cos(2.0 * M_PI * m / G::NC), (float)-std::sin(2.0 * M_PI * m / G::NC));
+        t.twr[m] = make_float2((float)std::cos(2.0 * M_PI * m / G::NFFT), (float)-std::sin(2.0 * M_PI * m / G::NFFT));
     }
-    // HTK filterbank: centre frequencies equally spaced on the mel scale between 20 and 8000 Hz
-    const double lo = mel_d(20.0), hi = mel_d(8000.0);
+    // HTK filterbank between 20 Hz and min(8000 Hz, Nyquist), equally spaced on the mel scale
+    const double fhi = std::min(8000.0, fs / 2.0);
+    const double lo = mel_d(20.0), hi = mel_d(fhi);
     double cf[NMEL + 2];
     for (int c = 0; c < NMEL + 2; ++c) cf[c] = lo + (hi - lo) * c / (NMEL + 1);
-    int lo_chan[NBINS];
-    for (int b = 0; b < NBINS; ++b) {
-        double f = b * (16000.0 / NFFT);
-        lo_chan[b] = -1;
-        if (f < 20.0 || f > 8000.0) continue;
-        double m = mel_d(f);
+    std::vector<int> lo_chan(G::NB, -1);
+    for (int b = 0; b < G::NB; ++b) {
+        const double f = b * df;
+        if (f < 20.0 || f > fhi) continue;
+        const double m = mel_d(f);
         int c = 0;
-        while (c < NMEL && cf[c + 1] <= m) ++c;   // cf[c] <= m < cf[c+1], capped at NMEL
+        while (c < NMEL && cf[c + 1] <= m) ++c;
         lo_chan[b] = c;
         t.lo_wt[b] = (float)((cf[c + 1] - m) / (cf[c + 1] - cf[c]));
     }
     int b = 0;
-    while (b < NBINS && lo_chan[b] < 0) ++b;
+    while (b < G::NB && lo_chan[b] < 0) ++b;
+    int max_seg = 0;
     for (int c = 0; c <= NMEL + 1; ++c) {
-        while (b < NBINS && lo_chan[b] >= 0 && lo_chan[b] < c) ++b;
+        while (b < G::NB && lo_chan[b] >= 0 && lo_chan[b] < c) ++b;
         t.seg_start[c] = b;
+        if (c > 0) max_seg = std::max(max_seg, t.seg_start[c] - t.seg_start[c - 1]);
     }
+    t.max_seg = max_seg;
     for (int k = 1; k <= NMFCC; ++k) {
-        double lift = 1.0 + 11.0 * std::sin(M_PI * k / 22.0);
+        const double lift = 1.0 + 11.0 * std::sin(M_PI * k / 22.0);
         for (int j = 1; j <= NMEL; ++j)
-            t.dct[(k - 1) * NMEL + (j - 1)] =
-                (float)(std::sqrt(2.0 / NMEL) * std::cos(M_PI * k * (j - 0.5) / NMEL) * lift);
+            t.dct[(k - 1) * NMEL + (j - 1)] = (float)(std::sqrt(2.0 / NMEL) * std::cos(M_PI * k * (j - 0.5) / NMEL) * lift);
     }
-    for (int bb = 0; bb < NBINS; ++bb) {
-        double f = bb * (16000.0 / NFFT);
-        double z = 13.0 * std::atan(0.00076 * f) + 3.5 * std::atan((f / 7500.0) * (f / 7500.0));
-        double g = z < 14.0 ? 1.0 : 0.066 * std::exp(0.171 * z);
+    for (int bb = 0; bb < G::NB; ++bb) {
+        const double f = bb * df;
+        const double z = 13.0 * std::atan(0.00076 * f) + 3.5 * std::atan((f / 7500.0) * (f / 7500.0));
+        const double g = z < 14.0 ? 1.0 : 0.066 * std::exp(0.171 * z);
         t.sharp[bb] = (float)(z * g);
+    }
+    t.band1_lo = 250.f; t.band1_hi = 650.f; t.band2_lo = 1000.f; t.band2_hi = 4000.f;
+    {   // spectral slope: sum f and sum f^2 over bins 0..NC
+        const double n = G::NC;
+        const double sf = df * n * (n + 1) / 2.0, sff = df * df * n * (n + 1) * (2 * n + 1) / 6.0;
+        t.slope_sf = (float)sf;
+        t.slope_den = (float)(G::NB * sff - sf * sf);
+    }
+    // cSpecScale: octave axis from 25 Hz to fs/2 with NB points; natural spline through the equally spaced bins
+    const double fmin_l2 = std::log2(25.0), fmax_l2 = std::log2(fs / 2.0);
+    const double dl2 = (fmax_l2 - fmin_l2) / (G::NB - 1);
+    const double ppo = 1.0 / dl2;
+    t.fmin_l2 = (float)fmin_l2;
+    t.dl2 = (float)dl2;
+    const double atans = ppo * std::log2(65.0 / 50.0) - 1.0;
+    for (int i = 0; i < G::NB; ++i) {
+        const double pos = std::exp2(fmin_l2 + dl2 * i) / df;
+        int k = (int)std::floor(pos);
+        if (k > G::NB - 2) k = G::NB - 2;
+        t.klo[i] = k;
+        t.tb[i] = (float)(pos - k);
+        t.audw[i] = (float)(0.5 + std::atan(3.0 * (i + 1.0 - atans) / ppo) / M_PI);
+    }
+    for (int h = 1; h <= NHARM; ++h) {
+        t.shs_shift[h - 1] = (int)std::floor(ppo * std::log2((double)h));
+        t.shs_w[h - 1] = (float)std::pow(0.85, h - 1);
+    }
+    // Thomas factors of tridiag(1, 4, 1) on unknowns at bins 1..NC-1 (m_0 = m_NC = 0):
+    //   forward  dp_b = g_b (r_b - dp_{b-1}),  backward  x_b = dp_b - g_b x_{b+1},  g_1 = 1/4, g_b = 1 / (4 - g_{b-1})
+    std::vector<double> g(G::NC + 1, 0.0), P(64, 1.0);
+    for (int bb = 1; bb < G::NC; ++bb) g[bb] = 1.0 / (4.0 - g[bb - 1]);
+    for (int bb = 0; bb < G::NC; ++bb) t.sp_g[bb] = (float)g[bb];
+    for (int L = 0; L < 64; ++L)
+        for (int i = 0; i < G::PPL; ++i) P[L] *= -g[G::PPL * L + i];
+    for (int L = 0; L < 64; ++L) {
+        double cf_ = 1.0, cb_ = 1.0;
+        for (int d = 2; d <= CARRY; ++d) {
+            cf_ *= (L - (d - 1) >= 0) ? P[L - (d - 1)] : 0.0;
+            cb_ *= (L + (d - 1) < 64) ? P[L + (d - 1)] : 0.0;
+            t.sp_cf[d - 2][L] = (float)cf_;
+            t.sp_cb[d - 2][L] = (float)cb_;
+        }
     }
 }
 
 static std::mutex g_mu;
-static Tables* g_dev_tables[64] = {nullptr};
+static std::map<std::pair<int, int>, void*> g_dev_tables;   // (device, fs) -> device blob
 
-int get_tables(const Tables** out) {
-    int dev = 0;
-    RSAF_CHECK_HIP(hipGetDevice(&dev));
-    RSAF_CHECK_ARG(dev >= 0 && dev < 64, "device index out of range");
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_dev_tables[dev]) {
-        std::vector<Tables> h(1);
-        build_tables(h[0]);
-        Tables* d = nullptr;
-        RSAF_CHECK_HIP(hipMalloc(&d, sizeof(Tables)));
-        RSAF_CHECK_HIP(hipMemcpy(d, h.data(), sizeof(Tables), hipMemcpyHostToDevice));
-        g_dev_tables[dev] = d;
-    }
-    *out = g_dev_tables[dev];
+static int log2n_for_frame(int frame) {
+    int l = 1;
+    while ((1 << l) < frame) ++l;
+    return l;
+}
+
+static int round_half_up(double x) { return (int)std::floor(x + 0.5); }
+
+int smile_geometry(int fs, int* frame, int* hop, int* log2n) {
+    RSAF_CHECK_ARG(fs >= 4000 && fs <= 65536, "sample rate must be in [4000, 65536] Hz");
+    const double T = 1.0 / (double)fs;
+    *frame = round_half_up(0.025 / T);
+    *hop = round_half_up(0.010 / T);
+    *log2n = log2n_for_frame(*frame);
+    RSAF_CHECK_ARG(*log2n >= 8 && *log2n <= 11, "unsupported frame length for this sample rate");
     return RSAF_OK;
 }
 
-// ---- device code -----------------------------------------------------------------------------
-struct __attribute__((aligned(16))) Smem {
-    Tables tab;
-    float samp[NSAMP];
-    float2 fa[4][256];       // per-wave FFT ping
-    float2 fb[4][256];       // per-wave FFT pong
-    float mag[4][2][260];    // per-wave magnitude spectra (current / previous frame)
-    float logmel[4][32];
-    float out[NLLD][RUN];    // LLD rows of this run
-};
+template <int LOG2N>
+static int get_tables(int fs, int frame, int hop, const Tables<LOG2N>** out) {
+    int dev = 0;
+    RSAF_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, fs);
+    auto it = g_dev_tables.find(key);
+    if (it == g_dev_tables.end()) {
+        std::vector<Tables<LOG2N>> h(1);
+        build_tables<LOG2N>(h[0], fs, frame, hop);
+        void* d = nullptr;
+        RSAF_CHECK_HIP(hipMalloc(&d, sizeof(Tables<LOG2N>)));
+        RSAF_CHECK_HIP(hipMemcpy(d, h.data(), sizeof(Tables<LOG2N>), hipMemcpyHostToDevice));
+        it = g_dev_tables.emplace(key, d).first;
+    }
+    *out = static_cast<const Tables<LOG2N>*>(it->second);
+    return RSAF_OK;
+}
 
+// ---- device helpers ----------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f vmax2(v2f a, v2f b) { return (v2f){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ v2f wave_sum2(v2f a) { return (v2f){wave_sum(a.x), wave_sum(a.y)}; }
+__device__ __forceinline__ float wave_shr1(float v) { return dpp_f32<0x138>(v); }   // lane l <- lane l-1, 0 into lane 0
+__device__ __forceinline__ float wave_shl1(float v) { return dpp_f32<0x130>(v); }   // lane l <- lane l+1, 0 into lane 63
+
+// complex multiply of a packed pair (re, im) by the twiddle (c, s)
+__device__ __forceinline__ void cmul2(v2f& re, v2f& im, float2 w) {
+    const v2f r = re * w.x - im * w.y;
+    const v2f i = re * w.y + im * w.x;
+    re = r; im = i;
 }
 
-__device__ __forceinline__ void radix4(float2& v0, float2& v1, float2& v2, float2& v3) {
-    float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-    float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-    float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-    float2 t = make_float2(v1.x - v3.x, v1.y - v3.y);
-    float2 a3 = make_float2(t.y, -t.x);   // -i * t
-    v0 = make_float2(a0.x + a2.x, a0.y + a2.y);
-    v1 = make_float2(a1.x + a3.x, a1.y + a3.y);
-    v2 = make_float2(a0.x - a2.x, a0.y - a2.y);
-    v3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+struct C2 { v2f re, im; };
+
+__device__ __forceinline__ void radix4(C2& v0, C2& v1, C2& v2, C2& v3) {
+    const C2 a0{v0.re + v2.re, v0.im + v2.im};
+    const C2 a1{v0.re - v2.re, v0.im - v2.im};
+    const C2 a2{v1.re + v3.re, v1.im + v3.im};
+    const C2 t{v1.re - v3.re, v1.im - v3.im};
+    const C2 a3{t.im, -t.re};                       // -i * t
+    v0 = C2{a0.re + a2.re, a0.im + a2.im};
+    v1 = C2{a1.re + a3.re, a1.im + a3.im};
+    v2 = C2{a0.re - a2.re, a0.im - a2.im};
+    v3 = C2{a1.re - a3.re, a1.im - a3.im};
 }
 
-template <int NS>
-__device__ __forceinline__ void stockham_stage(const float2* __restrict__ src, float2* __restrict__ dst,
-                                               const float2* __restrict__ tw, int j) {
-    float2 v0 = src[j], v1 = src[j + 64], v2 = src[j + 128], v3 = src[j + 192];
-    const int k = j & (NS - 1);
-    const int m = k * (64 / NS);
-    v1 = cmul(v1, tw[m]);
-    v2 = cmul(v2, tw[2 * m]);
-    v3 = cmul(v3, tw[3 * m]);
-    radix4(v0, v1, v2, v3);
-    const int j0 = ((j - k) << 2) + k;
-    dst[j0] = v0;
-    dst[j0 + NS] = v1;
-    dst[j0 + 2 * NS] = v2;
-    dst[j0 + 3 * NS] = v3;
+__device__ __forceinline__ C2 ldc(const v4f* X, int i) { const v4f v = X[i]; return C2{(v2f){v.x, v.y}, (v2f){v.z, v.w}}; }
+__device__ __forceinline__ void stc(v4f* X, int i, C2 c) { X[i] = (v4f){c.re.x, c.re.y, c.im.x, c.im.y}; }
+
+// one Stockham radix-4 stage in place: all butterflies of the wave are read, then written
+template <int NC, int NS>
+__device__ __forceinline__ void fft_stage4(v4f* X, const float2* __restrict__ tw, int lane) {
+    constexpr int NBF = NC / 4;
+    constexpr int U = (NBF + 63) / 64;
+    C2 v[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = lane + 64 * u;
+        if (NBF >= 64 || j < NBF) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[u][t] = ldc(X, j + t * NBF);
+            if (NS > 1) {
+                const int m = (j & (NS - 1)) * (NC / (NS * 4));
+                cmul2(v[u][1].re, v[u][1].im, tw[m]);
+                cmul2(v[u][2].re, v[u][2].im, tw[2 * m]);
+                cmul2(v[u][3].re, v[u][3].im, tw[3 * m]);
+            }
+            radix4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        }
+    }
+    lds_fence();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = lane + 64 * u;
+        if (NBF >= 64 || j < NBF) {
+            const int k = j & (NS - 1);
+            const int j0 = ((j - k) << 2) + k;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) stc(X, j0 + t * NS, v[u][t]);
+        }
+    }
+    lds_fence();
 }
 
-__global__ __launch_bounds__(256) void smile_lld_kernel(const float* __restrict__ wav,
-                                                        const int64_t* __restrict__ clip_off,
-                                                        const int64_t* __restrict__ frame_off,
-                                                        int64_t total_frames,
-                                                        float* __restrict__ lld,
-                                                        const Tables* __restrict__ gtab) {
+template <int NC, int NS>
+__device__ __forceinline__ void fft_stage2(v4f* X, const float2* __restrict__ tw, int lane) {
+    constexpr int NBF = NC / 2;
+    constexpr int U = (NBF + 63) / 64;
+    C2 v[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = lane + 64 * u;
+        v[u][0] = ldc(X, j);
+        v[u][1] = ldc(X, j + NBF);
+        const int m = (j & (NS - 1)) * (NC / (NS * 2));
+        cmul2(v[u][1].re, v[u][1].im, tw[m]);
+        const C2 a{v[u][0].re + v[u][1].re, v[u][0].im + v[u][1].im};
+        const C2 b{v[u][0].re - v[u][1].re, v[u][0].im - v[u][1].im};
+        v[u][0] = a; v[u][1] = b;
+    }
+    lds_fence();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = lane + 64 * u;
+        const int k = j & (NS - 1);
+        const int j0 = ((j - k) << 1) + k;
+        stc(X, j0, v[u][0]);
+        stc(X, j0 + NS, v[u][1]);
+    }
+    lds_fence();
+}
+
+// stages after the first one (which takes its input from registers)
+template <int NC, int NS>
+__device__ __forceinline__ void fft_rest(v4f* X, const float2* __restrict__ tw, int lane) {
+    if constexpr (NS * 4 <= NC) {
+        fft_stage4<NC, NS>(X, tw, lane);
+        fft_rest<NC, NS * 4>(X, tw, lane);
+    } else if constexpr (NS * 2 <= NC) {
+        fft_stage2<NC, NS>(X, tw, lane);
+    }
+}
+
+// best-first selection of up to NCAND peaks of one frame: every lane offers its unconsumed peaks (score > 0), the wave
+// takes the maximum NCAND times (ties: lowest lane = lowest frequency); lane r < NCAND returns slot r's (position, score)
+template <int PPL>
+__device__ __forceinline__ void select_peaks(float (&score)[PPL], const float (&pos)[PPL], int lane, float& out_pos,
+                                             float& out_score) {
+    out_pos = 0.f;
+    out_score = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < NCAND; ++r) {
+        float best = 0.f, bpos = 0.f;
+        int bi = -1;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i)
+            if (score[i] > best) { best = score[i]; bpos = pos[i]; bi = i; }
+        const float wmax = wave_max_nonneg(best);
+        if (!(wmax > 0.f)) break;                       // wave-uniform
+        const unsigned long long mask = __ballot(best == wmax);
+        const int wl = __ffsll((long long)mask) - 1;
+        const float spos = readlane_f32(bpos, wl);
+        if (lane == r) { out_pos = spos; out_score = wmax; }
+        if (lane == wl) {
+#pragma unroll
+            for (int i = 0; i < PPL; ++i)
+                if (i == bi) score[i] = 0.f;
+        }
+    }
+}
+
+template <int LOG2N>
+struct Smem {
+    using G = Geo<LOG2N>;
+    Tables<LOG2N> tab;
+    float x[G::WAVES][G::XF];             // per-wave FFT buffer, later [a | m], [S | H] (two halves of HALF float2)
+    float mag[G::WAVES][G::MF];           // per-wave magnitudes of the current pair (float2 per bin)
+    float logmel[G::WAVES][64];
+    float out[NLOCAL][G::RUN];            // LLD rows of this run
+};
+
+// local row of an LLD index (the six pitch-chain rows 14, 15, 18..21 are written by smile_pitch.hip)
+__host__ __device__ constexpr int local_row(int lld) { return lld < 14 ? lld : (lld < 18 ? lld - 2 : lld - 6); }
+__host__ __device__ constexpr int lld_of_local(int r) { return r < 14 ? r : (r < 16 ? r + 2 : r + 6); }
+
+template <int LOG2N>
+__global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
+    const float* __restrict__ wav, const int64_t* __restrict__ clip_off, const int64_t* __restrict__ frame_off,
+    int64_t total_frames, float* __restrict__ lld, float* __restrict__ cand, float* __restrict__ octave_dbg,
+    const Tables<LOG2N>* __restrict__ gtab) {
+    using G = Geo<LOG2N>;
+    constexpr int NC = G::NC, NB = G::NB, PPL = G::PPL, HALF = G::HALF;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+    Smem<LOG2N>& S = *reinterpret_cast<Smem<LOG2N>*>(smem_raw);
+    const Tables<LOG2N>& T = S.tab;
 
     const int clip = blockIdx.y;
     const int64_t s0 = clip_off[clip];
     const int64_t n_samp = clip_off[clip + 1] - s0;
-    const int64_t n_fr = n_samp < FRAME ? 0 : (n_samp - FRAME) / HOP + 1;
-    const int64_t f0 = (int64_t)blockIdx.x * RUN;
-    if (f0 >= n_fr) return;                       // uniform per workgroup
+    const int frame = gtab->frame, hop = gtab->hop;
+    const int64_t n_fr = n_samp < frame ? 0 : (n_samp - frame) / hop + 1;
+    const int64_t f0 = (int64_t)blockIdx.x * G::RUN;
+    if (f0 >= n_fr) return;                            // uniform per workgroup
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
 
-    // ---- stage tables + samples (coalesced) ----
-    {
+    {   // tables -> LDS
         const float4* g4 = reinterpret_cast<const float4*>(gtab);
         float4* s4 = reinterpret_cast<float4*>(&S.tab);
-        for (int i = tid; i < (int)(sizeof(Tables) / 16); i += 256) s4[i] = g4[i];
-        const int64_t base = f0 * HOP - HOP;      // sample index of S.samp[0] within the clip
-        const float* src = wav + s0;
-        for (int i = tid; i < NSAMP; i += 256) {
-            const int64_t si = base + i;
-            S.samp[i] = (si >= 0 && si < n_samp) ? src[si] : 0.0f;
-        }
+        for (int i = tid; i < (int)(sizeof(Tables<LOG2N>) / 16); i += G::WAVES * 64) s4[i] = g4[i];
     }
     __syncthreads();
 
-    const float2* tw = S.tab.tw256;
-    float2* FA = S.fa[w];
-    float2* FB = S.fb[w];
-    int cur = 0;
-    bool have_prev = false;
+    float* xs = S.x[w];
+    v4f* X = reinterpret_cast<v4f*>(xs);
+    v2f* XA = reinterpret_cast<v2f*>(xs);              // first half: a (spline ordinates), later S (octave spectrum)
+    v2f* XB = XA + HALF;                               // second half: flags / m (spline coefficients), later H (SHS)
+    v2f* M = reinterpret_cast<v2f*>(S.mag[w]);
+    const float* src = wav + s0;
+    const float df = T.df;
+    const float inv_frame = 1.0f / (float)frame;
 
-    for (int ff = -1; ff < FPW; ++ff) {
-        const int fl = w * FPW + ff;              // frame index within the run (-1 = warm-up)
-        const int64_t f = f0 + fl;
-        if (f < 0) continue;                      // clip's first frame has no predecessor
-        if (ff >= 0 && f >= n_fr) break;
-        const bool warm = ff < 0;
-        const float* x = &S.samp[(fl + 1) * HOP]; // +1: one hop of history in front
-
-        // ---- pre-emphasis, Hamming, frame energies, first Stockham stage from registers ----
-        float2 v[4];
-        float e_rms = 0.f, e_int = 0.f, zc = 0.f;
+    const int64_t fw = f0 + (int64_t)w * (2 * G::PPW);  // first frame of this wave
+    bool have_prev = false, deferred = false;
+    v2f prevB[PPL], stash[PPL];
+    float prevBx = 0.f, stashx = 0.f;                   // bin NC (kept on lane 63)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 2 * lane + 128 * r;
-            float y0 = 0.f, y1 = 0.f;
-            if (i < FRAME) {
-                const float xm = (i > 0) ? x[i - 1] : 0.0f;
-                const float xa = x[i], xb = x[i + 1];
-                const float p0 = (i > 0) ? (xa - PREEMPH * xm) : (xa * (1.0f - PREEMPH));
-                const float p1 = xb - PREEMPH * xa;
-                const float h0 = S.tab.ham[i], h1 = S.tab.ham[i + 1];
-                y0 = p0 * h0;
-                y1 = p1 * h1;
-                e_rms += y0 * y0 + y1 * y1;
-                e_int += h0 * y0 * y0 + h1 * y1 * y1;
-                zc += ((i > 0 && xa * xm < 0.0f) ? 1.0f : 0.0f) + ((xb * xa < 0.0f) ? 1.0f : 0.0f);
+    for (int i = 0; i < PPL; ++i) { prevB[i] = splat(0.f); stash[i] = splat(0.f); }
+
+    // pass -1 is wave 0's extra transform of the frame in front of the run (flux history only)
+    const int p_first = (w == 0 && f0 > 0) ? -1 : 0;
+#pragma unroll 1
+    for (int p = p_first; p < G::PPW; ++p) {
+        const bool warm = p < 0;
+        const int64_t fA = warm ? f0 - 1 : fw + 2 * p;
+        if (fA >= n_fr) break;                          // wave-uniform
+        const bool validB = !warm && (fA + 1 < n_fr);
+        const int offB = warm ? 0 : hop;
+        const int fl = (int)(fA - f0);                  // local frame index of A within the run
+
+        // ---- stage the pair's samples (coalesced; overlap between pairs and waves is served by L2) ----
+        {
+            const int span = frame + offB;
+            const int64_t sA = fA * hop;
+            for (int i = lane; i < span; i += 64) {
+                const int64_t si = sA + i;
+                xs[i] = (si < n_samp) ? src[si] : 0.0f;
             }
-            v[r] = make_float2(y0, y1);
         }
-        radix4(v[0], v[1], v[2], v[3]);           // stage Ns=1 (twiddles are 1)
+        lds_fence();
+
+        // ---- pre-emphasis, Hamming, frame energies; first radix-4 stage straight from registers ----
+        v2f e_rms = splat(0.f), e_int = splat(0.f), zc = splat(0.f);
         {
-            float4* d4 = reinterpret_cast<float4*>(FA);
-            d4[2 * lane] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-            d4[2 * lane + 1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
-        }
-        lds_fence();
-        stockham_stage<4>(FA, FB, tw, lane);
-        lds_fence();
-        stockham_stage<16>(FB, FA, tw, lane);
-        lds_fence();
-        {   // last stage (Ns = 64): outputs stay in registers, a copy goes to FB for the mirror reads
-            float2 v0 = FA[lane], v1 = FA[lane + 64], v2 = FA[lane + 128], v3 = FA[lane + 192];
-            v1 = cmul(v1, tw[lane]);
-            v2 = cmul(v2, tw[2 * lane]);
-            v3 = cmul(v3, tw[3 * lane]);
-            radix4(v0, v1, v2, v3);
-            v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
-            FB[lane] = v0; FB[lane + 64] = v1; FB[lane + 128] = v2; FB[lane + 192] = v3;
-        }
-        lds_fence();
-        float* M = S.mag[w][cur];
-        const float* Mp = S.mag[w][cur ^ 1];
+            constexpr int NBF = NC / 4;
+            constexpr int U = (NBF + 63) / 64;
+            C2 v[U][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = lane + 64 * q;
-            const float2 zk = v[q];
-            const float2 zn = FB[(256 - k) & 255];
-            const float ex = 0.5f * (zk.x + zn.x), ey = 0.5f * (zk.y - zn.y);
-            const float dx = zk.x - zn.x, dy = zk.y + zn.y;
-            const float2 o = make_float2(0.5f * dy, -0.5f * dx);
-            const float2 wo = cmul(S.tab.tw512[k], o);
-            const float xr = ex + wo.x, xi = ey + wo.y;
-            M[k] = sqrtf(xr * xr + xi * xi);
-            if (k == 0) M[256] = fabsf(zk.x - zk.y);
-        }
-        lds_fence();
-        if (warm) { cur ^= 1; have_prev = true; continue; }
-
-        // ---- frame energies ----
-        const float rms = sqrtf(wave_sum(e_rms) / FRAME);
-        const float inten = wave_sum(e_int) / S.tab.ham_sum * 1.0e6f;
-        const float zcr = wave_sum(zc) / FRAME;
-
-        // ---- HTK mel bank as segment sums, log, DCT ----
-        {
-            float sa = 0.f, sb = 0.f;
-            if (lane <= NMEL) {
-                const int b0 = S.tab.seg_start[lane], b1 = S.tab.seg_start[lane + 1];
-                for (int b = b0; b < b1; ++b) {
-                    const float m = M[b];
-                    const float a = S.tab.lo_wt[b] * m;
-                    sa += a;
-                    sb += m - a;
+            for (int u = 0; u < U; ++u) {
+                const int j = lane + 64 * u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i0 = 2 * (j + t * NBF), i1 = i0 + 1;
+                    v2f y0 = splat(0.f), y1 = splat(0.f);
+                    if ((NBF >= 64 || j < NBF) && i0 < frame) {
+                        const bool has1 = i1 < frame;
+                        const float h0 = T.ham[i0], h1 = T.ham[i1];      // 0 beyond the frame
+                        const v2f S0 = {xs[i0], xs[i0 + offB]};
+                        const v2f S1 = has1 ? (v2f){xs[i1], xs[i1 + offB]} : splat(0.f);
+                        const v2f SM = i0 > 0 ? (v2f){xs[i0 - 1], xs[i0 - 1 + offB]} : splat(0.f);
+                        const v2f p0 = i0 > 0 ? (S0 - PREEMPH * SM) : (S0 * (1.0f - PREEMPH));
+                        const v2f p1 = S1 - PREEMPH * S0;
+                        y0 = p0 * h0;
+                        y1 = p1 * h1;
+                        e_rms += y0 * y0 + y1 * y1;
+                        e_int += h0 * (y0 * y0) + h1 * (y1 * y1);
+                        const v2f c0 = S0 * SM, c1 = S1 * S0;
+                        zc += (v2f){(i0 > 0 && c0.x < 0.f) ? 1.f : 0.f, (i0 > 0 && c0.y < 0.f) ? 1.f : 0.f};
+                        zc += (v2f){(has1 && c1.x < 0.f) ? 1.f : 0.f, (has1 && c1.y < 0.f) ? 1.f : 0.f};
+                    }
+                    v[u][t] = C2{y0, y1};
+                }
+                radix4(v[u][0], v[u][1], v[u][2], v[u][3]);
+            }
+            lds_fence();                                   // every lane has read its samples: the buffer becomes the FFT array
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = lane + 64 * u;
+                if (NBF >= 64 || j < NBF) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) stc(X, 4 * j + t, v[u][t]);
                 }
             }
-            const float sb_prev = __shfl_up(sb, 1, 64);
-            // lane c (1..26) holds band c
-            const float band = (sa + sb_prev) * HTK_SCALE;
-            if (lane >= 1 && lane <= NMEL) S.logmel[w][lane - 1] = logf(fmaxf(band, MEL_FLOOR));
             lds_fence();
-            if (lane < NMFCC) {
-                float acc = 0.f;
+        }
+        fft_rest<NC, 4>(X, T.twc, lane);
+
+        // ---- packed-real unpack -> magnitudes (bin k = lane + 64 q), to the wave's magnitude slot ----
 #pragma unroll
-                for (int j = 0; j < NMEL; ++j) acc += S.logmel[w][j] * S.tab.dct[lane * NMEL + j];
-                S.out[1 + lane][fl] = acc;
+        for (int q = 0; q < PPL; ++q) {
+            const int k = lane + 64 * q;
+            const C2 zk = ldc(X, k);
+            const C2 zn = ldc(X, (NC - k) & (NC - 1));
+            const v2f ex = 0.5f * (zk.re + zn.re), ey = 0.5f * (zk.im - zn.im);
+            const v2f dx = zk.re - zn.re, dy = zk.im + zn.im;
+            v2f orr = 0.5f * dy, oi = -0.5f * dx;
+            cmul2(orr, oi, T.twr[k]);
+            const v2f xr = ex + orr, xi = ey + oi;
+            const v2f m2 = xr * xr + xi * xi;
+            M[k] = (v2f){sqrtf(m2.x), sqrtf(m2.y)};
+            if (k == 0) {
+                const v2f ny = zk.re - zk.im;
+                M[NC] = (v2f){fabsf(ny.x), fabsf(ny.y)};
+            }
+        }
+        lds_fence();
+
+        // ---- consecutive layout: lane owns bins PPL*lane .. PPL*lane + PPL-1, lane 63 also bin NC ----
+        const int b0 = PPL * lane;
+        v2f m[PPL];
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) m[i] = M[b0 + i];
+        const v2f mleft = lane > 0 ? M[b0 - 1] : splat(0.f);
+        const v2f mright = M[b0 + PPL];                    // lane 63: bin NC
+        const bool last = lane == 63;
+        const v2f mx = last ? mright : splat(0.f);
+
+        if (warm) {
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) prevB[i] = m[i];
+            prevBx = mx.x;
+            have_prev = true;
+            continue;
+        }
+
+        // ---- HTK mel bank: lanes 2(c-1) / 2(c-1)+1 sum the falling / rising side of band c ----
+        {
+            const int c = (lane >> 1) + 1;
+            const bool rising = lane & 1;
+            const int seg = rising ? c - 1 : c;
+            int sb = 0, se = 0;
+            if (c <= NMEL) { sb = T.seg_start[seg]; se = T.seg_start[seg + 1]; }
+            v2f acc = splat(0.f);
+            const int ms = T.max_seg;
+#pragma unroll 4
+            for (int it = 0; it < ms; ++it) {
+                const int b = sb + it;
+                if (b < se) {
+                    const float wt = T.lo_wt[b];
+                    acc += (rising ? 1.0f - wt : wt) * M[b];
+                }
+            }
+            const v2f other = {dpp_f32<0xB1>(acc.x), dpp_f32<0xB1>(acc.y)};       // quad_perm [1,0,3,2]
+            const v2f band = (acc + other) * HTK_SCALE;
+            if (!(lane & 1) && c <= NMEL) {
+                v2f* lm = reinterpret_cast<v2f*>(S.logmel[w]);
+                lm[c - 1] = (v2f){logf(fmaxf(band.x, MEL_FLOOR)), logf(fmaxf(band.y, MEL_FLOOR))};
+            }
+            lds_fence();
+            // DCT-II + lifter: lane 4k + part sums 7 mel channels of cepstral coefficient k + 1
+            const int kk = lane >> 2, part = lane & 3;
+            v2f dsum = splat(0.f);
+            if (kk < NMFCC) {
+                const v2f* lm = reinterpret_cast<const v2f*>(S.logmel[w]);
+#pragma unroll
+                for (int jj = 0; jj < 7; ++jj) {
+                    const int j = 7 * part + jj;
+                    if (j < NMEL) dsum += T.dct[kk * NMEL + j] * lm[j];
+                }
+            }
+            dsum += (v2f){dpp_f32<0xB1>(dsum.x), dpp_f32<0xB1>(dsum.y)};          // quad_perm [1,0,3,2]
+            dsum += (v2f){dpp_f32<0x4E>(dsum.x), dpp_f32<0x4E>(dsum.y)};          // quad_perm [2,3,0,1]
+            if (kk < NMFCC && part == 0) {
+                S.out[1 + kk][fl] = dsum.x;
+                if (validB) S.out[1 + kk][fl + 1] = dsum.y;
             }
         }
 
-        // ---- cSpectral on the power spectrum: lane owns bins 4*lane .. 4*lane+3 (+ bin 256 on lane 0)
-        float m4[4], p4[4];
-        {
-            const float4 mm = reinterpret_cast<const float4*>(M)[lane];
-            m4[0] = mm.x; m4[1] = mm.y; m4[2] = mm.z; m4[3] = mm.w;
-        }
-        const float m256 = M[256];
-        const float p256 = m256 * m256;
-        float s_p = 0.f, s_fp = 0.f, s_b1 = 0.f, s_b2 = 0.f, s_fl = 0.f, s_sh = 0.f, s_m = 0.f, s_lg = 0.f,
-              s_pk = 0.f;
+        // ---- cSpectral on the power spectrum ----
+        v2f pw[PPL];
+        v2f s_p = splat(0.f), s_fp = splat(0.f), s_b1 = splat(0.f), s_b2 = splat(0.f), s_fl = splat(0.f),
+            s_sh = splat(0.f), s_m = splat(0.f), s_lg = splat(0.f), s_pk = splat(0.f);
+        const bool flux_a = have_prev;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int b = 4 * lane + i;
-            const float fq = b * DF;
-            const float m = m4[i];
-            const float p = m * m;
-            p4[i] = p;
+        for (int i = 0; i < PPL; ++i) {
+            const int b = b0 + i;
+            const float fq = b * df;
+            const v2f p = m[i] * m[i];
+            pw[i] = p;
             s_p += p;
             s_fp += p * fq;
-            s_b1 += (fq >= 250.f && fq <= 650.f) ? p : 0.f;
-            s_b2 += (fq >= 1000.f && fq <= 4000.f) ? p : 0.f;
-            const float dm = have_prev ? (m - Mp[b]) : 0.f;
+            if (fq >= T.band1_lo && fq <= T.band1_hi) s_b1 += p;
+            if (fq >= T.band2_lo && fq <= T.band2_hi) s_b2 += p;
+            const v2f dm = {flux_a ? m[i].x - prevB[i].y : 0.f, m[i].y - m[i].x};   // B's history is A
             s_fl += dm * dm;
-            s_sh += p * S.tab.sharp[b];
-            s_m += m;
-            s_lg += logf(fmaxf(p, 1e-30f));
+            s_sh += p * T.sharp[b];
+            s_m += m[i];
+            s_lg += (v2f){logf(fmaxf(p.x, 1e-30f)), logf(fmaxf(p.y, 1e-30f))};
             if (b >= 1) {
-                const float ml = M[b - 1], mr = M[b + 1];
-                s_pk += fmaxf(m - 0.5f * (ml + mr), 0.f);   // prominence over the neighbours' mean (continuous)
+                const v2f ml = i > 0 ? m[i - 1] : mleft;
+                const v2f mr = i < PPL - 1 ? m[i + 1] : mright;
+                s_pk += vmax2(m[i] - 0.5f * (ml + mr), splat(0.f));        // prominence over the neighbours' mean
             }
         }
-        if (lane == 0) {
-            const float fq = 256 * DF;
-            s_fp += p256 * fq;
-            s_b2 += 0.f;
-            const float dm = have_prev ? (m256 - Mp[256]) : 0.f;
+        const v2f px = mx * mx;                                                // bin NC (lane 63 only, 0 elsewhere)
+        if (last) {
+            const float fq = NC * df;
+            s_fp += px * fq;
+            if (fq >= T.band1_lo && fq <= T.band1_hi) s_b1 += px;
+            if (fq >= T.band2_lo && fq <= T.band2_hi) s_b2 += px;
+            const v2f dm = {flux_a ? mx.x - prevBx : 0.f, mx.y - mx.x};
             s_fl += dm * dm;
-            s_sh += p256 * S.tab.sharp[256];
-            s_m += m256;
-            s_lg += logf(fmaxf(p256, 1e-30f));
+            s_sh += px * T.sharp[NC];
+            s_m += mx;
+            s_lg += (v2f){logf(fmaxf(px.x, 1e-30f)), logf(fmaxf(px.y, 1e-30f))};
         }
-        // inclusive scan of per-lane power (bins 0..255), total adds bin 256
-        const float lane_p = s_p;
-        const float incl = wave_scan_incl(lane_p);
-        const float tot = readlane_f32(incl, 63) + p256;
-        const float excl = incl - lane_p;
-        const float tot_fp = wave_sum(s_fp);
-        const float band1 = wave_sum(s_b1);
-        const float band2 = wave_sum(s_b2);
-        const float flux = sqrtf(wave_sum(s_fl) / NBINS);
-        const float sharp = wave_sum(s_sh);
-        const float msum = wave_sum(s_m);
-        const float lgsum = wave_sum(s_lg);
-        const float pksum = wave_sum(s_pk);
-        const float safe = tot > 0.f ? tot : 1.0f;
-        const float cen = tot_fp / safe;
+        // inclusive scan of the per-lane power (bins 0..NC-1); the total adds bin NC
+        const v2f incl = {wave_scan_incl(s_p.x), wave_scan_incl(s_p.y)};
+        const v2f tot = (v2f){readlane_f32(incl.x, 63), readlane_f32(incl.y, 63)} + wave_sum2(px);
+        const v2f excl = incl - s_p;
+        const v2f tot_fp = wave_sum2(s_fp);
+        const v2f band1 = wave_sum2(s_b1), band2 = wave_sum2(s_b2);
+        const v2f flsum = wave_sum2(s_fl);
+        const v2f sharp = wave_sum2(s_sh), msum = wave_sum2(s_m), lgsum = wave_sum2(s_lg), pksum = wave_sum2(s_pk);
+        const v2f rms2 = wave_sum2(e_rms), int2 = wave_sum2(e_int), zc2 = wave_sum2(zc);
+        const v2f safe = {tot.x > 0.f ? tot.x : 1.0f, tot.y > 0.f ? tot.y : 1.0f};
+        const v2f inv = {1.0f / safe.x, 1.0f / safe.y};
+        const v2f cen = tot_fp * inv;
         // roll-off: first bin whose inclusive cumulative power reaches p * total
-        int ro[4];
+        int roA[4], roB[4];
         {
-            const float thr[4] = {0.25f * tot, 0.50f * tot, 0.75f * tot, 0.90f * tot};
-            float c = excl;
-            int cand[4] = {256, 256, 256, 256};
+            const float pr[4] = {0.25f, 0.50f, 0.75f, 0.90f};
+            int cA[4] = {NC, NC, NC, NC}, cB[4] = {NC, NC, NC, NC};
+            v2f run = excl;
+            v2f cs[PPL];
 #pragma unroll
-            for (int i = 3; i >= 0; --i) { (void)i; }
-            float cs[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { c += p4[i]; cs[i] = c; }
+            for (int i = 0; i < PPL; ++i) { run += pw[i]; cs[i] = run; }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                const v2f thr = pr[t] * tot;
 #pragma unroll
-                for (int i = 3; i >= 0; --i)
-                    if (cs[i] >= thr[t]) cand[t] = 4 * lane + i;
-                ro[t] = wave_min_i32(cand[t]);
+                for (int i = PPL - 1; i >= 0; --i) {
+                    if (cs[i].x >= thr.x) cA[t] = b0 + i;
+                    if (cs[i].y >= thr.y) cB[t] = b0 + i;
+                }
+                roA[t] = wave_min_i32(cA[t]);
+                roB[t] = wave_min_i32(cB[t]);
             }
         }
         // second pass: central moments + entropy
-        float s_e = 0.f, s_v = 0.f, s_s = 0.f, s_k = 0.f;
-        const float inv = 1.0f / safe;
+        v2f s_e = splat(0.f), s_v = splat(0.f), s_s = splat(0.f), s_k = splat(0.f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float fq = (4 * lane + i) * DF;
-            const float pr = p4[i] * inv;
-            const float d = fq - cen;
-            s_e += pr > 0.f ? pr * log2f(pr) : 0.f;
-            const float d2 = d * d;
-            s_v += d2 * pr;
-            s_s += d2 * d * pr;
-            s_k += d2 * d2 * pr;
+        for (int i = 0; i <= PPL; ++i) {
+            if (i == PPL && !last) break;
+            const float fq = (i < PPL ? b0 + i : NC) * df;
+            const v2f prb = (i < PPL ? pw[i] : px) * inv;
+            const v2f d = splat(fq) - cen;
+            s_e += (v2f){prb.x > 0.f ? prb.x * log2f(prb.x) : 0.f, prb.y > 0.f ? prb.y * log2f(prb.y) : 0.f};
+            const v2f d2 = d * d;
+            s_v += d2 * prb;
+            s_s += d2 * d * prb;
+            s_k += d2 * d2 * prb;
         }
+        const v2f ent = -wave_sum2(s_e), var = wave_sum2(s_v), sk = wave_sum2(s_s), ku = wave_sum2(s_k);
         if (lane == 0) {
-            const float pr = p256 * inv;
-            const float d = 256 * DF - cen;
-            s_e += pr > 0.f ? pr * log2f(pr) : 0.f;
-            const float d2 = d * d;
-            s_v += d2 * pr;
-            s_s += d2 * d * pr;
-            s_k += d2 * d2 * pr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !validB) break;
+                const int fo = fl + h;
+                const float tt = h ? tot.y : tot.x, sf = h ? safe.y : safe.x;
+                const float vr = h ? var.y : var.x;
+                const float vs = vr > 0.f ? vr : 1.0f;
+                const float inten = (h ? int2.y : int2.x) / T.ham_sum * 1.0e6f;
+                const int* ro = h ? roB : roA;
+                S.out[0][fo] = sqrtf((h ? rms2.y : rms2.x) * inv_frame);
+                S.out[13][fo] = (h ? zc2.y : zc2.x) * inv_frame;
+                S.out[local_row(16)][fo] = inten;
+                S.out[local_row(17)][fo] = powf(inten, 0.3f);
+                S.out[local_row(22)][fo] = h ? band1.y : band1.x;
+                S.out[local_row(23)][fo] = h ? band2.y : band2.x;
+                S.out[local_row(24)][fo] = ro[0] * df;
+                S.out[local_row(25)][fo] = ro[1] * df;
+                S.out[local_row(26)][fo] = ro[2] * df;
+                S.out[local_row(27)][fo] = ro[3] * df;
+                if (h == 1 || flux_a || fA == 0)
+                    S.out[local_row(28)][fo] = sqrtf((h ? flsum.y : flsum.x) / NB);
+                S.out[local_row(29)][fo] = h ? cen.y : cen.x;
+                S.out[local_row(30)][fo] = h ? ent.y : ent.x;
+                S.out[local_row(31)][fo] = vr;
+                S.out[local_row(32)][fo] = (h ? sk.y : sk.x) / (vs * sqrtf(vs));
+                S.out[local_row(33)][fo] = (h ? ku.y : ku.x) / (vs * vs);
+                S.out[local_row(34)][fo] = (NB * (h ? tot_fp.y : tot_fp.x) - T.slope_sf * tt) / T.slope_den;
+                S.out[local_row(35)][fo] = (h ? sharp.y : sharp.x) / sf;
+                const float ms_ = h ? msum.y : msum.x;
+                S.out[local_row(36)][fo] = (h ? pksum.y : pksum.x) / (ms_ > 0.f ? ms_ : 1.0f);
+                S.out[local_row(37)][fo] = expf((h ? lgsum.y : lgsum.x) / NB) / fmaxf(tt / NB, 1e-30f);
+            }
         }
-        const float ent = -wave_sum(s_e);
-        const float var = wave_sum(s_v);
-        const float sk = wave_sum(s_s);
-        const float ku = wave_sum(s_k);
-        if (lane == 0) {
-            const float vs = var > 0.f ? var : 1.0f;
-            // sum f = DF * 256*257/2, sum f^2 = DF^2 * 256*257*513/6  (bins 0..256)
-            const float sf = DF * 32896.0f;
-            const float sff = DF * DF * 5625216.0f;
-            S.out[0][fl] = rms;
-            S.out[13][fl] = zcr;
-            S.out[16][fl] = inten;
-            S.out[17][fl] = powf(inten, 0.3f);
-            S.out[22][fl] = band1;
-            S.out[23][fl] = band2;
-            S.out[24][fl] = ro[0] * DF;
-            S.out[25][fl] = ro[1] * DF;
-            S.out[26][fl] = ro[2] * DF;
-            S.out[27][fl] = ro[3] * DF;
-            S.out[28][fl] = flux;
-            S.out[29][fl] = cen;
-            S.out[30][fl] = ent;
-            S.out[31][fl] = var;
-            S.out[32][fl] = sk / (vs * sqrtf(vs));
-            S.out[33][fl] = ku / (vs * vs);
-            S.out[34][fl] = (NBINS * tot_fp - sf * tot) / (NBINS * sff - sf * sf);
-            S.out[35][fl] = sharp / safe;
-            S.out[36][fl] = pksum / (msum > 0.f ? msum : 1.0f);
-            S.out[37][fl] = expf(lgsum / NBINS) / fmaxf(tot / NBINS, 1e-30f);
+        if (!flux_a && fA != 0) {                          // first frame of a wave > 0: history arrives after the barrier
+            deferred = true;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) stash[i] = m[i];
+            stashx = mx.x;
         }
-        cur ^= 1;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) prevB[i] = m[i];
+        prevBx = mx.y;
         have_prev = true;
+
+        // ---- cSpecScale: peak enhancement + smoothing on the linear spectrum ----
+        // flags word per bin: bit 0 / 1 = "local maximum" in frame A / B
+        unsigned* FL = reinterpret_cast<unsigned*>(XB);
+        bool anyA = false, anyB = false;
+        int firstA = 0x7fffffff, firstB = 0x7fffffff, lastA = -1, lastB = -1, cntA = 0, cntB = 0;
+#pragma unroll
+        for (int i = 0; i <= PPL; ++i) {
+            if (i == PPL && !last) break;
+            const int b = i < PPL ? b0 + i : NC;
+            const v2f me = i < PPL ? m[i] : mx;
+            const v2f ml = i == 0 ? mleft : m[i - 1];
+            const v2f mr = i < PPL - 1 ? m[i + 1] : (i == PPL - 1 ? mright : splat(0.f));
+            bool fa, fb;
+            if (b == 0) { fa = me.x > mr.x; fb = me.y > mr.y; }
+            else if (b == NC) { fa = me.x > ml.x; fb = me.y > ml.y; }
+            else { fa = me.x > ml.x && me.x >= mr.x; fb = me.y > ml.y && me.y >= mr.y; }
+            FL[b] = (fa ? 1u : 0u) | (fb ? 2u : 0u);
+            if (fa) { anyA = true; firstA = min(firstA, b); lastA = max(lastA, b); ++cntA; }
+            if (fb) { anyB = true; firstB = min(firstB, b); lastB = max(lastB, b); ++cntB; }
+        }
+        if (lane == 0) { FL[NC + 1] = 0u; FL[NC + 2] = 0u; FL[NC + 3] = 0u; }
+        lds_fence();
+        // wave-wide first / last maximum and their count
+        const int gfirstA = wave_min_i32(firstA), gfirstB = wave_min_i32(firstB);
+        const int glastA = -wave_min_i32(-lastA), glastB = -wave_min_i32(-lastB);
+        const int ncA = (int)wave_sum((float)cntA), ncB = (int)wave_sum((float)cntB);
+        (void)anyA; (void)anyB;
+        // window of flags for bins b0-3 .. b0+PPL+2
+        unsigned fw_[PPL + 6];
+#pragma unroll
+        for (int o = 0; o < PPL + 6; ++o) {
+            const int b = b0 - 3 + o;
+            fw_[o] = (b >= 0 && b <= NC) ? FL[b] : 0u;
+        }
+        // enhanced value of bin b0 - 1 + o, o = 0 .. PPL+1 (own bins and one neighbour on each side)
+        v2f en[PPL + 2];
+#pragma unroll
+        for (int o = 0; o < PPL + 2; ++o) {
+            const int b = b0 - 1 + o;
+            const unsigned near = fw_[o] | fw_[o + 1] | fw_[o + 2] | fw_[o + 3] | fw_[o + 4];   // bins b-2 .. b+2
+            const v2f val = o == 0 ? mleft : (o <= PPL ? m[o - 1] : mright);
+            const bool zA = !(near & 1u) && (ncA == 1 || (ncA >= 2 && b > gfirstA && b < glastA));
+            const bool zB = !(near & 2u) && (ncB == 1 || (ncB >= 2 && b > gfirstB && b < glastB));
+            en[o] = (b >= 0 && b <= NC) ? (v2f){zA ? 0.f : val.x, zB ? 0.f : val.y} : splat(0.f);
+        }
+        lds_fence();                                         // flags consumed: the second half is free again
+        // smoothing (1, 2, 1) / 4, zero left of bin 0, bin NC untouched; a -> first half
+        v2f a[PPL];
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            a[i] = 0.25f * (en[i] + 2.0f * en[i + 1] + en[i + 2]);
+            XA[b0 + i] = a[i];
+        }
+        if (last) XA[NC] = en[PPL + 1];                      // bin NC keeps its enhanced value
+        lds_fence();
+        // ---- natural cubic spline through the bins: m_{b-1} + 4 m_b + m_{b+1} = a_{b-1} - 2 a_b + a_{b+1} ----
+        {
+            const v2f aleft = lane > 0 ? XA[b0 - 1] : splat(0.f);
+            const v2f aright = XA[b0 + PPL];
+            float g[PPL];
+            v2f d[PPL];
+            // forward elimination, local part (carry 0), then the carry of up to CARRY lanes
+            v2f run = splat(0.f);
+            float qf[PPL];
+            float q = 1.0f;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                g[i] = T.sp_g[b0 + i];
+                const v2f al = i == 0 ? aleft : a[i - 1];
+                const v2f ar = i == PPL - 1 ? aright : a[i + 1];
+                const v2f r = al - 2.0f * a[i] + ar;
+                run = g[i] * (r - run);
+                d[i] = run;
+                q *= -g[i];
+                qf[i] = q;
+            }
+            {
+                v2f e = run, carry = splat(0.f);
+#pragma unroll
+                for (int dd = 1; dd <= CARRY; ++dd) {
+                    e = (v2f){wave_shr1(e.x), wave_shr1(e.y)};
+                    carry += (dd == 1 ? 1.0f : T.sp_cf[dd - 2][lane]) * e;
+                }
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) d[i] += qf[i] * carry;
+            }
+            // back substitution x_b = dp_b - g_b x_{b+1}
+            v2f x[PPL];
+            float qb[PPL];
+            run = splat(0.f);
+            q = 1.0f;
+#pragma unroll
+            for (int i = PPL - 1; i >= 0; --i) {
+                run = d[i] - g[i] * run;
+                x[i] = run;
+                q *= -g[i];
+                qb[i] = q;
+            }
+            {
+                v2f e = run, carry = splat(0.f);
+#pragma unroll
+                for (int dd = 1; dd <= CARRY; ++dd) {
+                    e = (v2f){wave_shl1(e.x), wave_shl1(e.y)};
+                    carry += (dd == 1 ? 1.0f : T.sp_cb[dd - 2][lane]) * e;
+                }
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) x[i] += qb[i] * carry;
+            }
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) XB[b0 + i] = x[i];
+            if (last) XB[NC] = splat(0.f);
+        }
+        lds_fence();
+        // ---- octave-scale targets i = b0 .. b0+PPL-1 (+ NC on lane 63): spline value, clip, auditory weighting ----
+        v2f sv[PPL + 1];
+#pragma unroll
+        for (int i = 0; i <= PPL; ++i) {
+            sv[i] = splat(0.f);
+            if (i == PPL && !last) break;
+            const int ti = i < PPL ? b0 + i : NC;
+            const int k = T.klo[ti];
+            const float bb = T.tb[ti], aa = 1.0f - bb;
+            const float ca = aa * aa * aa - aa, cb = bb * bb * bb - bb;
+            const v2f y = aa * XA[k] + bb * XA[k + 1] + ca * XB[k] + cb * XB[k + 1];
+            sv[i] = vmax2(y, splat(0.f)) * T.audw[ti];
+        }
+        lds_fence();                                         // all reads of a / m done: reuse the halves for S / H
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) XA[b0 + i] = sv[i];
+        if (last) { XA[NC] = sv[PPL]; XA[NC + 1] = splat(0.f); }   // entry NC+1 = 0: target of out-of-range shifts
+        if (octave_dbg) {
+            const int64_t fg = frame_off[clip] + fA;
+#pragma unroll
+            for (int i = 0; i <= PPL; ++i) {
+                if (i == PPL && !last) break;
+                const int ti = i < PPL ? b0 + i : NC;
+                octave_dbg[fg * NB + ti] = sv[i].x;
+                if (validB) octave_dbg[(fg + 1) * NB + ti] = sv[i].y;
+            }
+        }
+        lds_fence();
+        // ---- cPitchShs: sub-harmonic summation H[i] = sum_h 0.85^(h-1) S[i + shift_h] ----
+        v2f hv[PPL + 1];
+        v2f hsum = splat(0.f);
+#pragma unroll
+        for (int i = 0; i <= PPL; ++i) {
+            hv[i] = splat(0.f);
+            if (i == PPL && !last) break;
+            const int ti = i < PPL ? b0 + i : NC;
+            v2f acc = splat(0.f);
+#pragma unroll
+            for (int h = 0; h < NHARM; ++h) {
+                const int src_i = min(ti + T.shs_shift[h], NC + 1);
+                acc += T.shs_w[h] * XA[src_i];
+            }
+            hv[i] = acc;
+            hsum += acc;
+        }
+        const v2f hmean = wave_sum2(hsum) * (1.0f / NB);
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) XB[b0 + i] = hv[i];
+        if (last) XB[NC] = hv[PPL];
+        lds_fence();
+        {
+            const v2f hleft = lane > 0 ? XB[b0 - 1] : splat(0.f);
+            const v2f hright = XB[b0 + PPL];
+            float scA[PPL], scB[PPL], poA[PPL], poB[PPL];
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                const int ti = b0 + i;
+                const v2f y1 = i == 0 ? hleft : hv[i - 1];
+                const v2f y2 = hv[i];
+                const v2f y3 = i == PPL - 1 ? hright : hv[i + 1];
+                scA[i] = scB[i] = 0.f;
+                poA[i] = poB[i] = 0.f;
+                if (ti >= 1) {                                   // ti <= NC - 1 always: bin NC is never a peak centre
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float a1 = h ? y1.y : y1.x, a2 = h ? y2.y : y2.x, a3 = h ? y3.y : y3.x;
+                        if (a2 > a1 && a2 >= a3) {
+                            const float den = a1 - 2.0f * a2 + a3;
+                            const float dxp = 0.5f * (a1 - a3) / den;
+                            const float sc = a2 - 0.125f * (a1 - a3) * (a1 - a3) / den;
+                            const float ps = (float)ti + dxp;
+                            const float fq = exp2f(T.fmin_l2 + ps * T.dl2);
+                            if (fq >= 52.0f && fq <= 620.0f && sc > 0.f) {
+                                if (h) { scB[i] = sc; poB[i] = ps; } else { scA[i] = sc; poA[i] = ps; }
+                            }
+                        }
+                    }
+                }
+            }
+            float rp, rs;
+            const int64_t fg = frame_off[clip] + fA;
+            select_peaks<PPL>(scA, poA, lane, rp, rs);
+            if (lane < NCAND) {
+                const float fq = rs > 0.f ? exp2f(T.fmin_l2 + rp * T.dl2) : 0.f;
+                const float vo = rs > 0.f ? fmaxf(0.f, 1.0f - hmean.x / rs) : 0.f;
+                reinterpret_cast<float2*>(cand)[fg * NCAND + lane] = make_float2(fq, vo);
+            }
+            if (validB) {
+                select_peaks<PPL>(scB, poB, lane, rp, rs);
+                if (lane < NCAND) {
+                    const float fq = rs > 0.f ? exp2f(T.fmin_l2 + rp * T.dl2) : 0.f;
+                    const float vo = rs > 0.f ? fmaxf(0.f, 1.0f - hmean.y / rs) : 0.f;
+                    reinterpret_cast<float2*>(cand)[(fg + 1) * NCAND + lane] = make_float2(fq, vo);
+                }
+            }
+        }
+        lds_fence();
+    }
+    __syncthreads();
+    if (deferred) {                                          // flux of this wave's first frame against the previous wave's last
+        const v2f* Mp = reinterpret_cast<const v2f*>(S.mag[w - 1]);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const float dm = stash[i].x - Mp[PPL * lane + i].y;
+            acc += dm * dm;
+        }
+        if (lane == 63) {
+            const float dm = stashx - Mp[NC].y;
+            acc += dm * dm;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) S.out[local_row(28)][(int)(fw - f0)] = sqrtf(acc / NB);
     }
     __syncthreads();
 
     // ---- coalesced contour-major store of the run ----
     const int64_t fbase = frame_off[clip] + f0;
-    const int nvalid = (int)min((int64_t)RUN, n_fr - f0);
-    const float qnan = __int_as_float(0x7fc00000);
-    for (int idx = tid; idx < NLLD * RUN; idx += 256) {
-        const int i = idx / RUN, t = idx % RUN;
+    const int nvalid = (int)min((int64_t)G::RUN, n_fr - f0);
+    for (int idx = tid; idx < NLOCAL * G::RUN; idx += G::WAVES * 64) {
+        const int r = idx / G::RUN, t = idx % G::RUN;
         if (t >= nvalid) continue;
-        const bool built = !(i == 14 || i == 15 || (i >= 18 && i <= 21));
-        lld[(int64_t)i * total_frames + fbase + t] = built ? S.out[i][t] : qnan;
+        lld[(int64_t)lld_of_local(r) * total_frames + fbase + t] = S.out[r][t];
     }
+}
+
+template <int LOG2N>
+static int launch(const float* wav, const int64_t* clip_off, const int64_t* frame_off, int n_clips,
+                  int64_t max_clip_frames, int64_t total_frames, int fs, int frame, int hop, float* lld, float* cand,
+                  float* octave_dbg, hipStream_t s) {
+    using G = Geo<LOG2N>;
+    const Tables<LOG2N>* tab = nullptr;
+    int rc = get_tables<LOG2N>(fs, frame, hop, &tab);
+    if (rc != RSAF_OK) return rc;
+    const int64_t runs = (max_clip_frames + G::RUN - 1) / G::RUN;
+    RSAF_CHECK_ARG(runs <= 0x7fffffffLL, "clip too long");
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    RSAF_CHECK_HIP(hipGetDevice(&dev));
+    RSAF_CHECK_ARG(dev >= 0 && dev < 64, "device index out of range");
+    if (!attr_set[dev]) {
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)smile_lld_kernel<LOG2N>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<LOG2N>)));
+        attr_set[dev] = true;
+    }
+    // algorithmic bytes: every sample read once (4 B) + the LLD rows written (38 * 4 B per frame)
+    ProfScope prof("smile_lld", s, 0.0, 0.0);
+    dim3 grid((unsigned)runs, (unsigned)n_clips);
+    hipLaunchKernelGGL(smile_lld_kernel<LOG2N>, grid, dim3(G::WAVES * 64), sizeof(Smem<LOG2N>), s, wav, clip_off,
+                       frame_off, total_frames, lld, cand, octave_dbg, tab);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
 }
 
 }  // namespace smile
@@ -464,44 +980,44 @@ using namespace rsaf::smile;
 
 extern "C" {
 
-int64_t rsaf_smile_n_frames(int64_t n_samples) {
-    return n_samples < FRAME ? 0 : (n_samples - FRAME) / HOP + 1;
+int rsaf_smile_geometry(int sample_rate, int* frame_host, int* hop_host, int* nfft_host) {
+    RSAF_CHECK_ARG(frame_host && hop_host && nfft_host, "NULL output");
+    int l2 = 0;
+    int rc = smile_geometry(sample_rate, frame_host, hop_host, &l2);
+    if (rc != RSAF_OK) return rc;
+    *nfft_host = 1 << l2;
+    return RSAF_OK;
+}
+
+int64_t rsaf_smile_n_frames(int64_t n_samples, int sample_rate) {
+    int frame = 0, hop = 0, l2 = 0;
+    if (smile_geometry(sample_rate, &frame, &hop, &l2) != RSAF_OK) return -1;
+    return n_samples < frame ? 0 : (n_samples - frame) / hop + 1;
 }
 
 int rsaf_init_device(int device) {
     RSAF_CHECK_HIP(hipSetDevice(device));
-    const Tables* t = nullptr;
-    return get_tables(&t);
+    const Tables<9>* t = nullptr;
+    return get_tables<9>(16000, 400, 160, &t);
 }
 
 int rsaf_smile_lld_batch(const float* wav, const int64_t* clip_off, const int64_t* frame_off,
-                         int n_clips, int64_t max_clip_frames, int64_t total_frames, float* lld,
-                         rsaf_stream_t stream) {
+                         int n_clips, int64_t max_clip_frames, int64_t total_frames, int sample_rate, float* lld,
+                         float* cand, float* octave_spectrum, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535, "n_clips must be in [0, 65535] per call");
     RSAF_CHECK_ARG(total_frames >= 0 && max_clip_frames >= 0, "negative frame count");
-    if (n_clips == 0 || total_frames == 0 || max_clip_frames == 0) return RSAF_OK;
-    RSAF_CHECK_ARG(wav && clip_off && frame_off && lld, "NULL pointer");
-    const Tables* tab = nullptr;
-    int rc = get_tables(&tab);
+    int frame = 0, hop = 0, l2 = 0;
+    int rc = smile_geometry(sample_rate, &frame, &hop, &l2);
     if (rc != RSAF_OK) return rc;
-    const int64_t runs = (max_clip_frames + RUN - 1) / RUN;
-    RSAF_CHECK_ARG(runs <= 0x7fffffffLL, "clip too long");
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    RSAF_CHECK_HIP(hipGetDevice(&dev));
-    if (!attr_set[dev]) {
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)smile_lld_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-        attr_set[dev] = true;
-    }
+    if (n_clips == 0 || total_frames == 0 || max_clip_frames == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(wav && clip_off && frame_off && lld && cand, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    // algorithmic bytes: every sample read once (4 B) + the LLD rows written (38 * 4 B per frame)
-    ProfScope prof("smile_lld", s, 0.0, 0.0);
-    dim3 grid((unsigned)runs, (unsigned)n_clips);
-    hipLaunchKernelGGL(smile_lld_kernel, grid, dim3(256), sizeof(Smem), s, wav, clip_off, frame_off,
-                       total_frames, lld, tab);
-    RSAF_CHECK_HIP(hipGetLastError());
-    return RSAF_OK;
+    switch (l2) {
+        case 8: return launch<8>(wav, clip_off, frame_off, n_clips, max_clip_frames, total_frames, sample_rate, frame, hop, lld, cand, octave_spectrum, s);
+        case 9: return launch<9>(wav, clip_off, frame_off, n_clips, max_clip_frames, total_frames, sample_rate, frame, hop, lld, cand, octave_spectrum, s);
+        case 10: return launch<10>(wav, clip_off, frame_off, n_clips, max_clip_frames, total_frames, sample_rate, frame, hop, lld, cand, octave_spectrum, s);
+        default: return launch<11>(wav, clip_off, frame_off, n_clips, max_clip_frames, total_frames, sample_rate, frame, hop, lld, cand, octave_spectrum, s);
+    }
 }
 
 }  // extern "C"

@@ -128,13 +128,12 @@ class Pipeline:
         if "mshds" in self.stages:
             parts.append("MSHDS Praat-style 25/25 features (speech rate, pitch, intensity, HNR, LTAS slope/tilt, CPPS, formants, spectral moments; fp64)")
         if "smile" in self.stages:
-            parts.append("openSMILE-style 32/38 LLD + 912 functionals")
+            parts.append("openSMILE-style 38/38 LLD (incl. SHS pitch + Viterbi, jitter / shimmer / logHNR) + 912 functionals")
         if "w2v2" in self.stages:
             parts.append("Wav2Vec2-base frame embeddings (5 s windows / 4 s hop, fp32, seeded random weights)")
         if "cnnlstm" in self.stages:
             parts.append("CNN-LSTM-attn forward (C=H=128) on the Wav2Vec2 sequences")
-        return (f"{' -> '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU; "
-                "the six openSMILE pitch / voice-quality LLDs that are not built are NaN (DESIGN.md)")
+        return f"{' -> '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU"
 
 
 def roofline(prof, pipe, clips, seconds, steps, hbm_peak_gbs, mfma_peak_tflops):

@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from .wavio import read_wav_mono
 
-FRAME, HOP, NLLD, NFEAT = 400, 160, 38, 912
+FRAME, HOP, NLLD, NFEAT, NCAND = 400, 160, 38, 912, 6     # FRAME / HOP at 16 kHz
 SAMPLE_RATE = 16000
 
 LLD_NAMES = (
@@ -47,26 +47,45 @@ def feature_names():
     return names
 
 
-def n_frames(n_samples: int) -> int:
-    return 0 if n_samples < FRAME else (n_samples - FRAME) // HOP + 1
+_GEOMETRY = {}
+
+
+def geometry(fs: int = SAMPLE_RATE):
+    """(frame, hop, nfft) of the chain at sample rate ``fs`` (``rsaf_smile_geometry``: 25 ms / 10 ms frames,
+    Androids.conf:73-78, FFT zero-padded to the next power of two)."""
+    fs = int(fs)
+    if fs not in _GEOMETRY:
+        import ctypes as C
+        fr, hp, nf = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().rsaf_smile_geometry(fs, C.byref(fr), C.byref(hp), C.byref(nf)), "rsaf_smile_geometry")
+        _GEOMETRY[fs] = (fr.value, hp.value, nf.value)
+    return _GEOMETRY[fs]
+
+
+def n_frames(n_samples: int, fs: int = SAMPLE_RATE) -> int:
+    if int(fs) == SAMPLE_RATE:
+        return 0 if n_samples < FRAME else (n_samples - FRAME) // HOP + 1
+    frame, hop, _ = geometry(fs)
+    return 0 if n_samples < frame else (n_samples - frame) // hop + 1
 
 
 class PackedClips:
-    """A batch of mono 16 kHz clips concatenated in one device buffer (HBM layout of the path)."""
+    """A batch of mono clips of ONE sample rate concatenated in one device buffer (HBM layout of the path)."""
 
-    def __init__(self, wav, clip_off, frame_off, lengths, frames):
+    def __init__(self, wav, clip_off, frame_off, lengths, frames, fs=SAMPLE_RATE):
         self.wav = wav                  # float32 [total_samples]           (device)
         self.clip_off = clip_off        # int64   [n+1] sample offsets       (device)
         self.frame_off = frame_off      # int64   [n+1] frame offsets        (device)
         self.lengths = lengths          # python list of sample counts
         self.frames = frames            # python list of frame counts
+        self.fs = int(fs)
         self.n_clips = len(lengths)
         self.total_samples = int(sum(lengths))
         self.total_frames = int(sum(frames))
         self.max_frames = int(max(frames)) if frames else 0
 
 
-def pack_clips(clips, device="cuda") -> PackedClips:
+def pack_clips(clips, device="cuda", fs=SAMPLE_RATE) -> PackedClips:
     """clips: list of 1-D float32 arrays/tensors, or a 2-D [n, samples] array/tensor."""
     import torch
     _lib.require_gpu()
@@ -81,45 +100,65 @@ def pack_clips(clips, device="cuda") -> PackedClips:
         lengths = [int(a.shape[0]) for a in arrs]
         host = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.float32)
         wav = torch.from_numpy(host).to(device)
-    frames = [n_frames(n) for n in lengths]
+    frames = [n_frames(n, fs) for n in lengths]
     co = np.zeros(len(lengths) + 1, dtype=np.int64)
     co[1:] = np.cumsum(lengths)
     fo = np.zeros(len(lengths) + 1, dtype=np.int64)
     fo[1:] = np.cumsum(frames)
     return PackedClips(wav, torch.from_numpy(co).to(device), torch.from_numpy(fo).to(device),
-                       lengths, frames)
+                       lengths, frames, fs)
 
 
-def smile_lld(p: PackedClips, stream=None):
-    """LLD contours, float32 [38, total_frames] (contour-major)."""
+def smile_lld(p: PackedClips, stream=None, octave_spectrum=False, return_candidates=False):
+    """All 38 LLD contours, float32 [38, total_frames] (contour-major): the frame kernel
+    (``rsaf_smile_lld_batch``) followed by the Viterbi smoother / energy gate / jitter pass (``rsaf_smile_pitch_track``).
+    ``octave_spectrum`` also returns the cSpecScale level [total_frames, nfft/2+1]; ``return_candidates`` the
+    cPitchShs candidates [total_frames, 6, 2] (f0, voicing)."""
     import torch
     lib = _lib.load()
-    lld = torch.empty((NLLD, max(p.total_frames, 1)), dtype=torch.float32, device=p.wav.device)
+    dev = p.wav.device
+    lld = torch.empty((NLLD, max(p.total_frames, 1)), dtype=torch.float32, device=dev)
+    cand = torch.zeros((max(p.total_frames, 1), NCAND, 2), dtype=torch.float32, device=dev)
+    oct_ = None
+    if octave_spectrum:
+        oct_ = torch.zeros((max(p.total_frames, 1), geometry(p.fs)[2] // 2 + 1), dtype=torch.float32, device=dev)
     if p.total_frames == 0:
-        return lld[:, :0]
-    for c0 in range(0, p.n_clips, 65535):
-        n = min(65535, p.n_clips - c0)
-        mx = max(p.frames[c0:c0 + n])
-        _lib.check(lib.rsaf_smile_lld_batch(
-            _lib.ptr(p.wav), _lib.c_void_p_off(p.clip_off, c0), _lib.c_void_p_off(p.frame_off, c0),
-            n, mx, p.total_frames, _lib.ptr(lld), _lib.stream_ptr(stream)), "rsaf_smile_lld_batch")
-    return lld
+        res = [lld[:, :0]]
+    else:
+        back = torch.empty((p.total_frames, 8), dtype=torch.uint8, device=dev)
+        for c0 in range(0, p.n_clips, 65535):
+            n = min(65535, p.n_clips - c0)
+            mx = max(p.frames[c0:c0 + n])
+            _lib.check(lib.rsaf_smile_lld_batch(
+                _lib.ptr(p.wav), _lib.c_void_p_off(p.clip_off, c0), _lib.c_void_p_off(p.frame_off, c0),
+                n, mx, p.total_frames, p.fs, _lib.ptr(lld), _lib.ptr(cand),
+                _lib.ptr(oct_) if oct_ is not None else None, _lib.stream_ptr(stream)), "rsaf_smile_lld_batch")
+            _lib.check(lib.rsaf_smile_pitch_track(
+                _lib.ptr(p.wav), _lib.c_void_p_off(p.clip_off, c0), _lib.c_void_p_off(p.frame_off, c0), n,
+                p.total_frames, p.fs, _lib.ptr(cand), _lib.ptr(back), _lib.ptr(lld), _lib.stream_ptr(stream)),
+                "rsaf_smile_pitch_track")
+        res = [lld]
+    if octave_spectrum:
+        res.append(oct_[:p.total_frames])
+    if return_candidates:
+        res.append(cand[:p.total_frames])
+    return res[0] if len(res) == 1 else tuple(res)
 
 
-def smile_functionals(lld, p: PackedClips, stream=None):
-    """[n_clips, 912] float32 functionals of the LLD contours."""
+def smile_functionals(lld, p: PackedClips, stream=None, window_frames: int = 0):
+    """[n_clips, 912] float32 functionals of the LLD contours (``window_frames`` = 0: whole clip)."""
     import torch
     lib = _lib.load()
     out = torch.empty((p.n_clips, NFEAT), dtype=torch.float32, device=p.wav.device)
     if p.n_clips:
         _lib.check(lib.rsaf_smile_functionals(
             _lib.ptr(lld) if lld.numel() else None, _lib.ptr(p.frame_off), p.n_clips,
-            p.total_frames, _lib.ptr(out), _lib.stream_ptr(stream)), "rsaf_smile_functionals")
+            p.total_frames, int(window_frames), _lib.ptr(out), _lib.stream_ptr(stream)), "rsaf_smile_functionals")
     return out
 
 
-def smile_features(p: PackedClips, stream=None):
-    return smile_functionals(smile_lld(p, stream), p, stream)
+def smile_features(p: PackedClips, stream=None, window_frames: int = 0):
+    return smile_functionals(smile_lld(p, stream), p, stream, window_frames)
 
 
 # ---- Androids.conf validation -------------------------------------------------------------------
@@ -149,6 +188,22 @@ def parse_smile_conf(path: str):
     return sections
 
 
+def functionals_window(sec, frame_period: float = 0.010) -> int:
+    """cFunctionals framing of a parsed config (``Androids.conf:349-356``): 0 = the whole file (frameSize 0 or
+    frameMode full), else the window in LLD frames when read literally (frameStep 0 = frameSize: round(frameSize / T))."""
+    f = sec.get("functL1", {})
+    if f.get("framemode", "").lower().startswith("full"):
+        return 0
+    size, step = float(f.get("framesize", 0.0)), float(f.get("framestep", 0.0))
+    if size < 0 or step < 0:
+        raise ValueError("[functL1] negative frameSize / frameStep")
+    if size == 0.0:
+        return 0
+    if step not in (0.0, size):
+        raise ValueError("[functL1] overlapping / gapped functional windows (frameStep != frameSize) are not implemented")
+    return int(np.floor(size / frame_period + 0.5))
+
+
 def validate_smile_conf(path: str):
     """Raise ValueError unless the config is the chain the kernels implement (Androids.conf)."""
     sec = parse_smile_conf(path)
@@ -162,64 +217,72 @@ def validate_smile_conf(path: str):
     fe = sec.get("functL1", {}).get("functionalsenabled", "")
     if [s.strip() for s in fe.split(";")] != ["Extremes", "Regression", "Moments"]:
         raise ValueError("functionalsEnabled must be Extremes;Regression;Moments")
+    functionals_window(sec)                     # framing must be one the kernels can produce
     return sec
 
 
 def extract_opensmile_features(input_df, opensmile_exe_path, config_file_path,
-                               audio_file_column="filepath", verbose=True, batch_clips=256):
+                               audio_file_column="filepath", verbose=True, batch_clips=256,
+                               functionals="whole-file"):
     """Drop-in for ``src/opensmile_extractor.py:9-103`` backed by the HIP kernels.
 
     ``opensmile_exe_path`` is accepted for signature compatibility and ignored (no process is
     spawned).  ``config_file_path`` must be the reference's ``Androids.conf`` chain; a missing or
     unsupported config follows the reference's fatal-error convention (message + empty DataFrame,
     ``src/opensmile_extractor.py:41-43``).  Files that cannot be processed are omitted
-    (``:89-96``).  The six LLDs whose kernels are not built yet give NaN columns.
+    (``:89-96``).  Every file is analysed at its own sample rate, as SMILExtract does (frame sizes are
+    seconds); files are grouped by rate, one kernel launch per group.
+
+    ``functionals``: how ``[functL1]`` (``Androids.conf:349-356``: ``frameSize=0.025``, ``frameStep=0`` under a
+    comment that says "functionals over complete input") is read.  ``"whole-file"`` (default) = one row of
+    statistics over the complete input, what the reference's caller assumes (``:80-83`` "the single output row");
+    ``"first-window"`` = the literal reading (windows of frameSize, the reference's ``.iloc[0]`` keeps the first).
+    No SMILExtract output exists here to decide; see ``oracle/smile_oracle.py``.  PARITY UNPINNED: the numbers
+    follow this repository's restatement of the openSMILE components, not a recorded SMILExtract run.
     """
     import pandas as pd
     import torch
+    if functionals not in ("whole-file", "first-window"):
+        raise ValueError("functionals must be 'whole-file' or 'first-window'")
     try:
-        validate_smile_conf(config_file_path)
+        sec = validate_smile_conf(config_file_path)
+        window = functionals_window(sec) if functionals == "first-window" else 0
     except (OSError, ValueError) as e:
         print(f"FATAL ERROR: unusable openSMILE config '{config_file_path}': {e}")
         return pd.DataFrame()
     _lib.load()
     _lib.require_gpu()
     names = feature_names()
-    rows = []
+    rows = {}
     paths = list(input_df[audio_file_column])
     for b0 in range(0, len(paths), batch_clips):
-        clips, fnames = [], []
-        for pth in paths[b0:b0 + batch_clips]:
+        groups = {}                                  # sample rate -> [(position, filename, samples)]
+        for k, pth in enumerate(paths[b0:b0 + batch_clips]):
             filename = os.path.basename(pth)
             try:
                 x, fs = read_wav_mono(pth)
-                if fs != SAMPLE_RATE:
-                    # SMILExtract analyses at the file's own rate (frame sizes in seconds); that is not built.
-                    # Opt-in approximation: convert to 16 kHz on the device and run the 16 kHz chain.
-                    if os.environ.get("RSAF_SMILE_RESAMPLE", "0") != "1":
-                        raise ValueError(f"sample rate {fs} Hz: only 16 kHz input is supported "
-                                         "(set RSAF_SMILE_RESAMPLE=1 to convert to 16 kHz first; results then "
-                                         "differ from a native-rate analysis)")
-                    from .resample import resample_sinc_hann
-                    x = resample_sinc_hann(x, fs, SAMPLE_RATE).cpu().numpy()
-                if n_frames(len(x)) == 0:
+                if n_frames(len(x), fs) == 0:
                     raise ValueError("shorter than one 25 ms frame")
-                clips.append(x)
-                fnames.append(filename)
+                groups.setdefault(int(fs), []).append((b0 + k, filename, x))
             except Exception as e:  # per-file failure -> file omitted (reference :89-96)
                 if verbose:
                     print(f"ERROR: OpenSMILE failed for file '{filename}'. Stderr: {e}")
-        if not clips:
-            continue
-        p = pack_clips(clips)
-        feats = smile_features(p)
-        torch.cuda.synchronize()
-        host = feats.cpu().numpy()
-        for fn, r in zip(fnames, host):
-            d = dict(zip(names, r.tolist()))
-            d["filename"] = fn
-            rows.append(d)
+        for fs, items in groups.items():
+            try:
+                p = pack_clips([x for _, _, x in items], fs=fs)
+                feats = smile_features(p, window_frames=window)
+                torch.cuda.synchronize()
+                host = feats.cpu().numpy()
+            except _lib.RsafError as e:
+                if verbose:
+                    for _, filename, _ in items:
+                        print(f"ERROR: OpenSMILE failed for file '{filename}'. Stderr: {e}")
+                continue
+            for (pos, fn, _), r in zip(items, host):
+                d = dict(zip(names, r.tolist()))
+                d["filename"] = fn
+                rows[pos] = d
     if not rows:
         print("Warning: No features were successfully extracted. The returned DataFrame is empty.")
         return pd.DataFrame()
-    return pd.DataFrame(rows)
+    return pd.DataFrame([rows[k] for k in sorted(rows)])

@@ -8,7 +8,7 @@ from robust_speech_analysis_framework_amd import smile, synth
 from robust_speech_analysis_framework_amd.w2v2 import W2V2Engine
 from robust_speech_analysis_framework_amd.w2v2_config import W2V2Config, random_state_dict
 from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
-from tests.test_smile_gpu import _check_lld
+from tests.test_smile_gpu import _check_frame_rows, _check_pitch_chain
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -18,11 +18,14 @@ clips = [synth.synth_clip(first + k, d) for k, d in enumerate(durs)]
 
 # ---- openSMILE chain ----
 p = smile.pack_clips(clips)
-lld = smile.smile_lld(p)
+lld, octv, cand = smile.smile_lld(p, octave_spectrum=True, return_candidates=True)
 torch.cuda.synchronize()
 assert p.frames == [so.n_frames(len(c)) for c in clips]
 ref = np.concatenate([so.lld(c) for c in clips if so.n_frames(len(c)) > 0], axis=1)
-_check_lld(lld.cpu().numpy().astype(np.float64), ref)
+P = so.Params(16000)
+g = lld.cpu().numpy().astype(np.float64)
+_check_frame_rows(g, ref, P)
+_check_pitch_chain(clips, p, g, octv.cpu().numpy().astype(np.float64), cand.cpu().numpy().astype(np.float64), P, min_voiced=0.0)
 print(f"smile: {count} clips, {sum(p.frames)} frames: LLD parity ok (tolerances of tests/test_smile_gpu.py)", flush=True)
 
 # ---- Wav2Vec2 (seeded random base weights) -> CNN-LSTM ----

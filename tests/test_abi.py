@@ -28,10 +28,11 @@ def test_python_binding_covers_header(rsaf_lib):
 
 
 def test_abi_version_and_host_only_calls(rsaf_lib):
-    assert rsaf_lib.rsaf_abi_version() == 1
+    assert rsaf_lib.rsaf_abi_version() == 2
     # integer-exact frame-count contract (Androids.conf:73-78): no GPU needed
     for n, want in [(0, 0), (399, 0), (400, 1), (559, 1), (560, 2), (80000, 498), (480000, 2998)]:
-        assert rsaf_lib.rsaf_smile_n_frames(n) == want
+        assert rsaf_lib.rsaf_smile_n_frames(n, 16000) == want
+    assert rsaf_lib.rsaf_smile_n_frames(44100, 44100) == (44100 - 1103) // 441 + 1      # native-rate geometry
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
