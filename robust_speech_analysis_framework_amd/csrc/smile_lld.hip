@@ -19,9 +19,9 @@
 // Templated on the FFT length (256 / 512 / 1024 / 2048 <-> 8 / 16 / 22.05-32 / 44.1-48 kHz; frame and hop
 // lengths are run-time).
 //
-// Spectral flux needs the previous frame's magnitudes: inside a pair they are in registers; a wave's first
-// frame takes them from the previous wave's last pair after the workgroup barrier; only wave 0 transforms
-// one extra frame (the last one of the previous run).
+// Spectral flux needs the previous frame's magnitudes: inside a wave's span they are in registers; for its first
+// frame the wave transforms the frame in front of its span once more (window + FFT only: +6 % work), which keeps
+// the waves independent of each other.
 //
 // Semantics are those of oracle/smile_oracle.py (the CPU restatement), parity unpinned.
 #include <cmath>
@@ -42,7 +42,6 @@ constexpr int NMEL = 26;
 constexpr int NMFCC = 12;
 constexpr int NCAND = RSAF_SMILE_NCAND;
 constexpr int NHARM = 15;
-constexpr int CARRY = 6;                 // lanes of carry kept in the blocked tridiagonal solve (0.268^(4*6) ~ 2e-14)
 constexpr int NLOCAL = 32;               // LLD rows this kernel produces (38 minus the six pitch-chain rows)
 constexpr float PREEMPH = 0.97f;
 constexpr float HTK_SCALE = 32767.0f;
@@ -54,8 +53,11 @@ struct Geo {
     static constexpr int NC = NFFT / 2;              // complex points of the packed-real transform
     static constexpr int NB = NC + 1;                // magnitude bins
     static constexpr int PPL = NC / 64;              // bins per lane
-    static constexpr int NBP = NC + 16;              // padded length of the per-bin tables
-    static constexpr int HALF = NC + 8;              // float2 entries of one half of the wave's FFT buffer
+    static constexpr int NBP = NC + 8;               // padded length of the per-bin tables
+    // lanes of carry kept in the lane-blocked tridiagonal solve: a lane block damps a carry by 0.268^PPL, so
+    // 4 lanes reach 0.268^12 ~ 1e-7 of a term that is itself < 0.27 of the local one (PPL = 2: 6 lanes)
+    static constexpr int CARRY = PPL >= 4 ? 4 : 6;
+    static constexpr int HALF = NC + 8 + (NC + 8) / 32 + 1;   // float2 entries of one half of the wave's FFT buffer (swizzled)
     static constexpr int XF = 4 * HALF;              // floats of the wave's FFT buffer
     static constexpr int MF = 2 * HALF;              // floats of the wave's magnitude slot
     static constexpr int WAVES = LOG2N >= 11 ? 4 : 8;
@@ -67,8 +69,8 @@ struct Geo {
 template <int LOG2N>
 struct __attribute__((aligned(16))) Tables {
     using G = Geo<LOG2N>;
-    float2 twc[G::NC];                // exp(-2 pi i m / NC)
-    float2 twr[G::NC];                // exp(-2 pi i k / NFFT)
+    float2 twr[G::NC + G::NC / 2];    // exp(-2 pi i k / NFFT), k < 3 NC / 2: the packed-real unpack uses k < NC, the
+                                      // complex stages exp(-2 pi i m / NC) = twr[2 m], m < 3 NC / 4
     float ham[G::NFFT];               // Hamming window, zero beyond the frame
     float lo_wt[G::NBP];              // HTK lower-channel weight per bin (0 where unused)
     float sharp[G::NBP];              // bark(f) * g(bark) per bin
@@ -76,16 +78,19 @@ struct __attribute__((aligned(16))) Tables {
     float audw[G::NBP];               // auditory weighting of target i
     int klo[G::NBP];
     float sp_g[G::NBP];               // tridiagonal (1, 4, 1) elimination factors, 0 at bin 0
-    float sp_cf[CARRY - 1][64];       // forward / backward carry coefficients of the lane-blocked solve
-    float sp_cb[CARRY - 1][64];
-    float dct[NMFCC * NMEL + 8];      // DCT-II rows 1..12 with the lifter folded in
+    float sp_cf[G::CARRY - 1][64];    // forward / backward carry coefficients of the lane-blocked solve
+    float sp_cb[G::CARRY - 1][64];
+    float dct[NMFCC * NMEL];          // DCT-II rows 1..12 with the lifter folded in
     int seg_start[32];                // bins with lower channel c are [seg_start[c], seg_start[c+1]), c = 0..26
+    int mel_lane[64];                 // lane's chunk of a band side: start bin | length << 12 | rising << 20 (0 = idle)
+    int mel_band[32];                 // band c-1: first lane | number of lanes << 8
     int shs_shift[16];
     float shs_w[16];
     float ham_sum, df, fmin_l2, dl2;
     float band1_lo, band1_hi, band2_lo, band2_hi;
     float slope_sf, slope_den, pad0, pad1;
     int frame, hop, fs, max_seg;
+    int mel_iters, mel_max_n, pad2, pad3;
 };
 
 static double mel_d(double f) { return 2595.0 * std::log10(1.0 + f / 700.0); }
@@ -104,10 +109,8 @@ static void build_tables(Tables<LOG2N>& t, int fs, int frame, int hop) {
         hs += w;
     }
     t.ham_sum = (float)hs;
-    for (int m = 0; m < G::NC; ++m) {
-        t.twc[m] = make_float2((float)std::cos(2.0 * M_PI * m / G::NC), (float)-std::sin(2.0 * M_PI * m / G::NC));
+    for (int m = 0; m < G::NC + G::NC / 2; ++m)
         t.twr[m] = make_float2((float)std::cos(2.0 * M_PI * m / G::NFFT), (float)-std::sin(2.0 * M_PI * m / G::NFFT));
-    }
     // HTK filterbank between 20 Hz and min(8000 Hz, Nyquist), equally spaced on the mel scale
     const double fhi = std::min(8000.0, fs / 2.0);
     const double lo = mel_d(20.0), hi = mel_d(fhi);
@@ -132,6 +135,34 @@ static void build_tables(Tables<LOG2N>& t, int fs, int frame, int hop) {
         if (c > 0) max_seg = std::max(max_seg, t.seg_start[c] - t.seg_start[c - 1]);
     }
     t.max_seg = max_seg;
+    // lane-balanced schedule of the 52 band sides (falling side of band c = bins with lower channel c weighted lo_wt,
+    // rising side = bins with lower channel c-1 weighted 1 - lo_wt): chunks of at most CH bins, one chunk per lane
+    for (int CH = 1; CH <= G::NB; ++CH) {
+        int need = 0;
+        for (int c = 1; c <= NMEL; ++c)
+            for (int side = 0; side < 2; ++side) {
+                const int seg = side ? c - 1 : c;
+                const int L = t.seg_start[seg + 1] - t.seg_start[seg];
+                need += (L + CH - 1) / CH;
+            }
+        if (need > 64) continue;
+        int lane = 0, max_n = 0;
+        for (int c = 1; c <= NMEL; ++c) {
+            const int first = lane;
+            for (int side = 0; side < 2; ++side) {
+                const int seg = side ? c - 1 : c;
+                for (int b0 = t.seg_start[seg]; b0 < t.seg_start[seg + 1]; b0 += CH) {
+                    const int L = std::min(CH, t.seg_start[seg + 1] - b0);
+                    t.mel_lane[lane++] = b0 | (L << 12) | (side << 20);
+                }
+            }
+            t.mel_band[c - 1] = first | ((lane - first) << 8);
+            max_n = std::max(max_n, lane - first);
+        }
+        t.mel_iters = CH;
+        t.mel_max_n = max_n;
+        break;
+    }
     for (int k = 1; k <= NMFCC; ++k) {
         const double lift = 1.0 + 11.0 * std::sin(M_PI * k / 22.0);
         for (int j = 1; j <= NMEL; ++j)
@@ -178,7 +209,7 @@ static void build_tables(Tables<LOG2N>& t, int fs, int frame, int hop) {
         for (int i = 0; i < G::PPL; ++i) P[L] *= -g[G::PPL * L + i];
     for (int L = 0; L < 64; ++L) {
         double cf_ = 1.0, cb_ = 1.0;
-        for (int d = 2; d <= CARRY; ++d) {
+        for (int d = 2; d <= G::CARRY; ++d) {
             cf_ *= (L - (d - 1) >= 0) ? P[L - (d - 1)] : 0.0;
             cb_ *= (L + (d - 1) < 64) ? P[L + (d - 1)] : 0.0;
             t.sp_cf[d - 2][L] = (float)cf_;
@@ -235,8 +266,67 @@ __device__ __forceinline__ void lds_fence() {
 }
 
 __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+// LDS index of entry b of a float2 array read PPL-consecutive-per-lane (32 B lane stride): one pad entry per 32 spreads
+// the 32 lanes of a b64 access group over all 64 banks (plain indexing is a 4-way conflict)
+__device__ __forceinline__ int sw(int b) { return b + (b >> 5); }
 __device__ __forceinline__ v2f vmax2(v2f a, v2f b) { return (v2f){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
 __device__ __forceinline__ v2f wave_sum2(v2f a) { return (v2f){wave_sum(a.x), wave_sum(a.y)}; }
+// 1-ulp hardware forms (the IEEE expansions of /, sqrtf, logf cost ~10 instructions each; the parity bar is 1e-4)
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog(float x) { return flog2(x) * 0.6931471805599453f; }
+__device__ __forceinline__ v2f frcp2(v2f a) { return (v2f){frcp(a.x), frcp(a.y)}; }
+__device__ __forceinline__ v2f fsqrt2(v2f a) { return (v2f){fsqrt(a.x), fsqrt(a.y)}; }
+__device__ __forceinline__ v2f flog2_2(v2f a) { return (v2f){flog2(a.x), flog2(a.y)}; }
+__device__ __forceinline__ v2f fexp2_2(v2f a) { return (v2f){fexp2(a.x), fexp2(a.y)}; }
+
+// Eight wave reductions at once (gfx950 lane swaps): v_permlane32_swap / v_permlane16_swap fold two registers into
+// one whose halves / rows hold different quantities, then three DPP steps finish inside 8-lane groups: 18 vector
+// instructions + 8 v_readlane for eight totals instead of 8 x 7.  v[] comes back wave-uniform.
+template <bool IS_MIN>
+__device__ __forceinline__ void wave_reduce8(float (&v)[8]) {
+    auto op = [](float a, float b) { return IS_MIN ? fminf(a, b) : a + b; };
+    float a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        a[i] = op(__uint_as_float(r[0]), __uint_as_float(r[1]));           // lanes < 32: v[i], lanes >= 32: v[i+4]
+    }
+    float b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[2 * i]), __float_as_uint(a[2 * i + 1]), false, false);
+        b[i] = op(__uint_as_float(r[0]), __uint_as_float(r[1]));           // rows: v[2i], v[2i+1], v[2i+4], v[2i+5]
+    }
+    const bool hi8 = (threadIdx.x & 8) != 0;
+    const float keep = hi8 ? b[1] : b[0], give = hi8 ? b[0] : b[1];
+    float z = op(keep, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0x128, 0xF, 0xF, false)));   // row_ror:8
+    z = op(z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z), 0xB1, 0xF, 0xF, false)));
+    z = op(z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z), 0x4E, 0xF, 0xF, false)));
+    z = op(z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z), 0x141, 0xF, 0xF, false)));             // row_half_mirror
+    // row r, half h holds: (r0: v0 | v2) (r1: v1 | v3) (r2: v4 | v6) (r3: v5 | v7)
+    v[0] = readlane_f32(z, 0);  v[2] = readlane_f32(z, 8);
+    v[1] = readlane_f32(z, 16); v[3] = readlane_f32(z, 24);
+    v[4] = readlane_f32(z, 32); v[6] = readlane_f32(z, 40);
+    v[5] = readlane_f32(z, 48); v[7] = readlane_f32(z, 56);
+}
+__device__ __forceinline__ void wave_sum4x2(v2f& a, v2f& b, v2f& c, v2f& d) {
+    float v[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+    wave_reduce8<false>(v);
+    a = (v2f){v[0], v[1]}; b = (v2f){v[2], v[3]}; c = (v2f){v[4], v[5]}; d = (v2f){v[6], v[7]};
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {      // zero fill of the shifts is neutral
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
 __device__ __forceinline__ float wave_shr1(float v) { return dpp_f32<0x138>(v); }   // lane l <- lane l-1, 0 into lane 0
 __device__ __forceinline__ float wave_shl1(float v) { return dpp_f32<0x130>(v); }   // lane l <- lane l+1, 0 into lane 63
 
@@ -278,9 +368,9 @@ __device__ __forceinline__ void fft_stage4(v4f* X, const float2* __restrict__ tw
             for (int t = 0; t < 4; ++t) v[u][t] = ldc(X, j + t * NBF);
             if (NS > 1) {
                 const int m = (j & (NS - 1)) * (NC / (NS * 4));
-                cmul2(v[u][1].re, v[u][1].im, tw[m]);
-                cmul2(v[u][2].re, v[u][2].im, tw[2 * m]);
-                cmul2(v[u][3].re, v[u][3].im, tw[3 * m]);
+                cmul2(v[u][1].re, v[u][1].im, tw[2 * m]);             // tw = exp(-2 pi i k / (2 NC)): every other entry
+                cmul2(v[u][2].re, v[u][2].im, tw[4 * m]);
+                cmul2(v[u][3].re, v[u][3].im, tw[6 * m]);
             }
             radix4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
@@ -310,7 +400,7 @@ __device__ __forceinline__ void fft_stage2(v4f* X, const float2* __restrict__ tw
         v[u][0] = ldc(X, j);
         v[u][1] = ldc(X, j + NBF);
         const int m = (j & (NS - 1)) * (NC / (NS * 2));
-        cmul2(v[u][1].re, v[u][1].im, tw[m]);
+        cmul2(v[u][1].re, v[u][1].im, tw[2 * m]);
         const C2 a{v[u][0].re + v[u][1].re, v[u][0].im + v[u][1].im};
         const C2 b{v[u][0].re - v[u][1].re, v[u][0].im - v[u][1].im};
         v[u][0] = a; v[u][1] = b;
@@ -338,41 +428,13 @@ __device__ __forceinline__ void fft_rest(v4f* X, const float2* __restrict__ tw, 
     }
 }
 
-// best-first selection of up to NCAND peaks of one frame: every lane offers its unconsumed peaks (score > 0), the wave
-// takes the maximum NCAND times (ties: lowest lane = lowest frequency); lane r < NCAND returns slot r's (position, score)
-template <int PPL>
-__device__ __forceinline__ void select_peaks(float (&score)[PPL], const float (&pos)[PPL], int lane, float& out_pos,
-                                             float& out_score) {
-    out_pos = 0.f;
-    out_score = 0.f;
-#pragma unroll 1
-    for (int r = 0; r < NCAND; ++r) {
-        float best = 0.f, bpos = 0.f;
-        int bi = -1;
-#pragma unroll
-        for (int i = 0; i < PPL; ++i)
-            if (score[i] > best) { best = score[i]; bpos = pos[i]; bi = i; }
-        const float wmax = wave_max_nonneg(best);
-        if (!(wmax > 0.f)) break;                       // wave-uniform
-        const unsigned long long mask = __ballot(best == wmax);
-        const int wl = __ffsll((long long)mask) - 1;
-        const float spos = readlane_f32(bpos, wl);
-        if (lane == r) { out_pos = spos; out_score = wmax; }
-        if (lane == wl) {
-#pragma unroll
-            for (int i = 0; i < PPL; ++i)
-                if (i == bi) score[i] = 0.f;
-        }
-    }
-}
-
 template <int LOG2N>
 struct Smem {
     using G = Geo<LOG2N>;
     Tables<LOG2N> tab;
     float x[G::WAVES][G::XF];             // per-wave FFT buffer, later [a | m], [S | H] (two halves of HALF float2)
     float mag[G::WAVES][G::MF];           // per-wave magnitudes of the current pair (float2 per bin)
-    float logmel[G::WAVES][64];
+    float melbuf[G::WAVES][180];          // per-wave: 64 float2 chunk sums, then 26 float2 log mel energies
     float out[NLOCAL][G::RUN];            // LLD rows of this run
 };
 
@@ -381,12 +443,12 @@ __host__ __device__ constexpr int local_row(int lld) { return lld < 14 ? lld : (
 __host__ __device__ constexpr int lld_of_local(int r) { return r < 14 ? r : (r < 16 ? r + 2 : r + 6); }
 
 template <int LOG2N>
-__global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
+__global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64, LOG2N <= 9 ? 4 : (LOG2N == 10 ? 2 : 1)) void smile_lld_kernel(
     const float* __restrict__ wav, const int64_t* __restrict__ clip_off, const int64_t* __restrict__ frame_off,
     int64_t total_frames, float* __restrict__ lld, float* __restrict__ cand, float* __restrict__ octave_dbg,
     const Tables<LOG2N>* __restrict__ gtab) {
     using G = Geo<LOG2N>;
-    constexpr int NC = G::NC, NB = G::NB, PPL = G::PPL, HALF = G::HALF;
+    constexpr int NC = G::NC, NB = G::NB, PPL = G::PPL, HALF = G::HALF, CARRY = G::CARRY;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem<LOG2N>& S = *reinterpret_cast<Smem<LOG2N>*>(smem_raw);
     const Tables<LOG2N>& T = S.tab;
@@ -419,19 +481,20 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
     const float inv_frame = 1.0f / (float)frame;
 
     const int64_t fw = f0 + (int64_t)w * (2 * G::PPW);  // first frame of this wave
-    bool have_prev = false, deferred = false;
-    v2f prevB[PPL], stash[PPL];
-    float prevBx = 0.f, stashx = 0.f;                   // bin NC (kept on lane 63)
+    bool have_prev = false;
+    v2f prevB[PPL];
+    float prevBx = 0.f;                                 // bin NC (kept on lane 63)
 #pragma unroll
-    for (int i = 0; i < PPL; ++i) { prevB[i] = splat(0.f); stash[i] = splat(0.f); }
+    for (int i = 0; i < PPL; ++i) prevB[i] = splat(0.f);
 
-    // pass -1 is wave 0's extra transform of the frame in front of the run (flux history only)
-    const int p_first = (w == 0 && f0 > 0) ? -1 : 0;
+    // pass -1 transforms the frame in front of the wave's span (spectral-flux history only: window + FFT + magnitudes,
+    // a quarter of a full pass); the waves stay independent of each other
+    const int p_first = fw > 0 ? -1 : 0;
 #pragma unroll 1
     for (int p = p_first; p < G::PPW; ++p) {
         const bool warm = p < 0;
-        const int64_t fA = warm ? f0 - 1 : fw + 2 * p;
-        if (fA >= n_fr) break;                          // wave-uniform
+        const int64_t fA = warm ? fw - 1 : fw + 2 * p;
+        if (fA >= n_fr || fw >= n_fr) break;            // wave-uniform
         const bool validB = !warm && (fA + 1 < n_fr);
         const int offB = warm ? 0 : hop;
         const int fl = (int)(fA - f0);                  // local frame index of A within the run
@@ -491,7 +554,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
             }
             lds_fence();
         }
-        fft_rest<NC, 4>(X, T.twc, lane);
+        fft_rest<NC, 4>(X, T.twr, lane);
 
         // ---- packed-real unpack -> magnitudes (bin k = lane + 64 q), to the wave's magnitude slot ----
 #pragma unroll
@@ -505,21 +568,22 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
             cmul2(orr, oi, T.twr[k]);
             const v2f xr = ex + orr, xi = ey + oi;
             const v2f m2 = xr * xr + xi * xi;
-            M[k] = (v2f){sqrtf(m2.x), sqrtf(m2.y)};
+            M[sw(k)] = fsqrt2(m2);
             if (k == 0) {
                 const v2f ny = zk.re - zk.im;
-                M[NC] = (v2f){fabsf(ny.x), fabsf(ny.y)};
+                M[sw(NC)] = (v2f){fabsf(ny.x), fabsf(ny.y)};
             }
         }
         lds_fence();
 
         // ---- consecutive layout: lane owns bins PPL*lane .. PPL*lane + PPL-1, lane 63 also bin NC ----
         const int b0 = PPL * lane;
+        const int sb0 = sw(b0);                            // a lane's PPL entries stay contiguous (PPL divides 32)
         v2f m[PPL];
 #pragma unroll
-        for (int i = 0; i < PPL; ++i) m[i] = M[b0 + i];
-        const v2f mleft = lane > 0 ? M[b0 - 1] : splat(0.f);
-        const v2f mright = M[b0 + PPL];                    // lane 63: bin NC
+        for (int i = 0; i < PPL; ++i) m[i] = M[sb0 + i];
+        const v2f mleft = lane > 0 ? M[sw(b0 - 1)] : splat(0.f);
+        const v2f mright = M[sw(b0 + PPL)];                    // lane 63: bin NC
         const bool last = lane == 63;
         const v2f mx = last ? mright : splat(0.f);
 
@@ -531,119 +595,131 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
             continue;
         }
 
-        // ---- HTK mel bank: lanes 2(c-1) / 2(c-1)+1 sum the falling / rising side of band c ----
+        // ---- HTK mel bank: one chunk of one band side per lane (host-built balanced schedule), then per-band sums ----
         {
-            const int c = (lane >> 1) + 1;
-            const bool rising = lane & 1;
-            const int seg = rising ? c - 1 : c;
-            int sb = 0, se = 0;
-            if (c <= NMEL) { sb = T.seg_start[seg]; se = T.seg_start[seg + 1]; }
+            v2f* part = reinterpret_cast<v2f*>(S.melbuf[w]);
+            v2f* lm = part + 64;
+            const int ml = T.mel_lane[lane];
+            const int mb = ml & 0xFFF, mlen = (ml >> 12) & 0xFF;
+            const bool rising = (ml >> 20) & 1;
             v2f acc = splat(0.f);
-            const int ms = T.max_seg;
-#pragma unroll 4
-            for (int it = 0; it < ms; ++it) {
-                const int b = sb + it;
-                if (b < se) {
-                    const float wt = T.lo_wt[b];
-                    acc += (rising ? 1.0f - wt : wt) * M[b];
+            const int iters = gtab->mel_iters;
+#pragma unroll 2
+            for (int it = 0; it < iters; ++it) {
+                if (it < mlen) {
+                    const float wt = T.lo_wt[mb + it];
+                    acc += (rising ? 1.0f - wt : wt) * M[sw(mb + it)];
                 }
             }
-            const v2f other = {dpp_f32<0xB1>(acc.x), dpp_f32<0xB1>(acc.y)};       // quad_perm [1,0,3,2]
-            const v2f band = (acc + other) * HTK_SCALE;
-            if (!(lane & 1) && c <= NMEL) {
-                v2f* lm = reinterpret_cast<v2f*>(S.logmel[w]);
-                lm[c - 1] = (v2f){logf(fmaxf(band.x, MEL_FLOOR)), logf(fmaxf(band.y, MEL_FLOOR))};
+            part[lane] = acc;
+            lds_fence();
+            if (lane < NMEL) {
+                const int bd = T.mel_band[lane];
+                const int first = bd & 0xFF, n = bd >> 8;
+                v2f band = splat(0.f);
+                const int mx_n = gtab->mel_max_n;
+                for (int k = 0; k < mx_n; ++k)
+                    if (k < n) band += part[first + k];
+                band = band * HTK_SCALE;
+                lm[lane] = (v2f){flog(fmaxf(band.x, MEL_FLOOR)), flog(fmaxf(band.y, MEL_FLOOR))};
             }
             lds_fence();
             // DCT-II + lifter: lane 4k + part sums 7 mel channels of cepstral coefficient k + 1
-            const int kk = lane >> 2, part = lane & 3;
+            const int kk = lane >> 2, prt = lane & 3;
             v2f dsum = splat(0.f);
             if (kk < NMFCC) {
-                const v2f* lm = reinterpret_cast<const v2f*>(S.logmel[w]);
 #pragma unroll
                 for (int jj = 0; jj < 7; ++jj) {
-                    const int j = 7 * part + jj;
+                    const int j = 7 * prt + jj;
                     if (j < NMEL) dsum += T.dct[kk * NMEL + j] * lm[j];
                 }
             }
             dsum += (v2f){dpp_f32<0xB1>(dsum.x), dpp_f32<0xB1>(dsum.y)};          // quad_perm [1,0,3,2]
             dsum += (v2f){dpp_f32<0x4E>(dsum.x), dpp_f32<0x4E>(dsum.y)};          // quad_perm [2,3,0,1]
-            if (kk < NMFCC && part == 0) {
-                S.out[1 + kk][fl] = dsum.x;
-                if (validB) S.out[1 + kk][fl + 1] = dsum.y;
-            }
+            if (kk < NMFCC && prt == 0) *reinterpret_cast<v2f*>(&S.out[1 + kk][fl]) = dsum;
         }
 
         // ---- cSpectral on the power spectrum ----
-        v2f pw[PPL];
         v2f s_p = splat(0.f), s_fp = splat(0.f), s_b1 = splat(0.f), s_b2 = splat(0.f), s_fl = splat(0.f),
             s_sh = splat(0.f), s_m = splat(0.f), s_lg = splat(0.f), s_pk = splat(0.f);
         const bool flux_a = have_prev;
+        const float b1lo = gtab->band1_lo, b1hi = gtab->band1_hi, b2lo = gtab->band2_lo, b2hi = gtab->band2_hi;
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
             const int b = b0 + i;
             const float fq = b * df;
             const v2f p = m[i] * m[i];
-            pw[i] = p;
             s_p += p;
             s_fp += p * fq;
-            if (fq >= T.band1_lo && fq <= T.band1_hi) s_b1 += p;
-            if (fq >= T.band2_lo && fq <= T.band2_hi) s_b2 += p;
+            if (fq >= b1lo && fq <= b1hi) s_b1 += p;
+            if (fq >= b2lo && fq <= b2hi) s_b2 += p;
             const v2f dm = {flux_a ? m[i].x - prevB[i].y : 0.f, m[i].y - m[i].x};   // B's history is A
             s_fl += dm * dm;
             s_sh += p * T.sharp[b];
             s_m += m[i];
-            s_lg += (v2f){logf(fmaxf(p.x, 1e-30f)), logf(fmaxf(p.y, 1e-30f))};
+            s_lg += flog2_2(vmax2(p, splat(1e-30f)));
             if (b >= 1) {
-                const v2f ml = i > 0 ? m[i - 1] : mleft;
-                const v2f mr = i < PPL - 1 ? m[i + 1] : mright;
-                s_pk += vmax2(m[i] - 0.5f * (ml + mr), splat(0.f));        // prominence over the neighbours' mean
+                const v2f ml_ = i > 0 ? m[i - 1] : mleft;
+                const v2f mr_ = i < PPL - 1 ? m[i + 1] : mright;
+                s_pk += vmax2(m[i] - 0.5f * (ml_ + mr_), splat(0.f));      // prominence over the neighbours' mean
             }
         }
         const v2f px = mx * mx;                                                // bin NC (lane 63 only, 0 elsewhere)
         if (last) {
             const float fq = NC * df;
             s_fp += px * fq;
-            if (fq >= T.band1_lo && fq <= T.band1_hi) s_b1 += px;
-            if (fq >= T.band2_lo && fq <= T.band2_hi) s_b2 += px;
+            if (fq >= b1lo && fq <= b1hi) s_b1 += px;
+            if (fq >= b2lo && fq <= b2hi) s_b2 += px;
             const v2f dm = {flux_a ? mx.x - prevBx : 0.f, mx.y - mx.x};
             s_fl += dm * dm;
             s_sh += px * T.sharp[NC];
             s_m += mx;
-            s_lg += (v2f){logf(fmaxf(px.x, 1e-30f)), logf(fmaxf(px.y, 1e-30f))};
+            s_lg += flog2_2(vmax2(px, splat(1e-30f)));
         }
-        // inclusive scan of the per-lane power (bins 0..NC-1); the total adds bin NC
+        {   // window sums of the pair (a fourth slot of the group is free)
+            v2f dummy = splat(0.f);
+            wave_sum4x2(e_rms, e_int, zc, dummy);
+            if (lane == 0) {
+                auto put0 = [&](int row, v2f val) { *reinterpret_cast<v2f*>(&S.out[local_row(row)][fl]) = val; };
+                const v2f inten = e_int * (1.0e6f / gtab->ham_sum);
+                put0(0, fsqrt2(e_rms * inv_frame));
+                put0(13, zc * inv_frame);
+                put0(16, inten);
+                put0(17, fexp2_2(0.3f * flog2_2(inten)));                   // inten^0.3 (0 -> 0)
+            }
+        }
+        // inclusive scan of the per-lane power (bins 0..NC-1); the total adds bin NC (held by lane 63)
         const v2f incl = {wave_scan_incl(s_p.x), wave_scan_incl(s_p.y)};
-        const v2f tot = (v2f){readlane_f32(incl.x, 63), readlane_f32(incl.y, 63)} + wave_sum2(px);
+        const v2f tot = (v2f){readlane_f32(incl.x, 63) + readlane_f32(px.x, 63), readlane_f32(incl.y, 63) + readlane_f32(px.y, 63)};
         const v2f excl = incl - s_p;
-        const v2f tot_fp = wave_sum2(s_fp);
-        const v2f band1 = wave_sum2(s_b1), band2 = wave_sum2(s_b2);
-        const v2f flsum = wave_sum2(s_fl);
-        const v2f sharp = wave_sum2(s_sh), msum = wave_sum2(s_m), lgsum = wave_sum2(s_lg), pksum = wave_sum2(s_pk);
-        const v2f rms2 = wave_sum2(e_rms), int2 = wave_sum2(e_int), zc2 = wave_sum2(zc);
+        wave_sum4x2(s_fp, s_b1, s_b2, s_fl);
+        wave_sum4x2(s_sh, s_m, s_lg, s_pk);
+        const v2f tot_fp = s_fp, band1 = s_b1, band2 = s_b2, flsum = s_fl, sharp = s_sh, msum = s_m, pksum = s_pk;
+        const v2f lgsum = s_lg * 0.6931471805599453f;                          // sum of natural logs
         const v2f safe = {tot.x > 0.f ? tot.x : 1.0f, tot.y > 0.f ? tot.y : 1.0f};
-        const v2f inv = {1.0f / safe.x, 1.0f / safe.y};
+        const v2f inv = frcp2(safe);
         const v2f cen = tot_fp * inv;
         // roll-off: first bin whose inclusive cumulative power reaches p * total
-        int roA[4], roB[4];
+        float ro[8];
         {
             const float pr[4] = {0.25f, 0.50f, 0.75f, 0.90f};
-            int cA[4] = {NC, NC, NC, NC}, cB[4] = {NC, NC, NC, NC};
             v2f run = excl;
             v2f cs[PPL];
 #pragma unroll
-            for (int i = 0; i < PPL; ++i) { run += pw[i]; cs[i] = run; }
+            for (int i = 0; i < PPL; ++i) { run += m[i] * m[i]; cs[i] = run; }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const v2f thr = pr[t] * tot;
+                int cA = NC, cB = NC;
 #pragma unroll
                 for (int i = PPL - 1; i >= 0; --i) {
-                    if (cs[i].x >= thr.x) cA[t] = b0 + i;
-                    if (cs[i].y >= thr.y) cB[t] = b0 + i;
+                    if (cs[i].x >= thr.x) cA = b0 + i;
+                    if (cs[i].y >= thr.y) cB = b0 + i;
                 }
-                roA[t] = wave_min_i32(cA[t]);
-                roB[t] = wave_min_i32(cB[t]);
+                ro[2 * t] = (float)cA;                                          // bin indices are exact in float
+                ro[2 * t + 1] = (float)cB;
             }
+            wave_reduce8<true>(ro);
         }
         // second pass: central moments + entropy
         v2f s_e = splat(0.f), s_v = splat(0.f), s_s = splat(0.f), s_k = splat(0.f);
@@ -651,87 +727,75 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
         for (int i = 0; i <= PPL; ++i) {
             if (i == PPL && !last) break;
             const float fq = (i < PPL ? b0 + i : NC) * df;
-            const v2f prb = (i < PPL ? pw[i] : px) * inv;
+            const v2f mi_ = i < PPL ? m[i] : mx;
+            const v2f prb = mi_ * mi_ * inv;
             const v2f d = splat(fq) - cen;
-            s_e += (v2f){prb.x > 0.f ? prb.x * log2f(prb.x) : 0.f, prb.y > 0.f ? prb.y * log2f(prb.y) : 0.f};
+            const v2f lg = flog2_2(vmax2(prb, splat(1e-37f)));
+            s_e += (v2f){prb.x > 0.f ? prb.x * lg.x : 0.f, prb.y > 0.f ? prb.y * lg.y : 0.f};
             const v2f d2 = d * d;
             s_v += d2 * prb;
             s_s += d2 * d * prb;
             s_k += d2 * d2 * prb;
         }
-        const v2f ent = -wave_sum2(s_e), var = wave_sum2(s_v), sk = wave_sum2(s_s), ku = wave_sum2(s_k);
+        wave_sum4x2(s_e, s_v, s_s, s_k);
+        // the three window sums of this pair travel with the sub-harmonic sum below (one more group of four)
         if (lane == 0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 1 && !validB) break;
-                const int fo = fl + h;
-                const float tt = h ? tot.y : tot.x, sf = h ? safe.y : safe.x;
-                const float vr = h ? var.y : var.x;
-                const float vs = vr > 0.f ? vr : 1.0f;
-                const float inten = (h ? int2.y : int2.x) / T.ham_sum * 1.0e6f;
-                const int* ro = h ? roB : roA;
-                S.out[0][fo] = sqrtf((h ? rms2.y : rms2.x) * inv_frame);
-                S.out[13][fo] = (h ? zc2.y : zc2.x) * inv_frame;
-                S.out[local_row(16)][fo] = inten;
-                S.out[local_row(17)][fo] = powf(inten, 0.3f);
-                S.out[local_row(22)][fo] = h ? band1.y : band1.x;
-                S.out[local_row(23)][fo] = h ? band2.y : band2.x;
-                S.out[local_row(24)][fo] = ro[0] * df;
-                S.out[local_row(25)][fo] = ro[1] * df;
-                S.out[local_row(26)][fo] = ro[2] * df;
-                S.out[local_row(27)][fo] = ro[3] * df;
-                if (h == 1 || flux_a || fA == 0)
-                    S.out[local_row(28)][fo] = sqrtf((h ? flsum.y : flsum.x) / NB);
-                S.out[local_row(29)][fo] = h ? cen.y : cen.x;
-                S.out[local_row(30)][fo] = h ? ent.y : ent.x;
-                S.out[local_row(31)][fo] = vr;
-                S.out[local_row(32)][fo] = (h ? sk.y : sk.x) / (vs * sqrtf(vs));
-                S.out[local_row(33)][fo] = (h ? ku.y : ku.x) / (vs * vs);
-                S.out[local_row(34)][fo] = (NB * (h ? tot_fp.y : tot_fp.x) - T.slope_sf * tt) / T.slope_den;
-                S.out[local_row(35)][fo] = (h ? sharp.y : sharp.x) / sf;
-                const float ms_ = h ? msum.y : msum.x;
-                S.out[local_row(36)][fo] = (h ? pksum.y : pksum.x) / (ms_ > 0.f ? ms_ : 1.0f);
-                S.out[local_row(37)][fo] = expf((h ? lgsum.y : lgsum.x) / NB) / fmaxf(tt / NB, 1e-30f);
-            }
-        }
-        if (!flux_a && fA != 0) {                          // first frame of a wave > 0: history arrives after the barrier
-            deferred = true;
-#pragma unroll
-            for (int i = 0; i < PPL; ++i) stash[i] = m[i];
-            stashx = mx.x;
+            const v2f var = s_v;
+            const v2f vs = {var.x > 0.f ? var.x : 1.0f, var.y > 0.f ? var.y : 1.0f};
+            const v2f ivs = frcp2(vs);
+            auto put = [&](int row, v2f val) { *reinterpret_cast<v2f*>(&S.out[local_row(row)][fl]) = val; };
+            put(22, band1);
+            put(23, band2);
+            put(24, (v2f){ro[0], ro[1]} * df);
+            put(25, (v2f){ro[2], ro[3]} * df);
+            put(26, (v2f){ro[4], ro[5]} * df);
+            put(27, (v2f){ro[6], ro[7]} * df);
+            put(28, fsqrt2(flsum * (1.0f / NB)));                           // the clip's first frame: history = itself -> 0
+            put(29, cen);
+            put(30, -s_e);
+            put(31, var);
+            put(32, s_s * ivs * fsqrt2(ivs));
+            put(33, s_k * ivs * ivs);
+            put(34, ((float)NB * tot_fp - gtab->slope_sf * tot) * (1.0f / gtab->slope_den));
+            put(35, sharp * inv);
+            put(36, pksum * frcp2((v2f){msum.x > 0.f ? msum.x : 1.0f, msum.y > 0.f ? msum.y : 1.0f}));
+            put(37, fexp2_2(s_lg * (1.0f / NB)) * frcp2(vmax2(tot * (1.0f / NB), splat(1e-30f))));
         }
 #pragma unroll
         for (int i = 0; i < PPL; ++i) prevB[i] = m[i];
         prevBx = mx.y;
         have_prev = true;
+        (void)lgsum;
 
         // ---- cSpecScale: peak enhancement + smoothing on the linear spectrum ----
-        // flags word per bin: bit 0 / 1 = "local maximum" in frame A / B
+        // flags word per bin: bit 0 / 1 = "local maximum" in frame A / B; first / last / count from wave ballots (SALU)
         unsigned* FL = reinterpret_cast<unsigned*>(XB);
-        bool anyA = false, anyB = false;
-        int firstA = 0x7fffffff, firstB = 0x7fffffff, lastA = -1, lastB = -1, cntA = 0, cntB = 0;
+        int gfirstA = 0x7fffffff, gfirstB = 0x7fffffff, glastA = -1, glastB = -1, ncA = 0, ncB = 0;
 #pragma unroll
         for (int i = 0; i <= PPL; ++i) {
-            if (i == PPL && !last) break;
             const int b = i < PPL ? b0 + i : NC;
             const v2f me = i < PPL ? m[i] : mx;
-            const v2f ml = i == 0 ? mleft : m[i - 1];
-            const v2f mr = i < PPL - 1 ? m[i + 1] : (i == PPL - 1 ? mright : splat(0.f));
+            const v2f ml_ = i == 0 ? mleft : m[i - 1];
+            const v2f mr_ = i < PPL - 1 ? m[i + 1] : (i == PPL - 1 ? mright : splat(0.f));
             bool fa, fb;
-            if (b == 0) { fa = me.x > mr.x; fb = me.y > mr.y; }
-            else if (b == NC) { fa = me.x > ml.x; fb = me.y > ml.y; }
-            else { fa = me.x > ml.x && me.x >= mr.x; fb = me.y > ml.y && me.y >= mr.y; }
-            FL[b] = (fa ? 1u : 0u) | (fb ? 2u : 0u);
-            if (fa) { anyA = true; firstA = min(firstA, b); lastA = max(lastA, b); ++cntA; }
-            if (fb) { anyB = true; firstB = min(firstB, b); lastB = max(lastB, b); ++cntB; }
+            if (i == PPL) { fa = last && me.x > ml_.x; fb = last && me.y > ml_.y; }
+            else if (b == 0) { fa = me.x > mr_.x; fb = me.y > mr_.y; }
+            else { fa = me.x > ml_.x && me.x >= mr_.x; fb = me.y > ml_.y && me.y >= mr_.y; }
+            if (i < PPL || last) FL[b] = (fa ? 1u : 0u) | (fb ? 2u : 0u);
+            const unsigned long long ka = __ballot(fa), kb = __ballot(fb);
+            const int stride = i < PPL ? PPL : 0, base = i < PPL ? i : NC;
+            if (ka) {
+                gfirstA = min(gfirstA, stride * (__ffsll((long long)ka) - 1) + base);
+                glastA = max(glastA, stride * (63 - __clzll((long long)ka)) + base);
+                ncA += __popcll(ka);
+            }
+            if (kb) {
+                gfirstB = min(gfirstB, stride * (__ffsll((long long)kb) - 1) + base);
+                glastB = max(glastB, stride * (63 - __clzll((long long)kb)) + base);
+                ncB += __popcll(kb);
+            }
         }
-        if (lane == 0) { FL[NC + 1] = 0u; FL[NC + 2] = 0u; FL[NC + 3] = 0u; }
         lds_fence();
-        // wave-wide first / last maximum and their count
-        const int gfirstA = wave_min_i32(firstA), gfirstB = wave_min_i32(firstB);
-        const int glastA = -wave_min_i32(-lastA), glastB = -wave_min_i32(-lastB);
-        const int ncA = (int)wave_sum((float)cntA), ncB = (int)wave_sum((float)cntB);
-        (void)anyA; (void)anyB;
         // window of flags for bins b0-3 .. b0+PPL+2
         unsigned fw_[PPL + 6];
 #pragma unroll
@@ -756,14 +820,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
             a[i] = 0.25f * (en[i] + 2.0f * en[i + 1] + en[i + 2]);
-            XA[b0 + i] = a[i];
+            XA[sb0 + i] = a[i];
         }
-        if (last) XA[NC] = en[PPL + 1];                      // bin NC keeps its enhanced value
+        if (last) XA[sw(NC)] = en[PPL + 1];                      // bin NC keeps its enhanced value
         lds_fence();
         // ---- natural cubic spline through the bins: m_{b-1} + 4 m_b + m_{b+1} = a_{b-1} - 2 a_b + a_{b+1} ----
         {
-            const v2f aleft = lane > 0 ? XA[b0 - 1] : splat(0.f);
-            const v2f aright = XA[b0 + PPL];
+            const v2f aleft = lane > 0 ? XA[sw(b0 - 1)] : splat(0.f);
+            const v2f aright = XA[sw(b0 + PPL)];
             float g[PPL];
             v2f d[PPL];
             // forward elimination, local part (carry 0), then the carry of up to CARRY lanes
@@ -814,8 +878,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
                 for (int i = 0; i < PPL; ++i) x[i] += qb[i] * carry;
             }
 #pragma unroll
-            for (int i = 0; i < PPL; ++i) XB[b0 + i] = x[i];
-            if (last) XB[NC] = splat(0.f);
+            for (int i = 0; i < PPL; ++i) XB[sb0 + i] = x[i];
+            if (last) XB[sw(NC)] = splat(0.f);
         }
         lds_fence();
         // ---- octave-scale targets i = b0 .. b0+PPL-1 (+ NC on lane 63): spline value, clip, auditory weighting ----
@@ -828,13 +892,13 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
             const int k = T.klo[ti];
             const float bb = T.tb[ti], aa = 1.0f - bb;
             const float ca = aa * aa * aa - aa, cb = bb * bb * bb - bb;
-            const v2f y = aa * XA[k] + bb * XA[k + 1] + ca * XB[k] + cb * XB[k + 1];
+            const v2f y = aa * XA[sw(k)] + bb * XA[sw(k + 1)] + ca * XB[sw(k)] + cb * XB[sw(k + 1)];
             sv[i] = vmax2(y, splat(0.f)) * T.audw[ti];
         }
         lds_fence();                                         // all reads of a / m done: reuse the halves for S / H
 #pragma unroll
-        for (int i = 0; i < PPL; ++i) XA[b0 + i] = sv[i];
-        if (last) { XA[NC] = sv[PPL]; XA[NC + 1] = splat(0.f); }   // entry NC+1 = 0: target of out-of-range shifts
+        for (int i = 0; i < PPL; ++i) XA[sb0 + i] = sv[i];
+        if (last) { XA[sw(NC)] = sv[PPL]; XA[sw(NC + 1)] = splat(0.f); }   // entry NC+1 = 0: target of out-of-range shifts
         if (octave_dbg) {
             const int64_t fg = frame_off[clip] + fA;
 #pragma unroll
@@ -857,80 +921,89 @@ __global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64) void smile_lld_kernel(
             v2f acc = splat(0.f);
 #pragma unroll
             for (int h = 0; h < NHARM; ++h) {
-                const int src_i = min(ti + T.shs_shift[h], NC + 1);
-                acc += T.shs_w[h] * XA[src_i];
+                const int src_i = min(ti + gtab->shs_shift[h], NC + 1);
+                acc += gtab->shs_w[h] * XA[sw(src_i)];
             }
             hv[i] = acc;
             hsum += acc;
         }
         const v2f hmean = wave_sum2(hsum) * (1.0f / NB);
 #pragma unroll
-        for (int i = 0; i < PPL; ++i) XB[b0 + i] = hv[i];
-        if (last) XB[NC] = hv[PPL];
+        for (int i = 0; i < PPL; ++i) XB[sb0 + i] = hv[i];
+        if (last) XB[sw(NC)] = hv[PPL];
         lds_fence();
         {
-            const v2f hleft = lane > 0 ? XB[b0 - 1] : splat(0.f);
-            const v2f hright = XB[b0 + PPL];
-            float scA[PPL], scB[PPL], poA[PPL], poB[PPL];
+            // local maxima with parabolic refinement, both frames at once; a peak's sort key carries its score in the
+            // high bits and (MASK - index) in the low ones: larger key = higher score, ties / near-ties to the lower index
+            constexpr unsigned MASK = (1u << (LOG2N - 1)) - 1u;
+            constexpr int MAXPK = PPL >= 2 ? PPL / 2 : 1;                    // peaks are never adjacent
+            const v2f hleft = lane > 0 ? XB[sw(b0 - 1)] : splat(0.f);
+            const v2f hright = XB[sw(b0 + PPL)];
+            unsigned kA[MAXPK], kB[MAXPK];
+#pragma unroll
+            for (int k = 0; k < MAXPK; ++k) { kA[k] = 0u; kB[k] = 0u; }
+            const float fmin_l2 = gtab->fmin_l2, dl2 = gtab->dl2;
 #pragma unroll
             for (int i = 0; i < PPL; ++i) {
                 const int ti = b0 + i;
                 const v2f y1 = i == 0 ? hleft : hv[i - 1];
                 const v2f y2 = hv[i];
                 const v2f y3 = i == PPL - 1 ? hright : hv[i + 1];
-                scA[i] = scB[i] = 0.f;
-                poA[i] = poB[i] = 0.f;
-                if (ti >= 1) {                                   // ti <= NC - 1 always: bin NC is never a peak centre
+                const v2f den = y1 - 2.0f * y2 + y3;
+                const v2f rden = frcp2(den);
+                const v2f dif = y1 - y3;
+                const v2f sc = y2 - 0.125f * dif * dif * rden;
+                const v2f fq = fexp2_2(splat(fmin_l2) + (splat((float)ti) + 0.5f * dif * rden) * dl2);
+                const bool okA = ti >= 1 && y2.x > y1.x && y2.x >= y3.x && fq.x >= 52.0f && fq.x <= 620.0f && sc.x > 0.f;
+                const bool okB = ti >= 1 && y2.y > y1.y && y2.y >= y3.y && fq.y >= 52.0f && fq.y <= 620.0f && sc.y > 0.f;
+                unsigned ka = okA ? ((__float_as_uint(sc.x) & ~MASK) | (MASK - (unsigned)ti)) : 0u;
+                unsigned kb = okB ? ((__float_as_uint(sc.y) & ~MASK) | (MASK - (unsigned)ti)) : 0u;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float a1 = h ? y1.y : y1.x, a2 = h ? y2.y : y2.x, a3 = h ? y3.y : y3.x;
-                        if (a2 > a1 && a2 >= a3) {
-                            const float den = a1 - 2.0f * a2 + a3;
-                            const float dxp = 0.5f * (a1 - a3) / den;
-                            const float sc = a2 - 0.125f * (a1 - a3) * (a1 - a3) / den;
-                            const float ps = (float)ti + dxp;
-                            const float fq = exp2f(T.fmin_l2 + ps * T.dl2);
-                            if (fq >= 52.0f && fq <= 620.0f && sc > 0.f) {
-                                if (h) { scB[i] = sc; poB[i] = ps; } else { scA[i] = sc; poA[i] = ps; }
-                            }
-                        }
-                    }
+                for (int k = 0; k < MAXPK; ++k) {                             // sorted insertion, largest first
+                    const unsigned ta = max(kA[k], ka), tb = max(kB[k], kb);
+                    ka = min(kA[k], ka); kb = min(kB[k], kb);
+                    kA[k] = ta; kB[k] = tb;
                 }
             }
-            float rp, rs;
-            const int64_t fg = frame_off[clip] + fA;
-            select_peaks<PPL>(scA, poA, lane, rp, rs);
-            if (lane < NCAND) {
-                const float fq = rs > 0.f ? exp2f(T.fmin_l2 + rp * T.dl2) : 0.f;
-                const float vo = rs > 0.f ? fmaxf(0.f, 1.0f - hmean.x / rs) : 0.f;
-                reinterpret_cast<float2*>(cand)[fg * NCAND + lane] = make_float2(fq, vo);
+            unsigned wA = 0u, wB = 0u;                                       // lane r keeps the key of slot r
+#pragma unroll 1
+            for (int r = 0; r < NCAND; ++r) {
+                const unsigned ma = wave_max_u32(kA[0]), mb_ = wave_max_u32(kB[0]);
+                if (!(ma | mb_)) break;                                       // wave-uniform
+                if (lane == r) { wA = ma; wB = mb_; }
+                if (kA[0] == ma && ma) {
+#pragma unroll
+                    for (int k = 0; k + 1 < MAXPK; ++k) kA[k] = kA[k + 1];
+                    kA[MAXPK - 1] = 0u;
+                }
+                if (kB[0] == mb_ && mb_) {
+#pragma unroll
+                    for (int k = 0; k + 1 < MAXPK; ++k) kB[k] = kB[k + 1];
+                    kB[MAXPK - 1] = 0u;
+                }
             }
-            if (validB) {
-                select_peaks<PPL>(scB, poB, lane, rp, rs);
-                if (lane < NCAND) {
-                    const float fq = rs > 0.f ? exp2f(T.fmin_l2 + rp * T.dl2) : 0.f;
-                    const float vo = rs > 0.f ? fmaxf(0.f, 1.0f - hmean.y / rs) : 0.f;
-                    reinterpret_cast<float2*>(cand)[(fg + 1) * NCAND + lane] = make_float2(fq, vo);
+            if (lane < NCAND) {
+                const int64_t fg = frame_off[clip] + fA;
+                const float* Hf = reinterpret_cast<const float*>(XB);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !validB) break;
+                    const unsigned key = h ? wB : wA;
+                    float fqo = 0.f, vo = 0.f;
+                    if (key) {
+                        const int ti = (int)(MASK - (key & MASK));
+                        const float y1 = Hf[2 * sw(ti - 1) + h], y2 = Hf[2 * sw(ti) + h], y3 = Hf[2 * sw(ti + 1) + h];
+                        const float rden = frcp(y1 - 2.0f * y2 + y3);
+                        const float dif = y1 - y3;
+                        const float sc = y2 - 0.125f * dif * dif * rden;
+                        fqo = fexp2(fmin_l2 + ((float)ti + 0.5f * dif * rden) * dl2);
+                        vo = fmaxf(0.f, 1.0f - (h ? hmean.y : hmean.x) * frcp(sc));
+                    }
+                    reinterpret_cast<float2*>(cand)[(fg + h) * NCAND + lane] = make_float2(fqo, vo);
                 }
             }
         }
         lds_fence();
-    }
-    __syncthreads();
-    if (deferred) {                                          // flux of this wave's first frame against the previous wave's last
-        const v2f* Mp = reinterpret_cast<const v2f*>(S.mag[w - 1]);
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) {
-            const float dm = stash[i].x - Mp[PPL * lane + i].y;
-            acc += dm * dm;
-        }
-        if (lane == 63) {
-            const float dm = stashx - Mp[NC].y;
-            acc += dm * dm;
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) S.out[local_row(28)][(int)(fw - f0)] = sqrtf(acc / NB);
     }
     __syncthreads();
 
