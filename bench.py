@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
-"""Headline benchmark: audio-seconds processed per second on synthetic 16 kHz mono 30 s clips.
+"""Benchmark of the hot path: audio-seconds processed per second on synthetic 16 kHz mono 30 s clips.
 
-A "step" is one pass of the hot path over one batch of clips that is already resident in HBM:
-every built stage of  extract (openSMILE-style chain, MSHDS, Wav2Vec2 frames) -> CNN-LSTM forward.
-One process per GPU; clips shard across ranks with no data-path collective, the per-clip result
-rows are all-gathered once per step (RCCL) when N > 1.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch that is already resident in HBM.  One process per GPU; clips
+shard across ranks with no data-path collective, the per-clip result rows are all-gathered once per step (RCCL) when
+N > 1.  Rank 0 prints ONE JSON line.
 
-    python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py                                   # e2e: MSHDS + openSMILE-style + Wav2Vec2 -> CNN-LSTM, 1 000 clips
+    python bench.py --config C2|C3|C4                 # BASELINE configs 2-4 on their own (own roofline object)
+    python bench.py --total-clips 10000 --gpus 8      # BASELINE config C5 (strong scaling: 1 250 clips per rank)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,6 +26,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (= fp64 MFMA issue) peak
 
 
 def parse_args():
@@ -31,156 +34,216 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=1000, help="clips per GPU (weak scaling)")
+    ap.add_argument("--config", type=str, default="e2e", choices=["e2e", "C2", "C3", "C4"],
+                    help="BASELINE config: e2e = extract -> CNN-LSTM (C5's per-GPU work), C2 = MSHDS + openSMILE-style, "
+                         "C3 = Wav2Vec2 frames, C4 = CNN-LSTM forward on randn(256, 1500, 768)")
+    ap.add_argument("--clips", type=int, default=None, help="clips per GPU (weak scaling); default 1000 (C4: batch 256)")
+    ap.add_argument("--total-clips", type=int, default=None,
+                    help="strong scaling: a fixed total sharded over the ranks (C5: 10000)")
     ap.add_argument("--seconds", type=float, default=30.0)
-    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic clips tiled to --clips")
-    ap.add_argument("--stages", type=str, default="all")
+    ap.add_argument("--pool", type=int, default=64, help="distinct synthetic clips; global clip g plays member g mod pool")
+    ap.add_argument("--stages", type=str, default=None, help="override the config's stage list (comma separated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-clips", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-inclusive", action="store_true", help="skip the PCM -> H2D -> ... -> D2H pass after the timed region")
+    ap.add_argument("--cpu-sample-clips", type=int, default=0, help="0 = auto")
     ap.add_argument("--w2v2-chunks-per-call", type=int, default=2048,
-                    help="Wav2Vec2 windows per sub-batch (workspace 118 GiB of the 288 GB at 2048; the larger GEMMs lose less to the "
-                         "last partial wave of tiles: stage time -2.8 %% against 256)")
+                    help="Wav2Vec2 windows per sub-batch (workspace 118 GiB of the 288 GB at 2048)")
     ap.add_argument("--overlap", action="store_true",
-                    help="run the MSHDS stage on a second HIP stream beside Wav2Vec2 (+6 %% throughput, but per-kernel "
-                         "event times then include time-sharing, so the roofline object is only clean without it)")
+                    help="run the MSHDS stage on a second HIP stream beside Wav2Vec2 (per-kernel event times then include "
+                         "time-sharing, so the roofline object is only clean without it)")
     return ap.parse_args()
-
-
-def usable_cpus() -> int:
-    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box
-    shows 256 host CPUs but grants a share of them; oversubscribing torch threads stalls for minutes)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                if q > 0:
-                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                    n = min(n, max(1, q // per))
-        except (OSError, ValueError, IndexError):
-            continue
-    return max(1, min(n, int(os.environ.get("RSAF_CPU_THREADS", "16"))))
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(stages, seconds, sample_clips):
-    """Time the CPU oracle (kind "port") on a bounded sample of the same synthetic workload.
+# ---- CPU baseline leg (the only place outside tests/ and smoke() that touches oracle/) -------------------------------
+def _dsp_worker(args):
+    """One clip through one numpy oracle in its own process (1 thread): (stage, clip id, seconds, result)."""
+    stage, k, seconds = args
+    from robust_speech_analysis_framework_amd import synth
+    x = synth.synth_clip(k, seconds)
+    t0 = time.perf_counter()
+    if stage == "smile":
+        from oracle import smile_oracle
+        res = smile_oracle.extract(x)
+    else:
+        from oracle import mshds_oracle
+        res, _ = mshds_oracle.extract(x)
+    return stage, k, time.perf_counter() - t0, res
 
-    This is the only place outside tests/ and smoke() that touches oracle/: it is the reported
-    baseline, never the product path.  DSP stages are numpy (one core), the model stages are
-    torch-CPU float32 with every host core, exactly the ops the reference's CPU path dispatches."""
+
+def _dsp_pool(stage, clip_ids, seconds, workers):
+    """The single-threaded numpy restatement on ``workers`` cores, one process per clip."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    t0 = time.perf_counter()
+    with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+        out = list(ex.map(_dsp_worker, [(stage, k, seconds) for k in clip_ids]))
+    return time.perf_counter() - t0, [o[2] for o in out], {o[1]: o[3] for o in out}
+
+
+def cpu_baseline(config, stages, seconds, sample_clips):
+    """The CPU restatement (kind "port": oracle/) on a bounded sample of the same synthetic workload, on the host cores of
+    the GPU box: all usable cores AND one thread.  DSP oracles are single-threaded numpy: one process per
+    clip, as many processes as clips (<= cores); model stages are torch-CPU float32 (the ops the reference's CPU path
+    dispatches): 1 warm-up + median of 5."""
     import numpy as np
     import torch
-    from robust_speech_analysis_framework_amd import synth
-    cores = usable_cpus()
-    torch.set_num_threads(cores)
-    n = sample_clips or 1
-    log(f"cpu_baseline: {n} clip(s) on {cores} thread(s)")
-    clips = [synth.synth_clip(900000 + k, seconds) for k in range(n)]
-    parts, total, ref = {}, 0.0, {"clip0": clips[0]}
+    from robust_speech_analysis_framework_amd import benchlib, synth
+    cores = benchlib.usable_cpus()
+    n = sample_clips or min(4, cores)
+    ids = [900000 + k for k in range(n)]
+    ref = {"clip_id": ids[0]}
+    all_cores, one_thread, notes = {}, {}, []
     if "smile" in stages:
-        from oracle import smile_oracle
-        t0 = time.perf_counter()
-        ref["smile"] = [smile_oracle.extract(c) for c in clips][0]
-        parts["smile"] = time.perf_counter() - t0
-        log(f"cpu_baseline smile {parts['smile']:.2f} s")
+        wall, per, res = _dsp_pool("smile", ids, seconds, min(n, cores))
+        all_cores["smile"] = wall / n
+        one_thread["smile"] = float(np.median(per))
+        ref["smile"] = res[ids[0]]
+        log(f"cpu_baseline smile: {n} clips on {min(n, cores)} processes {wall:.1f} s wall, {np.median(per):.2f} s per clip on one core")
     if "mshds" in stages:
-        from oracle import mshds_oracle
-        sub = clips[0][:int(16000 * min(seconds, 5.0))]          # bounded: 5 s of one clip (Python oracle)
-        t0 = time.perf_counter()
-        ref["mshds"], _ = mshds_oracle.extract(sub)
-        ref["mshds_input"] = sub
-        dt_m = time.perf_counter() - t0
-        parts["mshds"] = dt_m * (n * seconds) / (len(sub) / 16000.0)   # scaled to the sample's audio-seconds
-        log(f"cpu_baseline mshds {dt_m:.2f} s for {len(sub) / 16000.0:g} audio-s (scaled to {parts['mshds']:.1f} s)")
+        wall, per, res = _dsp_pool("mshds", ids, seconds, min(n, cores))     # full 30 s clips, not an excerpt
+        all_cores["mshds"] = wall / n
+        one_thread["mshds"] = float(np.median(per))
+        ref["mshds"] = res[ids[0]]
+        log(f"cpu_baseline mshds: {n} clips on {min(n, cores)} processes {wall:.1f} s wall, {np.median(per):.1f} s per clip on one core")
+        notes.append(f"DSP oracles: {n} full {seconds:g} s clips, one process (1 thread) per clip")
+    clips = [synth.synth_clip(k, seconds) for k in ids]
+    ref["clip0"] = clips[0]
     seqs = None
     if "w2v2" in stages:
         from oracle import w2v2_oracle
         from robust_speech_analysis_framework_amd.w2v2_config import W2V2Config, random_state_dict
         cfg = W2V2Config()
         sd = random_state_dict(cfg, 0)
-        w2v2_oracle.extract_sequence(sd, cfg, clips[0][:16000])          # warm-up
-        t0 = time.perf_counter()
-        seqs = [w2v2_oracle.extract_sequence(sd, cfg, c) for c in clips]
-        parts["w2v2"] = time.perf_counter() - t0
-        log(f"cpu_baseline w2v2 {parts['w2v2']:.2f} s")
-    if "cnnlstm" in stages and seqs is not None:
+        torch.set_num_threads(cores)
+        it = iter(range(10 ** 9))
+        seqs = [w2v2_oracle.extract_sequence(sd, cfg, c) for c in clips[:1]]           # also the warm-up
+        med, _ = benchlib.median_time(lambda: w2v2_oracle.extract_sequence(sd, cfg, clips[next(it) % n]), 0, 5)
+        all_cores["w2v2"] = med
+        torch.set_num_threads(1)
+        w5 = clips[0][:80000]                                                             # one 5 s window, batch 1 like the reference
+        w2v2_oracle.extract_sequence(sd, cfg, w5)
+        m1, _ = benchlib.median_time(lambda: w2v2_oracle.extract_sequence(sd, cfg, w5), 0, 3)
+        # a 30 s clip = 7 full windows + one 2 s tail: 529.64 / 71.66 full-window equivalents of work
+        one_thread["w2v2"] = m1 * (529.64 / 71.66) * (seconds / 30.0)
+        notes.append("Wav2Vec2 on 1 thread: median of 3 runs of ONE 5 s window, scaled by the clip's FLOP ratio 529.64 / 71.66")
+        torch.set_num_threads(cores)
+        log(f"cpu_baseline w2v2: {med:.2f} s per clip on {cores} threads, {one_thread['w2v2']:.1f} s on 1 thread (scaled)")
+    if "cnnlstm" in stages or "cnnlstm_only" in stages:
         from oracle import cnnlstm_oracle
         from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
         torch.manual_seed(0)
         sdm = {k: v.numpy() for k, v in CNNLSTM().state_dict().items()}
-        x = cnnlstm_oracle.collate_zero_pad(seqs)
-        t0 = time.perf_counter()
-        ref["logits"] = np.asarray(cnnlstm_oracle.forward_torch(sdm, x, "silu"))[0]
-        parts["cnnlstm"] = time.perf_counter() - t0
-    total = sum(parts.values())
-    cpu_model = ""
-    try:
-        for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                cpu_model = ln.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    model_stages = [s for s in stages if s in ("w2v2", "cnnlstm")]
-    return ref, {"value": round(n * seconds / total, 2), "unit": "audio-s/s", "cores": cores if model_stages else 1,
-            "kind": "port",
-            "sample": f"{n} x {seconds:g} s clips through stages {stages}: oracle/ (numpy float64 DSP on 1 core, "
-                      f"MSHDS timed on 5 s and scaled linearly; torch-CPU float32 models on {cores} threads, "
-                      f"batch-1 windows like the reference)",
-            "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
-            "seconds_per_stage": {k: round(v, 3) for k, v in parts.items()}}
+        if seqs is not None:
+            x = cnnlstm_oracle.collate_zero_pad(seqs)
+            per_clip = 1.0
+        else:                                                                             # C4: rows of the seed-1234 batch
+            xs = torch.randn(256, 1500, 768, generator=torch.Generator().manual_seed(1234))[:4].numpy()
+            x, per_clip = xs, 4.0
+            ref["c4_rows"] = x
+        torch.set_num_threads(cores)
+        ref["logits"] = np.asarray(cnnlstm_oracle.forward_torch(sdm, x, "silu"))
+        med, _ = benchlib.median_time(lambda: cnnlstm_oracle.forward_torch(sdm, x, "silu"), 1, 5)
+        all_cores["cnnlstm"] = med / per_clip
+        torch.set_num_threads(1)
+        m1, _ = benchlib.median_time(lambda: cnnlstm_oracle.forward_torch(sdm, x, "silu"), 1, 5)
+        one_thread["cnnlstm"] = m1 / per_clip
+        torch.set_num_threads(cores)
+    tot_all, tot_one = sum(all_cores.values()), sum(one_thread.values())
+    return ref, {"value": round(seconds / tot_all, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+                 "one_thread": {"value": round(seconds / tot_one, 4), "cores": 1,
+                                "seconds_per_clip_per_stage": {k: round(v, 3) for k, v in one_thread.items()}},
+                 "seconds_per_clip_per_stage": {k: round(v, 3) for k, v in all_cores.items()},
+                 "sample": ("4 rows of the randn(256, 1500, 768) seed-1234 batch through oracle/cnnlstm_oracle (torch-CPU float32, "
+                            f"{cores} threads and 1 thread; 1 warm-up + median of 5)") if config == "C4" else
+                           f"{n} x {seconds:g} s synthetic clips through {stages} of oracle/ (numpy float64 DSP restatements: one "
+                           f"single-threaded process per clip, {min(n, cores)} at a time; torch-CPU float32 models on {cores} threads, "
+                           f"batch-1 windows like the reference; 1 warm-up + median of 5).  " + "  ".join(notes),
+                 "host_cpus": os.cpu_count(), "usable_cpus": cores, "cpu_model": benchlib.cpu_model(),
+                 "note": "reported baseline, not the target: the restatement is a numpy port, not Praat / openSMILE C++"}
 
 
-def parity_vs_cpu(pipe, ref, stages, dev):
-    """BASELINE.json's second half of the metric ("feature max-abs-err vs CPU"): the HIP path on the very clip the
-    cpu_baseline leg just pushed through oracle/ (the oracle is the checker here, as in tests/ and smoke()).
-    rel = |gpu - cpu| / max(|cpu|, 1e-3 * max|cpu| of the stage's vector); NaN patterns must coincide."""
+def parity_vs_oracle(pipe, ref, stages, dev, model=None):
+    """BASELINE.json's second half of the metric ("feature max-abs-err vs CPU"): the HIP path on the first clip the
+    cpu_baseline leg pushed through oracle/ (the oracle is the checker here, as in tests/ and smoke()).  The MSHDS and
+    openSMILE oracles are this repository's own restatements (parity UNPINNED: no Praat / SMILExtract output exists);
+    the CNN-LSTM oracle is pinned by vectors captured from the reference module."""
     import numpy as np
     import torch
     out = {}
-    clip = torch.from_numpy(np.ascontiguousarray(ref["clip0"])).to(dev)[None, :]
-    row = pipe.run(clip)[0].double().cpu().numpy()
-    torch.cuda.synchronize()
-    col = 0
 
-    def cmp(name, got, want):
+    def cmp(name, got, want, pinned):
         got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
         both = ~np.isnan(got) & ~np.isnan(want)
         d = np.abs(got[both] - want[both])
         scale = np.maximum(np.abs(want[both]), 1e-3 * np.abs(want[both]).max()) if both.any() else np.ones(0)
-        own = d / np.maximum(np.abs(want[both]), 1e-30)                 # per column, no floor (harsh on ~0 columns)
-        out[name] = {"columns": int(got.size), "compared": int(both.sum()),
+        own = d / np.maximum(np.abs(want[both]), 1e-30)
+        out[name] = {"oracle_pinned_by": pinned, "columns": int(got.size), "compared": int(both.sum()),
                      "nan_pattern_equal": bool(np.array_equal(np.isnan(got), np.isnan(want))),
                      "max_abs_err": float(d.max()) if d.size else None,
                      "max_rel_err": float((d / scale).max()) if d.size else None,
                      "median_rel_err_per_column": float(np.median(own)) if d.size else None,
                      "columns_within_1e-4_per_column_rel": int((own <= 1e-4).sum()) if d.size else 0}
+    if "cnnlstm_only" in stages:
+        got = model(torch.from_numpy(ref["c4_rows"]).to(dev))
+        torch.cuda.synchronize()
+        cmp("cnnlstm_logits_4_rows_of_the_seed_1234_batch", got.cpu().numpy(), ref["logits"], "reference module (tests/golden)")
+        return out
+    clip = torch.from_numpy(np.ascontiguousarray(ref["clip0"])).to(dev)[None, :]
+    row = pipe.run(clip)[0].double().cpu().numpy()
+    torch.cuda.synchronize()
+    col = 0
     if "mshds" in stages:
-        if "mshds" in ref:                                   # the oracle ran on a 5 s excerpt: run the HIP path on the same
-            sub = torch.from_numpy(np.ascontiguousarray(ref["mshds_input"])).to(dev)
-            got, _ = pipe.mshds.extract_packed(sub, [0], [int(sub.numel())])
-            torch.cuda.synchronize()
-            cmp("mshds_25_features_5s_excerpt", got[0].cpu().numpy(), ref["mshds"])
+        if "mshds" in ref:
+            cmp("mshds_25_features_30s", row[col:col + 25], ref["mshds"], "none (own restatement of Praat)")
         col += 25
     if "smile" in stages:
         if "smile" in ref:
-            cmp("opensmile_912_functionals_30s", row[col:col + 912], ref["smile"])
+            names = __import__("oracle.smile_oracle", fromlist=["x"]).feature_names()
+            pitch = np.array([n.split("_sma")[0] in ("F0final", "voicingFinalUnclipped", "jitterLocal", "jitterDDP",
+                                                     "shimmerLocal", "logHNR") for n in names])
+            g, r = row[col:col + 912], np.asarray(ref["smile"])
+            cmp("opensmile_768_functionals_of_the_32_frame_local_LLDs_30s", g[~pitch], r[~pitch], "none (own restatement of openSMILE)")
+            cmp("opensmile_144_functionals_of_the_pitch_chain_LLDs_30s", g[pitch], r[pitch],
+                "none (own restatement; decision sequences: compared stage by stage in tests/)")
         col += 912
     if "cnnlstm" in stages and "logits" in ref:
-        cmp("wav2vec2_to_cnnlstm_logits_30s", row[col:col + 2], ref["logits"])
+        cmp("wav2vec2_to_cnnlstm_logits_30s", row[col:col + 2], ref["logits"][0], "reference module (CNN-LSTM) / transformers (Wav2Vec2 arithmetic)")
     return out
+
+
+def kernel_sha():
+    """Identity of the GEMM / Wav2Vec2 kernel sources: a stored PMC traffic figure is attached only to the code it measured."""
+    h = hashlib.sha256()
+    for f in ("gemm_f32.hip", "gemm_f32.h", "w2v2.hip"):
+        with open(os.path.join(ROOT, "robust_speech_analysis_framework_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def attach_traffic(roof, args, n_local):
+    """roofline.traffic = HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    MI355X_MICROARCH.md §HBM); PMC cannot run inside this process, so the figure comes from a committed profile and is
+    attached only when that profile was taken with this run's shape and kernel sources."""
+    if not roof:
+        return
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_bench_traffic.json")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            tj = json.load(f)
+        want = tj.get("run", {})
+        if (roof.get("kernel") == want.get("kernel") and want.get("clips") == n_local and want.get("config") == args.config
+                and want.get("w2v2_windows_per_call") == args.w2v2_chunks_per_call and want.get("kernel_sha") == kernel_sha()):
+            roof["traffic"] = round(tj["traffic_bytes_per_launch_fetch_x2_plus_write"])
+            roof["traffic_source"] = f"profiles/{rnd}/pmc_bench_traffic.json ({tj.get('source', '')})"
+            return
+    roof["traffic_note"] = "no committed PMC profile matches this run's shape and kernel sources"
 
 
 def main():
@@ -192,9 +255,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -202,25 +264,48 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from robust_speech_analysis_framework_amd import _lib, pipeline, synth
+    from robust_speech_analysis_framework_amd import _lib, benchlib, pipeline, synth
     from robust_speech_analysis_framework_amd.dist import gather_rows
     _lib.load()
-    torch.set_num_threads(min(usable_cpus(), 8))
+    torch.set_num_threads(min(benchlib.usable_cpus(), 8))
 
-    stages = pipeline.resolve_stages(args.stages)
-    # synthetic shard of this rank: clip index = rank*clips + i (pool-tiled), resident in HBM
-    host = synth.synth_batch(args.clips, args.seconds, pool=args.pool, first=rank * args.pool)
-    wav = torch.from_numpy(host).to(dev)
-    pipe = pipeline.Pipeline(stages, device=dev, seconds=args.seconds,
-                             w2v2_chunks_per_call=args.w2v2_chunks_per_call, overlap=args.overlap)
-    audio_s_per_step = args.clips * args.seconds * world
+    stages = pipeline.resolve_stages(args.stages) if args.stages else list(benchlib.CONFIGS[args.config])
+    c4 = stages == ["cnnlstm_only"]
+    if c4:
+        args.pool = max(args.pool, 256)                      # the config's input is the whole randn(256, 1500, 768) batch
+    clips_per_gpu = args.clips if args.clips is not None else (256 if c4 else 1000)
+    first, n_local, n_total, scaling = benchlib.shard_plan(rank, world, clips_per_gpu, args.total_clips)
+    members = benchlib.pool_members(first, n_local, args.pool)
+    pipe = model = None
+    if c4:
+        from robust_speech_analysis_framework_amd.cnnlstm import CNNLSTM
+        torch.manual_seed(0)
+        model = CNNLSTM().to(dev).eval()                     # reference defaults C = H = 128, silu, seed 0
+        xh = torch.randn(256, 1500, 768, generator=torch.Generator().manual_seed(1234))
+        x = xh[torch.as_tensor([m % 256 for m in members])].to(dev) if members != list(range(256)) else xh.to(dev)
+        frames_seconds = 30.0                                # 1 500 frames ~ 30 s of audio per sequence
+
+        def run_local():
+            return model(x)
+        audio_s_per_step = n_total * frames_seconds
+    else:
+        uniq = sorted(set(members))
+        base = {m: synth.synth_clip(m, args.seconds) for m in uniq}
+        host = np.stack([base[m] for m in members]) if n_local else np.zeros((0, int(args.seconds * 16000)), np.float32)
+        wav = torch.from_numpy(host).to(dev)
+        pipe = pipeline.Pipeline(stages, device=dev, seconds=args.seconds,
+                                 w2v2_chunks_per_call=args.w2v2_chunks_per_call, overlap=args.overlap)
+
+        def run_local():
+            return pipe.run(wav)
+        audio_s_per_step = n_total * args.seconds
 
     def step():
-        rows = pipe.run(wav)                       # [clips, row_width] float32 on device
-        return gather_rows(rows, args.clips * world)   # one RCCL all-gather of the result rows
+        return gather_rows(run_local(), n_total)             # one RCCL all-gather of the result rows
 
     if rank == 0:
-        log(f"setup done: stages {stages}, {args.clips} clips x {args.seconds:g} s per GPU, world {world}")
+        log(f"setup done: config {args.config}, stages {stages}, {n_local} clips on this rank of {n_total} ({scaling}), "
+            f"{len(set(members))} distinct, world {world}")
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -246,51 +331,72 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert torch.isfinite(out[:, pipe.finite_cols]).all(), "non-finite results in the timed region"
-    # size-independent property at full size: the batch is a pool of distinct clips tiled to --clips, and a
-    # clip's row must not depend on its position or on what else is in the batch -> duplicates bit-identical
-    local = out[rank * args.clips:(rank + 1) * args.clips] if world > 1 else out
-    uniq = min(args.pool, args.clips)
-    dup_ok = True
-    if args.clips > uniq:
-        ref_rows = local[:uniq]
-        reps = local[: (args.clips // uniq) * uniq].view(-1, uniq, local.shape[1])
-        same = (reps == ref_rows[None]) | (torch.isnan(reps) & torch.isnan(ref_rows[None]))
-        dup_ok = bool(same.all().item())
+    local = out[first:first + n_local] if world > 1 else out
+    m_cols = 25 if (not c4 and "mshds" in stages) else 0    # MSHDS cells may be NaN by contract (failed helper -> NaN)
+    assert torch.isfinite(local[:, m_cols:]).all(), "non-finite results in the timed region"
+    assert m_cols == 0 or (torch.isfinite(local[:, :m_cols]).sum(dim=1) >= 20).all(), "MSHDS rows mostly NaN"
+    dup_ok = benchlib.duplicates_bit_identical(local, members)
     assert dup_ok, "rows of duplicated clips differ: results depend on batch position"
+
+    # inclusive pass (outside the timed region): 16-bit PCM in pinned host memory -> H2D -> decode on the device -> hot
+    # path -> D2H of the result rows; reported beside the resident-in-HBM number, never as `value`
+    inclusive = None
+    if rank == 0 and not c4 and not args.no_inclusive and n_local:
+        import ctypes as C
+        pcm = torch.from_numpy(np.round(host * 32768.0).astype(np.int16)).pin_memory()
+        lib = _lib.load()
+        times = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            ti = time.perf_counter()
+            d_pcm = pcm.to(dev, non_blocking=True)
+            w2 = torch.empty(pcm.shape, dtype=torch.float32, device=dev)
+            _lib.check(lib.rsaf_pcm_to_mono_f32(_lib.ptr(d_pcm), 2, 1, C.c_int64(pcm.numel()), _lib.ptr(w2), _lib.stream_ptr(None)),
+                       "rsaf_pcm_to_mono_f32")
+            rows = pipe.run(w2).cpu()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - ti)
+        assert torch.equal(torch.nan_to_num(rows), torch.nan_to_num(local.cpu())), "decoded PCM path differs from the resident path"
+        inclusive = {"value": round(n_local * args.seconds / min(times), 2), "unit": "audio-s/s", "ms_per_step": round(1e3 * min(times), 3),
+                     "h2d_bytes": int(pcm.numel() * 2), "d2h_bytes": int(rows.numel() * 4), "ranks": 1,
+                     "what": "rank 0's shard: pinned int16 PCM -> H2D -> rsaf_pcm_to_mono_f32 -> hot path -> D2H rows (best of 2)"}
 
     if rank == 0:
         value = audio_s_per_step * args.steps / dt
-        roof = pipeline.roofline(prof, pipe, args.clips, args.seconds, args.steps,
-                                 HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS)
-        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
-        # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM); PMC cannot run inside this process
-        tpath = os.path.join(ROOT, "profiles", "r01", "pmc_bench_traffic.json")
-        if roof and roof.get("kernel") == "w2v2_gemm" and os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            roof["traffic"] = round(tj["traffic_bytes_per_launch_fetch_x2_plus_write"])
-            roof["traffic_source"] = "profiles/r01/pmc_bench_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        roofs = pipeline.rooflines(prof, stages, n_local, args.seconds, args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS,
+                                   F64_VECTOR_PEAK_TFLOPS)
+        roof = roofs[0] if roofs else None
+        for r in roofs:                                      # the recurrence is latency-bound: report the time per step
+            if r["kernel"] == "lstm_recurrent":
+                tp = 750 if c4 else (pipe.last_frames // 2 if pipe is not None and pipe.last_frames else None)
+                if tp:
+                    r["us_per_step"] = round(1e3 * r["avg_launch_ms"] / tp, 3)
+                    r["steps_per_launch"] = tp
+        attach_traffic(roof, args, n_local)
+        workload = (f"CNN-LSTM-attn forward (C=H=128, default init seed 0) on randn({n_local}, 1500, 768) seed 1234 per GPU"
+                    if c4 else pipe.describe(n_local, args.seconds))
         line = {
             "metric": "audio-seconds processed/sec (extract+CNN-LSTM fwd)",
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": pipe.describe(args.clips, args.seconds),
-                       "clips_per_gpu": args.clips, "clip_seconds": args.seconds,
-                       "stages": [s for s in stages], "sharding": f"clips/{world} ranks, all_gather of result rows",
+            "config": {"workload": workload, "baseline_config": args.config, "clips_per_gpu": n_local, "clips_total": n_total,
+                       "distinct_clips": len(set(members)), "clip_seconds": args.seconds, "stages": list(stages),
+                       "sharding": f"clips/{world} ranks, all_gather of result rows",
                        "w2v2_windows_per_call": args.w2v2_chunks_per_call},
-            "roofline": roof,
+            "roofline": roof, "other_rooflines": roofs[1:],
+            "inclusive_of_pcie_and_decode": inclusive,
             "checks": {"finite": True, "duplicate_clips_bit_identical": dup_ok,
-                       "note": "parity vs the CPU oracle is asserted by tests/ (-m gpu) and smoke(); parity_vs_cpu below reports it for the cpu_baseline sample, outside the timed run"},
+                       "note": "parity vs the CPU oracle is asserted by tests/ (-m gpu) and smoke(); parity_vs_oracle below reports it "
+                               "for the cpu_baseline sample, outside the timed run"},
             "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 and v["ms"] > 0 else {})}
                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if world == 1 and not args.no_cpu_baseline:
-            ref, line["cpu_baseline"] = cpu_baseline(stages, args.seconds, args.cpu_sample_clips)
-            line["parity_vs_cpu"] = parity_vs_cpu(pipe, ref, stages, dev)
+            ref, line["cpu_baseline"] = cpu_baseline(args.config, stages, args.seconds, args.cpu_sample_clips)
+            line["parity_vs_oracle"] = parity_vs_oracle(pipe, ref, stages, dev, model)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -736,8 +736,12 @@ def detect_silences(db, t1, dt, xmin, xmax, silence_threshold_db, min_silence, m
 
 def speechrate(x):
     """``_speechrate`` (:11-125) -> (Speaking_Rate, Articulation_Rate, Phonation_Ratio, Pause_Rate,
-    Mean_Pause_Dur).  The harmonicity call of :36-38 only feeds a no-op (mindip = 2 either way) and
-    is not evaluated."""
+    Mean_Pause_Dur).  The harmonicity call of :36-38 is not evaluated, and that changes nothing: (1) its value
+    only feeds a no-op (mindip = 2 either way; an undefined mean compares False); (2) its failure path (:123-124,
+    all five NaN) is contained in the failure path of the very next call: ``to_harmonicity_cc()`` raises when no cc frame
+    fits, i.e. for duration < 1/75 + 1/75 s = 26.7 ms (Sampled_shortTermAnalysis of a 1-period window + 1 period),
+    ``to_intensity(50 Hz)`` (:41) raises when duration < 6.4 / 50 = 128 ms, and both land in the same ``except``
+    (``harmonicity_failure_implies_intensity_failure`` checks the containment on the frame grids)."""
     nan5 = (np.nan,) * 5
     x = np.asarray(x, dtype=np.float64)
     silencedb, mindip, minpause = -25.0, 2.0, 0.3
@@ -808,6 +812,14 @@ def speechrate(x):
 
 
 # ---- glottal pulses: Sound & Pitch: To PointProcess (cc) -----------------------------------------------
+def harmonicity_failure_implies_intensity_failure(n_samples: int) -> bool:
+    """True when ``to_harmonicity_cc()`` (defaults: 75 Hz, 1 period per window) yielding no frame (Praat raises) implies
+    that ``to_intensity(50 Hz, 0.016)`` yields none either, for a clip of ``n_samples`` samples."""
+    nh, _ = short_term_frames(n_samples, 1.0 / 75.0 + 1.0 / 75.0, 0.01)
+    ni, _ = short_term_frames(n_samples, 6.4 / 50.0, 0.016)
+    return nh > 0 or ni == 0
+
+
 def pitch_value_at(p, t):
     """Pitch 'Get value at time' (Hertz, linear); NaN where undefined."""
     n = p.n_frames

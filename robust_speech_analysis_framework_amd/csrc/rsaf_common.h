@@ -34,7 +34,7 @@ void set_error(const std::string& msg);
 struct ProfScope {
     ProfScope(const char* name, hipStream_t s, double flops, double bytes);
     ~ProfScope();
-    int slot;
+    int slot, pair;
     hipStream_t stream;
 };
 

@@ -22,7 +22,7 @@ static bool g_prof_on = false;
 static std::vector<ProfEntry> g_prof;
 
 ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes)
-    : slot(-1), stream(s) {
+    : slot(-1), pair(-1), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on) return;
@@ -43,14 +43,15 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes
         return;
     }
     e.events.emplace_back(a, b);
+    pair = (int)e.events.size() - 1;          // this scope's own event pair: other threads may open the same family meanwhile
     (void)hipEventRecord(a, stream);
 }
 
 ProfScope::~ProfScope() {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (slot >= (int)g_prof.size() || g_prof[slot].events.empty()) return;
-    (void)hipEventRecord(g_prof[slot].events.back().second, stream);
+    if (slot >= (int)g_prof.size() || pair < 0 || pair >= (int)g_prof[slot].events.size()) return;
+    (void)hipEventRecord(g_prof[slot].events[pair].second, stream);
 }
 
 }  // namespace rsaf

@@ -244,7 +244,7 @@ class MshdsEngine:
 
     def speechrate(self, wav, sample_offs, lengths, gpeak, stream=None):
         """``_speechrate`` (:11-125): intensity(50 Hz, 16 ms) + the 4-candidate pitch pass of :104 ->
-        float64 [n, 5].  (The harmonicity call of :36-38 only feeds a no-op and is not evaluated.)"""
+        float64 [n, 5].  (The harmonicity call of :36-38 is not evaluated: its value only feeds a no-op and its failure path - clips shorter than 26.7 ms - lies inside the failure path of the intensity call of :41 - clips shorter than 128 ms -, which gives the same five NaN; tests/test_mshds_oracle.py checks the containment.)"""
         import torch
         lib = _lib.load()
         n = len(lengths)

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib, smile
 
-BUILT_STAGES = ["mshds", "smile", "w2v2", "cnnlstm"]
+BUILT_STAGES = ["mshds", "smile", "w2v2", "cnnlstm"]     # bench config C4 ("cnnlstm_only") runs the classifier without a Pipeline
 
 # algorithmic traffic per audio-second of the HBM-bound kernels:
 #   16 000 float32 samples read + 38 float32 LLDs x 100 frames/s written
@@ -42,6 +42,7 @@ class Pipeline:
         self._packed = None
         self._packed_key = None
         self.finite_cols = None
+        self.last_frames = None            # Wav2Vec2 frames per clip of the last run (CNN-LSTM sequence length)
         self.w2v2 = None
         self.model = None
         self.mshds = None
@@ -109,6 +110,7 @@ class Pipeline:
             offs = np.arange(n_clips, dtype=np.int64) * n_samp
             seq, frame_off = self.w2v2.extract_packed(p.wav, offs, [n_samp] * n_clips)
             frames = int(frame_off[1]) if n_clips else 0
+            self.last_frames = frames
             if self.model is not None:
                 logits = self.model(seq.view(n_clips, frames, self.w2v2.cfg.hidden_size))
                 cols.append(logits)
@@ -136,28 +138,37 @@ class Pipeline:
         return f"{' -> '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU"
 
 
-def roofline(prof, pipe, clips, seconds, steps, hbm_peak_gbs, mfma_peak_tflops):
-    """roofline object for the kernel family with the largest summed event time."""
-    if not prof:
-        return None
-    name = max(prof, key=lambda k: prof[k]["ms"])
-    rec = prof[name]
-    avg_ms = rec["ms"] / max(rec["launches"], 1)
-    if rec["flops"] > 0:
-        achieved = rec["flops"] / (rec["ms"] * 1e-3) / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak_tflops,
-                "unit": "TFLOP/s", "frac": round(achieved / mfma_peak_tflops, 4), "traffic": None,
-                "algorithmic_flops_per_launch": rec["flops"] / max(rec["launches"], 1),
-                "avg_launch_ms": round(avg_ms, 4), "launches": rec["launches"]}
-    if name == "smile_lld":
-        per_launch = SMILE_LLD_BYTES_PER_AUDIO_S * clips * seconds * steps / max(rec["launches"], 1)
-    elif rec["bytes"] > 0:
-        per_launch = rec["bytes"] / max(rec["launches"], 1)
-    else:
-        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": hbm_peak_gbs, "unit": "GB/s",
-                "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
-    achieved = per_launch / (avg_ms * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": hbm_peak_gbs,
-            "unit": "GB/s", "frac": round(achieved / hbm_peak_gbs, 5), "traffic": None,
-            "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": round(avg_ms, 4),
-            "launches": rec["launches"]}
+def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_tflops, f64_peak_tflops):
+    """roofline objects of the profiled kernel families that have an algorithmic work model, largest event time first
+    (the first one is the line's ``roofline``).  achieved = algorithmic FLOPs (or bytes) per launch / average launch
+    time from HIP events on the launch stream."""
+    out = []
+    for name, rec in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+        if rec["launches"] <= 0 or rec["ms"] <= 0:
+            continue
+        avg_ms = rec["ms"] / rec["launches"]
+        base = {"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": rec["launches"], "traffic": None,
+                "share_of_event_time": round(rec["ms"] / max(sum(r["ms"] for r in prof.values()), 1e-30), 4)}
+        if rec["flops"] > 0:
+            fp64 = name.startswith("mshds_")
+            peak = f64_peak_tflops if fp64 else mfma_f32_peak_tflops
+            ach = rec["flops"] / (rec["ms"] * 1e-3) / 1e12
+            r = {**base, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                 "arithmetic": "f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)" if fp64 else "f32 MFMA",
+                 "algorithmic_flops_per_launch": rec["flops"] / rec["launches"]}
+            if name == "lstm_recurrent":
+                r["note"] = "latency-bound persistent recurrence: the figure that matters is the time per step"
+            out.append(r)
+        elif name == "smile_lld":
+            per_launch = SMILE_LLD_BYTES_PER_AUDIO_S * clips * seconds * steps / rec["launches"]
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            out.append({**base, "bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s",
+                        "frac": round(ach / hbm_peak_gbs, 5), "algorithmic_bytes_per_launch": per_launch,
+                        "note": "SURVEY.md 8d assigns HBM (79 200 B per audio-second); measured: VALU-issue / LDS-latency bound "
+                                "(profiles/r02/pmc_smile_lld.json), see DESIGN.md"})
+        elif rec["bytes"] > 0:
+            per_launch = rec["bytes"] / rec["launches"]
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            out.append({**base, "bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s",
+                        "frac": round(ach / hbm_peak_gbs, 5), "algorithmic_bytes_per_launch": per_launch})
+    return out

@@ -214,17 +214,34 @@ def extract_wav2vec2_sequences(input_df, model_name="facebook/wav2vec2-base-960h
                     print(f"FATAL ERROR processing file '{filename}': {e}. Skipping.")
         if not clips:
             continue
-        lengths = [int(c.numel()) for c in clips]
-        offs = np.zeros(len(clips) + 1, dtype=np.int64)
-        offs[1:] = np.cumsum(lengths)
-        wav = torch.cat(clips) if len(clips) > 1 else clips[0].contiguous()
-        out, frame_off = eng.extract_packed(wav, offs[:-1], lengths, chunk_seconds, overlap_seconds)
-        torch.cuda.synchronize()
-        host = out.cpu().numpy()
-        for i, fn in enumerate(names):
-            a, b = int(frame_off[i]), int(frame_off[i + 1])
-            if b > a:                                                          # :123 (no chunk survived)
-                sequences[fn] = host[a:b].copy()
+        def run(batch_clips):
+            lengths = [int(c.numel()) for c in batch_clips]
+            offs = np.zeros(len(batch_clips) + 1, dtype=np.int64)
+            offs[1:] = np.cumsum(lengths)
+            wav = torch.cat(batch_clips) if len(batch_clips) > 1 else batch_clips[0].contiguous()
+            out, frame_off = eng.extract_packed(wav, offs[:-1], lengths, chunk_seconds, overlap_seconds)
+            torch.cuda.synchronize()
+            return out.cpu().numpy(), frame_off
+
+        try:
+            host, frame_off = run(clips)
+            for i, fn in enumerate(names):
+                a, b = int(frame_off[i]), int(frame_off[i + 1])
+                if b > a:                                                      # :123 (no chunk survived)
+                    sequences[fn] = host[a:b].copy()
+        except (_lib.RsafError, RuntimeError) as e:
+            # one bad file (or an allocation failure of the whole batch) must not take the other files of the batch or
+            # the files already done with it: the reference skips only the offending file (:127-129)
+            if verbose:
+                print(f"WARNING: batch of {len(clips)} files failed ({e}); retrying file by file.")
+            for fn, c in zip(names, clips):
+                try:
+                    host, frame_off = run([c])
+                    if int(frame_off[1]) > 0:
+                        sequences[fn] = host[:int(frame_off[1])].copy()
+                except (_lib.RsafError, RuntimeError) as e1:
+                    if verbose:
+                        print(f"FATAL ERROR processing file '{fn}': {e1}. Skipping.")
     return sequences
 
 

@@ -146,3 +146,13 @@ def test_sinc_cheb_table_reproduces_the_direct_interpolation():
             coef = tab.T @ taps                                        # 16 Chebyshev coefficients of S on the cell
             got[i] = Ch.chebval(2.0 * frac[i] - 1.0, coef)
         assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_speechrate_harmonicity_call_cannot_change_the_result():
+    """src/mshds_extractor.py:36-38: the HNR only selects mindip = 2 (both branches); a raise there (:123-124) needs a
+    clip shorter than one cc frame (26.7 ms), for which the intensity call of :41 (128 ms window) raises as well."""
+    from oracle import mshds_oracle as mo
+    assert all(mo.harmonicity_failure_implies_intensity_failure(n) for n in range(0, 4000))
+    assert mo.short_term_frames(426, 2.0 / 75.0, 0.01)[0] == 0 and mo.short_term_frames(427, 2.0 / 75.0, 0.01)[0] == 1
+    short = np.zeros(427, dtype=np.float32)                      # harmonicity would succeed, intensity cannot
+    assert all(np.isnan(v) for v in mo.speechrate(short))

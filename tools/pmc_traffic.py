@@ -1,23 +1,37 @@
 """Turn two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass on gfx950) into
-profiles/<round>/pmc_bench_traffic.json, the file bench.py reads for `roofline.traffic`.
+profiles/<round>/pmc_bench_traffic.json, the file bench.py reads for `roofline.traffic`, with the HBM traffic of the
+Wav2Vec2 GEMM kernel PER SHAPE (dispatches grouped by grid size) beside the algorithmic bytes of that shape.
 
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o f --output-format csv -- python3 bench.py ...
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o w --output-format csv -- python3 bench.py ...
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01/pmc_bench_traffic.json "<command>"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py ...
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write --output-format csv -- python3 bench.py ...
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02/pmc_bench_traffic.json \
+         --config e2e --clips 1000 --windows 2048 --command "<command>"
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB;
 on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so wide coalesced reads are doubled; WRITE_SIZE is exact.
 """
+import argparse
 import csv
 import glob
+import hashlib
 import json
 import os
-import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sha():
+    h = hashlib.sha256()
+    for f in ("gemm_f32.hip", "gemm_f32.h", "w2v2.hip"):
+        with open(os.path.join(ROOT, "robust_speech_analysis_framework_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def collect(root, counter):
-    agg = defaultdict(lambda: [0.0, 0])
+    """{kernel name: {grid size: [sum of counter, dispatches]}}"""
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     files = glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter_collection.csv under {root}")
@@ -26,31 +40,76 @@ def collect(root, counter):
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter:
                     continue
-                a = agg[row["Kernel_Name"]]
+                a = agg[row["Kernel_Name"]][int(row.get("Grid_Size", 0) or 0)]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
     return agg
 
 
+def w2v2_shapes(n_windows, chunk_len=80000):
+    """Wav2Vec2-base GEMMs of one sub-batch of n equal windows: {grid size (threads): (label, algorithmic bytes per launch)}.
+    128 x 128 tiles, 256 threads per workgroup; the conv GEMMs are batched over the windows (grid.y), the encoder GEMMs
+    run on all rows at once."""
+    T, t = [], chunk_len
+    for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+        t = (t - k) // s + 1
+        T.append(t)
+    C, H, inter = 512, 768, 3072
+    out = {}
+    tiles = lambda m, n: ((m + 127) // 128) * ((n + 127) // 128)           # noqa: E731
+    for i in range(1, 7):
+        k = 3 if i <= 4 else 2
+        grid = tiles(T[i], C) * n_windows * 256
+        out[grid] = (f"conv{i} [{T[i]} x {k * C}] x [{C}] x {n_windows} windows", 4.0 * n_windows * (T[i - 1] * C + T[i] * C) + 4.0 * C * k * C)
+    rows = n_windows * T[6]
+    for label, n, k, resid in (("feature projection", H, C, 0), ("qkv", 3 * H, H, 0), ("attention out-proj (+residual)", H, H, 1),
+                               ("ffn1 (GELU)", inter, H, 0), ("ffn2 (+residual)", H, inter, 1)):
+        out.setdefault(tiles(rows, n) * 256, (f"{label} [{rows} x {k}] x [{n}]", 4.0 * (rows * k + n * k + rows * n * (1 + resid))))
+    return out
+
+
 def main():
-    fetch_dir, write_dir, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else ""
-    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
-    per = {}
-    for k in sorted(set(fe) | set(wr)):
-        per[k] = {"fetch_raw_KB": fe[k][0] if k in fe else 0.0, "write_KB": wr[k][0] if k in wr else 0.0,
-                  "launches": fe[k][1] if k in fe else wr[k][1]}
-    gemm = [k for k in per if "gemm_f32" in k]
-    gl = sum(per[k]["launches"] for k in gemm)
-    gf = sum(per[k]["fetch_raw_KB"] for k in gemm)
-    gw = sum(per[k]["write_KB"] for k in gemm)
-    doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: {cmd}",
-           "gemm_kernels": gemm, "gemm_launches": gl, "fetch_KB_raw": gf, "write_KB": gw,
-           "traffic_bytes_per_launch_fetch_x2_plus_write": (2.0 * gf + gw) * 1024.0 / max(gl, 1),
-           "per_kernel_KB": per}
-    with open(out, "w") as f:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("out")
+    ap.add_argument("--config", default="e2e")
+    ap.add_argument("--clips", type=int, default=1000)
+    ap.add_argument("--windows", type=int, default=2048)
+    ap.add_argument("--kernel", default="w2v2_gemm")
+    ap.add_argument("--command", default="")
+    a = ap.parse_args()
+    fe, wr = collect(a.fetch_dir, "FETCH_SIZE"), collect(a.write_dir, "WRITE_SIZE")
+    gemm = [k for k in set(fe) | set(wr) if "gemm_f32" in k]
+    shapes = w2v2_shapes(a.windows)
+    per_shape, tot_f, tot_w, tot_l = [], 0.0, 0.0, 0
+    grids = sorted({g for k in gemm for g in list(fe.get(k, {})) + list(wr.get(k, {}))})
+    for g in grids:
+        f = sum(fe[k][g][0] for k in gemm if g in fe.get(k, {}))
+        w = sum(wr[k][g][0] for k in gemm if g in wr.get(k, {}))
+        n = max(sum(fe[k][g][1] for k in gemm if g in fe.get(k, {})), sum(wr[k][g][1] for k in gemm if g in wr.get(k, {})))
+        traffic = (2.0 * f + w) * 1024.0 / max(n, 1)
+        label, alg = shapes.get(g, (None, None))
+        per_shape.append({"grid_threads": g, "launches": n, "hbm_bytes_per_launch_fetch_x2_plus_write": traffic,
+                          "shape": label, "algorithmic_bytes_per_launch": alg,
+                          "traffic_over_algorithmic": (traffic / alg) if alg else None})
+        tot_f += f
+        tot_w += w
+        tot_l += n
+    per_shape.sort(key=lambda r: -r["launches"] * r["hbm_bytes_per_launch_fetch_x2_plus_write"])
+    doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: {a.command}",
+           "run": {"kernel": a.kernel, "config": a.config, "clips": a.clips, "w2v2_windows_per_call": a.windows,
+                   "kernel_sha": kernel_sha()},
+           "gemm_kernels": gemm, "gemm_launches": tot_l, "fetch_KB_raw": tot_f, "write_KB": tot_w,
+           "traffic_bytes_per_launch_fetch_x2_plus_write": (2.0 * tot_f + tot_w) * 1024.0 / max(tot_l, 1),
+           "note": "all gemm_f32 dispatches of the run share the kernel symbol (Wav2Vec2, CNN-LSTM and tail-window launches); "
+                   "per_shape separates them by grid size, shapes of the full-window sub-batches are labelled",
+           "per_shape": per_shape}
+    with open(a.out, "w") as f:
         json.dump(doc, f, indent=1)
-    print(json.dumps({k: doc[k] for k in ("gemm_launches", "fetch_KB_raw", "write_KB",
-                                          "traffic_bytes_per_launch_fetch_x2_plus_write")}))
+    print(json.dumps({k: doc[k] for k in ("gemm_launches", "traffic_bytes_per_launch_fetch_x2_plus_write")}))
+    for r in per_shape[:14]:
+        print(r)
 
 
 if __name__ == "__main__":
