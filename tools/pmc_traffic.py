@@ -30,19 +30,28 @@ def kernel_sha():
 
 
 def collect(root, counter):
-    """{kernel name: {grid size: [sum of counter, dispatches]}}"""
+    """{kernel name: {shape key: [sum of counter, dispatches]}}.  Shape key = grid size, and for the three GEMMs that
+    share the N = 768 grid (feature projection, attention out-projection, ffn2) the launch that preceded them in
+    dispatch order (the encoder issues qkv, out-proj, ffn1, ffn2 per layer): grid size alone cannot tell them apart."""
     agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     files = glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter_collection.csv under {root}")
     for fn in files:
         with open(fn, newline="") as f:
-            for row in csv.DictReader(f):
-                if row.get("Counter_Name") != counter:
-                    continue
-                a = agg[row["Kernel_Name"]][int(row.get("Grid_Size", 0) or 0)]
-                a[0] += float(row["Counter_Value"])
-                a[1] += 1
+            rows = [r for r in csv.DictReader(f) if r.get("Counter_Name") == counter]
+        rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+        prev = None
+        for row in rows:
+            k = row["Kernel_Name"]
+            g = int(row.get("Grid_Size", 0) or 0)
+            key = g
+            if "gemm_f32" in k:
+                key = (g, prev)
+                prev = g
+            a = agg[k][key]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
     return agg
 
 
@@ -57,14 +66,19 @@ def w2v2_shapes(n_windows, chunk_len=80000):
     C, H, inter = 512, 768, 3072
     out = {}
     tiles = lambda m, n: ((m + 127) // 128) * ((n + 127) // 128)           # noqa: E731
+    conv_grid = {}
     for i in range(1, 7):
         k = 3 if i <= 4 else 2
-        grid = tiles(T[i], C) * n_windows * 256
-        out[grid] = (f"conv{i} [{T[i]} x {k * C}] x [{C}] x {n_windows} windows", 4.0 * n_windows * (T[i - 1] * C + T[i] * C) + 4.0 * C * k * C)
+        conv_grid[i] = tiles(T[i], C) * n_windows * 256
+        out[conv_grid[i]] = (f"conv{i} [{T[i]} x {k * C}] x [{C}] x {n_windows} windows", 4.0 * n_windows * (T[i - 1] * C + T[i] * C) + 4.0 * C * k * C)
     rows = n_windows * T[6]
-    for label, n, k, resid in (("feature projection", H, C, 0), ("qkv", 3 * H, H, 0), ("attention out-proj (+residual)", H, H, 1),
-                               ("ffn1 (GELU)", inter, H, 0), ("ffn2 (+residual)", H, inter, 1)):
-        out.setdefault(tiles(rows, n) * 256, (f"{label} [{rows} x {k}] x [{n}]", 4.0 * (rows * k + n * k + rows * n * (1 + resid))))
+    g = {n: tiles(rows, n) * 256 for n in (H, 3 * H, inter)}
+    alg = lambda n, k, resid: 4.0 * (rows * k + n * k + rows * n * (1 + resid))      # noqa: E731
+    out[g[3 * H]] = (f"qkv [{rows} x {H}] x [{3 * H}]", alg(3 * H, H, 0))
+    out[g[inter]] = (f"ffn1 (GELU) [{rows} x {H}] x [{inter}]", alg(inter, H, 0))
+    out[(g[H], g[3 * H])] = (f"attention out-proj (+residual) [{rows} x {H}] x [{H}]", alg(H, H, 1))
+    out[(g[H], g[inter])] = (f"ffn2 (+residual) [{rows} x {inter}] x [{H}]", alg(H, inter, 1))
+    out[(g[H], conv_grid[6])] = (f"feature projection [{rows} x {C}] x [{H}]", alg(H, C, 0))
     return out
 
 
@@ -83,14 +97,28 @@ def main():
     gemm = [k for k in set(fe) | set(wr) if "gemm_f32" in k]
     shapes = w2v2_shapes(a.windows)
     per_shape, tot_f, tot_w, tot_l = [], 0.0, 0.0, 0
-    grids = sorted({g for k in gemm for g in list(fe.get(k, {})) + list(wr.get(k, {}))})
+    grids = sorted({g for k in gemm for g in list(fe.get(k, {})) + list(wr.get(k, {}))}, key=str)
+    # collapse (grid, previous grid) keys that the shape table does not distinguish
+    def canon(key):
+        return key if key in shapes else (key[0] if isinstance(key, tuple) else key)
+    merged_f, merged_w = defaultdict(lambda: [0.0, 0]), defaultdict(lambda: [0.0, 0])
+    for src, dst in ((fe, merged_f), (wr, merged_w)):
+        for k in gemm:
+            for key, (v, n) in src.get(k, {}).items():
+                dst[canon(key)][0] += v
+                dst[canon(key)][1] += n
+    fe = {"gemm": merged_f}
+    wr = {"gemm": merged_w}
+    gemm_names = gemm
+    gemm = ["gemm"]
+    grids = sorted(set(merged_f) | set(merged_w), key=str)
     for g in grids:
         f = sum(fe[k][g][0] for k in gemm if g in fe.get(k, {}))
         w = sum(wr[k][g][0] for k in gemm if g in wr.get(k, {}))
         n = max(sum(fe[k][g][1] for k in gemm if g in fe.get(k, {})), sum(wr[k][g][1] for k in gemm if g in wr.get(k, {})))
         traffic = (2.0 * f + w) * 1024.0 / max(n, 1)
         label, alg = shapes.get(g, (None, None))
-        per_shape.append({"grid_threads": g, "launches": n, "hbm_bytes_per_launch_fetch_x2_plus_write": traffic,
+        per_shape.append({"grid_threads": g[0] if isinstance(g, tuple) else g, "launches": n, "hbm_bytes_per_launch_fetch_x2_plus_write": traffic,
                           "shape": label, "algorithmic_bytes_per_launch": alg,
                           "traffic_over_algorithmic": (traffic / alg) if alg else None})
         tot_f += f
@@ -100,7 +128,7 @@ def main():
     doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: {a.command}",
            "run": {"kernel": a.kernel, "config": a.config, "clips": a.clips, "w2v2_windows_per_call": a.windows,
                    "kernel_sha": kernel_sha()},
-           "gemm_kernels": gemm, "gemm_launches": tot_l, "fetch_KB_raw": tot_f, "write_KB": tot_w,
+           "gemm_kernels": gemm_names, "gemm_launches": tot_l, "fetch_KB_raw": tot_f, "write_KB": tot_w,
            "traffic_bytes_per_launch_fetch_x2_plus_write": (2.0 * tot_f + tot_w) * 1024.0 / max(tot_l, 1),
            "note": "all gemm_f32 dispatches of the run share the kernel symbol (Wav2Vec2, CNN-LSTM and tail-window launches); "
                    "per_shape separates them by grid size, shapes of the full-window sub-batches are labelled",
