@@ -112,6 +112,21 @@ int rsaf_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
                   int nz, int nz2, const int64_t* strides8_host, int a_pad_k, int act, float alpha,
                   int b_kn, rsaf_stream_t stream);
 
+/* ---- fp32-accurate GEMM on the bf16 matrix pipe --------------------------------------------------------------
+ * The same contraction as rsaf_gemm_f32 for the plain case (row-major A [M,K], B [N,K], K % 16 == 0), for the same
+ * call sites (nn.Linear / nn.Conv1d inside Wav2Vec2Model, src/foundation_model_extractor.py:115), computed from
+ * three-way bf16 splits of both operands: six v_mfma_f32_32x32x16_bf16 partial products per term with fp32
+ * accumulation (csrc/gemm_bf16x6.hip).  The error against float64 is that of an fp32 FMA chain (a few fp32 roundings);
+ * the matrix pipe spends 2.7x fewer cycles than the fp32 MFMA.  Operands are bf16 bit patterns in three planes
+ * (`*_plane_stride` elements apart); rsaf_split_bf16x3 produces them (n % 4 == 0).  Outputs: C (fp32) and / or
+ * C_planes (the next GEMM's A), either may be NULL; ldc is the row stride of both.  Supported combinations:
+ * {act 0, C} {act 0, C, R} {act 0, C_planes} {act 0, C, C_planes} {act 1, C} {act 1, C_planes}.              */
+int rsaf_split_bf16x3(const float* src, int64_t n, uint16_t* planes, int64_t plane_stride, rsaf_stream_t stream);
+int rsaf_gemm_bf16x6(const uint16_t* A_planes, int64_t a_plane_stride, const uint16_t* B_planes,
+                     int64_t b_plane_stride, float* C, uint16_t* C_planes, int64_t c_plane_stride,
+                     const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
+                     int64_t ldc, int64_t ldr, int act, float alpha, rsaf_stream_t stream);
+
 /* ---- CNN-LSTM-with-attention classifier forward ----------------------------------------------------
  * Replaces CNNLSTM.forward (src/models.py:161-193) in eval mode: x[B,T,input_dim] float32 ->
  * logits[B,num_classes].  Zero-padded frames are processed like any other frame (the reference's

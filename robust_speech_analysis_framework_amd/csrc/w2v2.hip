@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "gemm_f32.h"
+#include "gemm_bf16x6.h"
 
 namespace rsaf {
 namespace w2v2 {
@@ -68,8 +69,8 @@ static Layout make_layout(const Cfg& c) {
 static int check_cfg(const Cfg& c) {
     RSAF_CHECK_ARG(c.C >= 32 && c.C <= 1024 && c.C % 32 == 0 && (c.C <= 256 || c.C % 256 == 0),
                    "conv_dim must be a multiple of 32 (<= 256) or of 256 (<= 1024)");
-    RSAF_CHECK_ARG(c.Hd >= 4 && c.Hd <= 1024 && c.Hd % 4 == 0, "hidden_size must be a multiple of 4, <= 1024");
-    RSAF_CHECK_ARG(c.I >= 4 && c.I % 4 == 0, "intermediate_size must be a multiple of 4");
+    RSAF_CHECK_ARG(c.Hd >= 16 && c.Hd <= 1024 && c.Hd % 16 == 0, "hidden_size must be a multiple of 16, <= 1024");
+    RSAF_CHECK_ARG(c.I >= 16 && c.I % 16 == 0, "intermediate_size must be a multiple of 16");
     RSAF_CHECK_ARG(c.L >= 1 && c.L <= 64, "num_hidden_layers out of range");
     RSAF_CHECK_ARG(c.NH >= 1 && c.Hd % c.NH == 0 && (c.Hd / c.NH) % 4 == 0, "head_dim must be a multiple of 4");
     RSAF_CHECK_ARG(c.PG >= 1 && c.Hd % c.PG == 0 && (c.Hd / c.PG) % 4 == 0 && c.PK >= 2 && c.PK % 2 == 0,
@@ -85,11 +86,18 @@ static void chunk_lengths(int len, int T[7]) {
     }
 }
 
+// The dense GEMMs run on rsaf's fp32-accurate bf16x6 kernel (gemm_bf16x6.hip): their operands live as three bf16
+// planes.  Offsets are in floats; a planes buffer of N elements takes 3 N uint16 = 1.5 N floats.
 struct Workspace {
-    int64_t xn, part, ab, bufP, bufQ, lnf, x, y, att, xg, qkv, S, ffn, total;
-    int slabs, Tp;
+    int64_t xn, part, ab, P, Q, c6, lnfp, x, xp, y, att, attp, xg, qkv, S, ffnp, wp, total;
+    int64_t wp_conv[6], wp_fp;
+    std::vector<int64_t> wp_qkv, wp_o, wp_1, wp_2;
+    int slabs, Tp, G;
 };
 constexpr int STAT_SLAB = 512;
+constexpr int CONV_GROUP = 512;      // windows per pass of the feature encoder (its ping-pong buffers are the big ones)
+
+static inline int64_t planes_floats(int64_t n) { return pad4((3 * n + 1) / 2); }
 
 static Workspace make_ws(const Cfg& c, int n, int len) {
     int T[7];
@@ -98,21 +106,35 @@ static Workspace make_ws(const Cfg& c, int n, int len) {
     int64_t o = 0;
     auto take = [&](int64_t k) { int64_t s = o; o += pad4(k); return s; };
     const int Tt = T[6];
+    const int G = n < CONV_GROUP ? n : CONV_GROUP;
+    w.G = G;
     w.slabs = (T[0] + STAT_SLAB - 1) / STAT_SLAB;
     w.Tp = (int)pad4(Tt);
-    w.xn = take((int64_t)n * len);
-    w.part = take((int64_t)n * w.slabs * 2 * c.C);
-    w.ab = take((int64_t)n * 2 * c.C);
-    w.bufP = take((int64_t)n * T[0] * c.C);
-    w.bufQ = take((int64_t)n * T[1] * c.C);
-    w.lnf = take((int64_t)n * Tt * c.C);
+    w.xn = take((int64_t)G * len);
+    w.part = take((int64_t)G * w.slabs * 2 * c.C);
+    w.ab = take((int64_t)G * 2 * c.C);
+    w.P = take(planes_floats((int64_t)G * T[0] * c.C));
+    w.Q = take(planes_floats((int64_t)G * T[1] * c.C));
+    w.c6 = take((int64_t)n * Tt * c.C);
+    w.lnfp = take(planes_floats((int64_t)n * Tt * c.C));
     w.x = take((int64_t)n * Tt * c.Hd);
+    w.xp = take(planes_floats((int64_t)n * Tt * c.Hd));
     w.y = take((int64_t)n * Tt * c.Hd);
     w.att = take((int64_t)n * Tt * c.Hd);
+    w.attp = take(planes_floats((int64_t)n * Tt * c.Hd));
     w.xg = take((int64_t)n * (Tt + c.PK - 1) * c.Hd);
     w.qkv = take((int64_t)n * Tt * 3 * c.Hd);
     w.S = take((int64_t)n * c.NH * Tt * w.Tp);
-    w.ffn = take((int64_t)n * Tt * c.I);
+    w.ffnp = take(planes_floats((int64_t)n * Tt * c.I));
+    // weight planes (split once per forward call)
+    for (int i = 0; i < 6; ++i) w.wp_conv[i] = take(planes_floats((int64_t)c.C * KERN[i + 1] * c.C));
+    w.wp_fp = take(planes_floats((int64_t)c.Hd * c.C));
+    for (int l = 0; l < c.L; ++l) {
+        w.wp_qkv.push_back(take(planes_floats((int64_t)3 * c.Hd * c.Hd)));
+        w.wp_o.push_back(take(planes_floats((int64_t)c.Hd * c.Hd)));
+        w.wp_1.push_back(take(planes_floats((int64_t)c.I * c.Hd)));
+        w.wp_2.push_back(take(planes_floats((int64_t)c.Hd * c.I)));
+    }
     w.total = o;
     return w;
 }
@@ -147,12 +169,18 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
 }
 
 // ---- conv0 (1 -> C, k = 10, s = 5) + GroupNorm(C groups) + GELU, two passes ----------------------
+__device__ __forceinline__ unsigned short bf16_bits_w(float x) {
+    const __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf16_to_f32_w(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
 // thread <-> channel(s); the 10 samples of a frame are wave-uniform (scalar loads)
 template <int CPT, bool APPLY>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn, const float* __restrict__ w0,
                                                     float* __restrict__ part, const float* __restrict__ ab,
-                                                    float* __restrict__ out, int len, int T0, int C, int slab,
-                                                    int slabs) {
+                                                    unsigned short* __restrict__ outp, int64_t plane, int len,
+                                                    int T0, int C, int slab, int slabs) {
     const int chunk = blockIdx.y, sl = blockIdx.x;
     const int t0 = sl * slab, t1 = min(T0, t0 + slab);
     const float* __restrict__ x = xn + (int64_t)chunk * len;
@@ -177,7 +205,14 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
             for (int j = 0; j < 10; ++j) y = fmaf(wr[k][j], xv[j], y);
             if (APPLY) {
                 const float v = fmaf(y, a[k], b[k]);
-                out[((int64_t)chunk * T0 + t) * C + ch[k]] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                const float gl = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                // the next layer's GEMM takes its A operand as three bf16 planes (gemm_bf16x6.hip)
+                const unsigned short hh = bf16_bits_w(gl);
+                const float r1 = gl - bf16_to_f32_w(hh);
+                const unsigned short mm = bf16_bits_w(r1);
+                const unsigned short ll = bf16_bits_w(r1 - bf16_to_f32_w(mm));
+                const int64_t o = ((int64_t)chunk * T0 + t) * C + ch[k];
+                outp[o] = hh; outp[plane + o] = mm; outp[2 * plane + o] = ll;
             } else {
                 s[k] += y; q[k] += y * y;
             }
@@ -216,7 +251,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         float* __restrict__ out, int64_t rows, int D, float eps,
-                                                        const int64_t* __restrict__ out_row_start, int T) {
+                                                        const int64_t* __restrict__ out_row_start, int T,
+                                                        unsigned short* __restrict__ planes, int64_t plane) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -248,7 +284,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
-    float4* o4 = reinterpret_cast<float4*>(out + orow * D);
+    float4* o4 = out ? reinterpret_cast<float4*>(out + orow * D) : nullptr;
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const float4* b4 = reinterpret_cast<const float4*>(b);
 #pragma unroll
@@ -256,8 +292,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int idx = lane + 64 * i;
         if (idx < D4) {
             const float4 gg = g4[idx], bb = b4[idx];
-            o4[idx] = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
-                                  (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+            const float4 y = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                                         (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+            if (o4) o4[idx] = y;
+            if (planes) {                                  // the same values as three bf16 planes (A operand of the next GEMM)
+                const float yy[4] = {y.x, y.y, y.z, y.w};
+                unsigned short hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    hh[k] = bf16_bits_w(yy[k]);
+                    const float r1 = yy[k] - bf16_to_f32_w(hh[k]);
+                    mm[k] = bf16_bits_w(r1);
+                    ll[k] = bf16_bits_w(r1 - bf16_to_f32_w(mm[k]));
+                }
+                unsigned short* pp = planes + row * D + 4 * idx;
+                *reinterpret_cast<uint2*>(pp) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+                *reinterpret_cast<uint2*>(pp + plane) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
+                *reinterpret_cast<uint2*>(pp + 2 * plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+            }
         }
     }
 }
@@ -473,25 +525,26 @@ __global__ __launch_bounds__(256) void regroup_kernel(const float4* __restrict__
 }
 
 static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
-              float eps, hipStream_t s, const int64_t* out_row_start = nullptr, int T = 1) {
+              float eps, hipStream_t s, const int64_t* out_row_start = nullptr, int T = 1,
+              unsigned short* planes = nullptr) {
     const int64_t blocks = (rows + 3) / 4;
     RSAF_CHECK_ARG(blocks <= 0x7fffffffLL, "too many rows");
-    ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * 4 * (r ? 3 : 2));
+    ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * (4 * (r ? 2 : 1) + (out ? 4 : 0) + (planes ? 6 : 0)));
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, r, g, b, out, rows, D, eps,
-                       out_row_start, T);
+                       out_row_start, T, planes, rows * D);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }
 
 template <bool APPLY>
-static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* part, const float* ab, float* out,
-                        int n, int len, int T0, int slab, int slabs, hipStream_t s) {
+static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* part, const float* ab,
+                        unsigned short* outp, int64_t plane, int n, int len, int T0, int slab, int slabs, hipStream_t s) {
     const int threads = c.C <= 256 ? c.C : 256;
     const int cpt = c.C / threads;
     dim3 grid((unsigned)slabs, (unsigned)n);
     ProfScope prof(APPLY ? "w2v2_conv0_apply" : "w2v2_conv0_stats", s, 2.0 * 10 * c.C * (double)T0 * n, 0.0);
 #define RSAF_C0(CPT)                                                                                       \
-    hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, out, len, T0, \
+    hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, outp, plane, len, T0, \
                        c.C, slab, slabs)
     switch (cpt) {
         case 1: RSAF_C0(1); break;
@@ -579,48 +632,80 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     const int64_t rows = (int64_t)n * Tt;
     RSAF_CHECK_ARG(rows <= 0x7fffffffLL, "too many frames per call");
 
-    // 1. per-chunk normalisation (HF feature extractor)
+    auto planes_at = [&](int64_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
+    // helper: C = act(A B^T + bias (+ R)) on the bf16x6 kernel; A / B as planes
+    auto gemm6 = [&](const uint16_t* A, int64_t a_plane, int64_t lda, int64_t sA, const uint16_t* B, int M, int N, int K,
+                     float* Cf, int64_t sC, uint16_t* Cp, int64_t c_plane, int64_t sCp, const float* bias, const float* R,
+                     int nz, int act, const char* tag) {
+        Gemm6Params p{};
+        p.A = A; p.a_plane = a_plane; p.lda = lda; p.sA = sA;
+        p.B = B; p.b_plane = (int64_t)N * K; p.ldb = K;
+        p.C = Cf; p.ldc = N; p.sC = sC;
+        p.Cp = Cp; p.c_plane = c_plane; p.ldcp = N; p.sCp = sCp;
+        p.bias = bias; p.R = R; p.ldr = N; p.sR = sC;
+        p.M = M; p.N = N; p.K = K; p.nz = nz; p.act = act; p.alpha = 1.0f; p.group_m = 0;
+        return launch_gemm_bf16x6(p, s, tag);
+    };
+    // 0. weights of the dense layers as bf16 planes (once per call: 0.6 GB at base geometry, < 1 ms)
     {
-        ProfScope prof("w2v2_normalize", s, 0.0, (double)n * chunk_len * 4 * 3);
-        hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, wav, chunk_start, chunk_len, ws + W.xn);
-        RSAF_CHECK_HIP(hipGetLastError());
+        auto split_w = [&](int64_t src_off, int64_t count, int64_t dst_off) {
+            return launch_split_bf16x3(Wt + src_off, count, planes_at(dst_off), count, s);
+        };
+        for (int i = 0; i < 6; ++i)
+            if ((rc = split_w(L.conv[i], (int64_t)C * KERN[i + 1] * C, W.wp_conv[i]))) return rc;
+        if ((rc = split_w(L.fpw, (int64_t)Hd * C, W.wp_fp))) return rc;
+        for (int l = 0; l < c.L; ++l) {
+            const LayerOff& lo = L.layers[l];
+            if ((rc = split_w(lo.wqkv, (int64_t)3 * Hd * Hd, W.wp_qkv[l]))) return rc;
+            if ((rc = split_w(lo.wo, (int64_t)Hd * Hd, W.wp_o[l]))) return rc;
+            if ((rc = split_w(lo.w1, (int64_t)c.I * Hd, W.wp_1[l]))) return rc;
+            if ((rc = split_w(lo.w2, (int64_t)Hd * c.I, W.wp_2[l]))) return rc;
+        }
     }
-    // 2. conv0 + GroupNorm + GELU (stats pass, finalize, apply pass)
-    rc = conv0_launch<false>(c, ws + W.xn, Wt + L.conv0, ws + W.part, nullptr, nullptr, n, chunk_len, T[0],
-                             STAT_SLAB, W.slabs, s);
+    // 1-3. feature encoder, CONV_GROUP windows at a time (its activations are the large ones: 15 999 x 512 per window)
+    for (int g0 = 0; g0 < n; g0 += W.G) {
+        const int g = std::min(W.G, n - g0);
+        // 1. per-chunk normalisation (HF feature extractor)
+        {
+            ProfScope prof("w2v2_normalize", s, 0.0, (double)g * chunk_len * 4 * 3);
+            hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(256), 0, s, wav, chunk_start + g0, chunk_len, ws + W.xn);
+            RSAF_CHECK_HIP(hipGetLastError());
+        }
+        // 2. conv0 + GroupNorm + GELU (stats pass, finalize, apply pass); the apply pass writes bf16 planes
+        rc = conv0_launch<false>(c, ws + W.xn, Wt + L.conv0, ws + W.part, nullptr, nullptr, 0, g, chunk_len, T[0],
+                                 STAT_SLAB, W.slabs, s);
+        if (rc) return rc;
+        {
+            const int64_t tot = (int64_t)g * C;
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ws + W.part,
+                               Wt + L.gng, Wt + L.gnb, ws + W.ab, g, C, W.slabs, T[0]);
+            RSAF_CHECK_HIP(hipGetLastError());
+        }
+        {
+            const int slab = 128;
+            rc = conv0_launch<true>(c, ws + W.xn, Wt + L.conv0, nullptr, ws + W.ab, planes_at(W.P), (int64_t)g * T[0] * C, g,
+                                    chunk_len, T[0], slab, (T[0] + slab - 1) / slab, s);
+            if (rc) return rc;
+        }
+        // 3. conv1..6 as GEMMs over the channels-last sequence (lda = stride * C, K = taps * C) with fused GELU;
+        //    the output goes out as planes (the next layer's A), the last one as fp32 rows for the LayerNorm
+        uint16_t* cur = planes_at(W.P);
+        uint16_t* nxt = planes_at(W.Q);
+        for (int i = 1; i < 7; ++i) {
+            const bool last = i == 6;
+            rc = gemm6(cur, (int64_t)g * T[i - 1] * C, (int64_t)STRD[i] * C, (int64_t)T[i - 1] * C, planes_at(W.wp_conv[i - 1]),
+                       T[i], C, KERN[i] * C, last ? ws + W.c6 + (int64_t)g0 * Tt * C : nullptr, (int64_t)T[i] * C,
+                       last ? nullptr : nxt, (int64_t)g * T[i] * C, (int64_t)T[i] * C, nullptr, nullptr, g, ACT_GELU, "w2v2_gemm");
+            if (rc) return rc;
+            std::swap(cur, nxt);
+        }
+    }
+    // 4. feature projection: LayerNorm (-> planes) + Linear
+    rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, 1, planes_at(W.lnfp));
     if (rc) return rc;
-    {
-        const int64_t tot = (int64_t)n * C;
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ws + W.part,
-                           Wt + L.gng, Wt + L.gnb, ws + W.ab, n, C, W.slabs, T[0]);
-        RSAF_CHECK_HIP(hipGetLastError());
-    }
-    {
-        const int slab = 128;
-        rc = conv0_launch<true>(c, ws + W.xn, Wt + L.conv0, nullptr, ws + W.ab, ws + W.bufP, n, chunk_len, T[0],
-                                slab, (T[0] + slab - 1) / slab, s);
-        if (rc) return rc;
-    }
-    // 3. conv1..6 as GEMMs with fused GELU
-    float* cur = ws + W.bufP;
-    float* nxt = ws + W.bufQ;
-    for (int i = 1; i < 7; ++i) {
-        GemmParams p = gemm_params_plain(cur, Wt + L.conv[i - 1], nxt, T[i], C, KERN[i] * C, (int64_t)STRD[i] * C,
-                                         (int64_t)KERN[i] * C, C);
-        p.nz = n; p.sA1 = (int64_t)T[i - 1] * C; p.sC1 = (int64_t)T[i] * C; p.act = ACT_GELU;
-        rc = launch_gemm_f32(p, s, "w2v2_gemm");
-        if (rc) return rc;
-        std::swap(cur, nxt);
-    }
-    // 4. feature projection: LayerNorm + Linear
-    rc = ln(cur, nullptr, Wt + L.fplg, Wt + L.fplb, ws + W.lnf, rows, C, c.eps, s);
+    rc = gemm6(planes_at(W.lnfp), rows * C, C, 0, planes_at(W.wp_fp), (int)rows, Hd, C, ws + W.x, 0, nullptr, 0, 0,
+               Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm");
     if (rc) return rc;
-    {
-        GemmParams p = gemm_params_plain(ws + W.lnf, Wt + L.fpw, ws + W.x, (int)rows, Hd, C, C, C, Hd);
-        p.bias = Wt + L.fpb;
-        rc = launch_gemm_f32(p, s, "w2v2_gemm");
-        if (rc) return rc;
-    }
     // 5. positional conv embedding (grouped, weight norm folded), GELU, x = LN(x + pos)
     {
         const int cg = Hd / c.PG;
@@ -641,7 +726,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         p.bias = Wt + L.posb; p.sBias2 = cg; p.act = ACT_GELU;
         rc = launch_gemm_f32(p, s, "w2v2_posconv_gemm");
         if (rc) return rc;
-        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s);
+        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp));
         if (rc) return rc;
     }
     // 6. encoder layers (post-LN)
@@ -650,12 +735,10 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     float* x = ws + W.x;
     for (int l = 0; l < c.L; ++l) {
         const LayerOff& lo = L.layers[l];
-        {   // fused q,k,v projection
-            GemmParams p = gemm_params_plain(x, Wt + lo.wqkv, ws + W.qkv, (int)rows, 3 * Hd, Hd, Hd, Hd, 3 * Hd);
-            p.bias = Wt + lo.bqkv;
-            rc = launch_gemm_f32(p, s, "w2v2_gemm");
-            if (rc) return rc;
-        }
+        // fused q,k,v projection (A = the planes the previous LayerNorm wrote beside x)
+        rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_qkv[l]), (int)rows, 3 * Hd, Hd, ws + W.qkv, 0, nullptr, 0, 0,
+                   Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm");
+        if (rc) return rc;
         static const bool fused_attn = [] { const char* e = getenv("RSAF_W2V2_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
         if (fused_attn && hd == 64 && Tt <= 256) {
             // 2 x 2 T^2 hd flops per (chunk, head)
@@ -701,25 +784,24 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         }
         }
         {   // y = attn Wo^T + bo + x ; x = LN(y)
-            GemmParams p = gemm_params_plain(ws + W.att, Wt + lo.wo, ws + W.y, (int)rows, Hd, Hd, Hd, Hd, Hd);
-            p.bias = Wt + lo.bo; p.R = x; p.ldr = Hd;
-            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+            rc = launch_split_bf16x3(ws + W.att, rows * Hd, planes_at(W.attp), rows * Hd, s);
             if (rc) return rc;
-            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s);
+            rc = gemm6(planes_at(W.attp), rows * Hd, Hd, 0, planes_at(W.wp_o[l]), (int)rows, Hd, Hd, ws + W.y, 0, nullptr, 0, 0,
+                       Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm");
+            if (rc) return rc;
+            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp));
             if (rc) return rc;
         }
-        {   // feed forward
-            GemmParams p = gemm_params_plain(x, Wt + lo.w1, ws + W.ffn, (int)rows, c.I, Hd, Hd, Hd, c.I);
-            p.bias = Wt + lo.b1; p.act = ACT_GELU;
-            rc = launch_gemm_f32(p, s, "w2v2_gemm");
+        {   // feed forward: the GELU output only exists as planes (A of the second GEMM)
+            rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_1[l]), (int)rows, c.I, Hd, nullptr, 0,
+                       planes_at(W.ffnp), rows * c.I, 0, Wt + lo.b1, nullptr, 1, ACT_GELU, "w2v2_gemm");
             if (rc) return rc;
-            GemmParams p2 = gemm_params_plain(ws + W.ffn, Wt + lo.w2, ws + W.y, (int)rows, Hd, c.I, c.I, c.I, Hd);
-            p2.bias = Wt + lo.b2; p2.R = x; p2.ldr = Hd;
-            rc = launch_gemm_f32(p2, s, "w2v2_gemm");
+            rc = gemm6(planes_at(W.ffnp), rows * c.I, c.I, 0, planes_at(W.wp_2[l]), (int)rows, Hd, c.I, ws + W.y, 0, nullptr, 0, 0,
+                       Wt + lo.b2, x, 1, ACT_NONE, "w2v2_gemm");
             if (rc) return rc;
             const bool last = (l == c.L - 1);
             rc = ln(ws + W.y, nullptr, Wt + lo.ln2g, Wt + lo.ln2b, last ? out : x, rows, Hd, c.eps, s,
-                    last ? out_row_start : nullptr, Tt);
+                    last ? out_row_start : nullptr, Tt, last ? nullptr : planes_at(W.xp));
             if (rc) return rc;
         }
     }

@@ -2,15 +2,11 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02
-P="python3 bench.py --no-cpu-baseline --no-inclusive"
-rocprofv3 --kernel-trace --stats -d gpurun_out/r02/stats_e2e --output-format csv -- $P > gpurun_out/r02/bench_e2e_under_rocprof.json 2> gpurun_out/r02/stats.err
-echo stats done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/r02/pmc_fetch --output-format csv -- $P > gpurun_out/r02/pmc_fetch.json 2> gpurun_out/r02/pmc_fetch.err
-echo fetch done
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/r02/pmc_write --output-format csv -- $P > gpurun_out/r02/pmc_write.json 2> gpurun_out/r02/pmc_write.err
-echo write done
-python tools/pmc_traffic.py gpurun_out/r02/pmc_fetch gpurun_out/r02/pmc_write gpurun_out/r02/pmc_bench_traffic.json --config e2e --clips 1000 --windows 2048 --command "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- $P" | head -20
-ls gpurun_out/r02/stats_e2e/*/ | head
-# keep only the summaries (the traces are large)
-find gpurun_out/r02/pmc_fetch gpurun_out/r02/pmc_write -name "*counter_collection.csv" -size +20M -delete || true
-find gpurun_out/r02/stats_e2e -name "*kernel_trace.csv" -size +20M -delete || true
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r02/t7.log 2>&1 || { tail -60 gpurun_out/r02/t7.log; exit 1; }
+tail -3 gpurun_out/r02/t7.log
+timeout -k 10 600 python bench.py --no-cpu-baseline > gpurun_out/r02/bench_e2e_split6.json 2> gpurun_out/r02/bench_e2e_split6.err || { tail -30 gpurun_out/r02/bench_e2e_split6.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02/bench_e2e_split6.json').read())
+print(d['value'], d['ms_per_step'], d['roofline']['fp32_equivalent_tflops'], d['roofline']['frac'], d['inclusive_of_pcie_and_decode'])
+PY
