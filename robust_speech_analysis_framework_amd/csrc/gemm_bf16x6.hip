@@ -17,6 +17,8 @@
 // split_bf16x3_kernel).  256 x 256 x 16 block tile, 8 waves of 128 x 64 (4 x 2 MFMA tiles, 48 MFMAs per k-tile and
 // wave), one workgroup per CU.  The tile size is what the data path needs: a 128 x 128 tile wants ~62 B/clk/CU from
 // L2 to keep the six-product pipe busy (the chip's L2 delivers ~34.5 TB/s = 56 B/clk/CU), 256 x 256 wants 16.
+// (Measured and dropped: an L2 prefetch of the lines 8 k-tiles ahead by two extra DMA instructions per k-tile into a scratch
+// patch: 185 -> 151 TFLOP/s-equivalent; the fills are not what the waves wait for, the extra DMA issue slots cost more.)
 // k-tiles travel global -> LDS by DMA (global_load_lds, 16 B per lane, no VGPR staging), three stages of 48 KB, two
 // k-tiles in flight; the two 16-byte chunks of a 32-byte row are swapped on the SOURCE side for rows with
 // (row >> 2) & 1 so that the ds_read_b128 fragment reads are conflict-free.

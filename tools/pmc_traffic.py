@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_sha():
     h = hashlib.sha256()
-    for f in ("gemm_f32.hip", "gemm_f32.h", "w2v2.hip"):
+    for f in ("gemm_bf16x6.hip", "gemm_bf16x6.h", "w2v2.hip"):
         with open(os.path.join(ROOT, "robust_speech_analysis_framework_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -46,7 +46,7 @@ def collect(root, counter):
             k = row["Kernel_Name"]
             g = int(row.get("Grid_Size", 0) or 0)
             key = g
-            if "gemm_f32" in k:
+            if "gemm_bf16x6" in k:
                 key = (g, prev)
                 prev = g
             a = agg[k][key]
@@ -55,30 +55,33 @@ def collect(root, counter):
     return agg
 
 
-def w2v2_shapes(n_windows, chunk_len=80000):
+def w2v2_shapes(n_windows, chunk_len=80000, conv_group=512):
     """Wav2Vec2-base GEMMs of one sub-batch of n equal windows: {grid size (threads): (label, algorithmic bytes per launch)}.
-    128 x 128 tiles, 256 threads per workgroup; the conv GEMMs are batched over the windows (grid.y), the encoder GEMMs
-    run on all rows at once."""
+    gemm_bf16x6: 256 x 256 tiles, 512 threads per workgroup; the conv GEMMs are batched over groups of 512 windows
+    (grid.y), the encoder GEMMs run on all rows at once.  Algorithmic bytes: every operand element once as three bf16
+    planes (6 B), outputs as fp32 (4 B) or planes (6 B), fp32 residual 4 B."""
     T, t = [], chunk_len
     for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
         t = (t - k) // s + 1
         T.append(t)
     C, H, inter = 512, 768, 3072
     out = {}
-    tiles = lambda m, n: ((m + 127) // 128) * ((n + 127) // 128)           # noqa: E731
+    tiles = lambda m, n: ((m + 255) // 256) * ((n + 255) // 256)           # noqa: E731
     conv_grid = {}
+    gw = min(conv_group, n_windows)
     for i in range(1, 7):
         k = 3 if i <= 4 else 2
-        conv_grid[i] = tiles(T[i], C) * n_windows * 256
-        out[conv_grid[i]] = (f"conv{i} [{T[i]} x {k * C}] x [{C}] x {n_windows} windows", 4.0 * n_windows * (T[i - 1] * C + T[i] * C) + 4.0 * C * k * C)
+        conv_grid[i] = tiles(T[i], C) * gw * 512
+        out[conv_grid[i]] = (f"conv{i} [{T[i]} x {k * C}] x [{C}] x {gw} windows",
+                             gw * (6.0 * T[i - 1] * C + (4.0 if i == 6 else 6.0) * T[i] * C) + 6.0 * C * k * C)
     rows = n_windows * T[6]
-    g = {n: tiles(rows, n) * 256 for n in (H, 3 * H, inter)}
-    alg = lambda n, k, resid: 4.0 * (rows * k + n * k + rows * n * (1 + resid))      # noqa: E731
-    out[g[3 * H]] = (f"qkv [{rows} x {H}] x [{3 * H}]", alg(3 * H, H, 0))
-    out[g[inter]] = (f"ffn1 (GELU) [{rows} x {H}] x [{inter}]", alg(inter, H, 0))
-    out[(g[H], g[3 * H])] = (f"attention out-proj (+residual) [{rows} x {H}] x [{H}]", alg(H, H, 1))
-    out[(g[H], g[inter])] = (f"ffn2 (+residual) [{rows} x {inter}] x [{H}]", alg(H, inter, 1))
-    out[(g[H], conv_grid[6])] = (f"feature projection [{rows} x {C}] x [{H}]", alg(H, C, 0))
+    g = {n: tiles(rows, n) * 512 for n in (H, 3 * H, inter)}
+    alg = lambda n, k, out_b, resid: 6.0 * (rows * k + n * k) + rows * n * (out_b + 4.0 * resid)      # noqa: E731
+    out[g[3 * H]] = (f"qkv [{rows} x {H}] x [{3 * H}]", alg(3 * H, H, 4.0, 0))
+    out[g[inter]] = (f"ffn1 (GELU -> planes) [{rows} x {H}] x [{inter}]", alg(inter, H, 6.0, 0))
+    out[(g[H], g[3 * H])] = (f"attention out-proj (+residual) [{rows} x {H}] x [{H}]", alg(H, H, 4.0, 1))
+    out[(g[H], g[inter])] = (f"ffn2 (+residual) [{rows} x {inter}] x [{H}]", alg(H, inter, 4.0, 1))
+    out[(g[H], conv_grid[6])] = (f"feature projection [{rows} x {C}] x [{H}]", alg(H, C, 4.0, 0))
     return out
 
 
@@ -94,7 +97,7 @@ def main():
     ap.add_argument("--command", default="")
     a = ap.parse_args()
     fe, wr = collect(a.fetch_dir, "FETCH_SIZE"), collect(a.write_dir, "WRITE_SIZE")
-    gemm = [k for k in set(fe) | set(wr) if "gemm_f32" in k]
+    gemm = [k for k in set(fe) | set(wr) if "gemm_bf16x6" in k]
     shapes = w2v2_shapes(a.windows)
     per_shape, tot_f, tot_w, tot_l = [], 0.0, 0.0, 0
     grids = sorted({g for k in gemm for g in list(fe.get(k, {})) + list(wr.get(k, {}))}, key=str)
@@ -130,7 +133,7 @@ def main():
                    "kernel_sha": kernel_sha()},
            "gemm_kernels": gemm_names, "gemm_launches": tot_l, "fetch_KB_raw": tot_f, "write_KB": tot_w,
            "traffic_bytes_per_launch_fetch_x2_plus_write": (2.0 * tot_f + tot_w) * 1024.0 / max(tot_l, 1),
-           "note": "all gemm_f32 dispatches of the run share the kernel symbol (Wav2Vec2, CNN-LSTM and tail-window launches); "
+           "note": "all gemm_bf16x6 dispatches of the run (full-window and tail-window sub-batches); "
                    "per_shape separates them by grid size, shapes of the full-window sub-batches are labelled",
            "per_shape": per_shape}
     with open(a.out, "w") as f:
