@@ -2,5 +2,10 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02
-timeout -k 10 600 python -m pytest tests/test_cache_formats_gpu.py -x -q -m gpu > gpurun_out/r02/t8.log 2>&1 || { tail -60 gpurun_out/r02/t8.log; exit 1; }
-tail -3 gpurun_out/r02/t8.log
+timeout -k 10 900 python -m pytest tests/test_gemm_gpu.py tests/test_w2v2_gpu.py -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 600 python bench.py --config C3 --no-cpu-baseline --no-inclusive > gpurun_out/r02/bench_C3_x.json 2> gpurun_out/r02/bench_C3_x.err || { tail -5 gpurun_out/r02/bench_C3_x.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02/bench_C3_x.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline'])
+PY
