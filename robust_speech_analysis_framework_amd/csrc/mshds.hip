@@ -17,6 +17,9 @@
 // where the depth is clipped, on wave-cooperative sinc sums), one wave per frame for intensity, one wave per clip
 // for the path finder and the per-clip statistics, one wave per voiced stretch for the pulse walker.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "rsaf_common.h"
 
@@ -47,6 +50,7 @@ struct PitchParams {
     double refine_margin;   // > 0: only candidates within this margin of the best first-pass strength are refined
     int nsamp_window, half_window, nsamp_period, half_period, min_lag, max_lag, brent_ixmax, max_cand;
     int refine_depth, is_cc;
+    int nfft;               // AC: FFT length, the smallest power of two >= 1.5 nsamp_window (Praat's nsampFFT)
     double voicing_thr2;    // >= 0: also emit the candidate lists for this (lower) voicing threshold into out2
     int debug_stop;         // profiling aid (env RSAF_PITCH_STOP): leave the frame kernel after phase k; 0 = run all
 };
@@ -456,21 +460,21 @@ __device__ void refine_candidates(const RefineArgs& A, int tid, int nthreads) {
     }
 }
 
-// Kernel 1 of 2: one 256-thread workgroup per frame computes the normalised correlation r[0..L] (and the frame's
-// relative intensity) into a global row; kernel 2 (one wave per frame) turns rows into candidates.  The split keeps
-// the four-wave matrix-pipe phase free of the single-wave phases (maxima, candidate lists, Brent refinement),
-// during which three of the four waves used to sit at barriers (PMC: waves parked 49 % of their cycles).
+// Kernel 1 of 2 (cross-correlation method; the autocorrelation method uses pitch_ac_kernel below): one 256-thread
+// workgroup per frame computes the normalised correlation r[0..L] (and the frame's relative intensity) into a global
+// row; kernel 2 (one wave per frame) turns rows into candidates.  The split keeps the four-wave matrix-pipe phase free of
+// the single-wave phases (maxima, candidate lists, Brent refinement), during which three of the four waves used to sit
+// at barriers (PMC: waves parked 49 % of their cycles).
 __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
-                                                         const double* __restrict__ gpeak, const double* __restrict__ win,
-                                                         const double* __restrict__ wr, const PitchParams P,
+                                                         const double* __restrict__ gpeak, const PitchParams P,
                                                          double* __restrict__ rbuf, int rstride, int max_frames) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
     if (f >= c.n_frames) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nw = P.nsamp_window, L = P.is_cc ? P.max_lag : P.brent_ixmax;
-    const int seg_len = P.is_cc ? nw + P.max_lag + 1 : nw;
+    const int nw = P.nsamp_window, L = P.max_lag;
+    const int seg_len = nw + P.max_lag + 1;
     const int part_doubles = pitch_part_doubles(nw, L);
     // all LDS lives in the dynamic region (keeps every double 8-byte aligned, guide G17)
     double* seg = reinterpret_cast<double*>(smem_raw);
@@ -495,23 +499,11 @@ __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict
     }
     __syncthreads();
     const double local_mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (2.0 * P.nsamp_period);
-    int64_t start;
-    int loc_max_lag = P.max_lag;
-    if (!P.is_cc) {
-        start = right - P.half_window;
-        for (int j = tid; j < nw; j += 256) {
-            int64_t i = start + j;
-            i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-            seg[j] = ((double)x[i] - local_mean) * win[j];
-        }
-    } else {
-        start = 0;
-    }
-    __syncthreads();
-    if (P.is_cc) {
+    int loc_max_lag;
+    {
         // Praat: startTime = t - 0.5 * (1 / minimumPitch + dt_window), dt_window = periods / minimumPitch
         const double start_time = t - 0.5 * (1.0 / P.min_pitch + P.dt_window);
-        start = low_index(start_time);
+        int64_t start = low_index(start_time);
         if (start < 0) start = 0;
         int64_t span = P.max_lag + nw;
         if (span > n - start) span = n - start;
@@ -599,10 +591,7 @@ __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict
     if (P.debug_stop == 2) return;
     // ---- normalise into the global row ----
     if (tid == 0) { rb[0] = 1.0; rb[L + 1] = intensity; }
-    if (!P.is_cc) {
-        const double r0 = raw(0);
-        for (int l = 1 + tid; l <= L; l += 256) rb[l] = r0 > 0.0 ? raw(l) / (r0 * wr[l]) : 0.0;
-    } else {
+    {
         const double sumx2 = raw(0);
         // sumy2(lag) = sum_{j=lag}^{lag+nw-1} seg[j]^2 = csq[lag+nw] - csq[lag] with the exclusive prefix sums
         // csq[j] = sum_{i<j} seg[i]^2 (block scan; the O(L*nw) direct loop was a quarter of this kernel)
@@ -629,6 +618,243 @@ __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict
             const double den = sumx2 * sy;
             rb[l] = (l <= loc_max_lag && den > 0.0) ? raw(l) / sqrt(den) : 0.0;
         }
+    }
+}
+
+// ---- AC: windowed autocorrelation by FFT ---------------------------------------------------------------------
+// Praat's Sound_to_Pitch (ac) transforms the windowed frame with an FFT of nsampFFT >= 1.5 nsamp_window points, squares
+// the spectrum and transforms back; so does this kernel, in fp64: about 2.5 N log2 N flops per transform against
+// 2 nw L for the direct sum (nine times fewer at nw = 960, L = 512).  The real transform of N points is a complex
+// transform of M = N / 2 points on z[j] = x[2 j] + i x[2 j + 1] (the zero-padded frame, as it lies in LDS, IS z), a
+// pass that separates X[k], squares it and packs the even spectrum P back into M complex points, and a second complex
+// transform whose output is r[2 j] + i r[2 j + 1].  The complex transform is a Stockham autosort FFT (radix 4, a final
+// radix 2 when M is not a power of 4): natural order in and out, ping-pong between two LDS buffers, 256 threads.
+// Twiddles W_N^k = exp(-2 pi i k / N), k < N / 2, come from a table built on the host in double precision.
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double2_t cmul(double2_t a, double2_t b) {
+    return double2_t{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+__device__ __forceinline__ double2_t tw_at(const double2_t* __restrict__ tw, int t, int M) {   // W_N^t, 0 <= t < N
+    const bool neg = t >= M;
+    const double2_t w = tw[neg ? t - M : t];
+    return neg ? double2_t{-w.x, -w.y} : w;
+}
+
+// The transform length is a template parameter: the stages unroll, and for M <= 1024 every twiddle a thread needs
+// (a function of the stage and the thread only) is fetched ONCE, in front of the frame's first pass over the samples, and
+// kept in registers; the table loads (L2 latency) no longer sit between the barriers of every stage.
+template <int LOG2M>
+struct FftPlan {
+    static constexpr int M = 1 << LOG2M, N = 2 * M;
+    static constexpr int N4 = LOG2M / 2;                    // radix-4 stages
+    static constexpr bool HAS2 = (LOG2M & 1) != 0;          // one radix-2 stage behind them
+    static constexpr int T4 = M / 4, T2 = M / 2;
+    static constexpr int BPT4 = T4 > 256 ? T4 / 256 : 1, BPT2 = T2 > 256 ? T2 / 256 : 1;
+    static constexpr bool PRE = LOG2M <= 10;                // twiddles in registers
+    static constexpr int NTW4 = PRE && N4 > 1 ? (N4 - 1) * BPT4 * 3 : 1, NTW2 = PRE && HAS2 ? BPT2 : 1;
+};
+
+template <int LOG2M>
+struct FftTw {
+    double2_t w4[FftPlan<LOG2M>::NTW4];
+    double2_t w2[FftPlan<LOG2M>::NTW2];
+};
+
+template <int LOG2M>
+__device__ __forceinline__ void fft_load_twiddles(FftTw<LOG2M>& R, const double2_t* __restrict__ tw, int tid) {
+    using PL = FftPlan<LOG2M>;
+    if (!PL::PRE) return;
+#pragma unroll
+    for (int st = 1; st < PL::N4; ++st) {
+        const int Ns = 1 << (2 * st), step = PL::N / (Ns * 4);
+#pragma unroll
+        for (int bq = 0; bq < PL::BPT4; ++bq) {
+            const int j = tid + 256 * bq, t1 = (j & (Ns - 1)) * step;
+#pragma unroll
+            for (int r = 1; r <= 3; ++r) R.w4[((st - 1) * PL::BPT4 + bq) * 3 + r - 1] = tw_at(tw, (r * t1) & (PL::N - 1), PL::M);
+        }
+    }
+    if (PL::HAS2) {
+        const int Ns = 1 << (2 * PL::N4), step = PL::N / (Ns * 2);
+#pragma unroll
+        for (int bq = 0; bq < PL::BPT2; ++bq) R.w2[bq] = tw_at(tw, ((tid + 256 * bq) & (Ns - 1)) * step, PL::M);
+    }
+}
+
+// forward complex FFT of M points from `a` (result in the returned buffer, `a` or `b`); every stage ends at a barrier
+template <int LOG2M>
+__device__ __forceinline__ double2_t* fft_stockham(double2_t* a, double2_t* b, const FftTw<LOG2M>& R,
+                                                   const double2_t* __restrict__ tw, int tid) {
+    using PL = FftPlan<LOG2M>;
+    constexpr int M = PL::M, N = PL::N, T4 = PL::T4, T2 = PL::T2;
+    double2_t* src = a;
+    double2_t* dst = b;
+#pragma unroll
+    for (int st = 0; st < PL::N4; ++st) {
+        const int Ns = 1 << (2 * st), step = N / (Ns * 4);
+#pragma unroll
+        for (int bq = 0; bq < PL::BPT4; ++bq) {
+            const int j = tid + 256 * bq;
+            if (T4 >= 256 || j < T4) {
+                const int k = j & (Ns - 1);
+                double2_t v0 = src[j], v1 = src[j + T4], v2 = src[j + 2 * T4], v3 = src[j + 3 * T4];
+                if (st > 0) {
+                    if (PL::PRE) {
+                        const int o = ((st - 1) * PL::BPT4 + bq) * 3;
+                        v1 = cmul(v1, R.w4[o]);
+                        v2 = cmul(v2, R.w4[o + 1]);
+                        v3 = cmul(v3, R.w4[o + 2]);
+                    } else {
+                        const int t1 = k * step;
+                        v1 = cmul(v1, tw_at(tw, t1, M));
+                        v2 = cmul(v2, tw_at(tw, 2 * t1, M));
+                        v3 = cmul(v3, tw_at(tw, 3 * t1, M));
+                    }
+                }
+                const double2_t a0 = v0 + v2, a1 = v0 - v2, a2 = v1 + v3;
+                const double2_t d = v1 - v3;
+                const double2_t a3 = double2_t{d.y, -d.x};             // (v1 - v3) * (-i)
+                const int j0 = ((j - k) << 2) + k;
+                dst[j0] = a0 + a2;
+                dst[j0 + Ns] = a1 + a3;
+                dst[j0 + 2 * Ns] = a0 - a2;
+                dst[j0 + 3 * Ns] = a1 - a3;
+            }
+        }
+        __syncthreads();
+        double2_t* t_ = src; src = dst; dst = t_;
+    }
+    if (PL::HAS2) {                                                     // one radix-2 stage left (M = 2 * 4^a)
+        const int Ns = 1 << (2 * PL::N4), step = N / (Ns * 2);
+#pragma unroll
+        for (int bq = 0; bq < PL::BPT2; ++bq) {
+            const int j = tid + 256 * bq;
+            if (T2 >= 256 || j < T2) {
+                const int k = j & (Ns - 1);
+                const double2_t v0 = src[j];
+                const double2_t v1 = cmul(src[j + T2], PL::PRE ? R.w2[bq] : tw_at(tw, k * step, M));
+                const int j0 = ((j - k) << 1) + k;
+                dst[j0] = v0 + v1;
+                dst[j0 + Ns] = v0 - v1;
+            }
+        }
+        __syncthreads();
+        double2_t* t_ = src; src = dst; dst = t_;
+    }
+    return src;
+}
+
+constexpr int AC_FRAMES_PER_WG = 8;
+
+template <int LOG2M>
+__global__ __launch_bounds__(256) void pitch_ac_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                       const double* __restrict__ gpeak, const double* __restrict__ win,
+                                                       const double* __restrict__ wr, const PitchParams P,
+                                                       const double2_t* __restrict__ tw, double* __restrict__ rbuf,
+                                                       int rstride, int max_frames) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const ClipInfo c = ci[blockIdx.y];
+    if ((int)blockIdx.x * AC_FRAMES_PER_WG >= c.n_frames) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int N = FftPlan<LOG2M>::N, M = FftPlan<LOG2M>::M;
+    const int nw = P.nsamp_window, L = P.brent_ixmax;
+    FftTw<LOG2M> twr;
+    fft_load_twiddles<LOG2M>(twr, tw, tid);                // in flight during the passes over the samples
+    constexpr int NPK = (M / 2) / 256 + 1;                  // spectrum pass: k = tid + 256 i <= M / 2
+    double2_t twp[NPK];
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) twp[i] = tw[tid + 256 * i <= M / 2 ? tid + 256 * i : 0];
+    double* seg = reinterpret_cast<double*>(smem_raw);      // [N]: the windowed frame, zero-padded = M complex points
+    double* buf = seg + N;                                  // [N]
+    double* s_red = buf + N;                                // [4]
+    double* s_val = s_red + 4;                              // [4]
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples;
+    const double gp = gpeak[blockIdx.y];
+    // a workgroup takes AC_FRAMES_PER_WG consecutive frames: the twiddles (72 KB of table reads per workgroup at M = 1024)
+    // are fetched once for all of them
+    for (int f = blockIdx.x * AC_FRAMES_PER_WG; f < (int)(blockIdx.x + 1) * AC_FRAMES_PER_WG && f < c.n_frames; ++f) {
+    double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
+    const double t = c.t1 + f * P.dt;
+    const int64_t left = low_index(t), right = left + 1;
+    // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat)
+    {
+        int64_t s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
+        s0 = s0 < 0 ? 0 : (s0 > n - 1 ? n - 1 : s0);
+        s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
+        double s = 0.0;
+        for (int64_t i = s0 + tid; i <= s1; i += 256) s += (double)x[i];
+        s = wave_sum_f64(s);
+        if (lane == 0) s_red[wv] = s;
+    }
+    __syncthreads();
+    const double local_mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (2.0 * P.nsamp_period);
+    const int64_t start = right - P.half_window;
+    for (int j = tid; j < N; j += 256) {
+        int64_t i = start + j;
+        i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+        seg[j] = j < nw ? ((double)x[i] - local_mean) * win[j] : 0.0;
+    }
+    __syncthreads();
+    // local peak over half a longest period around the window centre
+    {
+        int a = P.half_window - P.half_period, b = P.half_window + P.half_period;
+        a = a < 0 ? 0 : a;
+        b = b > nw ? nw : b;
+        double m = 0.0;
+        for (int j = a + tid; j < b; j += 256) m = fmax(m, fabs(seg[j]));
+        m = wave_max_f64(m);
+        if (lane == 0) s_val[wv] = m;
+    }
+    __syncthreads();
+    const double local_peak = fmax(fmax(s_val[0], s_val[1]), fmax(s_val[2], s_val[3]));
+    const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
+    if (P.debug_stop == 1) { __syncthreads(); continue; }
+
+    double2_t* za = reinterpret_cast<double2_t*>(seg);
+    double2_t* zb = reinterpret_cast<double2_t*>(buf);
+    double2_t* Z = fft_stockham<LOG2M>(za, zb, twr, tw, tid);
+    double2_t* Y = Z == za ? zb : za;
+    // X[k] = E + W^k O, X[M - k] = conj(E - W^k O) with E = (Z[k] + conj Z[M-k]) / 2, O = (Z[k] - conj Z[M-k]) / 2i;
+    // P = |X|^2 is real and even, and the M-point input of the transform back is
+    // Y[k] = (P[k] + P[M-k]) + i conj(W^k) (P[k] - P[M-k]); it is stored conjugated (inverse by the forward transform)
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+        const int k = tid + 256 * i;
+        if (k > M / 2) continue;
+        if (k == 0) {
+            const double2_t z0 = Z[0];
+            const double p0 = (z0.x + z0.y) * (z0.x + z0.y), pm = (z0.x - z0.y) * (z0.x - z0.y);
+            Y[0] = double2_t{p0 + pm, -(p0 - pm)};
+        } else if (k == M / 2) {
+            const double2_t zk = Z[k];
+            Y[k] = double2_t{2.0 * (zk.x * zk.x + zk.y * zk.y), 0.0};
+        } else {
+            const double2_t zk = Z[k], zm = Z[M - k];
+            const double2_t E = double2_t{0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y)};
+            const double2_t D = double2_t{0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y)};
+            const double2_t O = double2_t{D.y, -D.x};
+            const double2_t w = twp[i];
+            const double2_t T = cmul(w, O);
+            const double2_t xa = E + T, xb = E - T;
+            const double pk = xa.x * xa.x + xa.y * xa.y, pm = xb.x * xb.x + xb.y * xb.y;
+            const double sum = pk + pm, d = pk - pm;
+            Y[k] = double2_t{sum + w.y * d, -(w.x * d)};
+            Y[M - k] = double2_t{sum - w.y * d, -(w.x * d)};
+        }
+    }
+    __syncthreads();
+    const double* r = reinterpret_cast<const double*>(fft_stockham<LOG2M>(Y, Y == za ? zb : za, twr, tw, tid));
+    if (P.debug_stop == 2) continue;
+    // r[2 j] = Re, r[2 j + 1] = -Im of the (conjugated) output; normalise into the global row
+    if (tid == 0) { rb[0] = 1.0; rb[L + 1] = intensity; }
+    const double r0 = r[0];
+    for (int l = 1 + tid; l <= L; l += 256) {
+        const double v = (l & 1) ? -r[l] : r[l];
+        rb[l] = r0 > 0.0 ? v / (r0 * wr[l]) : 0.0;
+    }
+    __syncthreads();                                        // the next frame overwrites both buffers
     }
 }
 
@@ -769,23 +995,23 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     // get a whole wave each, a full list gets 16 lanes each, so one or two rounds cover every frame.
     auto refine_list = [&](int nc, const int* place_lag, double* cf, double* cs) {
         if (cheb != nullptr) {
-            // Chebyshev coefficients of both cells of every candidate.  Wave w takes candidates w, w+4, ... (<= 4);
-            // lane = (tap residue mod 4, coefficient j): one table load feeds the wave's 8 accumulators, the four
-            // tap residues are folded with two cross-lane adds, and no partial sums cross waves.
+            // Chebyshev coefficients of both cells of every candidate, four candidates per round (candidates 1..4, 5..8, ...:
+            // the usual AC frame has at most four and is done in one round); lane = (tap residue mod 4, coefficient j):
+            // one table load feeds the round's 8 accumulators, the four tap residues are folded with two cross-lane adds.
             double* s_P = s_part;                                    // [MAXC][2][NCH], the partial sums are dead by now
             const int d = P.refine_depth;
             const int chunk = lane >> 4, j = lane & 15;
-            for (int wq = 0; wq < 4; ++wq) {                         // the single wave takes the four candidate slots in turn
+            for (int wq = 0; wq < 4; ++wq) {                         // rounds of four candidates
             int bq[4];
             int bmin = 0x7fffffff, bmax = -0x7fffffff;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int k = 1 + wq + 4 * q;
+                const int k = 1 + 4 * wq + q;
                 const bool on = k < nc;
                 bq[q] = place_lag[on ? k : 1] + RC - 1;              // 0-based left sample of cell 0 (cell 1: + 1)
                 if (on) { bmin = bq[q] < bmin ? bq[q] : bmin; bmax = bq[q] > bmax ? bq[q] : bmax; }
             }
-            if (1 + wq < nc) {
+            if (1 + 4 * wq < nc) {
                 // r is zero outside [nz_lo, nz_hi]: taps that reach no candidate's non-zero range are skipped
                 int o_lo = nz_lo - (bmax + 1), o_hi = nz_hi - bmin;
                 o_lo = o_lo < -(d - 1) ? -(d - 1) : o_lo;
@@ -821,7 +1047,7 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
                         double v = acc[q][cell];
                         v += __shfl_xor(v, 16, 64);
                         v += __shfl_xor(v, 32, 64);
-                        const int k = 1 + wq + 4 * q;
+                        const int k = 1 + 4 * wq + q;
                         if (chunk == 0 && k < nc) s_P[(k * 2 + cell) * NCH + j] = v;
                     }
             }
@@ -2223,6 +2449,32 @@ int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, i
     return RSAF_OK;
 }
 
+// W_N^k = exp(-2 pi i k / N), k < N / 2, in double precision (host libm), one table per (device, N), kept for the
+// life of the process (pitch_ac_kernel)
+static int fft_twiddles(int N, const double** out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, double*> cache;
+    int dev = 0;
+    RSAF_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({dev, N});
+    if (it == cache.end()) {
+        std::vector<double> h((size_t)N);                          // N / 2 complex numbers
+        for (int k = 0; k < N / 2; ++k) {
+            const double a = 2.0 * M_PI * (double)k / (double)N;
+            h[2 * k] = cos(a);
+            h[2 * k + 1] = -sin(a);
+        }
+        if (N >= 4) { h[2 * (N / 4)] = 0.0; h[2 * (N / 4) + 1] = -1.0; }      // exactly -i
+        double* d = nullptr;
+        RSAF_CHECK_HIP(hipMalloc(&d, (size_t)N * sizeof(double)));
+        RSAF_CHECK_HIP(hipMemcpy(d, h.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+        it = cache.emplace(std::make_pair(dev, N), d).first;
+    }
+    *out = it->second;
+    return RSAF_OK;
+}
+
 // second_*: optional outputs of the same analysis with another voicing threshold (h2_voicing_thr >= 0): the frame
 // kernel shares the correlation and the refinement, the path finder runs once per threshold
 static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
@@ -2254,13 +2506,19 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     RSAF_CHECK_ARG(P.nsamp_window >= 4 && P.brent_ixmax >= 2 && P.max_lag >= 2, "window too short");
     RSAF_CHECK_ARG(P.is_cc || (window && window_r), "AC needs the window tables");
     RSAF_CHECK_ARG((P.is_cc ? P.max_lag : P.brent_ixmax) <= 1023, "more than 1023 lags (pitch floor below ~16 Hz) is not supported");
+    P.nfft = 1;                                                    // Praat: while (nsampFFT < nsamp_window * (1 + 0.5)) nsampFFT *= 2
+    while ((double)P.nfft < (double)P.nsamp_window * 1.5) P.nfft *= 2;
+    if (P.nfft < 16) P.nfft = 16;
+    RSAF_CHECK_ARG(P.is_cc || P.nsamp_window + P.brent_ixmax <= P.nfft, "brent_ixmax must not exceed half the analysis window");
     const int seg_len = P.is_cc ? P.nsamp_window + P.max_lag + 1 : P.nsamp_window;
     const int Lr = P.is_cc ? P.max_lag : P.brent_ixmax;
     const int rstride = Lr + 2;                                    // r[0..L] + the frame's relative intensity
-    RSAF_CHECK_ARG(P.nsamp_window / 16 + 50 <= XR_ROW, "analysis window longer than 1 760 samples (pitch floor below ~28 Hz) is not supported");
-    const size_t lds_corr = (size_t)(((seg_len + SEG_PAD + 1) & ~1) + 8) * sizeof(double) +
-                            (size_t)pitch_part_doubles(P.nsamp_window, Lr) * sizeof(double) +
-                            (P.is_cc ? (size_t)(seg_len + 2) * sizeof(double) : 0);
+    RSAF_CHECK_ARG(!P.is_cc || P.nsamp_window / 16 + 50 <= XR_ROW, "cross-correlation window longer than 1 760 samples is not supported");
+    RSAF_CHECK_ARG(P.is_cc || P.nfft <= 8192, "autocorrelation window longer than 5 461 samples is not supported");
+    const size_t lds_corr = P.is_cc ? (size_t)(((seg_len + SEG_PAD + 1) & ~1) + 8) * sizeof(double) +
+                                          (size_t)pitch_part_doubles(P.nsamp_window, Lr) * sizeof(double) +
+                                          (size_t)(seg_len + 2) * sizeof(double)
+                                    : (size_t)(2 * P.nfft + 8) * sizeof(double);
     int r_lo_h, r_hi_h;
     pitch_r_range(P.brent_ixmax, Lr, P.min_lag, P.max_lag, P.refine_depth, &r_lo_h, &r_hi_h);
     const size_t lds_cand = (size_t)(((r_hi_h - r_lo_h + 2) & ~1) + 3 * MAX_MAXIMA + 6 * MAXC + MAXC * 2 * NCH) * sizeof(double) +
@@ -2272,9 +2530,18 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                    "workspace too small (rsaf_mshds_pitch_workspace_bytes)");
     const int group = max_frames == 0 ? n_clips : (int)std::min<int64_t>(n_clips, workspace_bytes / std::max<int64_t>(row_bytes_per_clip, 1));
     hipStream_t s = (hipStream_t)stream;
-    if (lds_corr > 48 * 1024)
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_corr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_corr));
+    int log2m = 0;
+    while ((2 << log2m) < P.nfft) ++log2m;                           // nfft = 2 M = 2^(log2m + 1)
+    if (lds_corr > 48 * 1024) {
+        const void* fn = (const void*)pitch_corr_kernel;
+        if (!P.is_cc) fn = log2m == 11 ? (const void*)pitch_ac_kernel<11> : (const void*)pitch_ac_kernel<12>;   // 64 / 128 KB
+        RSAF_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_corr));
+    }
+    const double* twiddles = nullptr;
+    if (!P.is_cc) {
+        const int rc = fft_twiddles(P.nfft, &twiddles);
+        if (rc != RSAF_OK) return rc;
+    }
     if (lds_cand > 48 * 1024)
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_cand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_cand));
@@ -2291,7 +2558,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         // matrix-pipe work of the correlation phase (v_mfma_f64_16x16x4: 1 024 MAC each), counted for equal-length
         // clips (an upper bound for ragged batches); the refinement's VALU work is not counted
         double mfma_per_frame = 0.0;
-        {
+        if (P.is_cc) {
             const int Lc = P.is_cc ? P.max_lag : P.brent_ixmax, NTc = (Lc + 256) / 256;
             for (int tile = 0; tile < NTc; ++tile) {
                 int j_hi = P.nsamp_window + 240 + 256 * tile;
@@ -2300,13 +2567,32 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                 if (j_hi > j_lo) mfma_per_frame += (double)((j_hi - j_lo + 3) / 4);
             }
         }
+        // AC: two complex FFTs of M = nfft / 2 points (5 M log2 M flops each) and the spectrum pass (~30 flops per point)
+        const double Mfft = 0.5 * (double)P.nfft;
+        const double ac_flops = 2.0 * 5.0 * Mfft * log2(Mfft) + 30.0 * Mfft;
         ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s,
-                       2048.0 * mfma_per_frame * (double)max_frames * (double)n_clips, 0.0);
+                       (P.is_cc ? 2048.0 * mfma_per_frame : ac_flops) * (double)max_frames * (double)n_clips, 0.0);
         for (int c0 = 0; c0 < n_clips; c0 += group) {
             const int nc = std::min(group, n_clips - c0);
             const ClipInfo* cig = (const ClipInfo*)clip_info + c0;
-            hipLaunchKernelGGL(pitch_corr_kernel, dim3(max_frames, nc), dim3(256), lds_corr, s, wav, cig, gpeak + c0, window,
-                               window_r, P, (double*)workspace, rstride, max_frames);
+            if (P.is_cc)
+                hipLaunchKernelGGL(pitch_corr_kernel, dim3(max_frames, nc), dim3(256), lds_corr, s, wav, cig, gpeak + c0, P,
+                                   (double*)workspace, rstride, max_frames);
+            else {
+#define RSAF_AC_CASE(LG)                                                                                              \
+    case LG:                                                                                                          \
+        hipLaunchKernelGGL(pitch_ac_kernel<LG>, dim3((max_frames + AC_FRAMES_PER_WG - 1) / AC_FRAMES_PER_WG, nc),      \
+                           dim3(256), lds_corr, s, wav, cig, gpeak + c0,                                              \
+                           window, window_r, P, reinterpret_cast<const double2_t*>(twiddles), (double*)workspace,     \
+                           rstride, max_frames);                                                                      \
+        break;
+                switch (log2m) {
+                    RSAF_AC_CASE(3) RSAF_AC_CASE(4) RSAF_AC_CASE(5) RSAF_AC_CASE(6) RSAF_AC_CASE(7) RSAF_AC_CASE(8)
+                    RSAF_AC_CASE(9) RSAF_AC_CASE(10) RSAF_AC_CASE(11) RSAF_AC_CASE(12)
+                    default: set_error("rsaf_mshds_pitch: unsupported FFT length"); return RSAF_ERR_ARG;
+                }
+#undef RSAF_AC_CASE
+            }
             RSAF_CHECK_HIP(hipGetLastError());
             hipLaunchKernelGGL(pitch_cand_kernel, dim3(max_frames, nc), dim3(CT), lds_cand, s, cig, gpeak + c0, P,
                                (const double*)workspace, rstride, max_frames, (FrameOut*)frame_out,
