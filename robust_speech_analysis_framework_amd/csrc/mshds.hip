@@ -995,64 +995,66 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     // get a whole wave each, a full list gets 16 lanes each, so one or two rounds cover every frame.
     auto refine_list = [&](int nc, const int* place_lag, double* cf, double* cs) {
         if (cheb != nullptr) {
-            // Chebyshev coefficients of both cells of every candidate, four candidates per round (candidates 1..4, 5..8, ...:
-            // the usual AC frame has at most four and is done in one round); lane = (tap residue mod 4, coefficient j):
-            // one table load feeds the round's 8 accumulators, the four tap residues are folded with two cross-lane adds.
+            // Chebyshev coefficients of both cells of every candidate on the fp64 matrix pipe:
+            //   P[j][(k, cell)] = sum_o cheb[o][j] * r[b_k + cell + o]      (16 coefficients x up to 30 columns x 2 d taps)
+            // as v_mfma_f64_16x16x4: A[m = j][kk] = cheb[o + kk][j] (a lane's table load is the A operand as it is),
+            // B[kk][n] = r[base_n + o + kk] with a per-lane base (column n = 2 (k - 1) + cell), one or two column tiles.
+            // The vector-ALU form of this sum (8 FMAs and 8 LDS reads per table element and round of four candidates)
+            // was 35-70 % of the harmonicity pass' frame time.
             double* s_P = s_part;                                    // [MAXC][2][NCH], the partial sums are dead by now
             const int d = P.refine_depth;
-            const int chunk = lane >> 4, j = lane & 15;
-            for (int wq = 0; wq < 4; ++wq) {                         // rounds of four candidates
-            int bq[4];
-            int bmin = 0x7fffffff, bmax = -0x7fffffff;
+            const int kq = lane >> 4, nn = lane & 15;
+            const int ncol = 2 * (nc - 1), tiles = (ncol + 15) >> 4;
+            if (nc > 1) {
+                int bmin = 0x7fffffff, bmax = -0x7fffffff;
+                for (int k = 1; k < nc; ++k) {                       // uniform: every lane scans the (<= 15) candidates
+                    const int bb = place_lag[k] + RC - 1;
+                    bmin = bb < bmin ? bb : bmin;
+                    bmax = bb > bmax ? bb : bmax;
+                }
+                int rbase[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = 1 + 4 * wq + q;
-                const bool on = k < nc;
-                bq[q] = place_lag[on ? k : 1] + RC - 1;              // 0-based left sample of cell 0 (cell 1: + 1)
-                if (on) { bmin = bq[q] < bmin ? bq[q] : bmin; bmax = bq[q] > bmax ? bq[q] : bmax; }
-            }
-            if (1 + 4 * wq < nc) {
+                for (int T = 0; T < 2; ++T) {
+                    const int n = 16 * T + nn, k = 1 + (n >> 1);
+                    rbase[T] = place_lag[k < nc ? k : 1] + RC - 1 + (n & 1);   // 0-based left sample of the cell
+                }
                 // r is zero outside [nz_lo, nz_hi]: taps that reach no candidate's non-zero range are skipped
                 int o_lo = nz_lo - (bmax + 1), o_hi = nz_hi - bmin;
                 o_lo = o_lo < -(d - 1) ? -(d - 1) : o_lo;
                 o_hi = o_hi > d ? d : o_hi;
-                double acc[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+                double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+                const double* ctab = cheb + (int64_t)(d - 1) * NCH + nn;
                 // eight table loads (L2-resident, ~500 cycles each) are issued together before they are consumed
-                const double* ctab = cheb + (int64_t)(d - 1) * NCH + j;
-                int o = o_lo + chunk;
-                for (; o + 28 <= o_hi; o += 32) {
+                int o = o_lo;
+                for (; o + 31 <= o_hi; o += 32) {
                     double cw[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) cw[u] = ctab[(int64_t)(o + 4 * u) * NCH];
+                    for (int u = 0; u < 8; ++u) cw[u] = ctab[(int64_t)(o + 4 * u + kq) * NCH];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc[q][0] += cw[u] * r[bq[q] + o + 4 * u];
-                            acc[q][1] += cw[u] * r[bq[q] + 1 + o + 4 * u];
-                        }
+                    for (int u = 0; u < 8; ++u) {
+                        const int oo = o + 4 * u + kq;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw[u], r[rbase[0] + oo], acc0, 0, 0, 0);
+                        if (tiles > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw[u], r[rbase[1] + oo], acc1, 0, 0, 0);
+                    }
                 }
                 for (; o <= o_hi; o += 4) {
-                    const double cw = ctab[(int64_t)o * NCH];
+                    const int oo = o + kq, oc = oo <= o_hi ? oo : o_hi;          // taps past o_hi contribute zero
+                    const double cw = oo <= o_hi ? ctab[(int64_t)oc * NCH] : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw, r[rbase[0] + oc], acc0, 0, 0, 0);
+                    if (tiles > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw, r[rbase[1] + oc], acc1, 0, 0, 0);
+                }
+                // D layout: lane (kq, nn), register v -> row j = kq + 4 v, column nn
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[q][0] += cw * r[bq[q] + o];
-                        acc[q][1] += cw * r[bq[q] + 1 + o];
+                for (int T = 0; T < 2; ++T) {
+                    const int n = 16 * T + nn, k = 1 + (n >> 1);
+                    if (T < tiles && k < nc) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) s_P[(k * 2 + (n & 1)) * NCH + kq + 4 * v] = T == 0 ? acc0[v] : acc1[v];
                     }
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int cell = 0; cell < 2; ++cell) {
-                        double v = acc[q][cell];
-                        v += __shfl_xor(v, 16, 64);
-                        v += __shfl_xor(v, 32, 64);
-                        const int k = 1 + 4 * wq + q;
-                        if (chunk == 0 && k < nc) s_P[(k * 2 + cell) * NCH + j] = v;
-                    }
-            }
             }
             __syncthreads();
+            if (P.debug_stop == 6) return;
             if (tid < 64) {                                          // nc <= 16: one lane per candidate
                 const int k = 1 + tid;
                 const bool live = k < nc;

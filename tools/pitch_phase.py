@@ -3,7 +3,8 @@
 Runs rsaf_mshds_pitch with env RSAF_PITCH_STOP=k (leave the frame kernel after phase k) for the four
 parameter sets the extractor uses and prints the frame-kernel event time per (config, k).
   1 = segment load + local mean/peak   2 = + correlation   3 = + normalise + maxima
-  4 = + first estimates (sinc 30)      5 = + candidate list   0 = everything (+ Brent refinement)
+  4 = + first estimates (sinc 30)      5 = + candidate list   6 = + Chebyshev coefficients of the candidates' cells
+  0 = everything (+ Brent refinement)
 """
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,7 +39,7 @@ cfgs = {
 }
 res = {}
 for name, kw in cfgs.items():
-    for stop in (1, 2, 3, 4, 5, 0):
+    for stop in (1, 2, 3, 4, 5, 6, 0):
         os.environ["RSAF_PITCH_STOP"] = str(stop)
         eng.pitch(flat, offs, lens, gpeak, **kw)           # warm
         torch.cuda.synchronize()
