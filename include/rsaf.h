@@ -126,6 +126,20 @@ int rsaf_gemm_bf16x6(const uint16_t* A_planes, int64_t a_plane_stride, const uin
                      int64_t b_plane_stride, float* C, uint16_t* C_planes, int64_t c_plane_stride,
                      const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
                      int64_t ldc, int64_t ldr, int act, float alpha, rsaf_stream_t stream);
+/* The same two calls with operands in the k16-panel layout: a plane of R rows holds element (r, k) at
+ * (k / 16) * (R * 16) + r * 16 + k % 16 (K / 16 panels of [R][16]), so that the 32 rows x 32 bytes one LDS-DMA instruction
+ * moves are 1 KiB contiguous.  rsaf_split_bf16x3_panels: row-major fp32 src[rows][K] -> panel planes.
+ * rsaf_gemm_bf16x6_panels: a_panels / b_panels / c_panels choose the layout per operand (R = M, N, M; a row-major operand
+ * uses its lda / ldb / ldc as in rsaf_gemm_bf16x6; c_panels applies to C_planes, laid out as the A of a GEMM with K = N).
+ * Results are bit-identical to the row-major call.                                                                      */
+int rsaf_split_bf16x3_panels(const float* src, int64_t rows, int K, uint16_t* planes, int64_t plane_stride,
+                             rsaf_stream_t stream);
+int rsaf_gemm_bf16x6_panels(const uint16_t* A_planes, int64_t a_plane_stride, const uint16_t* B_planes,
+                            int64_t b_plane_stride, float* C, uint16_t* C_planes, int64_t c_plane_stride,
+                            const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
+                            int64_t ldc, int64_t ldr, int act, float alpha, int a_panels, int b_panels, int c_panels,
+                            rsaf_stream_t stream);
+
 
 /* ---- CNN-LSTM-with-attention classifier forward ----------------------------------------------------
  * Replaces CNNLSTM.forward (src/models.py:161-193) in eval mode: x[B,T,input_dim] float32 ->

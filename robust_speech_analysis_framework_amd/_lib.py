@@ -44,6 +44,8 @@ SIGNATURES = {
                            C.POINTER(_L), _I, _I, _F, _I, _P]),
     "rsaf_split_bf16x3": (_I, [_P, _L, _P, _L, _P]),
     "rsaf_gemm_bf16x6": (_I, [_P, _L, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _F, _P]),
+    "rsaf_split_bf16x3_panels": (_I, [_P, _L, _I, _P, _L, _P]),
+    "rsaf_gemm_bf16x6_panels": (_I, [_P, _L, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _F, _I, _I, _I, _P]),
     "rsaf_cnnlstm_weight_floats": (_L, [_I, _I, _I, _I, _I]),
     "rsaf_cnnlstm_weight_offsets": (_I, [_I, _I, _I, _I, _I, C.POINTER(_L), _I, C.POINTER(_I)]),
     "rsaf_cnnlstm_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I]),

@@ -21,10 +21,17 @@ struct Gemm6Params {
     int act;
     float alpha;
     int group_m;             // row-tiles per L2 group of the tile order (0 = default)
+    // k16-panel layout of a plane of R rows: element (r, k) at (k / 16) * (R * 16) + r * 16 + k % 16, i.e. K / 16 panels of
+    // [R][16]: the 32 rows x 32 bytes one DMA instruction moves are 1 KiB contiguous (8 full 128-byte lines instead of
+    // a quarter of 32 lines).  a_panel: A (R = M; lda, sA unused, nz = 1); b_panel: B (R = N; ldb unused);
+    // cp_panel: the plane output, laid out as the A operand of the next GEMM (R = M, its K = N; ldcp unused).
+    int a_panel, b_panel, cp_panel;
 };
 
 int launch_gemm_bf16x6(const Gemm6Params& p, hipStream_t stream, const char* tag);
 // src[n] fp32 -> planes[0..2][n] (planes plane_stride elements apart)
 int launch_split_bf16x3(const float* src, int64_t n, uint16_t* planes, int64_t plane_stride, hipStream_t stream);
+// src[rows][K] fp32 (row-major) -> three planes in the k16-panel layout of `rows` rows (K % 16 == 0)
+int launch_split_bf16x3_panels(const float* src, int64_t rows, int K, uint16_t* planes, int64_t plane_stride, hipStream_t stream);
 
 }  // namespace rsaf

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     constexpr int IPW = (NI + NW - 1) / NW;                               // instructions (x 3 planes) per wave and k-tile
     const unsigned short* sbase[IPW];                                    // wave-uniform: operand + tile origin (SGPR pair)
     unsigned voff[IPW];                                                   // per lane: ((row in tile) * ld + chunk) * 2 bytes
-    int64_t pstride[IPW];
+    int64_t pstride[IPW], kstride[IPW];
     int ldsoff[IPW];
     bool live[IPW];
 #pragma unroll
@@ -150,15 +150,19 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         const int dch = (lane & 1) ^ ((row >> 3) & 1);
         if (isA) {
             const int rr = (m0 + row < p.M) ? row : p.M - 1 - m0;         // rows past M re-read the last row
-            sbase[i] = p.A + z * p.sA + (int64_t)m0 * p.lda;
-            voff[i] = 2u * ((unsigned)rr * (unsigned)p.lda + 8u * dch);
+            const int64_t rs = p.a_panel ? 16 : p.lda;                    // row stride; k-tile stride below (elements)
+            sbase[i] = p.A + z * p.sA + (int64_t)m0 * rs;
+            voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
             pstride[i] = p.a_plane;
+            kstride[i] = p.a_panel ? (int64_t)p.M * 16 : 16;
             ldsoff[i] = jj * 512;
         } else {
             const int rr = (n0 + row < p.N) ? row : p.N - 1 - n0;
-            sbase[i] = p.B + (int64_t)n0 * p.ldb;
-            voff[i] = 2u * ((unsigned)rr * (unsigned)p.ldb + 8u * dch);
+            const int64_t rs = p.b_panel ? 16 : p.ldb;
+            sbase[i] = p.B + (int64_t)n0 * rs;
+            voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
             pstride[i] = p.b_plane;
+            kstride[i] = p.b_panel ? (int64_t)p.N * 16 : 16;
             ldsoff[i] = 3 * A_PLANE + jj * 512;
         }
     }
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             if (live[i]) {                                                                                      \
                 const bool isA_ = (wave + NW * i) < CFG::A_INSTR;                                               \
                 _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                \
-                    __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)(KT) * BK), voff[i]), \
+                    __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)(KT) * kstride[i]), voff[i]), \
                         (lds_ptr6)(smem6 + (ST) * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0); \
             }                                                                                                   \
         }                                                                                                       \
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
                             if (refill && live[i]) {
                                 const bool isA_ = (wave + NW * i) < CFG::A_INSTR;
                                 __builtin_amdgcn_sched_barrier(0);
-                                __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * BK), voff[i]),
+                                __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
                                     (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
@@ -338,7 +342,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
                     unsigned short hh[16], mm[16], ll[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) split3(v[q], hh[q], mm[q], ll[q]);
-                    unsigned short* Pt = p.Cp + z * p.sCp + (int64_t)tm * p.ldcp + tn + prow * (int)p.ldcp + pcol;
+                    // row-major [M][ldcp], or the k16 panels of the next GEMM's A: panel (tn + pcol) / 16, row tm + prow
+                    unsigned short* Pt = p.cp_panel ? p.Cp + (int64_t)((tn + pcol) >> 4) * ((int64_t)p.M * 16) + (int64_t)(tm + prow) * 16
+                                                    : p.Cp + z * p.sCp + (int64_t)tm * p.ldcp + tn + prow * (int)p.ldcp + pcol;
                     auto pk = [](const unsigned short* s_, int o) {
                         return make_uint4(s_[o] | ((unsigned)s_[o + 1] << 16), s_[o + 2] | ((unsigned)s_[o + 3] << 16),
                                           s_[o + 4] | ((unsigned)s_[o + 5] << 16), s_[o + 6] | ((unsigned)s_[o + 7] << 16));
@@ -353,6 +359,43 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             }
         }
     }
+}
+
+// fp32 [rows][K] -> planes in k16 panels: a thread takes 16 consecutive k of one row (64 bytes in, 32 bytes per plane out),
+// lanes take consecutive rows, so a wave writes 2 KiB contiguous per plane
+__global__ __launch_bounds__(256) void split_bf16x3_panels_kernel(const float* __restrict__ src, int64_t rows, int K,
+                                                                  unsigned short* __restrict__ planes, int64_t plane_stride) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const int kb = blockIdx.y;                                       // panel
+    const float4* s4 = reinterpret_cast<const float4*>(src + row * K + 16 * kb);
+    unsigned short h[16], m[16], l[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = s4[q];
+        split3(v.x, h[4 * q], m[4 * q], l[4 * q]); split3(v.y, h[4 * q + 1], m[4 * q + 1], l[4 * q + 1]);
+        split3(v.z, h[4 * q + 2], m[4 * q + 2], l[4 * q + 2]); split3(v.w, h[4 * q + 3], m[4 * q + 3], l[4 * q + 3]);
+    }
+    auto pk = [](const unsigned short* s_, int o) {
+        return make_uint4(s_[o] | ((unsigned)s_[o + 1] << 16), s_[o + 2] | ((unsigned)s_[o + 3] << 16),
+                          s_[o + 4] | ((unsigned)s_[o + 5] << 16), s_[o + 6] | ((unsigned)s_[o + 7] << 16));
+    };
+    unsigned short* d = planes + (int64_t)kb * rows * 16 + row * 16;
+    *reinterpret_cast<uint4*>(d) = pk(h, 0); *reinterpret_cast<uint4*>(d + 8) = pk(h, 8);
+    *reinterpret_cast<uint4*>(d + plane_stride) = pk(m, 0); *reinterpret_cast<uint4*>(d + plane_stride + 8) = pk(m, 8);
+    *reinterpret_cast<uint4*>(d + 2 * plane_stride) = pk(l, 0); *reinterpret_cast<uint4*>(d + 2 * plane_stride + 8) = pk(l, 8);
+}
+
+int launch_split_bf16x3_panels(const float* src, int64_t rows, int K, uint16_t* planes, int64_t plane_stride, hipStream_t stream) {
+    RSAF_CHECK_ARG(rows >= 0 && K >= 0 && K % 16 == 0, "K must be a non-negative multiple of 16");
+    if (rows == 0 || K == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(src && planes, "NULL pointer");
+    RSAF_CHECK_ARG(plane_stride % 8 == 0 && K / 16 <= 65535, "plane stride must be a multiple of 8 elements; at most 65535 panels");
+    ProfScope prof("split_bf16x3", stream, 0.0, 10.0 * (double)rows * K);
+    hipLaunchKernelGGL(split_bf16x3_panels_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)(K / 16)), dim3(256), 0, stream, src,
+                       rows, K, reinterpret_cast<unsigned short*>(planes), plane_stride);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
 }
 
 int launch_split_bf16x3(const float* src, int64_t n, uint16_t* planes, int64_t plane_stride, hipStream_t stream) {
@@ -384,6 +427,7 @@ int launch_gemm_bf16x6(const Gemm6Params& p, hipStream_t stream, const char* tag
     RSAF_CHECK_ARG(!p.R || p.ldr > 0, "residual needs ldr");
     RSAF_CHECK_ARG(p.act >= 0 && p.act <= 2, "act must be 0 (none), 1 (gelu) or 2 (silu)");
     RSAF_CHECK_ARG(p.nz <= 65535, "at most 65535 batches per launch");
+    RSAF_CHECK_ARG(!(p.a_panel || p.cp_panel) || p.nz == 1, "panel layouts are for unbatched operands");
     RSAF_CHECK_ARG(p.ldc < (1 << 24) && p.ldcp < (1 << 24) && p.ldr < (1 << 24), "leading dimensions must be below 2^24");
     // algorithmic FLOPs of the contraction (2 M N K); the matrix pipe executes six bf16 products per term
     ProfScope prof(tag ? tag : "gemm_bf16x6", stream, 2.0 * p.M * (double)p.N * p.K * p.nz, 0.0);
@@ -441,5 +485,26 @@ extern "C" int rsaf_gemm_bf16x6(const uint16_t* A_planes, int64_t a_plane_stride
     p.Cp = C_planes; p.c_plane = c_plane_stride; p.ldcp = ldc; p.sCp = 0;
     p.bias = bias; p.R = R; p.ldr = ldr; p.sR = 0;
     p.M = M; p.N = N; p.K = K; p.nz = 1; p.act = act; p.alpha = alpha;
+    return launch_gemm_bf16x6(p, (hipStream_t)stream, "gemm_bf16x6");
+}
+
+extern "C" int rsaf_split_bf16x3_panels(const float* src, int64_t rows, int K, uint16_t* planes, int64_t plane_stride,
+                                        rsaf_stream_t stream) {
+    return launch_split_bf16x3_panels(src, rows, K, planes, plane_stride, (hipStream_t)stream);
+}
+
+extern "C" int rsaf_gemm_bf16x6_panels(const uint16_t* A_planes, int64_t a_plane_stride, const uint16_t* B_planes,
+                                       int64_t b_plane_stride, float* C, uint16_t* C_planes, int64_t c_plane_stride,
+                                       const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
+                                       int64_t ldc, int64_t ldr, int act, float alpha, int a_panels, int b_panels,
+                                       int c_panels, rsaf_stream_t stream) {
+    Gemm6Params p{};
+    p.A = A_planes; p.a_plane = a_plane_stride; p.lda = a_panels ? 16 : lda; p.sA = 0;
+    p.B = B_planes; p.b_plane = b_plane_stride; p.ldb = b_panels ? 16 : ldb;
+    p.C = C; p.ldc = ldc; p.sC = 0;
+    p.Cp = C_planes; p.c_plane = c_plane_stride; p.ldcp = c_panels ? 16 : ldc; p.sCp = 0;
+    p.bias = bias; p.R = R; p.ldr = ldr; p.sR = 0;
+    p.M = M; p.N = N; p.K = K; p.nz = 1; p.act = act; p.alpha = alpha;
+    p.a_panel = a_panels != 0; p.b_panel = b_panels != 0; p.cp_panel = c_panels != 0;
     return launch_gemm_bf16x6(p, (hipStream_t)stream, "gemm_bf16x6");
 }

@@ -636,8 +636,9 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     // helper: C = act(A B^T + bias (+ R)) on the bf16x6 kernel; A / B as planes
     auto gemm6 = [&](const uint16_t* A, int64_t a_plane, int64_t lda, int64_t sA, const uint16_t* B, int M, int N, int K,
                      float* Cf, int64_t sC, uint16_t* Cp, int64_t c_plane, int64_t sCp, const float* bias, const float* R,
-                     int nz, int act, const char* tag) {
+                     int nz, int act, const char* tag, bool a_panel = false, bool b_panel = false, bool cp_panel = false) {
         Gemm6Params p{};
+        p.a_panel = a_panel; p.b_panel = b_panel; p.cp_panel = cp_panel;
         p.A = A; p.a_plane = a_plane; p.lda = lda; p.sA = sA;
         p.B = B; p.b_plane = (int64_t)N * K; p.ldb = K;
         p.C = Cf; p.ldc = N; p.sC = sC;
@@ -651,15 +652,21 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         auto split_w = [&](int64_t src_off, int64_t count, int64_t dst_off) {
             return launch_split_bf16x3(Wt + src_off, count, planes_at(dst_off), count, s);
         };
+        // The dense layers' weights, and the one activation a GEMM epilogue produces (the GELU output, A of ffn2), travel in
+        // the k16-panel layout (gemm_bf16x6.h).  The planes LayerNorm and the attention split write stay row-major:
+        // scattering their rows into 48 panels cost those two kernels more (+77 % / +37 %) than the GEMMs gained.
+        auto split_wp = [&](int64_t src_off, int64_t nrows, int K, int64_t dst_off) {
+            return launch_split_bf16x3_panels(Wt + src_off, nrows, K, planes_at(dst_off), nrows * K, s);
+        };
         for (int i = 0; i < 6; ++i)
             if ((rc = split_w(L.conv[i], (int64_t)C * KERN[i + 1] * C, W.wp_conv[i]))) return rc;
-        if ((rc = split_w(L.fpw, (int64_t)Hd * C, W.wp_fp))) return rc;
+        if ((rc = split_wp(L.fpw, Hd, C, W.wp_fp))) return rc;
         for (int l = 0; l < c.L; ++l) {
             const LayerOff& lo = L.layers[l];
-            if ((rc = split_w(lo.wqkv, (int64_t)3 * Hd * Hd, W.wp_qkv[l]))) return rc;
-            if ((rc = split_w(lo.wo, (int64_t)Hd * Hd, W.wp_o[l]))) return rc;
-            if ((rc = split_w(lo.w1, (int64_t)c.I * Hd, W.wp_1[l]))) return rc;
-            if ((rc = split_w(lo.w2, (int64_t)Hd * c.I, W.wp_2[l]))) return rc;
+            if ((rc = split_wp(lo.wqkv, 3 * Hd, Hd, W.wp_qkv[l]))) return rc;
+            if ((rc = split_wp(lo.wo, Hd, Hd, W.wp_o[l]))) return rc;
+            if ((rc = split_wp(lo.w1, c.I, Hd, W.wp_1[l]))) return rc;
+            if ((rc = split_wp(lo.w2, Hd, c.I, W.wp_2[l]))) return rc;
         }
     }
     // 1-3. feature encoder, CONV_GROUP windows at a time (its activations are the large ones: 15 999 x 512 per window)
@@ -704,7 +711,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, 1, planes_at(W.lnfp));
     if (rc) return rc;
     rc = gemm6(planes_at(W.lnfp), rows * C, C, 0, planes_at(W.wp_fp), (int)rows, Hd, C, ws + W.x, 0, nullptr, 0, 0,
-               Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm");
+               Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", false, true);
     if (rc) return rc;
     // 5. positional conv embedding (grouped, weight norm folded), GELU, x = LN(x + pos)
     {
@@ -737,7 +744,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         const LayerOff& lo = L.layers[l];
         // fused q,k,v projection (A = the planes the previous LayerNorm wrote beside x)
         rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_qkv[l]), (int)rows, 3 * Hd, Hd, ws + W.qkv, 0, nullptr, 0, 0,
-                   Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm");
+                   Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", false, true);
         if (rc) return rc;
         static const bool fused_attn = [] { const char* e = getenv("RSAF_W2V2_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
         if (fused_attn && hd == 64 && Tt <= 256) {
@@ -787,17 +794,17 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             rc = launch_split_bf16x3(ws + W.att, rows * Hd, planes_at(W.attp), rows * Hd, s);
             if (rc) return rc;
             rc = gemm6(planes_at(W.attp), rows * Hd, Hd, 0, planes_at(W.wp_o[l]), (int)rows, Hd, Hd, ws + W.y, 0, nullptr, 0, 0,
-                       Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm");
+                       Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", false, true);
             if (rc) return rc;
             rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp));
             if (rc) return rc;
         }
         {   // feed forward: the GELU output only exists as planes (A of the second GEMM)
             rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_1[l]), (int)rows, c.I, Hd, nullptr, 0,
-                       planes_at(W.ffnp), rows * c.I, 0, Wt + lo.b1, nullptr, 1, ACT_GELU, "w2v2_gemm");
+                       planes_at(W.ffnp), rows * c.I, 0, Wt + lo.b1, nullptr, 1, ACT_GELU, "w2v2_gemm", false, true, true);
             if (rc) return rc;
             rc = gemm6(planes_at(W.ffnp), rows * c.I, c.I, 0, planes_at(W.wp_2[l]), (int)rows, Hd, c.I, ws + W.y, 0, nullptr, 0, 0,
-                       Wt + lo.b2, x, 1, ACT_NONE, "w2v2_gemm");
+                       Wt + lo.b2, x, 1, ACT_NONE, "w2v2_gemm", true, true);
             if (rc) return rc;
             const bool last = (l == c.L - 1);
             rc = ln(ws + W.y, nullptr, Wt + lo.ln2g, Wt + lo.ln2b, last ? out : x, rows, Hd, c.eps, s,
