@@ -649,17 +649,14 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     };
     // 0. weights of the dense layers as bf16 planes (once per call: 0.6 GB at base geometry, < 1 ms)
     {
-        auto split_w = [&](int64_t src_off, int64_t count, int64_t dst_off) {
-            return launch_split_bf16x3(Wt + src_off, count, planes_at(dst_off), count, s);
-        };
-        // The dense layers' weights, and the one activation a GEMM epilogue produces (the GELU output, A of ffn2), travel in
+        // Every GEMM weight, and the one activation a GEMM epilogue produces (the GELU output, A of ffn2), travel in
         // the k16-panel layout (gemm_bf16x6.h).  The planes LayerNorm and the attention split write stay row-major:
         // scattering their rows into 48 panels cost those two kernels more (+77 % / +37 %) than the GEMMs gained.
         auto split_wp = [&](int64_t src_off, int64_t nrows, int K, int64_t dst_off) {
             return launch_split_bf16x3_panels(Wt + src_off, nrows, K, planes_at(dst_off), nrows * K, s);
         };
         for (int i = 0; i < 6; ++i)
-            if ((rc = split_w(L.conv[i], (int64_t)C * KERN[i + 1] * C, W.wp_conv[i]))) return rc;
+            if ((rc = split_wp(L.conv[i], C, KERN[i + 1] * C, W.wp_conv[i]))) return rc;
         if ((rc = split_wp(L.fpw, Hd, C, W.wp_fp))) return rc;
         for (int l = 0; l < c.L; ++l) {
             const LayerOff& lo = L.layers[l];
@@ -702,7 +699,8 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             const bool last = i == 6;
             rc = gemm6(cur, (int64_t)g * T[i - 1] * C, (int64_t)STRD[i] * C, (int64_t)T[i - 1] * C, planes_at(W.wp_conv[i - 1]),
                        T[i], C, KERN[i] * C, last ? ws + W.c6 + (int64_t)g0 * Tt * C : nullptr, (int64_t)T[i] * C,
-                       last ? nullptr : nxt, (int64_t)g * T[i] * C, (int64_t)T[i] * C, nullptr, nullptr, g, ACT_GELU, "w2v2_gemm");
+                       last ? nullptr : nxt, (int64_t)g * T[i] * C, (int64_t)T[i] * C, nullptr, nullptr, g, ACT_GELU, "w2v2_gemm",
+                       false, true);
             if (rc) return rc;
             std::swap(cur, nxt);
         }
