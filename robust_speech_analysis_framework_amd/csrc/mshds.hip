@@ -213,6 +213,8 @@ __device__ double sinc_group(const double* __restrict__ y, int n, double x, int 
         }
         kmin = kmin < 0 ? 0 : kmin;
         const int k0 = kmin + lg;
+        // G is even: every term of a lane has the sign of its first one, (-1)^k0 hs is applied once behind the loop
+        double part = 0.0;
         if (RECUR) {
             const double th = (a0 + PI * k0) * iden, st = (PI * G) * iden;   // st < pi whenever a lane has 2+ terms
             double c = cos_0_pi(fmin(th, PI)), sn = sin_0_pi(fmin(th, PI));
@@ -220,7 +222,7 @@ __device__ double sinc_group(const double* __restrict__ y, int n, double x, int 
             for (int k = k0; k < kmax; k += G) {
                 const int idx = half == 0 ? midleft - k - 1 : midright + k - 1;
                 const double a = a0 + PI * k;
-                acc += y[idx] * (((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + c));
+                part += y[idx] * (fast_rcp(a) * (1.0 + c));
                 const double c2 = c * C - sn * S;
                 sn = sn * C + c * S;
                 c = c2;
@@ -229,9 +231,10 @@ __device__ double sinc_group(const double* __restrict__ y, int n, double x, int 
             for (int k = k0; k < kmax; k += G) {
                 const int idx = half == 0 ? midleft - k - 1 : midright + k - 1;
                 const double a = a0 + PI * k;
-                acc += y[idx] * (((k & 1) ? -hs : hs) * fast_rcp(a) * (1.0 + cos_0_pi(a * iden)));
+                part += y[idx] * (fast_rcp(a) * (1.0 + cos_0_pi(a * iden)));
             }
         }
+        acc += ((k0 & 1) ? -hs : hs) * part;
     }
     acc = group_sum<G>(acc);
     return special ? y[si] : acc;
@@ -958,32 +961,61 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     }
     __syncthreads();
     RSAF_PITCH_DBG_STOP(4)
-    // ---- candidate list with replacement of the weakest (one thread per list, sequential as in Praat) ----
+    // ---- candidate list with replacement of the weakest (sequential in the maxima as in Praat, cooperative per step) ----
     // The maxima were collected for the lower of the two voicing thresholds; each list takes the maxima whose
-    // correlation exceeds half its own threshold, in ascending lag order.
+    // correlation exceeds half its own threshold, in ascending lag order.  Lane z owns slot z of the list (its local
+    // strength and the index of its maximum); lanes also hold the maxima's local strengths (lane l: maxima l and l + 64),
+    // so the walk over the maxima reads them by v_readlane and the "weakest slot" is one wave reduction, redone only
+    // after a replacement.  (The one-thread form re-read 14 slots from LDS per maximum: with the harmonicity pass'
+    // threshold of 0 and up to 96 maxima that serial chain was a fifth of its frame time.)
+    const double mloc0 = lane < nmax ? s_mloc[lane] : 0.0, mloc1 = lane + 64 < nmax ? s_mloc[lane + 64] : 0.0;
+    const double mr0 = lane < nmax ? r[RC + s_maxlag[lane]] : -1.0, mr1 = lane + 64 < nmax ? r[RC + s_maxlag[lane + 64]] : -1.0;
     auto build_list = [&](double vthr, double* cf, double* cs, double* cloc, int* place_lag, int* ncand_out) {
-        int nc = 1;
-        cf[0] = 0.0; cs[0] = 0.0; place_lag[0] = 0;
-        for (int m = 0; m < nmax; ++m) {
-            if (!(r[RC + s_maxlag[m]] > 0.5 * vthr)) continue;
-            int place;
-            if (nc < P.max_cand) {
-                place = nc++;
-            } else {
-                double weakest = 2.0;
-                place = 0;
-                for (int z = 1; z < P.max_cand; ++z) {
-                    const double loc = cloc[z];
-                    if (loc < weakest) { weakest = loc; place = z; }
+        unsigned long long todo0 = __ballot(mr0 > 0.5 * vthr), todo1 = __ballot(mr1 > 0.5 * vthr);
+        double my_loc = 0.0;
+        int my_m = -1, nc = 1;
+        double weakest = 2.0;
+        int wplace = 0;
+        bool known = false;                                   // weakest / wplace describe the current slots
+        for (int half = 0; half < 2; ++half) {
+            unsigned long long todo = half ? todo1 : todo0;
+            while (todo) {
+                const int bit = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int m = 64 * half + bit;
+                const double loc_m = readlane_f64(half ? mloc1 : mloc0, bit);
+                int place;
+                if (nc < P.max_cand) {
+                    place = nc++;
+                } else {
+                    if (!known) {                             // first minimum over slots 1 .. max_cand - 1 (Praat: strict <)
+                        const double v = (lane >= 1 && lane < P.max_cand) ? my_loc : INFINITY;
+                        double mn = v;
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) mn = fmin(mn, __shfl_xor(mn, o, 64));
+                        if (mn < 2.0) { weakest = mn; wplace = __ffsll((long long)__ballot(v == mn)) - 1; }
+                        else { weakest = 2.0; wplace = 0; }
+                        known = true;
+                    }
+                    place = loc_m <= weakest ? 0 : wplace;
                 }
-                if (s_mloc[m] <= weakest) place = 0;
+                if (place) {
+                    if (lane == place) { my_loc = loc_m; my_m = m; }
+                    known = false;
+                }
             }
-            if (place) { cf[place] = s_mfreq[m]; cs[place] = s_mstr[m]; cloc[place] = s_mloc[m]; place_lag[place] = s_maxlag[m]; }
         }
-        *ncand_out = nc;
+        if (lane < MAXC) {
+            const bool on = lane >= 1 && lane < nc && my_m >= 0;
+            cf[lane] = on ? s_mfreq[my_m] : 0.0;
+            cs[lane] = on ? s_mstr[my_m] : 0.0;
+            cloc[lane] = on ? my_loc : 0.0;
+            place_lag[lane] = on ? s_maxlag[my_m] : 0;
+        }
+        if (lane == 0) *ncand_out = nc;
     };
-    if (tid == 0) build_list(P.voicing_thr, s_cf, s_cs, s_cloc, s_place, &s_cnt[1]);
-    if (tid == 32 && dual) build_list(P.voicing_thr2, s_cf2, s_cs2, s_cloc2, s_place2, &s_cnt[2]);
+    build_list(P.voicing_thr, s_cf, s_cs, s_cloc, s_place, &s_cnt[1]);
+    if (dual) build_list(P.voicing_thr2, s_cf2, s_cs2, s_cloc2, s_place2, &s_cnt[2]);
     __syncthreads();
     const int ncand = s_cnt[1];
     RSAF_PITCH_DBG_STOP(5)
