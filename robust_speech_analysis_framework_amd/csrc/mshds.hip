@@ -177,6 +177,18 @@ __device__ __forceinline__ double group_sum(double v) {
     return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
 }
 
+// maximum over the wave in every lane, same DPP / readlane structure (a ds_bpermute butterfly costs six LDS-crossbar
+// round trips per reduction: in the pitch frame kernels, three reductions per frame, that was a third of the time in
+// front of the correlation)
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+
 // ---- sinc interpolation of an LDS array by a G-lane group (Praat NUM_interpolate_sinc) -----------------
 // y: n samples (0-based); x: 0-based real position; only indices in [nz_lo, nz_hi] can be non-zero.
 // Every lane of the wave must call this (the 64/G groups of a wave evaluate different x).
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict
         s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
         double s = 0.0;
         for (int64_t i = s0 + tid; i <= s1; i += 256) s += (double)x[i];
-        s = wave_sum_f64(s);
+        s = group_sum<64>(s);
         if (lane == 0) s_red[wv] = s;
     }
     __syncthreads();
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict
         b = b > nw ? nw : b;
         double m = 0.0;
         for (int j = a + tid; j < b; j += 256) m = fmax(m, fabs(seg[j]));
-        m = wave_max_f64(m);
+        m = wave_max_dpp(m);
         if (lane == 0) s_val[wv] = m;
     }
     __syncthreads();
@@ -748,7 +760,7 @@ __device__ __forceinline__ double2_t* fft_stockham(double2_t* a, double2_t* b, c
     return src;
 }
 
-constexpr int AC_FRAMES_PER_WG = 8;
+constexpr int AC_FRAMES_PER_WG = 16;
 
 template <int LOG2M>
 __global__ __launch_bounds__(256) void pitch_ac_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(256) void pitch_ac_kernel(const float* __restrict__
         s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
         double s = 0.0;
         for (int64_t i = s0 + tid; i <= s1; i += 256) s += (double)x[i];
-        s = wave_sum_f64(s);
+        s = group_sum<64>(s);
         if (lane == 0) s_red[wv] = s;
     }
     __syncthreads();
@@ -807,7 +819,7 @@ __global__ __launch_bounds__(256) void pitch_ac_kernel(const float* __restrict__
         b = b > nw ? nw : b;
         double m = 0.0;
         for (int j = a + tid; j < b; j += 256) m = fmax(m, fabs(seg[j]));
-        m = wave_max_f64(m);
+        m = wave_max_dpp(m);
         if (lane == 0) s_val[wv] = m;
     }
     __syncthreads();

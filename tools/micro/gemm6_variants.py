@@ -64,7 +64,18 @@ def blocked(s):        # k16-panel operand layout [K/16][rows][16]: a DMA piece 
     return s
 
 
-VARIANTS = {"blocked": blocked,"nostagger": nostagger, "bunched": bunched, "firsthalf": firsthalf,"nowait": nowait, "samek": samek, "halfdma": halfdma,"base": lambda s: s, "nodma": nodma, "nolds": nolds, "nobar": nobar, "nodma_nolds": lambda s: nolds(nodma(s)),
+def regstage(s):       # timing only: k-tiles through registers (global_load_dwordx4, ds_write_b128 one k-tile later) instead of LDS-DMA
+    s = s.replace("    int st = 0;                                              // stage of k-tile kt",
+                  "    uint4 stg[NDMA];\n#pragma unroll\n    for (int d = 0; d < NDMA; ++d) stg[d] = make_uint4(0, 0, 0, 0);\n    int st = 0;")
+    old = """                                __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
+                                    (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);"""
+    new = """                                *reinterpret_cast<uint4*>(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE) + lane * 8) = stg[d];
+                                stg[d] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i])) + voff[i]);"""
+    assert old in s
+    return s.replace(old, new)
+
+
+VARIANTS = {"regstage": regstage,"blocked": blocked,"nostagger": nostagger, "bunched": bunched, "firsthalf": firsthalf,"nowait": nowait, "samek": samek, "halfdma": halfdma,"base": lambda s: s, "nodma": nodma, "nolds": nolds, "nobar": nobar, "nodma_nolds": lambda s: nolds(nodma(s)),
             "nodma_nolds_nobar": lambda s: nobar(nolds(nodma(s)))}
 which = sys.argv[1:] or list(VARIANTS)
 for name in which:
