@@ -321,6 +321,8 @@ __host__ __device__ inline void pitch_r_range(int rc, int L, int min_lag, int ma
     *lo = a < -span ? -span : a;
     *hi = b > span ? span : b;
 }
+// lags of a second 256-lag tile that are cheaper as dot products than as a tile of MFMAs (cross-correlation kernel)
+__host__ __device__ inline int pitch_extra_lags(int L) { return (L >= 256 && L - 255 <= 64) ? L - 255 : 0; }
 // doubles of the region shared by the skewed window copy and the per-wave partial correlations
 __host__ __device__ inline int pitch_part_doubles(int nw, int L) {
     const int a = 4 * 256 * ((L + 256) / 256), b = 16 * 160;       // partial sums | residue rows (XR_DOUBLES)
@@ -557,7 +559,11 @@ __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict
     // straight from the zero-padded `seg`; B[k][n] has a lane stride of 16 samples and is read from the residue
     // rows `xr`, see corr_groups).  The four waves split j'.
     // D layout (probed by tools/mfma_f64_layout.hip): lane l, register v -> row l/16 + 4 v, column l%16.
-    const int NT = (L + 256) / 256;                      // 256-lag tiles covering lags 0..L  (<= 4)
+    // 256-lag tiles covering lags 0..L (<= 4).  When the second tile would hold only a few lags (L = 267 at the 60 Hz
+    // floor: 12 of its 256), those lags are plain dot products on the vector ALU (16 lanes per lag) and the matrix pipe
+    // runs one tile: half the MFMA work of such a frame.
+    const int extra = pitch_extra_lags(L);               // lags 256 .. L by dot products (0: none)
+    const int NT = extra ? 1 : (L + 256) / 256;
     const int pstride = 256 * NT;
     {
         const int kq = lane >> 4, nn = lane & 15;
@@ -597,8 +603,20 @@ __global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict
             }
         }
     }
+    double* s_extra = s_part + 4 * pstride;              // [extra] (inside the region sized for two tiles)
+    for (int e0 = 0; e0 < extra; e0 += 16) {             // 16 lags per pass, 16 lanes per lag
+        const int e = e0 + (tid >> 4), l16 = tid & 15;
+        double v = 0.0;
+        if (e < extra) {
+            const double* sl = seg + 256 + e;
+            for (int j = l16; j < nw; j += 16) v += seg[j] * sl[j];
+        }
+        v = group_sum<16>(v);
+        if (e < extra && l16 == 0) s_extra[e] = v;
+    }
     __syncthreads();
     auto raw = [&](int l) {                             // the four waves' partial sums in wave order
+        if (l >= 256 * NT) return s_extra[l - 256];
         double v = 0.0;
         for (int q = 0; q < 4; ++q) v += s_part[q * pstride + l];
         return v;
@@ -2605,7 +2623,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         // clips (an upper bound for ragged batches); the refinement's VALU work is not counted
         double mfma_per_frame = 0.0;
         if (P.is_cc) {
-            const int Lc = P.is_cc ? P.max_lag : P.brent_ixmax, NTc = (Lc + 256) / 256;
+            const int Lc = P.is_cc ? P.max_lag : P.brent_ixmax, NTc = pitch_extra_lags(Lc) ? 1 : (Lc + 256) / 256;
             for (int tile = 0; tile < NTc; ++tile) {
                 int j_hi = P.nsamp_window + 240 + 256 * tile;
                 j_hi = j_hi < seg_len ? j_hi : seg_len;

@@ -159,7 +159,11 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
             # pipe, priced with the FLOPs the pipe actually executes; the algorithmic (fp32-equivalent) rate is kept beside it
             ach = 6.0 * alg if split6 else alg
             r = {**base, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                 "arithmetic": ("f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)" if fp64 else
+                 "arithmetic": (("f64 vector ALU: FFT autocorrelation (two complex FFTs + the spectrum pass per frame) and the "
+                                 "candidate kernel's Chebyshev coefficients (fp64 MFMA); the frames scope also spans the "
+                                 "latency-bound maxima / Brent phases, whose work is not in the FLOP count"
+                                 if name == "mshds_pitch_ac_frames" else
+                                 "f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)") if fp64 else
                                 ("fp32-accurate result from 6 bf16 MFMA products of three-way operand splits, fp32 accumulation"
                                  if split6 else "f32 MFMA")),
                  "algorithmic_flops_per_launch": rec["flops"] / rec["launches"]}
