@@ -1,7 +1,14 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02
-timeout -k 10 900 python -m pytest tests/test_mshds_gpu.py -m gpu -x -q 2>&1 | tail -3
-timeout -k 10 600 python tools/pitch_phase.py 64 > gpurun_out/r02/pitch_phase_fft.txt 2>&1 || { tail -20 gpurun_out/r02/pitch_phase_fft.txt; exit 1; }
-grep "^cc" gpurun_out/r02/pitch_phase_fft.txt | grep "stop 0\|stop 1 \|stop 2"
+mkdir -p gpurun_out/r02/final
+timeout -k 10 600 python3 tools/gemm6_bench.py > gpurun_out/r02/final/gemm_bf16x6_vs_fp32_shapes.txt 2>&1 || { tail -20 gpurun_out/r02/final/gemm_bf16x6_vs_fp32_shapes.txt; exit 1; }
+grep -v amdgpu.ids gpurun_out/r02/final/gemm_bf16x6_vs_fp32_shapes.txt | cut -c1-220
+for cfg in e2e C2 C3 C4; do
+  timeout -k 10 900 python bench.py --config $cfg > gpurun_out/r02/final/bench_$cfg.json 2> gpurun_out/r02/final/bench_$cfg.err || { tail -5 gpurun_out/r02/final/bench_$cfg.err; exit 1; }
+  python - <<PY
+import json
+d=json.loads(open('gpurun_out/r02/final/bench_$cfg.json').read().strip().splitlines()[-1])
+print("$cfg", d['value'], d['ms_per_step'], d['roofline'].get('kernel'), d['roofline'].get('frac'), (d.get('inclusive_of_pcie_and_decode') or {}).get('value'), d['cpu_baseline'].get('value'), d['roofline'].get('traffic'))
+PY
+done

@@ -42,16 +42,23 @@ for M, N, K, tag, act, resid in shapes:
     t6 = ev(lambda: _lib.check(lib.rsaf_gemm_bf16x6(_lib.ptr(ap), M * K, _lib.ptr(wp), N * K, _lib.ptr(C) if C is not None else None,
                                                     _lib.ptr(P) if P is not None else None, M * N, _lib.ptr(bias),
                                                     _lib.ptr(R) if resid else None, M, N, K, K, K, N, N, act, 1.0, None), "g6"))
+    # the layout the Wav2Vec2 stage uses: weights always as k16 panels, A as panels where a GEMM epilogue produced it (ffn2)
+    a_pan = tag.startswith("ffn2")
+    wpp = torch.empty((3, N * K), dtype=torch.int16, device="cuda")
+    _lib.check(lib.rsaf_split_bf16x3_panels(_lib.ptr(W), N, K, _lib.ptr(wpp), N * K, None), "split panels")
+    app = ap
+    if a_pan:
+        app = torch.empty((3, M * K), dtype=torch.int16, device="cuda")
+        _lib.check(lib.rsaf_split_bf16x3_panels(_lib.ptr(A), M, K, _lib.ptr(app), M * K, None), "split panels")
+    t6p = ev(lambda: _lib.check(lib.rsaf_gemm_bf16x6_panels(_lib.ptr(app), M * K, _lib.ptr(wpp), N * K, _lib.ptr(C) if C is not None else None,
+                                                            _lib.ptr(P) if P is not None else None, M * N, _lib.ptr(bias),
+                                                            _lib.ptr(R) if resid else None, M, N, K, K, K, N, N, act, 1.0,
+                                                            int(a_pan), 1, int(planes_out), None), "g6p"))
+    del wpp, app
     t32 = ev(lambda: ops.linear(A, W, bias=bias, residual=R, act="gelu" if act == 1 else None))
     fl = 2.0 * M * N * K
-    print(f"{tag:24s} M={M} N={N} K={K}: fp32 {t32:7.3f} ms {fl / t32 / 1e9:6.1f} TF | bf16x6 {t6:7.3f} ms {fl / t6 / 1e9:6.1f} TF-eq "
-          f"x{t32 / t6:.2f} | split of A {t_split:6.3f} ms -> x{t32 / (t6 + t_split):.2f} incl. split", flush=True)
+    print(f"{tag:24s} M={M} N={N} K={K}: fp32 {t32:7.3f} ms {fl / t32 / 1e9:6.1f} TF | bf16x6 row-major {t6:7.3f} ms {fl / t6 / 1e9:6.1f} TF-eq "
+          f"x{t32 / t6:.2f} | as used (B panels{', A panels' if a_pan else ''}) {t6p:7.3f} ms {fl / t6p / 1e9:6.1f} TF-eq x{t32 / t6p:.2f} "
+          f"| split of A {t_split:6.3f} ms", flush=True)
     del A, W, ap, wp, C, P, R
     torch.cuda.empty_cache()
-# conv1 shape: batched over windows, strided rows (lda = 2 C)
-n_win = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-T0, T1, Cc = 15999, 7999, 512
-X = torch.randn((n_win, T0, Cc), device="cuda")
-Wc = torch.randn((Cc, 3 * Cc), device="cuda") / (3 * Cc) ** 0.5
-t32 = ev(lambda: ops.gemm(X, Wc, M=T1, N=Cc, K=3 * Cc, lda=2 * Cc, nz=n_win, sA=T0 * Cc, sC=T1 * Cc, act="gelu") if hasattr(ops, "gemm") else None, reps=2) if hasattr(ops, "gemm") else float("nan")
-print("conv1 fp32 ms", t32)
