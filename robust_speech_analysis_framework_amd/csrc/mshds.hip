@@ -684,7 +684,7 @@ struct FftPlan {
     static constexpr bool HAS2 = (LOG2M & 1) != 0;          // one radix-2 stage behind them
     static constexpr int T4 = M / 4, T2 = M / 2;
     static constexpr int BPT4 = T4 > 256 ? T4 / 256 : 1, BPT2 = T2 > 256 ? T2 / 256 : 1;
-    static constexpr bool PRE = LOG2M <= 10;                // twiddles in registers
+    static constexpr bool PRE = LOG2M <= 11;                // twiddles in registers
     static constexpr int NTW4 = PRE && N4 > 1 ? (N4 - 1) * BPT4 * 3 : 1, NTW2 = PRE && HAS2 ? BPT2 : 1;
 };
 
@@ -2019,9 +2019,11 @@ __device__ double max_correlation_wave(const float* __restrict__ x, int n, doubl
         if (ileft2 <= l2max) {
             if (staged) {
                 const int o2 = (int)(ileft2 - l2min);
-                for (int i = 0; i < wlen; ++i) {
-                    const int64_t i1 = ileft1 + i, i2 = ileft2 + i;
-                    if (i1 < 0 || i1 >= n || i2 < 0 || i2 >= n) continue;      // Praat skips pairs outside the sound
+                // Praat skips pairs outside the sound: the pairs inside are one index range, worked out once per lag
+                int64_t lo = -ileft1 > -ileft2 ? -ileft1 : -ileft2, hi = n - ileft1 < n - ileft2 ? n - ileft1 : n - ileft2;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > wlen ? wlen : hi;
+                for (int i = (int)lo; i < (int)hi; ++i) {
                     const double a1 = ps1[i], a2 = ps2[o2 + i];
                     norm1 += a1 * a1; norm2 += a2 * a2; prod += a1 * a2;
                     lp = fmax(lp, fabs(a2));
@@ -2037,12 +2039,26 @@ __device__ double max_correlation_wave(const float* __restrict__ x, int n, doubl
         }
         const double rr = prod != 0.0 ? prod / sqrt(norm1 * norm2) : 0.0;
         const int cnt = (int)((l2max - b + 1) < 64 ? (l2max - b + 1) : 64);
-        for (int k = 0; k < cnt; ++k) {                          // sequential r1/r2/r3 scan (uniform)
-            const double rk = __shfl(rr, k, 64), lk = __shfl(lp, k, 64);
-            r1 = r2; r2 = r3; r3 = rk;
-            if (r2 > best && r2 >= r1 && r2 >= r3) { r1b = r1; best = r2; r3b = r3; ir = (double)(b + k - 1); pk = lk; }
+        // Praat's scan (r1 = r2; r2 = r3; r3 = r[k]; a strictly better r2 that is >= both neighbours wins, the local peak
+        // taken at the step that detects it) for the 64 shifts at once: lane k holds step k's (r1, r2, r3) = (r[k-2], r[k-1],
+        // r[k]) (r2, r3 carry the two last values across batches, zeros in front of the first shift), the winner is the FIRST
+        // lane whose r2 equals the maximum over the qualifying lanes, taken only if it beats the best so far
+        const double up1 = __shfl_up(rr, 1, 64), up2 = __shfl_up(rr, 2, 64);
+        const double s2 = lane == 0 ? r3 : up1;
+        const double s1 = lane == 0 ? r2 : (lane == 1 ? r3 : up2);
+        const bool ok = lane < cnt && s2 >= s1 && s2 >= rr;
+        const double m = wave_max_dpp(ok ? s2 : -INFINITY);
+        if (m > best) {
+            const int kw = __ffsll((long long)__ballot(ok && s2 == m)) - 1;
+            best = m;
+            r1b = readlane_f64(s1, kw); r3b = readlane_f64(rr, kw); pk = readlane_f64(lp, kw);
+            ir = (double)(b + kw - 1);
         }
+        const double last = readlane_f64(rr, cnt - 1);
+        r2 = cnt >= 2 ? readlane_f64(rr, cnt - 2) : r3;
+        r3 = last;
     }
+    (void)r1;
     *peak = pk;
     *tout = t1;
     if (best > -1.0) {
@@ -2578,7 +2594,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     const int Lr = P.is_cc ? P.max_lag : P.brent_ixmax;
     const int rstride = Lr + 2;                                    // r[0..L] + the frame's relative intensity
     RSAF_CHECK_ARG(!P.is_cc || P.nsamp_window / 16 + 50 <= XR_ROW, "cross-correlation window longer than 1 760 samples is not supported");
-    RSAF_CHECK_ARG(P.is_cc || P.nfft <= 8192, "autocorrelation window longer than 5 461 samples is not supported");
+    RSAF_CHECK_ARG(P.is_cc || P.nfft <= 4096, "autocorrelation window longer than 2 730 samples is not supported");
     const size_t lds_corr = P.is_cc ? (size_t)(((seg_len + SEG_PAD + 1) & ~1) + 8) * sizeof(double) +
                                           (size_t)pitch_part_doubles(P.nsamp_window, Lr) * sizeof(double) +
                                           (size_t)(seg_len + 2) * sizeof(double)
@@ -2598,7 +2614,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     while ((2 << log2m) < P.nfft) ++log2m;                           // nfft = 2 M = 2^(log2m + 1)
     if (lds_corr > 48 * 1024) {
         const void* fn = (const void*)pitch_corr_kernel;
-        if (!P.is_cc) fn = log2m == 11 ? (const void*)pitch_ac_kernel<11> : (const void*)pitch_ac_kernel<12>;   // 64 / 128 KB
+        if (!P.is_cc) fn = (const void*)pitch_ac_kernel<11>;          // 4 096 points: 64 KB (the only instance above 48 KB)
         RSAF_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_corr));
     }
     const double* twiddles = nullptr;
@@ -2652,7 +2668,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         break;
                 switch (log2m) {
                     RSAF_AC_CASE(3) RSAF_AC_CASE(4) RSAF_AC_CASE(5) RSAF_AC_CASE(6) RSAF_AC_CASE(7) RSAF_AC_CASE(8)
-                    RSAF_AC_CASE(9) RSAF_AC_CASE(10) RSAF_AC_CASE(11) RSAF_AC_CASE(12)
+                    RSAF_AC_CASE(9) RSAF_AC_CASE(10) RSAF_AC_CASE(11)
                     default: set_error("rsaf_mshds_pitch: unsupported FFT length"); return RSAF_ERR_ARG;
                 }
 #undef RSAF_AC_CASE

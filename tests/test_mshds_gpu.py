@@ -70,6 +70,29 @@ def test_pitch_ac_track_matches_oracle(eng, floor, ceil):
         assert st[i, 4] == len(p.voiced_values())
 
 
+@pytest.mark.parametrize("floor,ceil,dt", [(200.0, 800.0, 0.005), (400.0, 1600.0, 0.004), (30.0, 450.0, 0.02), (24.0, 300.0, 0.05)])
+def test_pitch_ac_other_fft_lengths_match_oracle(eng, floor, ceil, dt):
+    """The autocorrelation pass transforms with the smallest power of two >= 1.5 windows: the speaker ranges of the path use
+    1 024 and 2 048 points; these floors run the 512-, 256- and 4 096-point instances of the FFT kernel (the last one
+    with twiddles read from the table instead of registers, twice: 1 598- and 1 998-sample windows)."""
+    import torch
+    clips = [synth.synth_clip(120, 2.0), synth.synth_clip(121, 1.3)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    r = eng.pitch(wav, offs, lens, gp, time_step=dt, floor=floor, ceiling=ceil)
+    torch.cuda.synchronize()
+    sel = r["sel_freq"].cpu().numpy()
+    for i, c in enumerate(clips):
+        p = mo.pitch_ac(c, dt, floor, pitch_ceiling=ceil)
+        ci = r["ci"][i]
+        assert ci["n_frames"] == p.n_frames
+        got = sel[ci["frame_off"]:ci["frame_off"] + ci["n_frames"]]
+        ref = p.frequency()
+        assert np.array_equal(got > 0, ref > 0)
+        if (ref > 0).any():
+            assert _rel(got, ref) < 1e-7
+
+
 def test_pitch_dual_threshold_equals_two_separate_passes(eng):
     """:178 and :270 differ only in the voicing threshold: the dual launch must reproduce both standalone passes
     (candidate lists, selected track, statistics), including frames where a list overflows (max_candidates 4)."""

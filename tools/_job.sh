@@ -1,14 +1,12 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02/final
-timeout -k 10 600 python3 tools/gemm6_bench.py > gpurun_out/r02/final/gemm_bf16x6_vs_fp32_shapes.txt 2>&1 || { tail -20 gpurun_out/r02/final/gemm_bf16x6_vs_fp32_shapes.txt; exit 1; }
-grep -v amdgpu.ids gpurun_out/r02/final/gemm_bf16x6_vs_fp32_shapes.txt | cut -c1-220
-for cfg in e2e C2 C3 C4; do
-  timeout -k 10 900 python bench.py --config $cfg > gpurun_out/r02/final/bench_$cfg.json 2> gpurun_out/r02/final/bench_$cfg.err || { tail -5 gpurun_out/r02/final/bench_$cfg.err; exit 1; }
-  python - <<PY
+mkdir -p gpurun_out/r02
+timeout -k 10 900 python -m pytest tests/test_mshds_gpu.py -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 900 python bench.py --config C2 --no-cpu-baseline --no-inclusive > gpurun_out/r02/bench_C2_x.json 2> gpurun_out/r02/bench_C2_x.err || { tail -5 gpurun_out/r02/bench_C2_x.err; exit 1; }
+python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r02/final/bench_$cfg.json').read().strip().splitlines()[-1])
-print("$cfg", d['value'], d['ms_per_step'], d['roofline'].get('kernel'), d['roofline'].get('frac'), (d.get('inclusive_of_pcie_and_decode') or {}).get('value'), d['cpu_baseline'].get('value'), d['roofline'].get('traffic'))
+d=json.loads(open('gpurun_out/r02/bench_C2_x.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'])
+for k,v in sorted(d['kernels'].items(), key=lambda kv:-kv[1]['ms'])[:12]: print(k, v)
 PY
-done

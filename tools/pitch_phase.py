@@ -34,6 +34,8 @@ cfgs = {
     "cc_hnr_100": dict(time_step=0.005, floor=100.0, ceiling=8000.0, max_candidates=15, silence_threshold=0.1,
                        voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0, voiced_unvoiced_cost=0.0,
                        periods=4.5, is_cc=True, refine_depth=700),
+    "ac_speechrate_30_450": dict(time_step=0.02, floor=30.0, ceiling=450.0, max_candidates=4, silence_threshold=0.03, voicing_threshold=0.25,
+                                 octave_cost=0.01, octave_jump_cost=0.35, voiced_unvoiced_cost=0.25),
     "ac_60_250_dual": dict(time_step=0.005, floor=60.0, ceiling=250.0, voicing_threshold2=0.3),
     "ac_100_500_dual": dict(time_step=0.005, floor=100.0, ceiling=500.0, voicing_threshold2=0.3),
 }
