@@ -187,18 +187,22 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     // loop and the others one behind it: barriers match by count, so B runs the same stream one half k-tile later.  While
     // one wave of a SIMD waits for the LDS burst of a new k-tile, the other has 24 MFMAs whose operands are in registers,
     // and the 8 waves no longer read the LDS at once.  With slots numbered by barriers (A runs half s in slot s, B half s-1):
-    //   * k-tile kt + 2 goes to the stage of k-tile kt - 1; a wave issues its DMA share between the MFMA groups of its
-    //     SECOND half of k-tile kt (A: slot 2 kt + 1, B: slot 2 kt + 2); the last reads of k-tile kt - 1 (B, slot 2 kt)
-    //     are consumed in front of barrier 2 kt + 1;
-    //   * a wave waits for that share (vmcnt 0) in front of the middle barrier of its k-tile kt + 1 (A: barrier 2 kt + 3,
-    //     B: barrier 2 kt + 4); the first reader of k-tile kt + 2 is A behind barrier 2 kt + 4.
-    // One k-tile of DMA cover instead of two: measured to cost nothing (two stages ran within 2 % of three).
+    //   * a wave issues its six DMA instructions at the HEAD of its first half, behind the B-fragment reads of the new
+    //     k-tile: it waits for those reads anyway, and its SIMD partner is in a second half that needs nothing from LDS
+    //     (between the MFMA groups of the second half the same instructions cost 4-8 % more; in front of the fragment
+    //     reads, behind the first A-fragment reads or behind the first MFMA group 2-5 % more);
+    //   * group A (slot 2 kt) fetches k-tile kt + 1 into the stage of k-tile kt - 2 (last read by B in slot 2 kt - 2) and
+    //     waits for it (vmcnt 0) in front of its next top barrier, 2 kt + 2; group B (slot 2 kt + 1) fetches k-tile kt + 2
+    //     into the stage of k-tile kt - 1 (last read by B itself in slot 2 kt) and waits for it in front of the middle
+    //     barrier of its k-tile kt + 1 (barrier 2 kt + 4, counted: its next six DMA instructions stay in flight).  The first
+    //     reader of a k-tile is always A behind its top barrier: one k-tile of cover for A's share, 1.5 for B's
+    //     (two stages ran within 2 % of three: the loop is not waiting for the data).
     static_assert(NST == 3 && TM % 2 == 0, "the staggered loop needs three stages and an even number of m-tiles");
     G6_DMA(0, 0);
     if (nk > 1) G6_DMA(1, 1);
     const int grpB = wave >= NW / 2 ? 1 : 0;
     constexpr int NDMA = 3 * IPW;                            // DMA instructions of this wave per k-tile
-    constexpr int HM = TM / 2, HGROUPS = HM * TN;
+    constexpr int HM = TM / 2;
     if (nk > 1) {                                            // k-tile 0 has landed (k-tile 1 may stay in flight)
         if (IPW == 1 || !live[IPW - 1]) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (IPW - 1) > 0 ? 3 * (IPW - 1) : 3) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPW) : "memory");
@@ -207,12 +211,16 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     }
     if (grpB) __builtin_amdgcn_s_barrier();
     int st = 0;                                              // stage of k-tile kt
+    static_assert(NI == NW * IPW, "every wave issues the same number of DMA instructions");
     for (int kt = 0; kt < nk; ++kt) {
+        if (!grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A: its share of k-tile kt (issued one k-tile ago)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool refill = kt + 2 < nk;
-        const int rst = st == 0 ? NST - 1 : st - 1;          // stage of k-tile kt - 1
-        const int rkt = kt + 2;
+        // DMA at the head of the first half, behind the fragment reads of the new k-tile (the wave waits for those anyway):
+        // group A fetches k-tile kt + 1 (stage of kt - 2), group B - half a k-tile later in time - k-tile kt + 2 (stage of kt - 1)
+        const int rkt = kt + 1 + grpB;
+        const bool refill = rkt < nk && (grpB || kt >= 1);
+        const int rst = (st + 1 + grpB) % NST;
         const unsigned short* img = smem6 + st * STAGE;
         bf16x8 bf[TN][3];
 #pragma unroll
@@ -221,6 +229,17 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             const int off = row * BK + ((h ^ ((row >> 3) & 1)) << 3);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = *reinterpret_cast<const bf16x8*>(&img[3 * A_PLANE + pl * B_PLANE + off]);
+        }
+        if (refill) {
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d) {
+                const int i = d / 3, pl = d % 3;
+                const bool isA_ = (wave + NW * i) < CFG::A_INSTR;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
+                    (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         bf16x8 afp[3];                                       // A fragments of m-tile HM, fetched in the first half
 #pragma unroll
@@ -251,26 +270,14 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[nt][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[nt][0], c, 0, 0, 0);
                 acc[mt][nt] = c;
-                if (mt >= HM) {                              // DMA instructions d with d * HGROUPS / NDMA == this MFMA group
-                    const int grp_ = (mt - HM) * TN + nt;
-#pragma unroll
-                    for (int d = 0; d < NDMA; ++d) {
-                        if (d * HGROUPS / NDMA == grp_) {
-                            const int i = d / 3, pl = d % 3;
-                            if (refill && live[i]) {
-                                const bool isA_ = (wave + NW * i) < CFG::A_INSTR;
-                                __builtin_amdgcn_sched_barrier(0);
-                                __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
-                                    (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
-                    }
-                }
             }
             if (mt == HM - 1) {
-                // middle barrier: this wave's share of k-tile kt + 1 (issued one k-tile ago) has landed
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // middle barrier: group B's share of k-tile kt + 1 (issued 1.5 k-tiles ago) has landed; its share of
+                // k-tile kt + 2, issued at the head of this k-tile, stays in flight
+                if (grpB) {
+                    if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }

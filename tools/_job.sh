@@ -2,7 +2,11 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02
-timeout -k 10 500 python tests/sweeps/mshds_edge.py > gpurun_out/r02/mshds_edge_r02.log 2>&1 || { tail -30 gpurun_out/r02/mshds_edge_r02.log; exit 1; }
-tail -8 gpurun_out/r02/mshds_edge_r02.log
-timeout -k 10 600 python tests/sweeps/mshds_fuzz.py 7000 24 > gpurun_out/r02/mshds_fuzz_r02.log 2>&1 || { tail -30 gpurun_out/r02/mshds_fuzz_r02.log; exit 1; }
-tail -4 gpurun_out/r02/mshds_fuzz_r02.log
+timeout -k 10 900 python -m pytest tests/test_gemm_gpu.py tests/test_w2v2_gpu.py -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 600 python bench.py --config C3 --no-cpu-baseline --no-inclusive > gpurun_out/r02/bench_C3_x.json 2> gpurun_out/r02/bench_C3_x.err || { tail -5 gpurun_out/r02/bench_C3_x.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02/bench_C3_x.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['fp32_equivalent_tflops'], d['roofline']['frac'])
+for k,v in sorted(d['kernels'].items(), key=lambda kv:-kv[1]['ms'])[:3]: print(k, v)
+PY

@@ -1,4 +1,6 @@
-"""Where do the cycles of gemm_bf16x6's main loop go?  Runs ON THE GPU BOX (scratch copy of the repository): patches the
+"""Where do the cycles of gemm_bf16x6's main loop go?  (Variants of the first round-2 structure - DMA between the MFMA groups of the second
+half: bunched, next to the fragment reads, through registers, k16-panel addresses - are recorded in DESIGN.md 4.1; this file patches the
+current structure.)  Runs ON THE GPU BOX (scratch copy of the repository): patches the
 kernel source textually into diagnostic variants (wrong results, valid timing), rebuilds librsaf.so for each and times two
 shapes.  The product source in the repository is not touched (the box's copy is thrown away)."""
 import os
@@ -12,7 +14,7 @@ orig = open(SRC).read()
 
 
 def nodma(s):
-    return s.replace("const bool refill = kt + 2 < nk;", "const bool refill = false;")
+    return s.replace("const bool refill = rkt < nk && (grpB || kt >= 1);", "const bool refill = false;")
 
 
 def nolds(s):
@@ -29,54 +31,69 @@ def nobar(s):
 
 
 def nowait(s):
-    return s.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n                __builtin_amdgcn_s_barrier();',
-                     '__builtin_amdgcn_s_barrier();')
+    s = s.replace('if (!grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A: its share', '// A: its share')
+    return s.replace("if (grpB) {\n                    if (refill)", "if (false) {\n                    if (refill)")
 
 
 def samek(s):          # every k-tile fetches k-tile 0 again: same lines, L2 / TCP hits only
-    return s.replace("const int rkt = kt + 2;", "const int rkt = 0;")
+    return s.replace("const int rkt = kt + 1 + grpB;", "const int rkt = 0;")
 
 
 def halfdma(s):        # only the first DMA instruction triple of the wave (half the pieces)
-    return s.replace("if (refill && live[i]) {", "if (refill && live[i] && i == 0) {")
+    return s.replace("for (int d = 0; d < NDMA; ++d) {\n                const int i = d / 3, pl = d % 3;", "for (int d = 0; d < NDMA / 2; ++d) {\n                const int i = d / 3, pl = d % 3;")
 
 
 def nostagger(s):
     return s.replace("if (grpB) __builtin_amdgcn_s_barrier();", "").replace("if (!grpB) __builtin_amdgcn_s_barrier();", "")
 
 
-def bunched(s):        # all DMA instructions of the wave behind the first MFMA group of the second half
-    return s.replace("if (d * HGROUPS / NDMA == grp_) {", "if (grp_ == 0) {")
+def head_split(s):     # three DMA instructions behind the B-fragment reads, three behind the first A-fragment reads
+    a = s.index("        if (refill) {\n#pragma unroll\n            for (int d = 0; d < NDMA; ++d) {")
+    b = s.index("        bf16x8 afp[3];")
+    blk = s[a:b]
+    first = blk.replace("for (int d = 0; d < NDMA; ++d) {", "for (int d = 0; d < NDMA / 2; ++d) {")
+    second = blk.replace("for (int d = 0; d < NDMA; ++d) {", "for (int d = NDMA / 2; d < NDMA; ++d) {")
+    s = s[:a] + first + s[b:]
+    # second block behind the MFMAs of m-tile 0
+    marker = "            if (mt == HM - 1) {\n                // middle barrier"
+    i = s.index(marker)
+    return s[:i] + "            if (mt == 0) {\n" + second.replace("        if (refill) {", "            if (refill) {") + "            }\n" + s[i:]
 
 
-def firsthalf(s):      # DMA between the MFMA groups of the FIRST half (needs the stage to be free: timing only)
-    return s.replace("if (mt >= HM) {                              // DMA", "if (mt < HM) {  // DMA").replace(
-        "const int grp_ = (mt - HM) * TN + nt;", "const int grp_ = mt * TN + nt;")
+def head_after_mt0(s):  # all six DMA instructions behind the MFMAs of m-tile 0
+    a = s.index("        if (refill) {\n#pragma unroll\n            for (int d = 0; d < NDMA; ++d) {")
+    b = s.index("        bf16x8 afp[3];")
+    blk = s[a:b]
+    s = s[:a] + s[b:]
+    marker = "            if (mt == HM - 1) {\n                // middle barrier"
+    i = s.index(marker)
+    return s[:i] + "            if (mt == 0) {\n" + blk + "            }\n" + s[i:]
 
 
-def blocked(s):        # k16-panel operand layout [K/16][rows][16]: a DMA piece = 1 KiB contiguous (timing only, M, N % 256 == 0)
-    s = s.replace("voff[i] = 2u * ((unsigned)rr * (unsigned)p.lda + 8u * dch);", "voff[i] = 1024u * jj + 16u * lane;")
-    s = s.replace("voff[i] = 2u * ((unsigned)rr * (unsigned)p.ldb + 8u * dch);", "voff[i] = 1024u * jj + 16u * lane;")
-    s = s.replace("sbase[i] = p.A + z * p.sA + (int64_t)m0 * p.lda;", "sbase[i] = p.A + (int64_t)m0 * 16;")
-    s = s.replace("sbase[i] = p.B + (int64_t)n0 * p.ldb;", "sbase[i] = p.B + (int64_t)n0 * 16;")
-    s = s.replace("(int64_t)rkt * BK)", "(int64_t)rkt * BK * (isA_ ? p.M : p.N))")
-    s = s.replace("(int64_t)(KT) * BK)", "(int64_t)(KT) * BK * (isA_ ? p.M : p.N))")
-    return s
-
-
-def regstage(s):       # timing only: k-tiles through registers (global_load_dwordx4, ds_write_b128 one k-tile later) instead of LDS-DMA
-    s = s.replace("    int st = 0;                                              // stage of k-tile kt",
-                  "    uint4 stg[NDMA];\n#pragma unroll\n    for (int d = 0; d < NDMA; ++d) stg[d] = make_uint4(0, 0, 0, 0);\n    int st = 0;")
-    old = """                                __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
-                                    (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);"""
-    new = """                                *reinterpret_cast<uint4*>(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE) + lane * 8) = stg[d];
-                                stg[d] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i])) + voff[i]);"""
+def head_interleaved(s):   # one DMA instruction behind every B-fragment read
+    a = s.index("        if (refill) {\n#pragma unroll\n            for (int d = 0; d < NDMA; ++d) {")
+    b = s.index("        bf16x8 afp[3];")
+    s = s[:a] + s[b:]
+    old = "            for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = *reinterpret_cast<const bf16x8*>(&img[3 * A_PLANE + pl * B_PLANE + off]);"
+    new = """            for (int pl = 0; pl < 3; ++pl) {
+                bf[nt][pl] = *reinterpret_cast<const bf16x8*>(&img[3 * A_PLANE + pl * B_PLANE + off]);
+                const int d = nt * 3 + pl;
+                if (refill && d < NDMA) {
+                    const int i = d / 3, pl2 = d % 3;
+                    const bool isA_ = (wave + NW * i) < CFG::A_INSTR;
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl2 * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
+                        (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl2 * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }"""
     assert old in s
     return s.replace(old, new)
 
 
-VARIANTS = {"regstage": regstage,"blocked": blocked,"nostagger": nostagger, "bunched": bunched, "firsthalf": firsthalf,"nowait": nowait, "samek": samek, "halfdma": halfdma,"base": lambda s: s, "nodma": nodma, "nolds": nolds, "nobar": nobar, "nodma_nolds": lambda s: nolds(nodma(s)),
-            "nodma_nolds_nobar": lambda s: nobar(nolds(nodma(s)))}
+VARIANTS = {"head_interleaved": head_interleaved, "base": lambda s: s, "nodma": nodma, "nolds": nolds, "nobar": nobar, "nodma_nolds": lambda s: nolds(nodma(s)),
+            "nodma_nolds_nobar": lambda s: nobar(nolds(nodma(s))), "halfdma": halfdma, "samek": samek, "nowait": nowait,
+            "nostagger": nostagger, "head_split": head_split, "head_after_mt0": head_after_mt0}
 which = sys.argv[1:] or list(VARIANTS)
 for name in which:
     src = VARIANTS[name](orig)
@@ -87,8 +104,9 @@ for name in which:
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm6_bench.py")], capture_output=True, text=True, cwd=ROOT)
     for line in r.stdout.splitlines():
         if line.startswith(("qkv", "ffn2", "out-proj")):
-            m = re.search(r"bf16x6\s+([\d.]+) ms\s+([\d.]+) TF-eq", line)
-            print(f"{name:20s} {line.split()[0]:10s} {m.group(1)} ms {m.group(2)} TF-eq", flush=True)
+            m = re.search(r"bf16x6 row-major\s+([\d.]+) ms\s+([\d.]+) TF-eq", line)
+            u = re.search(r"as used \([^)]*\)\s+([\d.]+) ms\s+([\d.]+) TF-eq", line)
+            print(f"{name:20s} {line.split()[0]:10s} row-major {m.group(1)} ms {m.group(2)} TF-eq | as used {u.group(1)} ms {u.group(2)} TF-eq", flush=True)
     if r.returncode != 0:
         print(r.stderr[-2000:])
 open(SRC, "w").write(orig)
