@@ -1,12 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02/final
-for cfg in e2e C2 C3 C4; do
-  timeout -k 10 900 python bench.py --config $cfg > gpurun_out/r02/final/bench_$cfg.json 2> gpurun_out/r02/final/bench_$cfg.err || { tail -5 gpurun_out/r02/final/bench_$cfg.err; exit 1; }
-  python - <<PY
-import json
-d=json.loads(open('gpurun_out/r02/final/bench_$cfg.json').read().strip().splitlines()[-1])
-print("$cfg", d['value'], d['ms_per_step'], d['roofline'].get('kernel'), d['roofline'].get('frac'), d['roofline'].get('fp32_equivalent_tflops'), (d.get('inclusive_of_pcie_and_decode') or {}).get('value'), d['cpu_baseline'].get('value'), d['roofline'].get('traffic'))
-PY
-done
+mkdir -p gpurun_out/r02
+rm -rf gpurun_out/r02/clk
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d gpurun_out/r02/clk --output-format csv -- python3 tools/gemm6_bench.py > gpurun_out/r02/clk.log 2>&1 || { tail -5 gpurun_out/r02/clk.log; exit 1; }
+python tools/micro/gemm_clock.py gpurun_out/r02/clk | tee gpurun_out/r02/gemm_clock.txt
+head -2 $(find gpurun_out/r02/clk -name "*kernel_trace.csv" | head -1) | cut -c1-300
+find gpurun_out/r02/clk -name "*.csv" -size +1M -delete || true
