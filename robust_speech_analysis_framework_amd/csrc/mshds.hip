@@ -321,70 +321,6 @@ __host__ __device__ inline void pitch_r_range(int rc, int L, int min_lag, int ma
     *lo = a < -span ? -span : a;
     *hi = b > span ? span : b;
 }
-// lags of a second 256-lag tile that are cheaper as dot products than as a tile of MFMAs (cross-correlation kernel)
-__host__ __device__ inline int pitch_extra_lags(int L) { return (L >= 256 && L - 255 <= 64) ? L - 255 : 0; }
-// doubles of the region shared by the skewed window copy and the per-wave partial correlations
-__host__ __device__ inline int pitch_part_doubles(int nw, int L) {
-    const int a = 4 * 256 * ((L + 256) / 256), b = 16 * 160;       // partial sums | residue rows (XR_DOUBLES)
-    (void)nw;
-    return a > b ? a : b;
-}
-
-// ---- correlation inner loops ----
-// On gfx950 the fp64 MFMA runs at the vector fp64 rate and shares its issue with every other VALU instruction of
-// the SIMD, so the loop must be MFMA and LDS reads only: no clamps, no selects, no address arithmetic.
-//  * seg is followed by SEG_PAD zeros, so the A operand seg[y0 + 16 t + 4 p] needs no bound check.
-//  * the window samples xm[i] (zero outside [0, nw)) are stored by residue: XR[i mod 16][i div 16 + XR_Q0].  A row
-//    of 16 lanes needs xm[4 s + kq - 16 nn] = XR[4 p + kq][t - nn + XR_Q0] (s = 4 t + p): 16 consecutive doubles
-//    (conflict-free), the four phases p differ by a compile-time offset and t advances the address by 8 bytes.
-// One group = 4 k-steps (p = 0..3); a wave takes whole groups.
-constexpr int SEG_PAD = 64;
-constexpr int XR_ROW = 160;          // doubles per residue row: nw / 16 + 50 <= 160  (nw <= 1760 samples)
-constexpr int XR_Q0 = 32;            // quotient offset: i >= -512
-constexpr int XR_DOUBLES = 16 * XR_ROW;
-
-__device__ __forceinline__ double4_t corr_groups(const double* __restrict__ ap, const double* __restrict__ bp, int t0, int t1) {
-    double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0;
-    ap += 16 * t0;
-    bp += t0;
-    for (int t = t0; t < t1; ++t) {
-        const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-        const double b0 = bp[0], b1 = bp[4 * XR_ROW], b2 = bp[8 * XR_ROW], b3 = bp[12 * XR_ROW];
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, c1, 0, 0, 0);
-        ap += 16;
-        bp += 1;
-    }
-    return c0 + c1;
-}
-
-// two 256-lag tiles at once: same B operand, A moved by 256 samples (six LDS reads... eight MFMAs per group)
-__device__ __forceinline__ void corr_groups_pair(const double* __restrict__ ap, const double* __restrict__ bp, int t0, int t1,
-                                                 double4_t& out0, double4_t& out1) {
-    double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, d0 = c0, d1 = c0;
-    ap += 16 * t0;
-    bp += t0;
-    for (int t = t0; t < t1; ++t) {
-        const double b0 = bp[0], b1 = bp[4 * XR_ROW], b2 = bp[8 * XR_ROW], b3 = bp[12 * XR_ROW];
-        const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-        const double e0 = ap[256], e1 = ap[260], e2 = ap[264], e3 = ap[268];
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, b0, d0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, b1, d1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c0, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2, b2, d0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, c1, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3, b3, d1, 0, 0, 0);
-        ap += 16;
-        bp += 1;
-    }
-    out0 = c0 + c1;
-    out1 = d0 + d1;
-}
-
 // ---- sinc interpolation as a polynomial in the fractional position -----------------------------------------
 // Between two samples the depth-d interpolation is S(b + frac) = sum_o W_o(frac) y[b + o], o = -(d-1) .. d, and
 // every weight W_o is a smooth function of frac in [0, 1] alone (as long as the depth is not clipped by the
@@ -474,183 +410,6 @@ __device__ void refine_candidates(const RefineArgs& A, int tid, int nthreads) {
                                     live, xm, ym);
         if (ym > 1.0) ym = 1.0 / ym;
         if (live && lg == 0) { A.cf[k] = 1.0 / DXS / (xm - A.RC); A.cs[k] = ym; }
-    }
-}
-
-// Kernel 1 of 2 (cross-correlation method; the autocorrelation method uses pitch_ac_kernel below): one 256-thread
-// workgroup per frame computes the normalised correlation r[0..L] (and the frame's relative intensity) into a global
-// row; kernel 2 (one wave per frame) turns rows into candidates.  The split keeps the four-wave matrix-pipe phase free of
-// the single-wave phases (maxima, candidate lists, Brent refinement), during which three of the four waves used to sit
-// at barriers (PMC: waves parked 49 % of their cycles).
-__global__ __launch_bounds__(256) void pitch_corr_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
-                                                         const double* __restrict__ gpeak, const PitchParams P,
-                                                         double* __restrict__ rbuf, int rstride, int max_frames) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const ClipInfo c = ci[blockIdx.y];
-    const int f = blockIdx.x;
-    if (f >= c.n_frames) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nw = P.nsamp_window, L = P.max_lag;
-    const int seg_len = nw + P.max_lag + 1;
-    const int part_doubles = pitch_part_doubles(nw, L);
-    // all LDS lives in the dynamic region (keeps every double 8-byte aligned, guide G17)
-    double* seg = reinterpret_cast<double*>(smem_raw);
-    double* s_red = seg + ((seg_len + SEG_PAD + 1) & ~1);   // [4]   (seg is followed by SEG_PAD zeros)
-    double* s_val = s_red + 4;                      // [4]
-    double* s_part = s_val + 4;                     // [4][256 * NT] partial correlations of the four waves
-    double* xr = s_part;                            // [16][XR_ROW] window samples by residue until the partials are written
-    double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
-    const float* x = wav + c.sample_off;
-    const int n = c.n_samples;
-    const double t = c.t1 + f * P.dt;
-    const int64_t left = low_index(t), right = left + 1;
-    // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat)
-    {
-        int64_t s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
-        s0 = s0 < 0 ? 0 : (s0 > n - 1 ? n - 1 : s0);
-        s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
-        double s = 0.0;
-        for (int64_t i = s0 + tid; i <= s1; i += 256) s += (double)x[i];
-        s = group_sum<64>(s);
-        if (lane == 0) s_red[wv] = s;
-    }
-    __syncthreads();
-    const double local_mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (2.0 * P.nsamp_period);
-    int loc_max_lag;
-    {
-        // Praat: startTime = t - 0.5 * (1 / minimumPitch + dt_window), dt_window = periods / minimumPitch
-        const double start_time = t - 0.5 * (1.0 / P.min_pitch + P.dt_window);
-        int64_t start = low_index(start_time);
-        if (start < 0) start = 0;
-        int64_t span = P.max_lag + nw;
-        if (span > n - start) span = n - start;
-        loc_max_lag = (int)(span - nw);
-        for (int j = tid; j < seg_len; j += 256) {
-            const int64_t i = start + j;
-            seg[j] = i < n ? ((double)x[i < 0 ? 0 : i] - local_mean) : 0.0;
-        }
-    }
-    __syncthreads();
-    // local peak over half a longest period around the window centre
-    {
-        if (tid < SEG_PAD) seg[seg_len + tid] = 0.0;
-        for (int j = tid; j < XR_DOUBLES; j += 256) {          // xm[i], i = 16 (q - XR_Q0) + rho, zero outside [0, nw)
-            const int rho = j / XR_ROW, q = j - rho * XR_ROW;
-            const int i = 16 * (q - XR_Q0) + rho;
-            xr[j] = (i >= 0 && i < nw) ? seg[i] : 0.0;
-        }
-        int a = P.half_window - P.half_period, b = P.half_window + P.half_period;
-        a = a < 0 ? 0 : a;
-        b = b > nw ? nw : b;
-        double m = 0.0;
-        for (int j = a + tid; j < b; j += 256) m = fmax(m, fabs(seg[j]));
-        m = wave_max_dpp(m);
-        if (lane == 0) s_val[wv] = m;
-    }
-    __syncthreads();
-    const double local_peak = fmax(fmax(s_val[0], s_val[1]), fmax(s_val[2], s_val[3]));
-    const double gp = gpeak[blockIdx.y];
-    const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
-
-    if (P.debug_stop == 1) return;
-    // ---- correlation on the fp64 matrix pipe ----
-    // R[m + 16 n + 256 tile] = sum_j' seg[j' + m] * xm[j' - 16 n - 256 tile], xm = seg restricted to [0, nw):
-    // a 16 x 16 tile of lags per v_mfma_f64_16x16x4_f64 with j' as the k dimension (A[m][k] = seg[j'+m] is read
-    // straight from the zero-padded `seg`; B[k][n] has a lane stride of 16 samples and is read from the residue
-    // rows `xr`, see corr_groups).  The four waves split j'.
-    // D layout (probed by tools/mfma_f64_layout.hip): lane l, register v -> row l/16 + 4 v, column l%16.
-    // 256-lag tiles covering lags 0..L (<= 4).  When the second tile would hold only a few lags (L = 267 at the 60 Hz
-    // floor: 12 of its 256), those lags are plain dot products on the vector ALU (16 lanes per lag) and the matrix pipe
-    // runs one tile: half the MFMA work of such a frame.
-    const int extra = pitch_extra_lags(L);               // lags 256 .. L by dot products (0: none)
-    const int NT = extra ? 1 : (L + 256) / 256;
-    const int pstride = 256 * NT;
-    {
-        const int kq = lane >> 4, nn = lane & 15;
-        double4_t acc[4];
-#pragma unroll
-        for (int tile = 0; tile < 4; ++tile) acc[tile] = double4_t{0.0, 0.0, 0.0, 0.0};
-        auto tile_groups = [&](int tile) {                // groups of 4 k-steps; the zero padding absorbs the round-up
-            int j_hi = nw + 240 + 256 * tile;
-            j_hi = j_hi < seg_len ? j_hi : seg_len;
-            const int j_lo = 256 * tile;
-            return j_hi > j_lo ? (j_hi - j_lo + 15) / 16 : 0;
-        };
-        const double* ap = seg + kq + nn;                                  // A: seg[kq + nn + 16 t + 4 p (+ 256 tile)]
-        const double* bp = xr + kq * XR_ROW + (XR_Q0 - nn);                // B: XR[4 p + kq][t - nn + XR_Q0]
-        if (NT == 2) {
-            // groups [0, g1) exist in both tiles (shared B operand), [g1, g0) in tile 0 only
-            const int g0 = tile_groups(0), g1 = tile_groups(1) < g0 ? tile_groups(1) : g0;
-            corr_groups_pair(ap, bp, g1 * wv / 4, g1 * (wv + 1) / 4, acc[0], acc[1]);
-            const int rest = g0 - g1;
-            acc[0] = acc[0] + corr_groups(ap, bp, g1 + rest * wv / 4, g1 + rest * (wv + 1) / 4);
-        } else {
-#pragma unroll
-            for (int tile = 0; tile < 4; ++tile) {
-                if (tile < NT) {
-                    const int g = tile_groups(tile);
-                    acc[tile] = corr_groups(ap + 256 * tile, bp, g * wv / 4, g * (wv + 1) / 4);
-                }
-            }
-        }
-        __syncthreads();                                  // every wave is done with xr (it aliases s_part)
-#pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
-            if (tile < NT) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    s_part[wv * pstride + 256 * tile + kq + 4 * v + 16 * nn] = acc[tile][v];
-            }
-        }
-    }
-    double* s_extra = s_part + 4 * pstride;              // [extra] (inside the region sized for two tiles)
-    for (int e0 = 0; e0 < extra; e0 += 16) {             // 16 lags per pass, 16 lanes per lag
-        const int e = e0 + (tid >> 4), l16 = tid & 15;
-        double v = 0.0;
-        if (e < extra) {
-            const double* sl = seg + 256 + e;
-            for (int j = l16; j < nw; j += 16) v += seg[j] * sl[j];
-        }
-        v = group_sum<16>(v);
-        if (e < extra && l16 == 0) s_extra[e] = v;
-    }
-    __syncthreads();
-    auto raw = [&](int l) {                             // the four waves' partial sums in wave order
-        if (l >= 256 * NT) return s_extra[l - 256];
-        double v = 0.0;
-        for (int q = 0; q < 4; ++q) v += s_part[q * pstride + l];
-        return v;
-    };
-    if (P.debug_stop == 2) return;
-    // ---- normalise into the global row ----
-    if (tid == 0) { rb[0] = 1.0; rb[L + 1] = intensity; }
-    {
-        const double sumx2 = raw(0);
-        // sumy2(lag) = sum_{j=lag}^{lag+nw-1} seg[j]^2 = csq[lag+nw] - csq[lag] with the exclusive prefix sums
-        // csq[j] = sum_{i<j} seg[i]^2 (block scan; the O(L*nw) direct loop was a quarter of this kernel)
-        double* csq = s_part + part_doubles;                 // [seg_len + 1]
-        {
-            const int C = (seg_len + 255) / 256;
-            const int j0 = tid * C, j1 = (j0 + C < seg_len) ? j0 + C : seg_len;
-            double loc = 0.0;
-            for (int j = j0; j < j1; ++j) loc += seg[j] * seg[j];
-            double inc = loc;                                 // inclusive scan inside the wave
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const double t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
-            if (lane == 63) s_red[wv] = inc;
-            __syncthreads();
-            double off = inc - loc;
-            for (int q = 0; q < wv; ++q) off += s_red[q];
-            double run = off;
-            for (int j = j0; j < j1; ++j) { csq[j] = run; run += seg[j] * seg[j]; }
-            if (j1 == seg_len && j0 < seg_len) csq[seg_len] = run;
-        }
-        __syncthreads();
-        for (int l = 1 + tid; l <= L; l += 256) {
-            const double sy = csq[l + nw] - csq[l];
-            const double den = sumx2 * sy;
-            rb[l] = (l <= loc_max_lag && den > 0.0) ? raw(l) / sqrt(den) : 0.0;
-        }
     }
 }
 
@@ -824,10 +583,16 @@ __global__ __launch_bounds__(256) void pitch_ac_kernel(const float* __restrict__
     __syncthreads();
     const double local_mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (2.0 * P.nsamp_period);
     const int64_t start = right - P.half_window;
-    for (int j = tid; j < N; j += 256) {
-        int64_t i = start + j;
-        i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-        seg[j] = j < nw ? ((double)x[i] - local_mean) * win[j] : 0.0;
+    if (start >= 0 && start + nw <= n) {                    // the window lies inside the sound: no index clamps
+        const float* xs = x + start;
+#pragma unroll 4
+        for (int j = tid; j < N; j += 256) seg[j] = j < nw ? ((double)xs[j] - local_mean) * win[j] : 0.0;
+    } else {
+        for (int j = tid; j < N; j += 256) {
+            int64_t i = start + j;
+            i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+            seg[j] = j < nw ? ((double)x[i] - local_mean) * win[j] : 0.0;
+        }
     }
     __syncthreads();
     // local peak over half a longest period around the window centre
@@ -888,6 +653,164 @@ __global__ __launch_bounds__(256) void pitch_ac_kernel(const float* __restrict__
         rb[l] = r0 > 0.0 ? v / (r0 * wr[l]) : 0.0;
     }
     __syncthreads();                                        // the next frame overwrites both buffers
+    }
+}
+
+// ---- CC: forward cross-correlation by FFT ----------------------------------------------------------------------
+// r(l) = sum_{j < nw} seg[j] seg[j + l], l = 0 .. L, is the linear cross-correlation of a = seg[0, nw) with b = seg[0, nw + L]:
+// both are real, so ONE complex FFT of N >= nw + L + 1 points on z = a + i b gives A[k] = (Z[k] + conj Z[N-k]) / 2 and
+// B[k] = (Z[k] - conj Z[N-k]) / 2i; C = conj(A) B is the spectrum of the correlation, Hermitian, and goes back through a
+// complex FFT of N / 2 points like the autocorrelation kernel's second transform.  (On the fp64 matrix pipe the direct sum
+// cost 0.6 M multiply-adds per frame at the 60 Hz floor; this is 0.17 M flops.)  Normalisation as before: r / sqrt(sumx2 sumy2(l))
+// with sumy2 from a block prefix sum of the squares, taken before the transforms reuse the buffers.
+constexpr int CC_FRAMES_PER_WG = 16;
+
+template <int LOG2N>
+__global__ __launch_bounds__(256) void pitch_cc_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                       const double* __restrict__ gpeak, const PitchParams P,
+                                                       const double2_t* __restrict__ tw1, const double2_t* __restrict__ tw2,
+                                                       double* __restrict__ rbuf, int rstride, int max_frames) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const ClipInfo c = ci[blockIdx.y];
+    if ((int)blockIdx.x * CC_FRAMES_PER_WG >= c.n_frames) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int N = 1 << LOG2N, M = N >> 1;               // complex transform lengths: N forward, M back
+    const int nw = P.nsamp_window, L = P.max_lag;
+    const int seg_len = nw + L + 1;
+    FftTw<LOG2N> twa;                                       // tw1 = W_2N^k (k < N): twiddles of the N-point transform
+    FftTw<LOG2N - 1> twb;                                   // tw2 = W_N^k (k < M): the M-point transform and the spectrum pass
+    fft_load_twiddles<LOG2N>(twa, tw1, tid);
+    fft_load_twiddles<LOG2N - 1>(twb, tw2, tid);
+    constexpr int NPK = (M / 2) / 256 + 1;                  // spectrum pass: k = tid + 256 i <= M / 2
+    double2_t twp[NPK];
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) twp[i] = tw2[tid + 256 * i <= M / 2 ? tid + 256 * i : 0];
+    double2_t* za = reinterpret_cast<double2_t*>(smem_raw);  // [N]
+    double2_t* zb = za + N;                                  // [N]
+    double* s_sy = reinterpret_cast<double*>(zb + N);        // [L + 1] sumy2(l)
+    double* s_red = s_sy + ((L + 2) & ~1);                   // [8]
+    double* s_val = s_red + 8;                               // [4]
+    double* s_scan = s_val + 4;                              // [16] wave totals of the four 256-lag chunks of the scan
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples;
+    const double gp = gpeak[blockIdx.y];
+    for (int f = blockIdx.x * CC_FRAMES_PER_WG; f < (int)(blockIdx.x + 1) * CC_FRAMES_PER_WG && f < c.n_frames; ++f) {
+    double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
+    const double t = c.t1 + f * P.dt;
+    const int64_t left = low_index(t), right = left + 1;
+    // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat)
+    {
+        int64_t s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
+        s0 = s0 < 0 ? 0 : (s0 > n - 1 ? n - 1 : s0);
+        s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
+        double s = 0.0;
+        for (int64_t i = s0 + tid; i <= s1; i += 256) s += (double)x[i];
+        s = group_sum<64>(s);
+        if (lane == 0) s_red[wv] = s;
+    }
+    __syncthreads();
+    const double local_mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (2.0 * P.nsamp_period);
+    int loc_max_lag;
+    {
+        // Praat: startTime = t - 0.5 * (1 / minimumPitch + dt_window), dt_window = periods / minimumPitch
+        const double start_time = t - 0.5 * (1.0 / P.min_pitch + P.dt_window);
+        int64_t start = low_index(start_time);
+        if (start < 0) start = 0;
+        int64_t span = L + nw;
+        if (span > n - start) span = n - start;
+        loc_max_lag = (int)(span - nw);
+        // one pass: z = a + i b, the local peak (|b| over half a longest period around the window centre) and sumx2 = sum a^2
+        int pa = P.half_window - P.half_period, pb = P.half_window + P.half_period;
+        pa = pa < 0 ? 0 : pa;
+        pb = pb > nw ? nw : pb;
+        double m = 0.0, sx = 0.0;
+        const float* xs = x + start;                          // start >= 0
+        const int avail = (int)((n - start) < (int64_t)seg_len ? (n - start) : (int64_t)seg_len);   // samples of seg inside the sound
+#pragma unroll 4
+        for (int j = tid; j < N; j += 256) {
+            const double v = j < avail ? ((double)xs[j] - local_mean) : 0.0;
+            za[j] = double2_t{j < nw ? v : 0.0, v};          // z = a + i b
+            if (j >= pa && j < pb) m = fmax(m, fabs(v));
+            if (j < nw) sx += v * v;
+        }
+        m = wave_max_dpp(m);
+        sx = group_sum<64>(sx);
+        if (lane == 0) { s_val[wv] = m; s_red[4 + wv] = sx; }
+    }
+    __syncthreads();
+    const double local_peak = fmax(fmax(s_val[0], s_val[1]), fmax(s_val[2], s_val[3]));
+    const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
+    const double sumx2 = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    // sumy2(l) = sum_{j=l}^{l+nw-1} b_j^2 = sumx2 + sum_{i<l} (b_{i+nw}^2 - b_i^2): an inclusive scan over the L lags
+    {
+        constexpr int NQ = 4;                                 // L <= 1023
+        double inc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = tid + 256 * q;                      // term i feeds sumy2(i + 1)
+            double d = 0.0;
+            if (i < L) { const double u = za[i + nw].y, w0 = za[i].y; d = u * u - w0 * w0; }
+            double sc = d;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double t2 = __shfl_up(sc, o, 64); if (lane >= o) sc += t2; }
+            inc[q] = sc;
+            if (lane == 63) s_scan[4 * q + wv] = sc;
+        }
+        __syncthreads();
+        if (tid == 0) s_sy[0] = sumx2;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = tid + 256 * q;
+            if (i < L) {
+                double off = 0.0;
+                for (int z = 0; z < 4 * q + wv; ++z) off += s_scan[z];
+                s_sy[i + 1] = sumx2 + (off + inc[q]);
+            }
+        }
+    }
+    if (P.debug_stop == 1) continue;
+
+    double2_t* Z = fft_stockham<LOG2N>(za, zb, twa, tw1, tid);
+    double2_t* Y = Z == za ? zb : za;
+    // C[k] = conj(A[k]) B[k]; Y[k] = (C[k] + conj C[M-k]) + i conj(W_N^k) (C[k] - conj C[M-k]), stored conjugated
+    auto spec = [&](int k) {                                 // C[k] for 0 <= k <= M
+        const double2_t zk = Z[k], zn = Z[(N - k) & (N - 1)];
+        const double2_t A = double2_t{0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y)};
+        const double2_t Bm = double2_t{0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x)};   // (Z[k] - conj Z[N-k]) / 2i
+        return double2_t{A.x * Bm.x + A.y * Bm.y, A.x * Bm.y - A.y * Bm.x};          // conj(A) * B
+    };
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+        const int k = tid + 256 * i;
+        if (k > M / 2) continue;
+        const double2_t ck = spec(k), cm = spec(M - k);
+        const double2_t w = twp[i];                          // W_N^k
+        {   // Y[k]
+            const double2_t su = double2_t{ck.x + cm.x, ck.y - cm.y}, di = double2_t{ck.x - cm.x, ck.y + cm.y};
+            // i conj(w) di = i (w.x - i w.y)(di.x + i di.y) = (w.y di.x - w.x di.y) ... real: -(w.x di.y - w.y di.x)?  expand:
+            // conj(w) di = (w.x di.x + w.y di.y) + i (w.x di.y - w.y di.x);  times i: -(w.x di.y - w.y di.x) + i (w.x di.x + w.y di.y)
+            const double2_t yy = double2_t{su.x - (w.x * di.y - w.y * di.x), su.y + (w.x * di.x + w.y * di.y)};
+            Y[k] = double2_t{yy.x, -yy.y};
+        }
+        if (k != 0 && k != M - k) {   // Y[M - k]: roles swapped, W_N^(M-k) = -conj(W_N^k), so conj(W_N^(M-k)) = -w
+            const double2_t su = double2_t{cm.x + ck.x, cm.y - ck.y}, di = double2_t{cm.x - ck.x, cm.y + ck.y};
+            // i * (-w) * di = -i (w.x + i w.y)(di.x + i di.y) = (w.x di.y + w.y di.x) - i (w.x di.x - w.y di.y)
+            const double2_t yy = double2_t{su.x + (w.x * di.y + w.y * di.x), su.y - (w.x * di.x - w.y * di.y)};
+            Y[M - k] = double2_t{yy.x, -yy.y};
+        }
+    }
+    __syncthreads();
+    const double* r = reinterpret_cast<const double*>(fft_stockham<LOG2N - 1>(Y, Y == za ? zb : za, twb, tw2, tid));
+    if (P.debug_stop == 2) continue;
+    // r[2 j] = Re, r[2 j + 1] = -Im of the (conjugated) output, times N
+    if (tid == 0) { rb[0] = 1.0; rb[L + 1] = intensity; }
+    const double inv_n = 1.0 / (double)N;
+    for (int l = 1 + tid; l <= L; l += 256) {
+        const double v = ((l & 1) ? -r[l] : r[l]) * inv_n;
+        const double den = sumx2 * s_sy[l];
+        rb[l] = (l <= loc_max_lag && den > 0.0) ? v / sqrt(den) : 0.0;
+    }
+    __syncthreads();                                        // the next frame overwrites the buffers
     }
 }
 
@@ -2593,11 +2516,11 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     const int seg_len = P.is_cc ? P.nsamp_window + P.max_lag + 1 : P.nsamp_window;
     const int Lr = P.is_cc ? P.max_lag : P.brent_ixmax;
     const int rstride = Lr + 2;                                    // r[0..L] + the frame's relative intensity
-    RSAF_CHECK_ARG(!P.is_cc || P.nsamp_window / 16 + 50 <= XR_ROW, "cross-correlation window longer than 1 760 samples is not supported");
+    int ncc = 64;                                                  // CC: complex FFT length, >= nw + max_lag + 1
+    while (ncc < seg_len) ncc *= 2;
+    RSAF_CHECK_ARG(!P.is_cc || ncc <= 4096, "cross-correlation window + lag range longer than 4 095 samples is not supported");
     RSAF_CHECK_ARG(P.is_cc || P.nfft <= 4096, "autocorrelation window longer than 2 730 samples is not supported");
-    const size_t lds_corr = P.is_cc ? (size_t)(((seg_len + SEG_PAD + 1) & ~1) + 8) * sizeof(double) +
-                                          (size_t)pitch_part_doubles(P.nsamp_window, Lr) * sizeof(double) +
-                                          (size_t)(seg_len + 2) * sizeof(double)
+    const size_t lds_corr = P.is_cc ? (size_t)ncc * 2 * 2 * sizeof(double) + (size_t)(((Lr + 2) & ~1) + 32) * sizeof(double)   // two complex buffers + sumy2 + scratch
                                     : (size_t)(2 * P.nfft + 8) * sizeof(double);
     int r_lo_h, r_hi_h;
     pitch_r_range(P.brent_ixmax, Lr, P.min_lag, P.max_lag, P.refine_depth, &r_lo_h, &r_hi_h);
@@ -2612,14 +2535,22 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     hipStream_t s = (hipStream_t)stream;
     int log2m = 0;
     while ((2 << log2m) < P.nfft) ++log2m;                           // nfft = 2 M = 2^(log2m + 1)
+    int log2n = 0;
+    while ((1 << log2n) < ncc) ++log2n;
     if (lds_corr > 48 * 1024) {
-        const void* fn = (const void*)pitch_corr_kernel;
-        if (!P.is_cc) fn = (const void*)pitch_ac_kernel<11>;          // 4 096 points: 64 KB (the only instance above 48 KB)
+        const void* fn = (const void*)pitch_ac_kernel<11>;            // 4 096 points: 64 KB (the only AC instance above 48 KB)
+        if (P.is_cc) fn = log2n == 11 ? (const void*)pitch_cc_kernel<11> : (const void*)pitch_cc_kernel<12>;   // 64 / 128 KB
         RSAF_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_corr));
     }
     const double* twiddles = nullptr;
+    const double* twiddles2 = nullptr;
     if (!P.is_cc) {
         const int rc = fft_twiddles(P.nfft, &twiddles);
+        if (rc != RSAF_OK) return rc;
+    } else {
+        int rc = fft_twiddles(2 * ncc, &twiddles);                  // W_2N^k: the N-point complex transform
+        if (rc != RSAF_OK) return rc;
+        rc = fft_twiddles(ncc, &twiddles2);                         // W_N^k: the N/2-point transform and the spectrum pass
         if (rc != RSAF_OK) return rc;
     }
     if (lds_cand > 48 * 1024)
@@ -2635,30 +2566,32 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         if (!unclipped || getenv("RSAF_PITCH_NO_CHEB")) cheb = nullptr;
     }
     if (max_frames > 0) {
-        // matrix-pipe work of the correlation phase (v_mfma_f64_16x16x4: 1 024 MAC each), counted for equal-length
-        // clips (an upper bound for ragged batches); the refinement's VALU work is not counted
-        double mfma_per_frame = 0.0;
-        if (P.is_cc) {
-            const int Lc = P.is_cc ? P.max_lag : P.brent_ixmax, NTc = pitch_extra_lags(Lc) ? 1 : (Lc + 256) / 256;
-            for (int tile = 0; tile < NTc; ++tile) {
-                int j_hi = P.nsamp_window + 240 + 256 * tile;
-                j_hi = j_hi < seg_len ? j_hi : seg_len;
-                const int j_lo = 256 * tile;
-                if (j_hi > j_lo) mfma_per_frame += (double)((j_hi - j_lo + 3) / 4);
-            }
-        }
+        // algorithmic flops of the correlation kernels, counted for equal-length clips (an upper bound for ragged batches);
+        // the candidate kernel's work is not counted
         // AC: two complex FFTs of M = nfft / 2 points (5 M log2 M flops each) and the spectrum pass (~30 flops per point)
         const double Mfft = 0.5 * (double)P.nfft;
         const double ac_flops = 2.0 * 5.0 * Mfft * log2(Mfft) + 30.0 * Mfft;
+        // CC: one complex FFT of ncc points, one of ncc / 2, the spectrum pass (~40 flops per point) and the prefix sums
+        const double cc_flops = 5.0 * ncc * log2((double)ncc) + 2.5 * ncc * log2(0.5 * ncc) + 40.0 * 0.5 * ncc + 4.0 * seg_len;
         ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s,
-                       (P.is_cc ? 2048.0 * mfma_per_frame : ac_flops) * (double)max_frames * (double)n_clips, 0.0);
+                       (P.is_cc ? cc_flops : ac_flops) * (double)max_frames * (double)n_clips, 0.0);
         for (int c0 = 0; c0 < n_clips; c0 += group) {
             const int nc = std::min(group, n_clips - c0);
             const ClipInfo* cig = (const ClipInfo*)clip_info + c0;
-            if (P.is_cc)
-                hipLaunchKernelGGL(pitch_corr_kernel, dim3(max_frames, nc), dim3(256), lds_corr, s, wav, cig, gpeak + c0, P,
-                                   (double*)workspace, rstride, max_frames);
-            else {
+            if (P.is_cc) {
+#define RSAF_CC_CASE(LG)                                                                                              \
+    case LG:                                                                                                          \
+        hipLaunchKernelGGL(pitch_cc_kernel<LG>, dim3((max_frames + CC_FRAMES_PER_WG - 1) / CC_FRAMES_PER_WG, nc),      \
+                           dim3(256), lds_corr, s, wav, cig, gpeak + c0, P,                                           \
+                           reinterpret_cast<const double2_t*>(twiddles), reinterpret_cast<const double2_t*>(twiddles2), \
+                           (double*)workspace, rstride, max_frames);                                                  \
+        break;
+                switch (log2n) {
+                    RSAF_CC_CASE(6) RSAF_CC_CASE(7) RSAF_CC_CASE(8) RSAF_CC_CASE(9) RSAF_CC_CASE(10) RSAF_CC_CASE(11) RSAF_CC_CASE(12)
+                    default: set_error("rsaf_mshds_pitch: unsupported FFT length"); return RSAF_ERR_ARG;
+                }
+#undef RSAF_CC_CASE
+            } else {
 #define RSAF_AC_CASE(LG)                                                                                              \
     case LG:                                                                                                          \
         hipLaunchKernelGGL(pitch_ac_kernel<LG>, dim3((max_frames + AC_FRAMES_PER_WG - 1) / AC_FRAMES_PER_WG, nc),      \

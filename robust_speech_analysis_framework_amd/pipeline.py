@@ -163,7 +163,11 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
                                  "candidate kernel's Chebyshev coefficients (fp64 MFMA); the frames scope also spans the "
                                  "latency-bound maxima / Brent phases, whose work is not in the FLOP count"
                                  if name == "mshds_pitch_ac_frames" else
-                                 "f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)") if fp64 else
+                                 ("f64 vector ALU: cross-correlation by one complex FFT of N >= window + lags points and one of N / 2 "
+                                  "per frame; the frames scope also spans the candidate kernel (Chebyshev coefficients on the fp64 "
+                                  "matrix pipe, depth-clipped direct sinc sums, Brent), whose work is not in the FLOP count"
+                                  if name == "mshds_pitch_cc_frames" else
+                                  "f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)")) if fp64 else
                                 ("fp32-accurate result from 6 bf16 MFMA products of three-way operand splits, fp32 accumulation"
                                  if split6 else "f32 MFMA")),
                  "algorithmic_flops_per_launch": rec["flops"] / rec["launches"]}
