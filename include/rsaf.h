@@ -268,8 +268,8 @@ int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, i
  * sinc_cheb (may be NULL): [2 * refine_depth][16] Chebyshev coefficients on frac in [0, 1] of the sinc-interpolation
  *   weights of tap offsets -(depth-1) .. depth (mshds.sinc_cheb_table); with it the Brent refinement evaluates a
  *   16-term polynomial per step instead of the 2*depth-term sum whenever no candidate's depth is clipped.
- * workspace: the per-frame correlation rows between the correlation kernel (one workgroup per frame, fp64 MFMA)
- *   and the candidate kernel (one wave per frame); at least rsaf_mshds_pitch_workspace_bytes_per_clip bytes, the
+ * workspace: the per-frame correlation rows between the correlation kernel (fp64 FFT auto- / cross-correlation, one
+ *   workgroup per 16 frames) and the candidate kernel (one wave per frame); at least rsaf_mshds_pitch_workspace_bytes_per_clip bytes, the
  *   clips are processed in groups of floor(workspace_bytes / that). */
 int64_t rsaf_mshds_pitch_workspace_bytes_per_clip(int max_frames, const double* params_host);
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
