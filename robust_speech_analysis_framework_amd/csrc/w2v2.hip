@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
     int ch[CPT];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        ch[k] = threadIdx.x + blockDim.x * k;
+        ch[k] = CPT * threadIdx.x + k;                      // adjacent channels: the planes go out as packed pairs
 #pragma unroll
         for (int j = 0; j < 10; ++j) wr[k][j] = w0[ch[k] * 10 + j];
         s[k] = 0.f; q[k] = 0.f;
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
         float xv[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) xv[j] = x[5 * t + j];
+        unsigned short hh[CPT], mm[CPT], ll[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             float y = 0.f;
@@ -207,14 +208,26 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
                 const float v = fmaf(y, a[k], b[k]);
                 const float gl = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 // the next layer's GEMM takes its A operand as three bf16 planes (gemm_bf16x6.hip)
-                const unsigned short hh = bf16_bits_w(gl);
-                const float r1 = gl - bf16_to_f32_w(hh);
-                const unsigned short mm = bf16_bits_w(r1);
-                const unsigned short ll = bf16_bits_w(r1 - bf16_to_f32_w(mm));
-                const int64_t o = ((int64_t)chunk * T0 + t) * C + ch[k];
-                outp[o] = hh; outp[plane + o] = mm; outp[2 * plane + o] = ll;
+                hh[k] = bf16_bits_w(gl);
+                const float r1 = gl - bf16_to_f32_w(hh[k]);
+                mm[k] = bf16_bits_w(r1);
+                ll[k] = bf16_bits_w(r1 - bf16_to_f32_w(mm[k]));
             } else {
                 s[k] += y; q[k] += y * y;
+            }
+        }
+        if (APPLY) {
+            const int64_t o = ((int64_t)chunk * T0 + t) * C + ch[0];
+            if (CPT % 2 == 0) {                             // 4-byte stores of channel pairs (C and ch[0] are even)
+#pragma unroll
+                for (int k = 0; k < CPT; k += 2) {
+                    *reinterpret_cast<unsigned*>(outp + o + k) = hh[k] | ((unsigned)hh[k + 1] << 16);
+                    *reinterpret_cast<unsigned*>(outp + plane + o + k) = mm[k] | ((unsigned)mm[k + 1] << 16);
+                    *reinterpret_cast<unsigned*>(outp + 2 * plane + o + k) = ll[k] | ((unsigned)ll[k + 1] << 16);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) { outp[o + k] = hh[k]; outp[plane + o + k] = mm[k]; outp[2 * plane + o + k] = ll[k]; }
             }
         }
     }
@@ -331,8 +344,8 @@ using af32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 typedef const __attribute__((address_space(1))) void* attn_glb_ptr;
 
-__global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
-                                                            int NH, int Hd, float scale) {
+__global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ planes,
+                                                            int64_t plane_stride, int T, int NH, int Hd, float scale) {
     constexpr int HD = 64, KB = 128, TILE = KB * HD;                            // one staged block: 32 KB
     extern __shared__ __attribute__((aligned(1024))) float kvbuf[];             // two blocks
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -458,14 +471,27 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
             if (b == 0 && nblk > 1) drain();
         }
     }
-    // C layout: column = lane & 31 (d), row = (e & 3) + 8 (e >> 2) + 4 h (query within the wave's 32)
-    float* op = out + (int64_t)win * T * Hd + (int64_t)head * HD;
+    // C layout: column = lane & 31 (d), row = (e & 3) + 8 (e >> 2) + 4 h (query within the wave's 32).  The output only
+    // exists as the three bf16 planes the out-projection GEMM reads (no fp32 copy, no separate split pass).  Stored from
+    // the MFMA layout with 2-byte stores (32 lanes = 64 contiguous bytes of a row and plane): the kernel sits at its
+    // 256-register budget, and a transposing epilogue through LDS (16-byte stores) pushed two score tiles into scratch.
+    unsigned short* op = planes + (int64_t)win * T * Hd + (int64_t)head * HD + l31;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (q < T) {
-            op[(int64_t)q * Hd + l31] = o0[e];
-            op[(int64_t)q * Hd + 32 + l31] = o1[e];
+            unsigned short* d0 = op + (int64_t)q * Hd;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float x = u == 0 ? o0[e] : o1[e];
+                const unsigned short a2 = bf16_bits_w(x);
+                const float r1 = x - bf16_to_f32_w(a2);
+                const unsigned short b2 = bf16_bits_w(r1);
+                const unsigned short c2 = bf16_bits_w(r1 - bf16_to_f32_w(b2));
+                d0[32 * u] = a2;
+                d0[plane_stride + 32 * u] = b2;
+                d0[2 * plane_stride + 32 * u] = c2;
+            }
         }
     }
 }
@@ -755,7 +781,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
                 attn_attr = true;
             }
             hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256),
-                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, ws + W.att, Tt, c.NH, Hd, scale);
+                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, Tt, c.NH, Hd, scale);
             RSAF_CHECK_HIP(hipGetLastError());
         } else {
         {   // S = scale * Q K^T per (chunk, head)
@@ -786,11 +812,12 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             p.sC1 = (int64_t)Tt * Hd; p.sC2 = hd;
             rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
+            // (the fused kernel writes the planes itself)
+            rc = launch_split_bf16x3(ws + W.att, rows * Hd, planes_at(W.attp), rows * Hd, s);
+            if (rc) return rc;
         }
         }
         {   // y = attn Wo^T + bo + x ; x = LN(y)
-            rc = launch_split_bf16x3(ws + W.att, rows * Hd, planes_at(W.attp), rows * Hd, s);
-            if (rc) return rc;
             rc = gemm6(planes_at(W.attp), rows * Hd, Hd, 0, planes_at(W.wp_o[l]), (int)rows, Hd, Hd, ws + W.y, 0, nullptr, 0, 0,
                        Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", false, true);
             if (rc) return rc;
