@@ -43,7 +43,7 @@ for M, N, K, tag, act, resid in shapes:
                                                     _lib.ptr(P) if P is not None else None, M * N, _lib.ptr(bias),
                                                     _lib.ptr(R) if resid else None, M, N, K, K, K, N, N, act, 1.0, None), "g6"))
     # the layout the Wav2Vec2 stage uses: weights always as k16 panels, A as panels where a GEMM epilogue produced it (ffn2)
-    a_pan = tag.startswith("ffn2")
+    a_pan = tag.startswith("ffn2") or os.environ.get("G6_ALL_A_PANELS") == "1"      # (what-if: every A operand in panels)
     wpp = torch.empty((3, N * K), dtype=torch.int16, device="cuda")
     _lib.check(lib.rsaf_split_bf16x3_panels(_lib.ptr(W), N, K, _lib.ptr(wpp), N * K, None), "split panels")
     app = ap
