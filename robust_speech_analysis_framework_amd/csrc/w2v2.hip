@@ -265,9 +265,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         float* __restrict__ out, int64_t rows, int D, float eps,
                                                         const int64_t* __restrict__ out_row_start, int T,
-                                                        unsigned short* __restrict__ planes, int64_t plane) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+                                                        unsigned short* __restrict__ planes, int64_t plane, int panel) {
+    // panel != 0: the planes go out in the k16-panel layout of `rows` rows (gemm_bf16x6.h), staged through LDS so that the
+    // four rows of the workgroup leave as full 128-byte lines per panel (scattering 8-byte pieces from the row layout cost
+    // this kernel + 77 %)
+    __shared__ __attribute__((aligned(16))) unsigned short stg[3][4][1024];
+    const int64_t row_raw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool valid = row_raw < rows;
+    if (!valid && !(planes && panel)) return;
+    const int64_t row = valid ? row_raw : rows - 1;
     const int lane = threadIdx.x & 63;
     // optional scatter: row r of chunk i lands at output row out_row_start[i] + r (vstack order)
     const int64_t orow = out_row_start ? out_row_start[row / T] + row % T : row;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float4 gg = g4[idx], bb = b4[idx];
             const float4 y = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
                                          (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
-            if (o4) o4[idx] = y;
+            if (o4 && valid) o4[idx] = y;
             if (planes) {                                  // the same values as three bf16 planes (A operand of the next GEMM)
                 const float yy[4] = {y.x, y.y, y.z, y.w};
                 unsigned short hh[4], mm[4], ll[4];
@@ -318,10 +324,34 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     mm[k] = bf16_bits_w(r1);
                     ll[k] = bf16_bits_w(r1 - bf16_to_f32_w(mm[k]));
                 }
-                unsigned short* pp = planes + row * D + 4 * idx;
-                *reinterpret_cast<uint2*>(pp) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-                *reinterpret_cast<uint2*>(pp + plane) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
-                *reinterpret_cast<uint2*>(pp + 2 * plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+                const uint2 ph = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+                const uint2 pm = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
+                const uint2 pl = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+                if (panel) {
+                    const int wq = threadIdx.x >> 6;
+                    *reinterpret_cast<uint2*>(&stg[0][wq][4 * idx]) = ph;
+                    *reinterpret_cast<uint2*>(&stg[1][wq][4 * idx]) = pm;
+                    *reinterpret_cast<uint2*>(&stg[2][wq][4 * idx]) = pl;
+                } else {
+                    unsigned short* pp = planes + row * D + 4 * idx;
+                    *reinterpret_cast<uint2*>(pp) = ph;
+                    *reinterpret_cast<uint2*>(pp + plane) = pm;
+                    *reinterpret_cast<uint2*>(pp + 2 * plane) = pl;
+                }
+            }
+        }
+    }
+    if (planes && panel) {
+        __syncthreads();
+        const int64_t row0 = (int64_t)blockIdx.x * 4;
+        const int chunks = D >> 1;                          // 16-byte pieces per plane: D / 16 panels x 4 rows x 2 halves
+        for (int c = threadIdx.x; c < chunks; c += 256) {
+            const int pn = c >> 3, r4 = (c & 7) >> 1, hf = c & 1;
+            if (row0 + r4 < rows) {
+#pragma unroll
+                for (int p3 = 0; p3 < 3; ++p3)
+                    *reinterpret_cast<uint4*>(planes + p3 * plane + (int64_t)pn * (rows * 16) + (row0 + r4) * 16 + 8 * hf) =
+                        *reinterpret_cast<const uint4*>(&stg[p3][r4][16 * pn + 8 * hf]);
             }
         }
     }
@@ -345,7 +375,7 @@ typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 typedef const __attribute__((address_space(1))) void* attn_glb_ptr;
 
 __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ planes,
-                                                            int64_t plane_stride, int T, int NH, int Hd, float scale) {
+                                                            int64_t plane_stride, int64_t n_rows, int T, int NH, int Hd, float scale) {
     constexpr int HD = 64, KB = 128, TILE = KB * HD;                            // one staged block: 32 KB
     extern __shared__ __attribute__((aligned(1024))) float kvbuf[];             // two blocks
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -475,12 +505,14 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
     // exists as the three bf16 planes the out-projection GEMM reads (no fp32 copy, no separate split pass).  Stored from
     // the MFMA layout with 2-byte stores (32 lanes = 64 contiguous bytes of a row and plane): the kernel sits at its
     // 256-register budget, and a transposing epilogue through LDS (16-byte stores) pushed two score tiles into scratch.
-    unsigned short* op = planes + (int64_t)win * T * Hd + (int64_t)head * HD + l31;
+    // k16 panels of n_rows rows (gemm_bf16x6.h): column head * 64 + 32 u + l31 -> panel 4 head + 2 u + (l31 >> 4), k = l31 & 15
+    const int64_t panel_sz = n_rows * 16;
+    unsigned short* op = planes + ((int64_t)(head * 4) + (l31 >> 4)) * panel_sz + ((int64_t)win * T) * 16 + (l31 & 15);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (q < T) {
-            unsigned short* d0 = op + (int64_t)q * Hd;
+            unsigned short* d0 = op + (int64_t)q * 16;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const float x = u == 0 ? o0[e] : o1[e];
@@ -488,9 +520,9 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
                 const float r1 = x - bf16_to_f32_w(a2);
                 const unsigned short b2 = bf16_bits_w(r1);
                 const unsigned short c2 = bf16_bits_w(r1 - bf16_to_f32_w(b2));
-                d0[32 * u] = a2;
-                d0[plane_stride + 32 * u] = b2;
-                d0[2 * plane_stride + 32 * u] = c2;
+                d0[2 * u * panel_sz] = a2;
+                d0[plane_stride + 2 * u * panel_sz] = b2;
+                d0[2 * plane_stride + 2 * u * panel_sz] = c2;
             }
         }
     }
@@ -552,12 +584,12 @@ __global__ __launch_bounds__(256) void regroup_kernel(const float4* __restrict__
 
 static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
               float eps, hipStream_t s, const int64_t* out_row_start = nullptr, int T = 1,
-              unsigned short* planes = nullptr) {
+              unsigned short* planes = nullptr, bool panel = false) {
     const int64_t blocks = (rows + 3) / 4;
     RSAF_CHECK_ARG(blocks <= 0x7fffffffLL, "too many rows");
     ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * (4 * (r ? 2 : 1) + (out ? 4 : 0) + (planes ? 6 : 0)));
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, r, g, b, out, rows, D, eps,
-                       out_row_start, T, planes, rows * D);
+                       out_row_start, T, planes, rows * D, panel ? 1 : 0);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }
@@ -675,9 +707,10 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     };
     // 0. weights of the dense layers as bf16 planes (once per call: 0.6 GB at base geometry, < 1 ms)
     {
-        // Every GEMM weight, and the one activation a GEMM epilogue produces (the GELU output, A of ffn2), travel in
-        // the k16-panel layout (gemm_bf16x6.h).  The planes LayerNorm and the attention split write stay row-major:
-        // scattering their rows into 48 panels cost those two kernels more (+77 % / +37 %) than the GEMMs gained.
+        // Every GEMM weight and every encoder activation that feeds a GEMM travel in the k16-panel layout
+        // (gemm_bf16x6.h): the ffn1 epilogue and the fused attention kernel address panels directly, LayerNorm stages
+        // its four rows through LDS so that they leave as full lines (scattering 8-byte pieces cost it + 77 %).  Only
+        // the conv activations stay row-major (strided im2col windows).
         auto split_wp = [&](int64_t src_off, int64_t nrows, int K, int64_t dst_off) {
             return launch_split_bf16x3_panels(Wt + src_off, nrows, K, planes_at(dst_off), nrows * K, s);
         };
@@ -732,10 +765,10 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         }
     }
     // 4. feature projection: LayerNorm (-> planes) + Linear
-    rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, 1, planes_at(W.lnfp));
+    rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, 1, planes_at(W.lnfp), true);
     if (rc) return rc;
     rc = gemm6(planes_at(W.lnfp), rows * C, C, 0, planes_at(W.wp_fp), (int)rows, Hd, C, ws + W.x, 0, nullptr, 0, 0,
-               Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", false, true);
+               Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", true, true);
     if (rc) return rc;
     // 5. positional conv embedding (grouped, weight norm folded), GELU, x = LN(x + pos)
     {
@@ -757,7 +790,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         p.bias = Wt + L.posb; p.sBias2 = cg; p.act = ACT_GELU;
         rc = launch_gemm_f32(p, s, "w2v2_posconv_gemm");
         if (rc) return rc;
-        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp));
+        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true);
         if (rc) return rc;
     }
     // 6. encoder layers (post-LN)
@@ -768,7 +801,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         const LayerOff& lo = L.layers[l];
         // fused q,k,v projection (A = the planes the previous LayerNorm wrote beside x)
         rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_qkv[l]), (int)rows, 3 * Hd, Hd, ws + W.qkv, 0, nullptr, 0, 0,
-                   Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", false, true);
+                   Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true, true);
         if (rc) return rc;
         static const bool fused_attn = [] { const char* e = getenv("RSAF_W2V2_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
         if (fused_attn && hd == 64 && Tt <= 256) {
@@ -781,7 +814,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
                 attn_attr = true;
             }
             hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256),
-                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, Tt, c.NH, Hd, scale);
+                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, rows, Tt, c.NH, Hd, scale);
             RSAF_CHECK_HIP(hipGetLastError());
         } else {
         {   // S = scale * Q K^T per (chunk, head)
@@ -813,27 +846,27 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
             // (the fused kernel writes the planes itself)
-            rc = launch_split_bf16x3(ws + W.att, rows * Hd, planes_at(W.attp), rows * Hd, s);
+            rc = launch_split_bf16x3_panels(ws + W.att, rows, Hd, planes_at(W.attp), rows * Hd, s);
             if (rc) return rc;
         }
         }
         {   // y = attn Wo^T + bo + x ; x = LN(y)
             rc = gemm6(planes_at(W.attp), rows * Hd, Hd, 0, planes_at(W.wp_o[l]), (int)rows, Hd, Hd, ws + W.y, 0, nullptr, 0, 0,
-                       Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", false, true);
+                       Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", true, true);
             if (rc) return rc;
-            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp));
+            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true);
             if (rc) return rc;
         }
         {   // feed forward: the GELU output only exists as planes (A of the second GEMM)
             rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_1[l]), (int)rows, c.I, Hd, nullptr, 0,
-                       planes_at(W.ffnp), rows * c.I, 0, Wt + lo.b1, nullptr, 1, ACT_GELU, "w2v2_gemm", false, true, true);
+                       planes_at(W.ffnp), rows * c.I, 0, Wt + lo.b1, nullptr, 1, ACT_GELU, "w2v2_gemm", true, true, true);
             if (rc) return rc;
             rc = gemm6(planes_at(W.ffnp), rows * c.I, c.I, 0, planes_at(W.wp_2[l]), (int)rows, Hd, c.I, ws + W.y, 0, nullptr, 0, 0,
                        Wt + lo.b2, x, 1, ACT_NONE, "w2v2_gemm", true, true);
             if (rc) return rc;
             const bool last = (l == c.L - 1);
             rc = ln(ws + W.y, nullptr, Wt + lo.ln2g, Wt + lo.ln2b, last ? out : x, rows, Hd, c.eps, s,
-                    last ? out_row_start : nullptr, Tt, last ? nullptr : planes_at(W.xp));
+                    last ? out_row_start : nullptr, Tt, last ? nullptr : planes_at(W.xp), true);
             if (rc) return rc;
         }
     }
