@@ -1,13 +1,10 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02
-timeout -k 10 900 python -m pytest tests/test_gemm_gpu.py tests/test_w2v2_gpu.py -m gpu -x -q 2>&1 | tail -3
-RSAF_W2V2_FUSED_ATTN=0 timeout -k 10 900 python -m pytest tests/test_w2v2_gpu.py -m gpu -x -q 2>&1 | tail -2
-timeout -k 10 600 python bench.py --config C3 --no-cpu-baseline --no-inclusive > gpurun_out/r02/bench_C3_x.json 2> gpurun_out/r02/bench_C3_x.err || { tail -5 gpurun_out/r02/bench_C3_x.err; exit 1; }
-python - <<'PY'
+mkdir -p gpurun_out/r02/final
+timeout -k 10 900 python bench.py --config e2e > gpurun_out/r02/final/bench_e2e.json 2> gpurun_out/r02/final/bench_e2e.err || { tail -5 gpurun_out/r02/final/bench_e2e.err; exit 1; }
+python - <<PY
 import json
-d=json.loads(open('gpurun_out/r02/bench_C3_x.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['fp32_equivalent_tflops'], d['roofline']['frac'])
-for k,v in sorted(d['kernels'].items(), key=lambda kv:-kv[1]['ms'])[:7]: print(k, v)
+d=json.loads(open('gpurun_out/r02/final/bench_e2e.json').read().strip().splitlines()[-1])
+print("e2e", d['value'], d['ms_per_step'], d['roofline'].get('kernel'), d['roofline'].get('frac'), d['roofline'].get('fp32_equivalent_tflops'), (d.get('inclusive_of_pcie_and_decode') or {}).get('value'), d['cpu_baseline'].get('value'), d['roofline'].get('traffic'))
 PY

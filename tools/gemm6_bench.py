@@ -42,8 +42,8 @@ for M, N, K, tag, act, resid in shapes:
     t6 = ev(lambda: _lib.check(lib.rsaf_gemm_bf16x6(_lib.ptr(ap), M * K, _lib.ptr(wp), N * K, _lib.ptr(C) if C is not None else None,
                                                     _lib.ptr(P) if P is not None else None, M * N, _lib.ptr(bias),
                                                     _lib.ptr(R) if resid else None, M, N, K, K, K, N, N, act, 1.0, None), "g6"))
-    # the layout the Wav2Vec2 stage uses: weights always as k16 panels, A as panels where a GEMM epilogue produced it (ffn2)
-    a_pan = tag.startswith("ffn2") or os.environ.get("G6_ALL_A_PANELS") == "1"      # (what-if: every A operand in panels)
+    # the layout the Wav2Vec2 encoder uses: both operands as k16 panels
+    a_pan = os.environ.get("G6_A_ROW_MAJOR") != "1"      # (G6_A_ROW_MAJOR=1: what the conv layers see: A row-major, B panels)
     wpp = torch.empty((3, N * K), dtype=torch.int16, device="cuda")
     _lib.check(lib.rsaf_split_bf16x3_panels(_lib.ptr(W), N, K, _lib.ptr(wpp), N * K, None), "split panels")
     app = ap
