@@ -1,10 +1,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02/final
-timeout -k 10 900 python bench.py --config e2e > gpurun_out/r02/final/bench_e2e.json 2> gpurun_out/r02/final/bench_e2e.err || { tail -5 gpurun_out/r02/final/bench_e2e.err; exit 1; }
-python - <<PY
-import json
-d=json.loads(open('gpurun_out/r02/final/bench_e2e.json').read().strip().splitlines()[-1])
-print("e2e", d['value'], d['ms_per_step'], d['roofline'].get('kernel'), d['roofline'].get('frac'), d['roofline'].get('fp32_equivalent_tflops'), (d.get('inclusive_of_pcie_and_decode') or {}).get('value'), d['cpu_baseline'].get('value'), d['roofline'].get('traffic'))
-PY
+mkdir -p gpurun_out/r02
+timeout -k 10 500 python tests/sweeps/stage_fuzz.py 8100 16 > gpurun_out/r02/stage_fuzz_r02.log 2>&1 || { tail -30 gpurun_out/r02/stage_fuzz_r02.log; exit 1; }
+tail -4 gpurun_out/r02/stage_fuzz_r02.log
+FUZZ_MIN_S=3 FUZZ_MAX_S=9 timeout -k 10 700 python tests/sweeps/mshds_fuzz.py 7300 24 > gpurun_out/r02/mshds_fuzz_long_r02.log 2>&1 || { tail -30 gpurun_out/r02/mshds_fuzz_long_r02.log; exit 1; }
+tail -3 gpurun_out/r02/mshds_fuzz_long_r02.log
