@@ -2,9 +2,13 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02
-timeout -k 10 900 python -m pytest tests/test_mshds_gpu.py -m gpu -q 2>&1 | tail -5
-timeout -k 10 600 python tests/sweeps/mshds_fuzz.py 7000 24 > gpurun_out/r02/mshds_fuzz_lazy.log 2>&1 || true
-grep -c "MISMATCH" gpurun_out/r02/mshds_fuzz_lazy.log || true
-tail -2 gpurun_out/r02/mshds_fuzz_lazy.log
-timeout -k 10 600 python tools/pitch_phase.py 64 > gpurun_out/r02/pitch_phase_fft.txt 2>&1 || { tail -20 gpurun_out/r02/pitch_phase_fft.txt; exit 1; }
-grep "^cc_hnr" gpurun_out/r02/pitch_phase_fft.txt | grep "stop 0\|stop 5"
+for i in 1 2; do
+timeout -k 10 900 python bench.py --config C2 --no-cpu-baseline --no-inclusive > gpurun_out/r02/bench_C2_x.json 2> gpurun_out/r02/bench_C2_x.err || { tail -5 gpurun_out/r02/bench_C2_x.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02/bench_C2_x.json').read().strip().splitlines()[-1])
+k=d['kernels']
+print(d['value'], d['ms_per_step'], 'cc', k['mshds_pitch_cc_frames']['ms'], 'ac', k['mshds_pitch_ac_frames']['ms'])
+PY
+done
+git stash -q 2>/dev/null || true
