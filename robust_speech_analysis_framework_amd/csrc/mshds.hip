@@ -474,6 +474,13 @@ __device__ __forceinline__ void fft_load_twiddles(FftTw<LOG2M>& R, const double2
     }
 }
 
+// Between the first two radix-4 stages element e lives at slot fsw(e) (low two bits XOR-ed with bits 3-4): stage 0 writes
+// elements 4 j + r from lane j, a 64-byte lane stride = 4-way bank conflict for the 16-byte stores of 8 consecutive lanes
+// (PMC: 30 % of the LDS-active cycles of the autocorrelation kernel were conflict cycles, the LDS busy 65 % of the time);
+// swizzled, the 8 lanes hit 8 different slots of the 128-byte bank row, and the unit-stride reads of stage 1 stay
+// conflict-free (the permutation stays inside aligned blocks of 4 slots).  Every other pass sees the natural order.
+__device__ __forceinline__ int fsw(int e) { return e ^ ((e >> 3) & 3); }
+
 // forward complex FFT of M points from `a` (result in the returned buffer, `a` or `b`); every stage ends at a barrier
 template <int LOG2M>
 __device__ __forceinline__ double2_t* fft_stockham(double2_t* a, double2_t* b, const FftTw<LOG2M>& R,
@@ -490,7 +497,9 @@ __device__ __forceinline__ double2_t* fft_stockham(double2_t* a, double2_t* b, c
             const int j = tid + 256 * bq;
             if (T4 >= 256 || j < T4) {
                 const int k = j & (Ns - 1);
-                double2_t v0 = src[j], v1 = src[j + T4], v2 = src[j + 2 * T4], v3 = src[j + 3 * T4];
+                const bool rs = st == 1;                                  // stage 0 stored swizzled
+                double2_t v0 = src[rs ? fsw(j) : j], v1 = src[rs ? fsw(j + T4) : j + T4], v2 = src[rs ? fsw(j + 2 * T4) : j + 2 * T4],
+                          v3 = src[rs ? fsw(j + 3 * T4) : j + 3 * T4];
                 if (st > 0) {
                     if (PL::PRE) {
                         const int o = ((st - 1) * PL::BPT4 + bq) * 3;
@@ -508,10 +517,11 @@ __device__ __forceinline__ double2_t* fft_stockham(double2_t* a, double2_t* b, c
                 const double2_t d = v1 - v3;
                 const double2_t a3 = double2_t{d.y, -d.x};             // (v1 - v3) * (-i)
                 const int j0 = ((j - k) << 2) + k;
-                dst[j0] = a0 + a2;
-                dst[j0 + Ns] = a1 + a3;
-                dst[j0 + 2 * Ns] = a0 - a2;
-                dst[j0 + 3 * Ns] = a1 - a3;
+                const bool ws = st == 0 && PL::N4 >= 2;
+                dst[ws ? fsw(j0) : j0] = a0 + a2;
+                dst[ws ? fsw(j0 + Ns) : j0 + Ns] = a1 + a3;
+                dst[ws ? fsw(j0 + 2 * Ns) : j0 + 2 * Ns] = a0 - a2;
+                dst[ws ? fsw(j0 + 3 * Ns) : j0 + 3 * Ns] = a1 - a3;
             }
         }
         __syncthreads();
