@@ -26,6 +26,12 @@ struct Gemm6Params {
     // a quarter of 32 lines).  a_panel: A (R = M; lda, sA unused, nz = 1); b_panel: B (R = N; ldb unused);
     // cp_panel: the plane output, laid out as the A operand of the next GEMM (R = M, its K = N; ldcp unused).
     int a_panel, b_panel, cp_panel;
+    // Two-level batches (grouped convolution: batch z = z1 * nz2 + z2, z2 = group): A += z1 sA + z2 sA2, B += z2 sB2,
+    // C += z1 sC + z2 sC2, bias += z2 sBias2.  nz2 <= 1: one level (B and bias shared by every batch).  Only with the
+    // fp32 output, without residual, A row-major.
+    int nz2;
+    int64_t sA2, sB2, sC2, sBias2;
+    int b_panel_rows;        // b_panel: rows of the panels B lives in (0 = N); a group's rows are a slice of them
 };
 
 int launch_gemm_bf16x6(const Gemm6Params& p, hipStream_t stream, const char* tag);

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     const int n0 = (in_grp / gsz) * BN;
     const int wm0 = (wave / CFG::WN) * (32 * TM), wn0 = (wave % CFG::WN) * (32 * TN);
     const int64_t z = blockIdx.y;
+    const int64_t z1 = p.nz2 > 1 ? z / p.nz2 : z, z2 = p.nz2 > 1 ? z % p.nz2 : 0;   // (window, group) of a grouped convolution
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         if (isA) {
             const int rr = (m0 + row < p.M) ? row : p.M - 1 - m0;         // rows past M re-read the last row
             const int64_t rs = p.a_panel ? 16 : p.lda;                    // row stride; k-tile stride below (elements)
-            sbase[i] = p.A + z * p.sA + (int64_t)m0 * rs;
+            sbase[i] = p.A + z1 * p.sA + z2 * p.sA2 + (int64_t)m0 * rs;
             voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
             pstride[i] = p.a_plane;
             kstride[i] = p.a_panel ? (int64_t)p.M * 16 : 16;
@@ -159,10 +160,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         } else {
             const int rr = (n0 + row < p.N) ? row : p.N - 1 - n0;
             const int64_t rs = p.b_panel ? 16 : p.ldb;
-            sbase[i] = p.B + (int64_t)n0 * rs;
+            sbase[i] = p.B + z2 * p.sB2 + (int64_t)n0 * rs;
             voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
             pstride[i] = p.b_plane;
-            kstride[i] = p.b_panel ? (int64_t)p.N * 16 : 16;
+            kstride[i] = p.b_panel ? (int64_t)(p.b_panel_rows > 0 ? p.b_panel_rows : p.N) * 16 : 16;
             ldsoff[i] = 3 * A_PLANE + jj * 512;
         }
     }
@@ -211,7 +212,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     }
     if (grpB) __builtin_amdgcn_s_barrier();
     int st = 0;                                              // stage of k-tile kt
-    static_assert(NI == NW * IPW, "every wave issues the same number of DMA instructions");
     for (int kt = 0; kt < nk; ++kt) {
         if (!grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A: its share of k-tile kt (issued one k-tile ago)
         __builtin_amdgcn_s_barrier();
@@ -234,11 +234,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
 #pragma unroll
             for (int d = 0; d < NDMA; ++d) {
                 const int i = d / 3, pl = d % 3;
-                const bool isA_ = (wave + NW * i) < CFG::A_INSTR;
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
-                    (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                if (live[i]) {
+                    const bool isA_ = (wave + NW * i) < CFG::A_INSTR;
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_global_load_lds(G6_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
+                        (lds_ptr6)(smem6 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         bf16x8 afp[3];                                       // A fragments of m-tile HM, fetched in the first half
@@ -274,9 +276,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             if (mt == HM - 1) {
                 // middle barrier: group B's share of k-tile kt + 1 (issued 1.5 k-tiles ago) has landed; its share of
                 // k-tile kt + 2, issued at the head of this k-tile, stays in flight
-                if (grpB) {
-                    if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (grpB) {                                  // (the count is this wave's own: the last instruction slot may be empty)
+                    if (!refill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (live[IPW - 1]) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (IPW - 1) > 0 ? 3 * (IPW - 1) : 0) : "memory");
                 }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         float bias16[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b4 = (p.bias && c_ok) ? *reinterpret_cast<const float4*>(p.bias + gc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b4 = (p.bias && c_ok) ? *reinterpret_cast<const float4*>(p.bias + z2 * p.sBias2 + gc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
             bias16[4 * q] = b4.x; bias16[4 * q + 1] = b4.y; bias16[4 * q + 2] = b4.z; bias16[4 * q + 3] = b4.w;
         }
 #pragma unroll
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             }
             if (ok) {
                 if (OUT_F32) {
-                    float* Ct = p.C + z * p.sC + (int64_t)tm * p.ldc + tn + prow * (int)p.ldc + pcol;
+                    float* Ct = p.C + z1 * p.sC + z2 * p.sC2 + (int64_t)tm * p.ldc + tn + prow * (int)p.ldc + pcol;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         *reinterpret_cast<float4*>(Ct + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -439,6 +442,9 @@ int launch_gemm_bf16x6(const Gemm6Params& p, hipStream_t stream, const char* tag
     // algorithmic FLOPs of the contraction (2 M N K); the matrix pipe executes six bf16 products per term
     ProfScope prof(tag ? tag : "gemm_bf16x6", stream, 2.0 * p.M * (double)p.N * p.K * p.nz, 0.0);
     using CfgA = G6Cfg<4, 2, 2, 4, 3, 1>;                // 256 x 256 (a 256 x 128 / two-workgroup variant measured 10-50 % slower)
+    using CfgN = G6Cfg<2, 1, 4, 2, 3, 1>;                // 256 x 64: N <= 64 (the 48-wide groups of the positional convolution)
+    RSAF_CHECK_ARG(p.nz2 <= 1 || (p.C && !p.Cp && !p.R && !p.a_panel && p.nz % p.nz2 == 0),
+                   "two-level batches: fp32 output only, no residual, A row-major, nz a multiple of nz2");
 #define G6_LAUNCH_CFG(CFG, ACT, F32, PL, HR)                                                                            \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
@@ -460,6 +466,7 @@ int launch_gemm_bf16x6(const Gemm6Params& p, hipStream_t stream, const char* tag
     if (p.act == ACT_NONE && f32o && !plo && !hr) G6_LAUNCH(ACT_NONE, true, false, false);
     else if (p.act == ACT_NONE && f32o && !plo && hr) G6_LAUNCH(ACT_NONE, true, false, true);
     else if (p.act == ACT_GELU && !f32o && plo && !hr) G6_LAUNCH(ACT_GELU, false, true, false);
+    else if (p.act == ACT_GELU && f32o && !plo && !hr && p.N <= 64) G6_LAUNCH_CFG(CfgN, ACT_GELU, true, false, false);
     else if (p.act == ACT_GELU && f32o && !plo && !hr) G6_LAUNCH(ACT_GELU, true, false, false);
     else if (p.act == ACT_NONE && !f32o && plo && !hr) G6_LAUNCH(ACT_NONE, false, true, false);
     else if (p.act == ACT_NONE && f32o && plo && !hr) G6_LAUNCH(ACT_NONE, true, true, false);

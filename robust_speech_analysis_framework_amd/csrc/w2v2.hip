@@ -90,7 +90,7 @@ static void chunk_lengths(int len, int T[7]) {
 // planes.  Offsets are in floats; a planes buffer of N elements takes 3 N uint16 = 1.5 N floats.
 struct Workspace {
     int64_t xn, part, ab, P, Q, c6, lnfp, x, xp, y, att, attp, xg, qkv, S, ffnp, wp, total;
-    int64_t wp_conv[6], wp_fp;
+    int64_t wp_conv[6], wp_fp, wp_pos;
     std::vector<int64_t> wp_qkv, wp_o, wp_1, wp_2;
     int slabs, Tp, G;
 };
@@ -122,13 +122,14 @@ static Workspace make_ws(const Cfg& c, int n, int len) {
     w.y = take((int64_t)n * Tt * c.Hd);
     w.att = take((int64_t)n * Tt * c.Hd);
     w.attp = take(planes_floats((int64_t)n * Tt * c.Hd));
-    w.xg = take((int64_t)n * (Tt + c.PK - 1) * c.Hd);
+    w.xg = take(planes_floats((int64_t)n * (Tt + c.PK - 1) * c.Hd));     // fp32 or three bf16 planes (1.5 x)
     w.qkv = take((int64_t)n * Tt * 3 * c.Hd);
     w.S = take((int64_t)n * c.NH * Tt * w.Tp);
     w.ffnp = take(planes_floats((int64_t)n * Tt * c.I));
     // weight planes (split once per forward call)
     for (int i = 0; i < 6; ++i) w.wp_conv[i] = take(planes_floats((int64_t)c.C * KERN[i + 1] * c.C));
     w.wp_fp = take(planes_floats((int64_t)c.Hd * c.C));
+    w.wp_pos = take(planes_floats((int64_t)c.Hd * c.PK * (c.Hd / c.PG)));
     for (int l = 0; l < c.L; ++l) {
         w.wp_qkv.push_back(take(planes_floats((int64_t)3 * c.Hd * c.Hd)));
         w.wp_o.push_back(take(planes_floats((int64_t)c.Hd * c.Hd)));
@@ -582,6 +583,36 @@ __global__ __launch_bounds__(256) void regroup_kernel(const float4* __restrict__
     }
 }
 
+// the same regrouping as three bf16 planes (A operand of the positional convolution on the bf16x6 GEMM)
+__global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __restrict__ x, unsigned short* __restrict__ xg,
+                                                             int64_t plane, int n, int T, int Hd4, int G, int K) {
+    const int cg4 = Hd4 / G;
+    const int TT = T + K - 1;
+    const int64_t total = (int64_t)n * G * TT * cg4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % cg4);
+        int64_t r = i / cg4;
+        const int tt = (int)(r % TT); r /= TT;
+        const int g = (int)(r % G);
+        const int64_t chunk = r / G;
+        const int t = tt - K / 2;
+        const float4 v = (t >= 0 && t < T) ? x[(chunk * T + t) * Hd4 + g * cg4 + ci] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        unsigned short hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hh[k] = bf16_bits_w(vv[k]);
+            const float r1 = vv[k] - bf16_to_f32_w(hh[k]);
+            mm[k] = bf16_bits_w(r1);
+            ll[k] = bf16_bits_w(r1 - bf16_to_f32_w(mm[k]));
+        }
+        unsigned short* pp = xg + 4 * i;
+        *reinterpret_cast<uint2*>(pp) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+        *reinterpret_cast<uint2*>(pp + plane) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
+        *reinterpret_cast<uint2*>(pp + 2 * plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+    }
+}
+
 static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
               float eps, hipStream_t s, const int64_t* out_row_start = nullptr, int T = 1,
               unsigned short* planes = nullptr, bool panel = false) {
@@ -717,6 +748,9 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         for (int i = 0; i < 6; ++i)
             if ((rc = split_wp(L.conv[i], C, KERN[i + 1] * C, W.wp_conv[i]))) return rc;
         if ((rc = split_wp(L.fpw, Hd, C, W.wp_fp))) return rc;
+        if ((Hd / c.PG) % 16 == 0) {                       // positional conv on the bf16x6 GEMM: [G cg][PK cg] as panels of Hd rows
+            if ((rc = split_wp(L.posw, Hd, c.PK * (Hd / c.PG), W.wp_pos))) return rc;
+        }
         for (int l = 0; l < c.L; ++l) {
             const LayerOff& lo = L.layers[l];
             if ((rc = split_wp(lo.wqkv, 3 * Hd, Hd, W.wp_qkv[l]))) return rc;
@@ -775,6 +809,26 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         const int cg = Hd / c.PG;
         const int TT = Tt + c.PK - 1;
         const int64_t tot4 = (int64_t)n * TT * (Hd / 4);
+        if (cg % 16 == 0) {
+            // grouped conv as a two-level batched GEMM on the bf16x6 kernel's 256 x 64 tile: batch (window, group), M = T rows
+            // (overlapping windows of the regrouped sequence: lda = cg), N = cg output channels, K = PK cg
+            const int64_t plane = (int64_t)n * TT * Hd;
+            {
+                ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 40);
+                hipLaunchKernelGGL(regroup_planes_kernel, dim3((unsigned)std::min<int64_t>((tot4 + 255) / 256, 4096)), dim3(256),
+                                   0, s, reinterpret_cast<const float4*>(ws + W.x), reinterpret_cast<unsigned short*>(planes_at(W.xg)),
+                                   plane, n, Tt, Hd / 4, c.PG, c.PK);
+                RSAF_CHECK_HIP(hipGetLastError());
+            }
+            Gemm6Params p{};
+            p.A = planes_at(W.xg); p.a_plane = plane; p.lda = cg; p.sA = (int64_t)c.PG * TT * cg; p.sA2 = (int64_t)TT * cg;
+            p.B = planes_at(W.wp_pos); p.b_plane = (int64_t)Hd * c.PK * cg; p.ldb = 16; p.b_panel = 1; p.b_panel_rows = Hd; p.sB2 = (int64_t)cg * 16;
+            p.C = ws + W.y; p.ldc = Hd; p.sC = (int64_t)Tt * Hd; p.sC2 = cg;
+            p.bias = Wt + L.posb; p.sBias2 = cg;
+            p.M = Tt; p.N = cg; p.K = c.PK * cg; p.nz = n * c.PG; p.nz2 = c.PG; p.act = ACT_GELU; p.alpha = 1.0f;
+            rc = launch_gemm_bf16x6(p, s, "w2v2_posconv_gemm");
+            if (rc) return rc;
+        } else {
         {
             ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 32);
             hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)std::min<int64_t>((tot4 + 255) / 256, 4096)), dim3(256),
@@ -790,6 +844,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         p.bias = Wt + L.posb; p.sBias2 = cg; p.act = ACT_GELU;
         rc = launch_gemm_f32(p, s, "w2v2_posconv_gemm");
         if (rc) return rc;
+        }
         rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true);
         if (rc) return rc;
     }

@@ -152,7 +152,7 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
                 "share_of_event_time": round(rec["ms"] / max(sum(r["ms"] for r in prof.values()), 1e-30), 4)}
         if rec["flops"] > 0:
             fp64 = name.startswith("mshds_")
-            split6 = name == "w2v2_gemm"
+            split6 = name in ("w2v2_gemm", "w2v2_posconv_gemm")      # both on gemm_bf16x6 (base geometry)
             peak = f64_peak_tflops if fp64 else (BF16_MFMA_PEAK_TFLOPS if split6 else mfma_f32_peak_tflops)
             alg = rec["flops"] / (rec["ms"] * 1e-3) / 1e12
             # the bf16x6 GEMM executes six bf16 MFMA products per algorithmic multiply-add: its roofline is the bf16 matrix
