@@ -89,6 +89,23 @@ def test_base_geometry_window_matches_oracle(rsaf_lib):
     assert _rel(tail[0], wo.forward(sd, cfg, wo.hf_normalize(clip[100:32100])[None])[0]) < TOL
 
 
+def test_group_width_not_multiple_of_16_matches_oracle(rsaf_lib):
+    """The positional convolution runs on the bf16x6 GEMM when its group width is a multiple of 16 (base: 48, the small
+    golden geometry: 16) and on the fp32 MFMA GEMM otherwise: a geometry with 8-wide groups (and 16-wide heads: the
+    unfused attention with its panel split) against the oracle."""
+    from robust_speech_analysis_framework_amd.w2v2 import W2V2Engine
+    cfg = W2V2Config(conv_dim=(32,) * 7, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                     num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=8)
+    sd = random_state_dict(cfg, seed=3)
+    eng = W2V2Engine(cfg, sd)
+    clip = synth.synth_clip(71, 3.0)
+    got = _windows(eng, clip, [0, 8000], 32000)
+    for j, s in enumerate((0, 8000)):
+        ref = wo.forward(sd, cfg, wo.hf_normalize(clip[s:s + 32000])[None])[0]
+        assert got[j].shape == ref.shape
+        assert _rel(got[j], ref) < TOL, (j, _rel(got[j], ref))
+
+
 def test_30s_clip_frame_count_and_batch_independence(rsaf_lib):
     import torch
     from robust_speech_analysis_framework_amd.w2v2 import W2V2Engine
