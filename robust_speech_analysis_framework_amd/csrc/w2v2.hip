@@ -760,8 +760,10 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         }
     }
     // 1-3. feature encoder, CONV_GROUP windows at a time (its activations are the large ones: 15 999 x 512 per window)
-    for (int g0 = 0; g0 < n; g0 += W.G) {
-        const int g = std::min(W.G, n - g0);
+    // window groups of (almost) equal size: ceil(n / G) groups instead of full ones and a small remainder
+    const int n_groups = (n + W.G - 1) / W.G, gstep = (n + n_groups - 1) / n_groups;
+    for (int g0 = 0; g0 < n; g0 += gstep) {
+        const int g = std::min(gstep, n - g0);
         // 1. per-chunk normalisation (HF feature extractor)
         {
             ProfScope prof("w2v2_normalize", s, 0.0, (double)g * chunk_len * 4 * 3);

@@ -92,13 +92,14 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--config", default="e2e")
     ap.add_argument("--clips", type=int, default=1000)
-    ap.add_argument("--windows", type=int, default=2048)
+    ap.add_argument("--windows", type=int, default=2048)            # --w2v2-chunks-per-call of the run (recorded; bench.py matches it)
+    ap.add_argument("--shape-windows", type=int, default=0)         # windows per call the engine actually used (balanced sub-batches)
     ap.add_argument("--kernel", default="w2v2_gemm")
     ap.add_argument("--command", default="")
     a = ap.parse_args()
     fe, wr = collect(a.fetch_dir, "FETCH_SIZE"), collect(a.write_dir, "WRITE_SIZE")
     gemm = [k for k in set(fe) | set(wr) if "gemm_bf16x6" in k]
-    shapes = w2v2_shapes(a.windows)
+    shapes = w2v2_shapes(a.shape_windows or a.windows)
     per_shape, tot_f, tot_w, tot_l = [], 0.0, 0.0, 0
     grids = sorted({g for k in gemm for g in list(fe.get(k, {})) + list(wr.get(k, {}))}, key=str)
     # collapse (grid, previous grid) keys that the shape table does not distinguish
@@ -129,7 +130,7 @@ def main():
         tot_l += n
     per_shape.sort(key=lambda r: -r["launches"] * r["hbm_bytes_per_launch_fetch_x2_plus_write"])
     doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: {a.command}",
-           "run": {"kernel": a.kernel, "config": a.config, "clips": a.clips, "w2v2_windows_per_call": a.windows,
+           "run": {"kernel": a.kernel, "config": a.config, "clips": a.clips, "w2v2_windows_per_call": a.windows, "w2v2_windows_per_call_actual": a.shape_windows or a.windows,
                    "kernel_sha": kernel_sha()},
            "gemm_kernels": gemm_names, "gemm_launches": tot_l, "fetch_KB_raw": tot_f, "write_KB": tot_w,
            "traffic_bytes_per_launch_fetch_x2_plus_write": (2.0 * tot_f + tot_w) * 1024.0 / max(tot_l, 1),
