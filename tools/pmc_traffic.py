@@ -68,7 +68,8 @@ def w2v2_shapes(n_windows, chunk_len=80000, conv_group=512):
     out = {}
     tiles = lambda m, n: ((m + 255) // 256) * ((n + 255) // 256)           # noqa: E731
     conv_grid = {}
-    gw = min(conv_group, n_windows)
+    n_groups = (n_windows + conv_group - 1) // conv_group
+    gw = (n_windows + n_groups - 1) // n_groups                  # balanced window groups (w2v2.hip)
     for i in range(1, 7):
         k = 3 if i <= 4 else 2
         conv_grid[i] = tiles(T[i], C) * gw * 512
