@@ -359,10 +359,16 @@ int rsaf_pcm_to_mono_f32(const void* pcm, int sample_width, int n_channels, int6
  * taps (resample.sinc_hann_taps).  Replaces src/foundation_model_extractor.py:93-94. */
 int rsaf_resample_sinc_hann(const float* in, int64_t n_in, const float* taps, const int* tap_start, int n_phase, int orig,
                             int taps_per_phase, float* out, int64_t n_out, rsaf_stream_t stream);
-/* Praat Sound.resample(fs_out, precision) as one windowed sinc; n_out = round(n_in / fs_in * fs_out).
+/* Praat Sound.resample(fs_out, precision) as Praat does it (published Sound_resample): when the rate goes down, a
+ * brick-wall low-pass of the whole sound by a real FFT over the first power of two >= n_in + 2000 samples (bins from
+ * floor(fs_out / fs_in * nfft) in Praat's packed order cleared), then NUM_interpolate_sinc(precision) on the new sample
+ * grid centred in the old time domain; n_out = round(n_in / fs_in * fs_out).  `work`: device scratch of at least
+ * rsaf_resample_praat_work_bytes(...) bytes (0 when the rate goes up: may be NULL).  Sounds of up to 2^24 - 2000
+ * samples.  Not restated: the special case of a ratio of exactly 2 (Sound_upsample), which takes the general branch.
  * Replaces snd.resample(16000, 50), src/mshds_extractor.py:419. */
+int64_t rsaf_resample_praat_work_bytes(int64_t n_in, double fs_in, double fs_out);
 int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_out, int precision, float* out,
-                        int64_t n_out, rsaf_stream_t stream);
+                        int64_t n_out, void* work, int64_t work_bytes, rsaf_stream_t stream);
 
 /* ---- session aggregation and batch assembly behind the extractors ---------------------- */
 /* out[seg][col][2] = {mean, sample standard deviation (n-1)} over the rows row_index[seg_off[seg] .. seg_off[seg+1])

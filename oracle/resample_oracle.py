@@ -6,9 +6,9 @@ PARITY UNPINNED: ``torchaudio`` (reference pin 2.5.1) and Praat are absent from 
   ``sinc_interp_hann``, ``lowpass_filter_width=6``, ``rolloff=0.99``; kernel evaluated in float64 on a float32
   phase grid, stored as float32, applied as a strided correlation on the zero-padded waveform, output cut to
   ``ceil(new * n / orig)`` samples.  Written as a direct double loop over (frame, phase), not as a convolution call.
-* ``resample_praat`` restates ``Sound.resample(16000, 50)`` (``src/mshds_extractor.py:419``) with the free choice
-  documented in ``mshds_oracle.resample_10k``: Praat's whole-sound FFT low-pass and sinc interpolation are folded
-  into one raised-cosine windowed sinc.
+* ``resample_praat`` restates ``Sound.resample(16000, 50)`` (``src/mshds_extractor.py:419``) from Praat's published
+  source: whole-sound FFT brick-wall low-pass when the rate goes down (``praat_fft_lowpass``), then
+  ``NUM_interpolate_sinc`` of depth 50 on the re-centred sample grid (``praat_interpolate_sinc``).
 """
 from __future__ import annotations
 
@@ -51,26 +51,107 @@ def resample_sinc_hann(x, orig: int, new: int):
     return out.reshape(-1)[:target].astype(np.float32)
 
 
-def resample_praat(x, fs_in: float, fs_out: float = 16000.0, depth: int = 50):
+ANTI_TURN_AROUND = 1000      # zero samples Praat puts on either side of the sound before the FFT low-pass
+
+
+def praat_fft_lowpass(x, upfactor: float):
+    """The anti-aliasing step of Praat's ``Sound_resample`` (published source, ``fon/Sound.cpp``), taken when
+    ``upfactor = new_rate * dx < 1``: the sound is copied into a zero buffer of ``nfft`` samples (the first power of two
+    that holds it plus 1 000 zeros on either side), transformed by ``NUMrealft``, the packed array is cleared from the
+    1-based position ``floor(upfactor * nfft)`` to the end and at position 2 (the Nyquist bin), and transformed back.
+    In the packed array position 1 is the DC bin, position 2 the Nyquist bin, positions 2k + 1 / 2k + 2 the real /
+    imaginary part of bin k: when the first cleared position is even, the bin it falls in keeps its real part."""
     x = np.asarray(x, dtype=np.float64)
     n = len(x)
+    nfft = 1
+    while nfft < n + 2 * ANTI_TURN_AROUND:
+        nfft *= 2
+    data = np.zeros(nfft)
+    data[ANTI_TURN_AROUND:ANTI_TURN_AROUND + n] = x
+    spec = np.fft.rfft(data)
+    first_cleared = int(np.floor(upfactor * nfft))
+    k = np.arange(nfft // 2 + 1)
+    re = np.where(2 * k + 1 < first_cleared, spec.real, 0.0)
+    im = np.where(2 * k + 2 < first_cleared, spec.imag, 0.0)
+    re[0] = spec[0].real if first_cleared > 1 else 0.0
+    im[0] = 0.0
+    re[-1] = im[-1] = 0.0
+    return np.fft.irfft(re + 1j * im, nfft)[ANTI_TURN_AROUND:ANTI_TURN_AROUND + n]
+
+
+def praat_interpolate_sinc(y, pos, depth: int):
+    """``NUM_interpolate_sinc`` (published source, ``melder/NUMinterpol.cpp``) at the real 0-based positions ``pos`` of the
+    samples ``y``: the depth is cut to the samples that exist on either side; depth 0 -> nearest sample, 1 -> linear,
+    2 -> cubic; otherwise a sinc at the rate of ``y`` under a raised cosine that reaches zero one sample beyond the
+    outermost sample used on each side (so the window is asymmetric unless the position lies midway)."""
+    y = np.asarray(y, dtype=np.float64)
+    pos = np.asarray(pos, dtype=np.float64)
+    n = len(y)
+    out = np.empty(len(pos))
+    x = pos + 1.0                                        # Praat's 1-based index
+    midleft = np.floor(x).astype(np.int64)
+    midright = midleft + 1
+    md = np.minimum(np.minimum(depth, midright - 1), n - midleft)
+    beyond = x > n
+    before = x < 1
+    exact = x == midleft
+    easy = beyond | before | exact
+    out[beyond] = y[n - 1]
+    out[before] = y[0]
+    sel = exact & ~beyond & ~before
+    out[sel] = y[midleft[sel] - 1]
+    nearest = ~easy & (md <= 0)
+    out[nearest] = y[np.clip(np.floor(x[nearest] + 0.5).astype(np.int64) - 1, 0, n - 1)]
+    lin = ~easy & (md == 1)
+    yl, yr = y[midleft[lin] - 1], y[np.clip(midright[lin] - 1, 0, n - 1)]
+    out[lin] = yl + (x[lin] - midleft[lin]) * (yr - yl)
+    cub = ~easy & (md == 2)
+    if cub.any():
+        ml, mr = midleft[cub], midright[cub]
+        yl, yr = y[ml - 1], y[mr - 1]
+        dyl = 0.5 * (yr - y[ml - 2])
+        dyr = 0.5 * (y[mr] - yl)
+        fil, fir = x[cub] - ml, mr - x[cub]
+        out[cub] = yl * fir + yr * fil - fil * fir * (0.5 * (dyr - dyl) + (fil - 0.5) * (dyl + dyr - 2.0 * (yr - yl)))
+    gen = np.nonzero(~easy & (md > 2))[0]
+    k = np.arange(depth)
+    sgn = np.where(k % 2 == 0, 1.0, -1.0)
+    for i0 in range(0, len(gen), 4096):
+        g = gen[i0:i0 + 4096]
+        xg, ml, mr, d = x[g], midleft[g], midright[g], md[g]
+        left, right = mr - d, ml + d
+        acc = np.zeros(len(g))
+        for a0, span, first, step in ((np.pi * (xg - ml), xg - left + 1.0, ml, -1), (np.pi * (mr - xg), right - xg + 1.0, mr, 1)):
+            a = a0[:, None] + np.pi * k[None, :]
+            aa = (a0 / span)[:, None] + (np.pi / span)[:, None] * k[None, :]
+            w = 0.5 * np.sin(a0)[:, None] * sgn[None, :] / a * (1.0 + np.cos(aa))
+            idx = np.clip(first[:, None] + step * k[None, :] - 1, 0, n - 1)
+            acc += np.sum(np.where(k[None, :] < d[:, None], y[idx] * w, 0.0), axis=1)
+        out[g] = acc
+    return out
+
+
+def sound_resample(x, x1_in: float, dx_in: float, xmin: float, xmax: float, fs_out: float, depth: int):
+    """Praat's ``Sound_resample`` of the samples ``x`` (first sample at time ``x1_in``, period ``dx_in``, domain
+    ``[xmin, xmax]``): FFT low-pass when the rate goes down, new sample grid centred in the domain, sinc
+    interpolation of the given depth.  Returns (samples float64, x1_out, dx_out).  Not restated: the special
+    case of a rate ratio of exactly 2 (``Sound_upsample``), which goes through the general branch here."""
+    x = np.asarray(x, dtype=np.float64)
+    upfactor = fs_out * dx_in
+    m = int(np.floor((xmax - xmin) * fs_out + 0.5))
+    dxo = 1.0 / fs_out
+    x1o = 0.5 * (xmin + xmax - (m - 1) / fs_out)
+    if abs(upfactor - 1.0) < 1e-6:
+        return x.copy(), x1_in, dx_in
+    src = praat_fft_lowpass(x, upfactor) if upfactor < 1.0 else x
+    pos = (x1o + np.arange(max(m, 0)) * dxo - x1_in) / dx_in
+    return praat_interpolate_sinc(src, pos, depth), x1o, dxo
+
+
+def resample_praat(x, fs_in: float, fs_out: float = 16000.0, depth: int = 50):
+    x = np.asarray(x, dtype=np.float64)
     if fs_in == fs_out:
         return x.astype(np.float32)
-    duration = n / fs_in
-    m = int(np.floor(duration * fs_out + 0.5))
-    dxi, dxo = 1.0 / fs_in, 1.0 / fs_out
-    x1o = 0.5 * (duration - (m - 1) * dxo)
-    ratio = min(1.0, fs_out / fs_in)
-    out = np.empty(m)
-    k = np.arange(-depth, depth + 2)               # every |d| <= depth + 1 for any fractional position
-    for i0 in range(0, m, 4096):
-        idx = np.arange(i0, min(m, i0 + 4096))
-        pos = (x1o + idx * dxo - 0.5 * dxi) / dxi
-        base = np.floor(pos).astype(np.int64)
-        j = base[:, None] + k[None, :]
-        d = pos[:, None] - j
-        w = ratio * np.sinc(ratio * d) * (0.5 + 0.5 * np.cos(np.pi * d / (depth + 1.0)))
-        w = np.where(np.abs(d) <= depth + 1.0, w, 0.0)
-        ok = (j >= 0) & (j < n)
-        out[idx] = np.sum(np.where(ok, x[np.clip(j, 0, n - 1)] * w, 0.0), axis=1)
-    return out.astype(np.float32)
+    dxi = 1.0 / fs_in
+    y, _, _ = sound_resample(x, 0.5 * dxi, dxi, 0.0, len(x) * dxi, fs_out, depth)
+    return y.astype(np.float32)

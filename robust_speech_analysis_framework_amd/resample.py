@@ -76,9 +76,10 @@ def resample_sinc_hann(x, orig: int, new: int, device="cuda", stream=None):
 def resample_praat(x, fs_in: float, fs_out: float = 16000.0, precision: int = 50, device="cuda", stream=None):
     """Praat ``Sound.resample(fs_out, precision)`` of one mono clip -> torch float32 [round(n/fs_in*fs_out)] on the device.
 
-    The result is handed to the MSHDS kernels as if it had been read from a 16 kHz file (first sample at half a
-    sample period); Praat centres the new sample grid in the old time domain, a shift of less than a quarter
-    sample that this build does not model."""
+    Praat's own two steps: whole-sound FFT brick-wall low-pass when the rate goes down, then ``NUM_interpolate_sinc`` on
+    the new sample grid centred in the old time domain.  The result is handed to the MSHDS kernels as if it had been read
+    from a 16 kHz file (first sample at half a sample period): the offset of the centred grid against that, less than a
+    quarter sample, is not carried into the analyses."""
     import torch
     lib = _lib.load()
     _lib.require_gpu()
@@ -88,6 +89,8 @@ def resample_praat(x, fs_in: float, fs_out: float = 16000.0, precision: int = 50
     n_in = int(xd.numel())
     n_out = int(math.floor(n_in / float(fs_in) * float(fs_out) + 0.5))
     out = torch.empty(max(n_out, 1), dtype=torch.float32, device=xd.device)
+    wb = int(lib.rsaf_resample_praat_work_bytes(n_in, float(fs_in), float(fs_out)))
+    work = torch.empty(max(wb, 8) // 8, dtype=torch.float64, device=xd.device)
     _lib.check(lib.rsaf_resample_praat(_lib.ptr(xd), n_in, float(fs_in), float(fs_out), int(precision), _lib.ptr(out),
-                                       n_out, _lib.stream_ptr(stream)), "rsaf_resample_praat")
+                                       n_out, _lib.ptr(work), wb, _lib.stream_ptr(stream)), "rsaf_resample_praat")
     return out[:n_out]

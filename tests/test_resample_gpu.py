@@ -33,7 +33,7 @@ def test_sinc_hann_edges_and_identity(rsaf_lib):
         assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-6
 
 
-@pytest.mark.parametrize("fs", [44100, 48000, 8000])
+@pytest.mark.parametrize("fs", [44100, 48000, 32000, 22050, 8000, 11025])
 def test_praat_resample_matches_restatement(rsaf_lib, fs):
     from robust_speech_analysis_framework_amd.resample import resample_praat
     x = _clip(fs, 0.6, k=301)
@@ -41,6 +41,33 @@ def test_praat_resample_matches_restatement(rsaf_lib, fs):
     ref = ro.resample_praat(x, float(fs), 16000.0, 50)
     assert got.shape == ref.shape                                     # round(n / fs * 16000), exact
     assert np.abs(got - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max())   # float32 output of float64 sums
+
+
+@pytest.mark.parametrize("fs,n,depth", [(44100, 1, 50), (44100, 2, 50), (44100, 7, 50), (48000, 47, 50), (48000, 49, 3), (44100, 2096, 50),
+                                        (44100, 2097, 50), (22050, 30721, 50), (48000, 260145, 50), (44100, 1046577, 500),
+                                        (24000, 5000, 1), (20000, 5000, 2)])
+def test_praat_resample_sizes_and_depths(rsaf_lib, fs, n, depth):
+    """Every shape of the four-step transform (nfft 2^11 ... 2^21: 2 ... 512 rows), the clipped interpolation depths at the
+    edges (nearest / linear / cubic), odd and even first-cleared positions."""
+    from robust_speech_analysis_framework_amd.resample import resample_praat
+    rng = np.random.Generator(np.random.PCG64(n))
+    x = (0.3 * rng.standard_normal(n)).astype(np.float32)             # white: energy at every cleared and kept bin
+    got = resample_praat(x, fs, 16000, depth).cpu().numpy()
+    ref = ro.resample_praat(x, float(fs), 16000.0, depth)
+    assert got.shape == ref.shape                                     # (1 sample at 44.1 kHz -> 0 samples: Praat refuses, empty here)
+    assert len(ref) == 0 or np.abs(got - ref).max() <= 3e-7, np.abs(got - ref).max()
+
+
+def test_praat_resample_rejects_missing_workspace(rsaf_lib):
+    import torch
+    from robust_speech_analysis_framework_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(4000, device="cuda")
+    out = torch.zeros(2000, device="cuda")
+    assert lib.rsaf_resample_praat_work_bytes(4000, 32000.0, 16000.0) == 8192 * 8 + 4000 * 8
+    assert lib.rsaf_resample_praat_work_bytes(4000, 8000.0, 16000.0) == 0
+    rc = lib.rsaf_resample_praat(_lib.ptr(x), 4000, 32000.0, 16000.0, 50, _lib.ptr(out), 2000, None, 0, _lib.stream_ptr(None))
+    assert rc != 0 and b"workspace" in lib.rsaf_last_error()
 
 
 def test_mshds_dropin_accepts_44k1_files(rsaf_lib, tmp_path):

@@ -36,3 +36,79 @@ def test_praat_resample_grid_and_passband():
     assert np.abs(y[100:-100] - np.sin(2 * np.pi * 700.0 * to)[100:-100]).max() < 2e-3
     up = ro.resample_praat(x[:2000], 8000.0, 16000.0, 50)                           # upsampling keeps the full band
     assert len(up) == 4000
+
+
+def _interpolate_sinc_scalar(y, x, depth):
+    """NUM_interpolate_sinc written out sample by sample on Praat's 1-based index (the loop form of the published source)."""
+    n = len(y)
+    midleft = int(np.floor(x)); midright = midleft + 1
+    if x > n: return y[n - 1]
+    if x < 1: return y[0]
+    if x == midleft: return y[midleft - 1]
+    md = min(depth, midright - 1, n - midleft)
+    if md <= 0: return y[int(np.floor(x + 0.5)) - 1]
+    if md == 1: return y[midleft - 1] + (x - midleft) * (y[midright - 1] - y[midleft - 1])
+    if md == 2:
+        yl, yr = y[midleft - 1], y[midright - 1]
+        dyl, dyr = 0.5 * (yr - y[midleft - 2]), 0.5 * (y[midright] - yl)
+        fil, fir = x - midleft, midright - x
+        return yl * fir + yr * fil - fil * fir * (0.5 * (dyr - dyl) + (fil - 0.5) * (dyl + dyr - 2 * (yr - yl)))
+    left, right = midright - md, midleft + md
+    res = 0.0
+    a = np.pi * (x - midleft); halfsina = 0.5 * np.sin(a); aa = a / (x - left + 1.0); daa = np.pi / (x - left + 1.0)
+    for ix in range(midleft, left - 1, -1):
+        res += y[ix - 1] * (halfsina / a * (1.0 + np.cos(aa)))
+        a += np.pi; aa += daa; halfsina = -halfsina
+    a = np.pi * (midright - x); halfsina = 0.5 * np.sin(a); aa = a / (right - x + 1.0); daa = np.pi / (right - x + 1.0)
+    for ix in range(midright, right + 1):
+        res += y[ix - 1] * (halfsina / a * (1.0 + np.cos(aa)))
+        a += np.pi; aa += daa; halfsina = -halfsina
+    return res
+
+
+def test_praat_interpolate_sinc_matches_the_loop_form_including_the_clipped_depths():
+    rng = np.random.Generator(np.random.PCG64(11))
+    y = rng.standard_normal(40)
+    pos = np.concatenate([rng.uniform(-2.0, 42.0, 300), np.arange(-1, 41, dtype=np.float64), [0.25, 0.75, 1.5, 2.5, 37.5, 38.5, 38.99]])
+    for depth in (1, 2, 3, 7, 50):
+        got = ro.praat_interpolate_sinc(y, pos, depth)
+        ref = np.array([_interpolate_sinc_scalar(y, p + 1.0, depth) for p in pos])
+        assert np.abs(got - ref).max() <= 1e-13, depth
+    assert np.array_equal(ro.praat_interpolate_sinc(y, np.arange(40.0), 50), y)        # on a sample: that sample
+
+
+def test_praat_fft_lowpass_is_a_brick_wall_in_praats_packed_order():
+    n = 6192                                                                         # nfft = 8192 exactly
+    nfft = 8192
+    upfactor = 0.5                                                                   # first cleared position 4096 = Im of bin 2047
+    # the mask written out per position of NUMrealft's packed array
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = rng.standard_normal(n)
+    y = ro.praat_fft_lowpass(x, upfactor)
+    data = np.zeros(nfft); data[1000:1000 + n] = x
+    packed = np.zeros(nfft)                                                          # NUMrealft order: DC, Nyquist, Re 1, Im 1, ...
+    spec = np.fft.rfft(data)
+    packed[0], packed[1] = spec[0].real, spec[-1].real
+    packed[2::2], packed[3::2] = spec[1:-1].real, spec[1:-1].imag
+    packed[int(np.floor(upfactor * nfft)) - 1:] = 0.0                                # 1-based position -> 0-based
+    packed[1] = 0.0
+    back = np.zeros(nfft // 2 + 1, dtype=np.complex128)
+    back[0] = packed[0]
+    back[1:-1] = packed[2::2] + 1j * packed[3::2]
+    ref = np.fft.irfft(back, nfft)[1000:1000 + n]
+    assert np.abs(y - ref).max() <= 1e-12
+    assert back[2047].real != 0.0 and back[2047].imag == 0.0                         # the half-cleared bin of an even position
+    assert np.abs(y).max() > 0.1 and len(y) == n
+    assert ro.praat_fft_lowpass(x[:10], 0.3).shape == (10,)                          # nfft = 2048 for the shortest sounds
+
+
+def test_sound_resample_removes_what_lies_above_the_new_nyquist():
+    fs = 48000.0
+    n = 24000
+    t = (np.arange(n) + 0.5) / fs
+    low, high = np.sin(2 * np.pi * 1234.0 * t), np.sin(2 * np.pi * 9500.0 * t)
+    y_both = ro.resample_praat(low + high, fs, 16000.0, 50).astype(np.float64)
+    y_low = ro.resample_praat(low, fs, 16000.0, 50).astype(np.float64)
+    assert np.abs(y_both - y_low)[300:-300].max() < 2e-3                             # 9.5 kHz is gone, not folded to 6.5 kHz
+    same = ro.resample_praat(low, 16000.0, 16000.0, 50)
+    assert np.array_equal(same, low.astype(np.float32))
