@@ -298,11 +298,14 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
  * 50 Hz on a 10 kHz resampling of the clip, To Pitch (cc) (rsaf_mshds_pitch, is_cc), To PointProcess (cc),
  * then F1,B1,F2,B2 linearly interpolated at every pulse -> mean and sample SD.
  * resample_info: device array of {int64 sample_off; int64 out_off; double pos0; double x1o; int32 n_in;
- * int32 n_out; int32 table; int32 pad} (48 bytes); tables: [n_tables][5][2*depth+1] float64 windowed-sinc
- * weights; phase_base: [n_tables][5] int32 = floor(pos0 + 1.6 r) (output m = 5q + r reads input 8q + base).
+ * int32 n_out; int32 table; int32 pad} (48 bytes).  The 10 kHz resampling is Praat's Sound_resample(10000, 500):
+ * `lowpassed` = the clips after rsaf_praat_lowpass_batch (same layout as wav, float64); tables: [n_tables][5][2*depth+1]
+ * float64 NUM_interpolate_sinc weights at full depth (tap k belongs to input base + k - depth); phase_base:
+ * [n_tables][5] int32 = floor(pos0 + 1.6 r) (output m = 5q + r reads input 8q + base); outputs whose depth Praat
+ * clips at the ends of the sound are evaluated directly.
  * frames_out: per frame {double f[5]; double b[5]} (NaN padded); pulses: [n_clips][max_pulses] times (unsorted);
  * stats out[clip][8] = mean/SD of F1, B1, F2, B2 in the reference's column order. */
-int rsaf_mshds_resample10k(const float* wav, const void* resample_info, int n_clips, int max_out,
+int rsaf_mshds_resample10k(const double* lowpassed, const void* resample_info, int n_clips, int max_out,
                            const double* tables, const int* phase_base, int depth, double* out,
                            rsaf_stream_t stream);
 int rsaf_mshds_formants(const double* y10, const void* resample_info, const void* clip_info, int n_clips,
@@ -367,6 +370,13 @@ int rsaf_resample_sinc_hann(const float* in, int64_t n_in, const float* taps, co
  * samples.  Not restated: the special case of a ratio of exactly 2 (Sound_upsample), which takes the general branch.
  * Replaces snd.resample(16000, 50), src/mshds_extractor.py:419. */
 int64_t rsaf_resample_praat_work_bytes(int64_t n_in, double fs_in, double fs_out);
+/* The low-pass step alone over a batch of sounds (the 10 kHz resampling inside To Formant (burg)): sigs = device array of
+ * {int64 in_off; int64 out_off; int64 work_off; int32 n; int32 lg} (32 bytes): n float samples at in + in_off ->
+ * n float64 samples at out + out_off, through 2^(lg-1) complex numbers at work + work_off (2^lg = first power of two
+ * >= n + 2000, 11 <= lg <= lg_max <= 24); upfactor = new rate * old sample period < 1; work_complex = complex numbers
+ * in `work`. */
+int rsaf_praat_lowpass_batch(const float* in, const void* sigs, int n_sigs, int lg_max, double upfactor, void* work,
+                             int64_t work_complex, double* out, rsaf_stream_t stream);
 int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_out, int precision, float* out,
                         int64_t n_out, void* work, int64_t work_bytes, rsaf_stream_t stream);
 

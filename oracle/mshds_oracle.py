@@ -989,30 +989,12 @@ RS_RATE = 10000.0
 
 
 def resample_10k(x):
-    """Band-limited resampling 16 kHz -> 10 kHz.  Praat low-passes with a brick-wall FFT filter over the
-    whole sound and then sinc-interpolates (depth 500); here both steps are one raised-cosine windowed
-    sinc of half-width 500 input samples with its cut-off at the new Nyquist (documented free choice:
-    it avoids a 2^19-point FFT per clip and differs only in the transition band at 5 kHz)."""
+    """``Sound_resample (me, 10000, 500)`` at the head of Praat's ``Sound_to_Formant_burg``: whole-sound FFT brick-wall
+    low-pass, new sample grid centred in the sound's domain, ``NUM_interpolate_sinc`` of depth 500
+    (``resample_oracle.sound_resample``)."""
+    from .resample_oracle import sound_resample
     x = np.asarray(x, dtype=np.float64)
-    n = len(x)
-    duration = n * DX
-    m = int(np.floor(duration * RS_RATE + 0.5))
-    dxo = 1.0 / RS_RATE
-    x1o = 0.5 * (duration - (m - 1) * dxo)
-    ratio = RS_RATE / FS                                           # 0.625 = relative cut-off
-    out = np.empty(m)
-    k = np.arange(-RS_DEPTH, RS_DEPTH + 1)
-    for i0 in range(0, m, 4096):
-        idx = np.arange(i0, min(m, i0 + 4096))
-        pos = (x1o + idx * dxo - 0.5 * DX) / DX                    # real index into x
-        base = np.floor(pos).astype(np.int64)
-        j = base[:, None] + k[None, :]
-        d = pos[:, None] - j
-        w = ratio * np.sinc(ratio * d) * (0.5 + 0.5 * np.cos(np.pi * d / (RS_DEPTH + 1.0)))
-        w = np.where(np.abs(d) <= RS_DEPTH + 1.0, w, 0.0)
-        ok = (j >= 0) & (j < n)
-        out[idx] = np.sum(np.where(ok, x[np.clip(j, 0, n - 1)] * w, 0.0), axis=1)
-    return out, x1o, dxo
+    return sound_resample(x, 0.5 * DX, DX, 0.0, len(x) * DX, RS_RATE, RS_DEPTH)
 
 
 def _burg(x, m):

@@ -21,6 +21,7 @@
 #include <mutex>
 #include <vector>
 
+#include "praat_interp.h"
 #include "rsaf_common.h"
 
 // Frame times sit exactly on half-sample positions, where Praat's nearest/low index rounding is
@@ -1704,10 +1705,11 @@ struct ResampleInfo {        // per clip (host-built), 48 bytes
 };
 
 // 320-thread workgroup = 64 consecutive q x 5 phases (wave r owns phase r, so its weight row is a wave-
-// uniform LDS broadcast); the input tile is staged once in LDS as float with a 33/32 skew so that the
-// stride-8 reads of a wave fall on 32 different banks.
+// uniform LDS broadcast); the tile of the low-passed sound is staged once in LDS.  The tables hold NUM_interpolate_sinc's
+// weights at full depth for the five fractional positions of the 8 : 5 grid; outputs whose depth Praat clips (within
+// `depth` input samples of either end) are recomputed by resample_edge_kernel.
 constexpr int RS_QT = 64;
-__global__ __launch_bounds__(320) void resample_kernel(const float* __restrict__ wav, const ResampleInfo* __restrict__ ri,
+__global__ __launch_bounds__(320) void resample_kernel(const double* __restrict__ lp, const ResampleInfo* __restrict__ ri,
                                                        const double* __restrict__ tables,
                                                        const int* __restrict__ phase_base, int depth,
                                                        double* __restrict__ out) {
@@ -1717,7 +1719,7 @@ __global__ __launch_bounds__(320) void resample_kernel(const float* __restrict__
     if (5 * q0 >= c.n_out) return;
     const int taps = 2 * depth + 1;
     double* wl = reinterpret_cast<double*>(smem_raw);                 // [5][taps]
-    float* xs = reinterpret_cast<float*>(wl + 5 * taps);             // skewed input tile
+    double* xs = wl + 5 * taps;                                       // input tile
     const int tid = threadIdx.x;
     const int* pb = phase_base + c.table * 5;
     int bmin = pb[0], bmax = pb[0];
@@ -1726,10 +1728,10 @@ __global__ __launch_bounds__(320) void resample_kernel(const float* __restrict__
     const int span = 8 * (RS_QT - 1) + (bmax - bmin) + taps;
     const double* wg = tables + (int64_t)c.table * 5 * taps;
     for (int i = tid; i < 5 * taps; i += 320) wl[i] = wg[i];
-    const float* x = wav + c.sample_off;
+    const double* x = lp + c.sample_off;
     for (int i = tid; i < span; i += 320) {
         const int j = lo + i;
-        xs[i + (i >> 5)] = (j >= 0 && j < c.n_in) ? x[j] : 0.0f;
+        xs[i] = (j >= 0 && j < c.n_in) ? x[j] : 0.0;
     }
     __syncthreads();
     const int r = tid >> 6, ql = tid & 63;
@@ -1737,11 +1739,24 @@ __global__ __launch_bounds__(320) void resample_kernel(const float* __restrict__
     const double* w = wl + r * taps;
     const int i0 = 8 * ql + pb[r] - bmin;                             // tile index of tap 0
     double acc = 0.0;
-    for (int k = 0; k < taps; ++k) {
-        const int i = i0 + k;
-        acc += (double)xs[i + (i >> 5)] * w[k];
-    }
+    for (int k = 0; k < taps; ++k) acc += xs[i0 + k] * w[k];
     if (m < c.n_out) out[c.out_off + m] = acc;
+}
+
+// the first and last `n_edge` output samples of every clip by the general routine when their depth is clipped (or the
+// position falls outside the sound)
+__global__ __launch_bounds__(256) void resample_edge_kernel(const double* __restrict__ lp, const ResampleInfo* __restrict__ ri,
+                                                            int depth, int n_edge, double ratio_in_out, double* __restrict__ out) {
+    const ResampleInfo c = ri[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 2 * n_edge) return;
+    const int m = e < n_edge ? e : c.n_out - 1 - (e - n_edge);
+    if (m < 0 || m >= c.n_out) return;
+    const double x = c.pos0 + (double)m * ratio_in_out + 1.0;         // Praat's 1-based real index
+    const int64_t midleft = (int64_t)floor(x);
+    const bool full = x >= 1.0 && x <= (double)c.n_in && midleft >= depth && (int64_t)c.n_in - midleft >= depth;
+    if (full) return;
+    out[c.out_off + m] = praat_interpolate_sinc(lp + c.sample_off, (int64_t)c.n_in, x, depth);
 }
 
 // ---- Formant (burg): one wave per frame -----------------------------------------------------------------------
@@ -2708,22 +2723,26 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
     return RSAF_OK;
 }
 
-int rsaf_mshds_resample10k(const float* wav, const void* resample_info, int n_clips, int max_out, const double* tables,
+int rsaf_mshds_resample10k(const double* lowpassed, const void* resample_info, int n_clips, int max_out, const double* tables,
                            const int* phase_base, int depth, double* out, rsaf_stream_t stream) {
-    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_out >= 0 && depth >= 1, "bad argument");
+    RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_out >= 0 && depth >= 3, "bad argument");
     if (n_clips == 0 || max_out == 0) return RSAF_OK;
-    RSAF_CHECK_ARG(wav && resample_info && tables && phase_base && out, "NULL pointer");
+    RSAF_CHECK_ARG(lowpassed && resample_info && tables && phase_base && out, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     const int taps = 2 * depth + 1;
     const int span = 8 * (RS_QT - 1) + 8 + taps;                       // phase bases differ by < 8
-    const size_t lds = (size_t)5 * taps * sizeof(double) + (size_t)(span + span / 32 + 2) * sizeof(float);
+    const size_t lds = (size_t)5 * taps * sizeof(double) + (size_t)(span + 2) * sizeof(double);
     RSAF_CHECK_ARG(lds <= 150 * 1024, "resampler depth too large for LDS");
     if (lds > 48 * 1024)
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof("mshds_resample10k", s, 0.0, 0.0);
     const int nq = (max_out + 4) / 5;
-    hipLaunchKernelGGL(resample_kernel, dim3((nq + RS_QT - 1) / RS_QT, n_clips), dim3(320), lds, s, wav,
+    hipLaunchKernelGGL(resample_kernel, dim3((nq + RS_QT - 1) / RS_QT, n_clips), dim3(320), lds, s, lowpassed,
                        (const ResampleInfo*)resample_info, tables, phase_base, depth, out);
+    RSAF_CHECK_HIP(hipGetLastError());
+    const int n_edge = (int)((double)(depth + 2) * 0.625) + 3;         // output samples within depth + 2 input samples of an end
+    hipLaunchKernelGGL(resample_edge_kernel, dim3((2 * n_edge + 255) / 256, n_clips), dim3(256), 0, s, lowpassed,
+                       (const ResampleInfo*)resample_info, depth, n_edge, 1.6, out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -11,11 +11,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdint>
 #include <map>
 #include <mutex>
 #include <vector>
 
+#include "praat_interp.h"
 #include "rsaf_common.h"
 
 namespace rsaf {
@@ -63,12 +65,37 @@ __device__ __forceinline__ int bitrev(int v, int bits) { return bits ? (int)(__b
 
 struct LpTables {
     const c64* tw;      // [4096]  e^(-2 pi i j / 4096)
-    const c64* lo;      // [4096]  e^(-2 pi i j / nfft)
-    const c64* hi;      // [nfft / 4096 or 1]  e^(-2 pi i 4096 j / nfft)
+    const c64* lo;      // [4096]  e^(-2 pi i j / nfft_max)
+    const c64* hi;      // [nfft_max / 4096 or 1]  e^(-2 pi i 4096 j / nfft_max)
+    int lg_max;         // the tables belong to nfft_max = 2^lg_max; a shorter transform strides through them
 };
 
-// e^(-2 pi i p / nfft), 0 <= p < nfft
-__device__ __forceinline__ c64 w_nfft(const LpTables& T, int64_t p) {
+// one sound of a batch: n samples at in + in_off -> out + out_off, transform of 2^lg samples in work + work_off
+struct LpSig {
+    int64_t in_off, out_off, work_off;
+    int n, lg;
+};
+static_assert(sizeof(LpSig) == 32, "LpSig layout");
+struct LpBatch {
+    const LpSig* sigs;  // device array indexed by blockIdx.y, or nullptr: `one`
+    LpSig one;
+    double upfactor;
+};
+
+struct LpGeom { int log1, log2, C; };
+__host__ __device__ inline LpGeom lp_geom(int lg) {
+    LpGeom g;
+    const int logM = lg - 1;                            // lg >= 11
+    g.log2 = logM - 1 < 11 ? logM - 1 : 11;             // rows of at most 2 048 points, at least 2 rows
+    g.log1 = logM - g.log2;
+    g.C = 8;
+    while (g.C > 1 && ((int64_t)g.C << g.log1) > 4096) g.C >>= 1;
+    return g;
+}
+
+// e^(-2 pi i p / 2^lg), 0 <= p < 2^lg
+__device__ __forceinline__ c64 w_nfft(const LpTables& T, int64_t p, int lg) {
+    p <<= T.lg_max - lg;
     return cmul(T.lo[p & (TW_N - 1)], T.hi[p >> TW_LOG]);
 }
 
@@ -132,11 +159,19 @@ __device__ void lds_fft(c64* buf, int logL, int nseq, int es, int ss, const c64*
 // Column pass.  Forward: samples -> LDS [N1][C] -> transform over n1 -> times W_M^(n2 k1) -> work.  Inverse: work times
 // the conjugate twiddle -> inverse transform -> samples (scaled by 1 / M) to `out`.  grid = (N2 / C), C columns each.
 template <bool INV>
-__global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ x, int64_t nx, c64* __restrict__ work,
-                                                      double* __restrict__ out, int log1, int log2, int C, LpTables T) {
+__global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ in, c64* __restrict__ work_base,
+                                                      double* __restrict__ out_base, LpBatch B, LpTables T) {
     extern __shared__ c64 lp_lds[];
+    const LpSig sg = B.sigs ? B.sigs[blockIdx.y] : B.one;
+    const LpGeom g = lp_geom(sg.lg);
+    const int log1 = g.log1, log2 = g.log2, C = g.C;
     const int N1 = 1 << log1, N2 = 1 << log2;
     const int c0 = blockIdx.x * C;
+    if (c0 >= N2) return;
+    const float* x = in + sg.in_off;
+    c64* work = work_base + sg.work_off;
+    double* out = out_base + sg.out_off;
+    const int64_t nx = sg.n;
     const double scale = 1.0 / (double)((int64_t)N1 << log2);
     for (int e = threadIdx.x; e < N1 * C; e += 256) {
         const int r = e / C, c = e - r * C, n2 = c0 + c;
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ 
             lp_lds[e] = v;
         } else {
             const int64_t k1 = bitrev(r, log1);
-            lp_lds[e] = cmulc(work[((int64_t)r << log2) + n2], w_nfft(T, 2 * k1 * n2));
+            lp_lds[e] = cmulc(work[((int64_t)r << log2) + n2], w_nfft(T, 2 * k1 * n2, sg.lg));
         }
     }
     __syncthreads();
@@ -157,7 +192,7 @@ __global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ 
         const int r = e / C, c = e - r * C, n2 = c0 + c;
         if (!INV) {
             const int64_t k1 = bitrev(r, log1);
-            work[((int64_t)r << log2) + n2] = cmul(lp_lds[e], w_nfft(T, 2 * k1 * n2));
+            work[((int64_t)r << log2) + n2] = cmul(lp_lds[e], w_nfft(T, 2 * k1 * n2, sg.lg));
         } else {
             const int64_t i0 = 2 * (((int64_t)r << log2) + n2) - ANTI_TURN_AROUND;
             const c64 v = lp_lds[e];
@@ -169,8 +204,8 @@ __global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ 
 
 // bins k and M - k of the real transform from Z[k], Z[M - k]; Praat's clearing of the packed array (1-based position
 // 2k + 1 = real part, 2k + 2 = imaginary part of bin k, cleared from position `first_cleared`); back to Z'[k], Z'[M - k]
-__device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int64_t M, int64_t first_cleared, const LpTables& T) {
-    const c64 w = w_nfft(T, k);
+__device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int64_t M, int64_t first_cleared, const LpTables& T, int lg) {
+    const c64 w = w_nfft(T, k, lg);
     const c64 E = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
     const c64 O = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
     const c64 Tt = mul_pi(cmul(w, O));
@@ -188,10 +223,16 @@ __device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int6
 }
 
 // Row pass: workgroup b owns the logical rows k1 = b and N1 - b (stored at their bit-reversed positions), b = 0 .. N1 / 2.
-__global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work, int log1, int log2, int64_t first_cleared, LpTables T) {
+__global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work_base, LpBatch batch, LpTables T) {
     extern __shared__ c64 lp_lds[];
+    const LpSig sg = batch.sigs ? batch.sigs[blockIdx.y] : batch.one;
+    const LpGeom g = lp_geom(sg.lg);
+    const int log1 = g.log1, log2 = g.log2, lg = sg.lg;
     const int N1 = 1 << log1, N2 = 1 << log2;
+    if ((int)blockIdx.x > N1 / 2) return;
+    c64* work = work_base + sg.work_off;
     const int64_t M = (int64_t)N1 << log2;
+    const int64_t first_cleared = (int64_t)floor(batch.upfactor * (double)((int64_t)1 << lg));   // Praat: floor(upfactor * nfft)
     const int ka = blockIdx.x, kb = (N1 - ka) & (N1 - 1);
     const bool two = ka != kb;
     c64* rowA = work + ((int64_t)bitrev(ka, log1) << log2);
@@ -208,7 +249,7 @@ __global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work, in
         for (int k2 = threadIdx.x; k2 < N2; k2 += 256) {
             const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
             c64 zk = A[pa], zm = B[pb];
-            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T);
+            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
             A[pa] = zk;
             B[pb] = zm;
         }
@@ -216,7 +257,7 @@ __global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work, in
         for (int k2 = threadIdx.x; k2 < N2 / 2; k2 += 256) {
             const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
             c64 zk = A[pa], zm = A[pb];
-            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T);
+            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
             A[pa] = zk;
             A[pb] = zm;
         }
@@ -229,7 +270,7 @@ __global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work, in
             } else {
                 const int pa = bitrev(k2, log2), pb = bitrev(N2 - k2, log2);
                 c64 zk = A[pa], zm = A[pb];
-                lp_filter_pair(zk, zm, (int64_t)k2 << log1, M, first_cleared, T);
+                lp_filter_pair(zk, zm, (int64_t)k2 << log1, M, first_cleared, T, lg);
                 A[pa] = zk;
                 if (pb != pa) A[pb] = zm;
             }
@@ -254,46 +295,7 @@ __global__ __launch_bounds__(256) void praat_interp_kernel(const SRC* __restrict
     const double duration = (double)n_in * dx_in;
     const double x1o = 0.5 * (duration - (double)(n_out - 1) / fs_out);
     const double x = (x1o + (double)o * dx_out - 0.5 * dx_in) / dx_in + 1.0;   // Praat's 1-based real index
-    const int64_t midleft = (int64_t)floor(x), midright = midleft + 1;
-    double res;
-    if (x > (double)n_in) res = (double)y[n_in - 1];
-    else if (x < 1.0) res = (double)y[0];
-    else if (x == (double)midleft) res = (double)y[midleft - 1];
-    else {
-        int64_t md = depth;
-        if (md > midright - 1) md = midright - 1;
-        if (md > n_in - midleft) md = n_in - midleft;
-        if (md <= 0) res = (double)y[(int64_t)floor(x + 0.5) - 1];
-        else if (md == 1) res = (double)y[midleft - 1] + (x - (double)midleft) * ((double)y[midright - 1] - (double)y[midleft - 1]);
-        else if (md == 2) {
-            const double yl = (double)y[midleft - 1], yr = (double)y[midright - 1];
-            const double dyl = 0.5 * (yr - (double)y[midleft - 2]), dyr = 0.5 * ((double)y[midright] - yl);
-            const double fil = x - (double)midleft, fir = (double)midright - x;
-            res = yl * fir + yr * fil - fil * fir * (0.5 * (dyr - dyl) + (fil - 0.5) * (dyl + dyr - 2.0 * (yr - yl)));
-        } else {
-            const int64_t left = midright - md, right = midleft + md;
-            res = 0.0;
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const double a0 = PI * (side == 0 ? x - (double)midleft : (double)midright - x);
-                const double span = side == 0 ? x - (double)left + 1.0 : (double)right - x + 1.0;
-                double halfsina = 0.5 * sin(a0), a = a0;
-                double ws, wc, ds, dc;
-                sincos(a0 / span, &ws, &wc);                 // the window angle advances by pi / span per sample
-                sincos(PI / span, &ds, &dc);
-                const SRC* p = y + (side == 0 ? midleft - 1 : midright - 1);
-                const int64_t step = side == 0 ? -1 : 1;
-                for (int64_t k = 0; k < md; ++k) {
-                    res += (double)p[k * step] * (halfsina / a * (1.0 + wc));
-                    a += PI;
-                    halfsina = -halfsina;
-                    const double c2 = wc * dc - ws * ds, s2 = ws * dc + wc * ds;
-                    wc = c2; ws = s2;
-                }
-            }
-        }
-    }
-    out[o] = (float)res;
+    out[o] = (float)praat_interpolate_sinc(y, n_in, x, depth);
 }
 
 }  // namespace resample
@@ -333,7 +335,7 @@ static int lp_tables(int64_t nfft, LpTables* out) {
     const int64_t nhi = nfft > TW_N ? nfft / TW_N : 1;
     rc = get(2 * nfft + 1, nhi, TW_N, nfft, &hi);
     if (rc != RSAF_OK) return rc;
-    out->tw = tw; out->lo = lo; out->hi = hi;
+    out->tw = tw; out->lo = lo; out->hi = hi; out->lg_max = 0;
     return RSAF_OK;
 }
 
@@ -365,6 +367,59 @@ int64_t rsaf_resample_praat_work_bytes(int64_t n_in, double fs_in, double fs_out
     return nfft * 8 + n_in * 8;                         // nfft / 2 complex numbers + the low-passed sound (fp64)
 }
 
+}  // extern "C"
+
+// the three passes of the low-pass over a batch (sigs on the device, n_sigs of them) or over `one` sound
+static int launch_lowpass(const float* in, double* out, resample::c64* work, const resample::LpSig* sigs, int n_sigs,
+                          const resample::LpSig& one, int lg_max, double upfactor, hipStream_t s) {
+    using namespace resample;
+    RSAF_CHECK_ARG(lg_max >= 11 && lg_max <= 24, "sound longer than 2^24 - 2000 samples: the low-pass transform does not fit its two LDS passes");
+    LpTables T;
+    {
+        const int rc = lp_tables((int64_t)1 << lg_max, &T);
+        if (rc != RSAF_OK) return rc;
+    }
+    T.lg_max = lg_max;
+    unsigned gc = 1, gr = 1;
+    size_t lds_c = 0, lds_r = 0;
+    for (int lg = 11; lg <= lg_max; ++lg) {             // the batch may hold any shorter transform
+        const LpGeom g = lp_geom(lg);
+        gc = std::max(gc, (unsigned)((1 << g.log2) / g.C));
+        gr = std::max(gr, (unsigned)((1 << g.log1) / 2 + 1));
+        lds_c = std::max(lds_c, ((size_t)g.C << g.log1) * sizeof(c64));
+        lds_r = std::max(lds_r, ((size_t)2 << g.log2) * sizeof(c64));
+    }
+    if (lds_r > 48 * 1024)
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)lp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+    if (lds_c > 48 * 1024) {
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)lp_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)lp_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    }
+    LpBatch B;
+    B.sigs = sigs;
+    B.one = one;
+    B.upfactor = upfactor;
+    const unsigned ny = sigs ? (unsigned)n_sigs : 1u;
+    hipLaunchKernelGGL(lp_cols_kernel<false>, dim3(gc, ny), dim3(256), lds_c, s, in, work, (double*)nullptr, B, T);
+    hipLaunchKernelGGL(lp_rows_kernel, dim3(gr, ny), dim3(256), lds_r, s, work, B, T);
+    hipLaunchKernelGGL(lp_cols_kernel<true>, dim3(gc, ny), dim3(256), lds_c, s, (const float*)nullptr, work, out, B, T);
+    RSAF_CHECK_HIP(hipGetLastError());
+    return RSAF_OK;
+}
+
+extern "C" {
+
+int rsaf_praat_lowpass_batch(const float* in, const void* sigs, int n_sigs, int lg_max, double upfactor, void* work,
+                             int64_t work_complex, double* out, rsaf_stream_t stream) {
+    RSAF_CHECK_ARG(n_sigs >= 0 && n_sigs <= 65535 && upfactor > 0.0 && upfactor < 1.0, "bad argument");
+    if (n_sigs == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(in && sigs && work && out && work_complex >= 1, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("praat_lowpass_fft", s, 0.0, 6.0 * 16.0 * (double)work_complex);
+    resample::LpSig none{};
+    return launch_lowpass(in, out, (resample::c64*)work, (const resample::LpSig*)sigs, n_sigs, none, lg_max, upfactor, s);
+}
+
 int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_out, int precision, float* out,
                         int64_t n_out, void* work, int64_t work_bytes, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_in >= 0 && n_out >= 0 && fs_in > 0.0 && fs_out > 0.0 && precision >= 1 && precision <= 4096, "bad arguments");
@@ -386,31 +441,14 @@ int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_o
     while (nfft < n_in + 2 * resample::ANTI_TURN_AROUND) { nfft *= 2; ++lg; }
     RSAF_CHECK_ARG(lg <= 24, "sound longer than 2^24 - 2000 samples: the low-pass transform does not fit its two LDS passes");
     RSAF_CHECK_ARG(work && work_bytes >= rsaf_resample_praat_work_bytes(n_in, fs_in, fs_out), "workspace missing or too small");
-    const int logM = lg - 1;                            // lg >= 11
-    const int log2 = logM - 1 < 11 ? logM - 1 : 11;     // rows of at most 2 048 points, at least 2 rows
-    const int log1 = logM - log2;
-    int C = 8;
-    while (C > 1 && ((int64_t)C << log1) > 4096) C >>= 1;
-    resample::LpTables T;
-    {
-        const int rc = resample::lp_tables(nfft, &T);
-        if (rc != RSAF_OK) return rc;
-    }
     resample::c64* wk = (resample::c64*)work;
     double* lp = (double*)(wk + nfft / 2);
-    const int64_t first_cleared = (int64_t)floor(upfactor * (double)nfft);
-    const size_t lds_c = ((size_t)C << log1) * sizeof(resample::c64), lds_r = ((size_t)2 << log2) * sizeof(resample::c64);
-    if (lds_r > 48 * 1024)
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)resample::lp_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-    if (lds_c > 48 * 1024) {
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)resample::lp_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)resample::lp_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-    }
-    ProfScope prof("resample_praat", s, 2.0 * 2.5 * (double)nfft * (double)logM, 6.0 * 8.0 * (double)nfft + 4.0 * (double)(n_in + n_out));
-    const unsigned gc = (unsigned)((1 << log2) / C), gr = (unsigned)((1 << log1) / 2 + 1);
-    hipLaunchKernelGGL(resample::lp_cols_kernel<false>, dim3(gc), dim3(256), lds_c, s, in, n_in, wk, (double*)nullptr, log1, log2, C, T);
-    hipLaunchKernelGGL(resample::lp_rows_kernel, dim3(gr), dim3(256), lds_r, s, wk, log1, log2, first_cleared, T);
-    hipLaunchKernelGGL(resample::lp_cols_kernel<true>, dim3(gc), dim3(256), lds_c, s, (const float*)nullptr, n_in, wk, lp, log1, log2, C, T);
+    ProfScope prof("resample_praat", s, 2.0 * 2.5 * (double)nfft * (double)(lg - 1), 6.0 * 8.0 * (double)nfft + 4.0 * (double)(n_in + n_out));
+    resample::LpSig one{};
+    one.n = (int)n_in;
+    one.lg = lg;
+    const int rc = launch_lowpass(in, lp, wk, nullptr, 1, one, lg, upfactor, s);
+    if (rc != RSAF_OK) return rc;
     hipLaunchKernelGGL(resample::praat_interp_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)lp, n_in, fs_in, fs_out,
                        precision, out, n_out);
     RSAF_CHECK_HIP(hipGetLastError());

@@ -41,8 +41,35 @@ assert CLIP_INFO.itemsize == 32
 RESAMPLE_INFO = np.dtype([("sample_off", "<i8"), ("out_off", "<i8"), ("pos0", "<f8"), ("x1o", "<f8"),
                           ("n_in", "<i4"), ("n_out", "<i4"), ("table", "<i4"), ("pad", "<i4")])
 assert RESAMPLE_INFO.itemsize == 48
+LP_SIG = np.dtype([("in_off", "<i8"), ("out_off", "<i8"), ("work_off", "<i8"), ("n", "<i4"), ("lg", "<i4")])
+assert LP_SIG.itemsize == 32
 RS_DEPTH = 500
 RS_RATE = 10000.0
+
+
+def resample10k_tables(pos0: float, depth: int = RS_DEPTH):
+    """Weights of ``NUM_interpolate_sinc`` at full depth for the five fractional positions of the 16 kHz -> 10 kHz grid
+    (output sample 5q + r sits at the real input index pos0 + 1.6 r + 8q) -> (float64 [5, 2 depth + 1], bases [5]):
+    tap j of row r belongs to the input sample bases[r] + 8q + j - depth.  ``depth`` samples to the left of the position
+    (taps depth, depth - 1, ...) and ``depth`` to the right (taps depth + 1, ...), each side under its own raised cosine
+    that reaches zero one sample beyond its outermost sample."""
+    k = np.arange(depth)
+    sgn = np.where(k % 2 == 0, 1.0, -1.0)
+    rows, bs = [], []
+    for r in range(5):
+        pr = pos0 + 1.6 * r
+        b = int(math.floor(pr))
+        f = pr - b
+        w = np.zeros(2 * depth + 1)
+        if f == 0.0:
+            w[depth] = 1.0
+        else:
+            for a0, span, first, step in ((math.pi * f, f + depth, depth, -1), (math.pi * (1.0 - f), depth + 1.0 - f, depth + 1, 1)):
+                a = a0 + math.pi * k
+                w[first + step * k] = 0.5 * math.sin(a0) * sgn / a * (1.0 + np.cos(a / span))
+        rows.append(w)
+        bs.append(b)
+    return np.stack(rows), bs
 
 
 def short_term_frames(n_samples: int, window_duration: float, time_step: float):
@@ -69,7 +96,7 @@ def _clip_info(sample_offs, lengths, grid):
 def _dev(arr, device):
     import torch
     a = np.ascontiguousarray(arr)
-    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device) if a.dtype in (CLIP_INFO, RESAMPLE_INFO) else \
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device) if a.dtype.fields is not None else \
         torch.from_numpy(a).to(device)
 
 
@@ -322,28 +349,24 @@ class MshdsEngine:
         dxo = 1.0 / RS_RATE
         ratio = RS_RATE / FS
         ri = np.zeros(n, dtype=RESAMPLE_INFO)
+        lps = np.zeros(n, dtype=LP_SIG)
         tabs, bases, key_to_table = [], [], {}
-        out_off = 0
-        k = np.arange(-RS_DEPTH, RS_DEPTH + 1)
+        out_off = work_off = 0
         for i, (so, nn) in enumerate(zip(sample_offs, lengths)):
             duration = nn * DX
             m = int(math.floor(duration * RS_RATE + 0.5))
-            x1o = 0.5 * (duration - (m - 1) * dxo)
+            x1o = 0.5 * (duration - (m - 1) / RS_RATE)
             pos0 = (x1o - 0.5 * DX) / DX
             if pos0 not in key_to_table:
                 key_to_table[pos0] = len(tabs)
-                rows, bs = [], []
-                for r in range(5):
-                    pr = pos0 + 1.6 * r
-                    b = int(math.floor(pr))
-                    d = (pr - b) - k
-                    w = ratio * np.sinc(ratio * d) * (0.5 + 0.5 * np.cos(np.pi * d / (RS_DEPTH + 1.0)))
-                    rows.append(np.where(np.abs(d) <= RS_DEPTH + 1.0, w, 0.0))
-                    bs.append(b)
-                tabs.append(np.stack(rows))
+                rows, bs = resample10k_tables(pos0)
+                tabs.append(rows)
                 bases.append(bs)
             ri[i] = (int(so), out_off, pos0, x1o, int(nn), m, key_to_table[pos0], 0)
+            lg = max(11, int(nn + 2000 - 1).bit_length())
+            lps[i] = (int(so), int(so), work_off, int(nn), lg)
             out_off += m
+            work_off += 1 << (lg - 1)
         max_out = int(ri["n_out"].max()) if n else 0
         y10 = torch.empty(max(out_off, 1), dtype=torch.float64, device=dev)
         out = torch.full((max(n, 1), 8), float("nan"), dtype=torch.float64, device=dev)
@@ -352,8 +375,15 @@ class MshdsEngine:
         ri_d = _dev(ri, dev)
         tab_d = torch.from_numpy(np.ascontiguousarray(np.stack(tabs)).reshape(-1)).to(dev)
         base_d = torch.from_numpy(np.asarray(bases, dtype=np.int32).reshape(-1)).to(dev)
-        _lib.check(lib.rsaf_mshds_resample10k(_lib.ptr(wav), _lib.ptr(ri_d), n, max_out, _lib.ptr(tab_d), _lib.ptr(base_d),
+        # Sound_resample(10000, 500): whole-sound FFT low-pass (16 kHz -> 10 kHz goes down), then sinc interpolation
+        lp = torch.empty(int(wav.numel()), dtype=torch.float64, device=dev)
+        work = torch.empty(2 * work_off, dtype=torch.float64, device=dev)
+        _lib.check(lib.rsaf_praat_lowpass_batch(_lib.ptr(wav), _lib.ptr(_dev(lps, dev)), n, int(lps["lg"].max()), RS_RATE * DX,
+                                                _lib.ptr(work), work_off, _lib.ptr(lp), _lib.stream_ptr(stream)),
+                   "rsaf_praat_lowpass_batch")
+        _lib.check(lib.rsaf_mshds_resample10k(_lib.ptr(lp), _lib.ptr(ri_d), n, max_out, _lib.ptr(tab_d), _lib.ptr(base_d),
                                               RS_DEPTH, _lib.ptr(y10), _lib.stream_ptr(stream)), "rsaf_mshds_resample10k")
+        del work
         # Formant (burg): 5 ms, 5 formants, 5 kHz, 25 ms half-window, pre-emphasis from 50 Hz  (:319)
         dt_window = 0.05
         nsw = int(math.floor(dt_window / dxo))
