@@ -327,17 +327,22 @@ int rsaf_mshds_ltas_slope_tilt(const float* wav, const void* clip_info, int n_cl
                                double max_period_factor, double* out, rsaf_stream_t stream);
 /* Mean cepstral peak prominence (CPPS) of the voiced stretches: out[clip], NaN when no stretch exceeds 4 dB or
  * Praat would raise.  Voiced intervals from the time-sorted pulses ("To TextGrid (vuv)" 0.02 0.1, times rounded
- * to 6 decimals like "Down to Table"), each extracted, resampled to 10 kHz, "To PowerCepstrogram" 60 0.002 5000 50,
+ * to 6 decimals like "Down to Table"), each extracted, resampled to 10 kHz as Sound_resample (10000, 50) does it (FFT
+ * low-pass of the extracted part over its own power of two, NUM_interpolate_sinc), "To PowerCepstrogram" 60 0.002 5000 50,
  * "Get CPPS" no 0.01 0.001 60 330 0.05 parabolic 0.001 0 Straight Robust.
  * Replaces src/mshds_extractor.py:272-297.  Workspaces (caller-owned, per clip): seg_table
  * [max_seg][rsaf_mshds_cpp_seg_doubles()] doubles, hdr [4] ints, resampled [cap_res], cepstrogram
- * [cap_frames][513], cpp_frames [cap_frames] doubles.  window1000 = the 1000-point Gaussian window of
- * Sound_createGaussian, twiddle1024[k] = (cos, -sin)(2 pi k / 1024), k < 512. */
+ * [cap_frames][513], cpp_frames [cap_frames] doubles, lp_work [cap_work] complex doubles (cap_work >= longest clip +
+ * 2000 max_seg covers every case); lowpassed: float64 scratch for the samples wav[lp_origin ...] of the clips of this
+ * call (sample s of the batch at lowpassed[s - lp_origin]); lg_max = log2 of the first power of two >= longest clip +
+ * 2000.  window1000 = the 1000-point Gaussian window of Sound_createGaussian, twiddle1024[k] = (cos, -sin)(2 pi k / 1024),
+ * k < 512. */
 int rsaf_mshds_cpp_seg_doubles(void);
 int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const double* pulses, int max_pulses,
                    const int* n_pulses, const double* window1000, const double* twiddle1024, int max_seg, int cap_res,
                    int cap_frames, void* seg_table, int* hdr, double* resampled, double* cepstrogram, double* cpp_frames,
-                   double* out, rsaf_stream_t stream);
+                   double* lowpassed, int64_t lp_origin, void* lp_work, int64_t cap_work, int lg_max, double* out,
+                   rsaf_stream_t stream);
 int rsaf_mshds_formant_stats(const void* frames, const void* clip_info, int n_clips, double time_step,
                              const double* pulses, int max_pulses, const int* n_pulses, double* out,
                              rsaf_stream_t stream);

@@ -1282,28 +1282,12 @@ def vuv_intervals(pulses, xmin, xmax, max_period=0.02, mean_period=0.1):
     return out
 
 
-def resample_windowed_sinc(seg, x1_seg, duration, fs_out, depth):
-    """Sound_resample of a sound with n = len(seg) samples at 16 kHz whose first sample lies at x1_seg and whose
-    domain is [0, duration]: Praat's brick-wall low-pass + sinc interpolation folded into one raised-cosine
-    windowed sinc with the cut-off at the new Nyquist (the free choice documented at ``resample_10k``)."""
-    n = len(seg)
-    m = int(np.floor(duration * fs_out + 0.5))
-    dxo = 1.0 / fs_out
-    x1o = 0.5 * (duration - (m - 1) * dxo)
-    ratio = fs_out / FS
-    out = np.empty(max(m, 0))
-    k = np.arange(-depth, depth + 1)
-    for i0 in range(0, m, 4096):
-        idx = np.arange(i0, min(m, i0 + 4096))
-        pos = (x1o + idx * dxo - x1_seg) / DX
-        base = np.floor(pos).astype(np.int64)
-        j = base[:, None] + k[None, :]
-        d = pos[:, None] - j
-        w = ratio * np.sinc(ratio * d) * (0.5 + 0.5 * np.cos(np.pi * d / (depth + 1.0)))
-        w = np.where(np.abs(d) <= depth + 1.0, w, 0.0)
-        ok = (j >= 0) & (j < n)
-        out[idx] = np.sum(np.where(ok, seg[np.clip(j, 0, n - 1)] * w, 0.0), axis=1)
-    return out, x1o, dxo
+def resample_part(seg, x1_seg, duration, fs_out, depth):
+    """``Sound_resample`` of an extracted part: ``len(seg)`` samples at 16 kHz, the first one at ``x1_seg``, domain
+    ``[0, duration]`` -> (samples, x1, dx): FFT low-pass over the part's own power of two, grid centred in the
+    domain, ``NUM_interpolate_sinc`` (``resample_oracle.sound_resample``)."""
+    from .resample_oracle import sound_resample
+    return sound_resample(np.asarray(seg, dtype=np.float64), x1_seg, DX, 0.0, duration, fs_out, depth)
 
 
 def power_cepstrogram(seg, x1_seg, duration):
@@ -1313,7 +1297,7 @@ def power_cepstrogram(seg, x1_seg, duration):
     Returns z [nq, n_frames] (quefrency step 1e-4 s)."""
     n_in = len(seg)
     window = min(2.0 * 3.0 / CPP_PITCH_FLOOR, DX * n_in)
-    y, x1o, dxo = resample_windowed_sinc(seg, x1_seg, duration, CPP_FS, CPP_DEPTH)
+    y, x1o, dxo = resample_part(seg, x1_seg, duration, CPP_FS, CPP_DEPTH)
     a = np.exp(-2.0 * np.pi * CPP_PREEMPH_FROM * dxo)
     y = np.concatenate([y[:1], y[1:] - a * y[:-1]])
     my_duration = DX * n_in                                        # Sampled_shortTermAnalysis on the 16 kHz part

@@ -75,7 +75,7 @@ SIGNATURES = {
     "rsaf_mshds_pulses": (_I, [_P, _P, _I, _I, _P, C.c_double, C.c_double, _P, _L, _P, _I, _P, _P]),
     "rsaf_mshds_ltas_slope_tilt": (_I, [_P, _P, _I, _P, _I, _P, C.c_double, C.c_double, C.c_double, _P, _P]),
     "rsaf_mshds_cpp_seg_doubles": (_I, []),
-    "rsaf_mshds_cpp": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "rsaf_mshds_cpp": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P]),
     "rsaf_mshds_formant_stats": (_I, [_P, _P, _I, C.c_double, _P, _I, _P, _P, _P]),
     "rsaf_mshds_hnr_mean": (_I, [_P, _P, _P, _I, _P, _P]),
     "rsaf_mshds_spectral_moments": (_I, [_P, _P, _P, _I, _I, _P, C.c_double, C.c_double, _P, _P, _I, _I, _I,

@@ -4,15 +4,19 @@
 //   PointProcess "To TextGrid (vuv)" 0.02 0.1 -> "Down to Table" (6 decimals) -> Sound.extract_part ->
 //   "To PowerCepstrogram" 60 0.002 5000 50 -> "Get CPPS" no 0.01 0.001 60 330 0.05 parabolic 0.001 0 Straight Robust
 //   -> mean of the per-interval values above 4 dB.
-// Five kernels: segment table (one wave per clip), resampler to 10 kHz (one thread per output sample),
+// Kernels: segment table (one wave per clip), Praat's FFT low-pass of every interval (three passes, praat_lowpass.h),
+// sinc interpolation to 10 kHz (one thread per output sample),
 // power cepstrum per frame (two 1024-point fp64 FFTs in LDS), smoothed CPP per frame (moving averages,
 // two bitonic sorts for Theil's line, parabolic peak), reduction per interval and clip.
 // The arithmetic is fp64 and nothing is contracted to FMA where Praat's rounding decides an integer.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 
+#include "praat_interp.h"
+#include "praat_lowpass.h"
 #include "rsaf_common.h"
 
 #pragma clang fp contract(off)
@@ -29,7 +33,7 @@ constexpr double DT = 0.002;              // cepstrogram time step
 constexpr double DQ = 1.0e-4;             // quefrency step = 1 / FS_OUT
 constexpr int NFFT_MAX = 1024;            // 0.1 s window at 10 kHz = 1000 samples
 constexpr int NQ_MAX = NFFT_MAX / 2 + 1;  // 513
-constexpr int SEG_DOUBLES = 12;
+constexpr int SEG_DOUBLES = 15;
 
 struct ClipInfo {      // same 32-byte rows as csrc/mshds.hip
     int64_t sample_off;
@@ -42,6 +46,7 @@ struct ClipInfo {      // same 32-byte rows as csrc/mshds.hip
 // one voiced interval (all fields double so that the table is one plain array)
 struct Seg {
     double ix1, m_in, m_out, res_off, frame_off, nf, x1_seg, x1o, window, t1, nx, nfft;
+    double work_off, item_off, lg;   // low-pass transform: first complex number, first work item, log2 of its length
 };
 static_assert(sizeof(Seg) == SEG_DOUBLES * sizeof(double), "Seg layout");
 
@@ -59,12 +64,20 @@ __device__ __forceinline__ double round6(double t) {
     return (up ? q + 1.0 : q) / 1.0e6;
 }
 
+// work items (workgroups) of one pass of an interval's low-pass transform of 2^lg samples: the larger of the column and row pass
+__host__ __device__ inline int lp_items(int lg) {
+    const resample::LpGeom g = resample::lp_geom(lg);
+    const int cols = (1 << g.log2) / g.C, rows = (1 << g.log1) / 2 + 1;
+    return cols > rows ? cols : rows;
+}
+
 // ---- 1. voiced intervals -> segment table -----------------------------------------------------------------
 // hdr[clip] = {n_seg, fail, total_frames, total_resampled}
 __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict__ ci, const double* __restrict__ pulses,
                                                       int max_pulses, const int* __restrict__ n_pulses, double max_period,
                                                       double mean_period, double pitch_floor, Seg* __restrict__ segs,
-                                                      int max_seg, int cap_res, int cap_frames, int* __restrict__ hdr) {
+                                                      int max_seg, int cap_res, int cap_frames, int64_t cap_work, int lg_max,
+                                                      int* __restrict__ hdr) {
     const ClipInfo c = ci[blockIdx.x];
     const int lane = threadIdx.x;
     const double* t = pulses + (int64_t)blockIdx.x * max_pulses;
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict
     Seg* out = segs + (int64_t)blockIdx.x * max_seg;
     const double xmax = c.n_samples * DXS, half = 0.5 * mean_period;
     int nseg = 0, fail = 0;
-    int64_t res_off = 0, frame_off = 0;
+    int64_t res_off = 0, frame_off = 0, work_off = 0, item_off = 0;
     double begin_voiceless = 0.0;
     int cur_start = 0;
     // every lane keeps the same (uniform) state; lane 0 writes
@@ -100,7 +113,11 @@ __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict
         const int64_t nx = (int64_t)floor(window * FS_OUT + 0.5);
         int nfft = 2;
         while (nfft < nx) nfft *= 2;
-        if (nseg >= max_seg || res_off + m_out > cap_res || frame_off + nf > cap_frames || nx > NFFT_MAX || nx < 1 || nf < 1) {
+        int lg = 11;                                                         // Sound_resample: first power of two >= n + 2000
+        while (((int64_t)1 << lg) < m_in + 2 * resample::ANTI_TURN_AROUND) ++lg;
+        const int64_t work_len = (int64_t)1 << (lg - 1);
+        if (nseg >= max_seg || res_off + m_out > cap_res || frame_off + nf > cap_frames || nx > NFFT_MAX || nx < 1 || nf < 1 ||
+            lg > lg_max || work_off + work_len > cap_work) {
             fail = 1;
             return;
         }
@@ -110,11 +127,14 @@ __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict
             s.frame_off = (double)frame_off; s.nf = (double)nf; s.x1_seg = x1_seg;
             s.x1o = 0.5 * (dur - (double)(m_out - 1) * DXO);
             s.window = window; s.t1 = t1; s.nx = (double)nx; s.nfft = (double)nfft;
+            s.work_off = (double)work_off; s.item_off = (double)item_off; s.lg = (double)lg;
             out[nseg] = s;
         }
         ++nseg;
         res_off += m_out;
         frame_off += nf;
+        work_off += work_len;
+        item_off += lp_items(lg);
     };
     for (int base = 0; base < np_; base += 64) {
         const int i = base + lane;
@@ -147,13 +167,42 @@ __device__ __forceinline__ int find_seg(const Seg* __restrict__ s, int nseg, int
     return lo;
 }
 
-// ---- 2. 16 kHz -> 10 kHz of every interval ----------------------------------------------------------------
-// raised-cosine windowed sinc of half-width DEPTH + 1 input samples with the cut-off at the new Nyquist (the
-// free choice documented in oracle/mshds_oracle.py: Praat filters with a whole-sound FFT first).  The two
-// trigonometric factors advance by fixed angles per tap and are rotated instead of evaluated.
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
-                                                       const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
-                                                       int cap_res, double* __restrict__ res) {
+// ---- 2. 16 kHz -> 10 kHz of every interval: Sound_resample (10000, 50) --------------------------------------
+// FFT low-pass of the extracted part (its own transform length), then NUM_interpolate_sinc on the grid centred in the
+// part's domain.  The intervals are found on the device, so the three transform passes run as loops over work items:
+// item w of a clip = workgroup (w - item_off) of the interval that owns it; every pass uses the same item count.
+template <int PASS>
+__global__ __launch_bounds__(256) void seg_lowpass_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                          const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                          resample::c64* __restrict__ work, int64_t cap_work,
+                                                          double* __restrict__ lowpassed, int64_t lp_origin,
+                                                          resample::LpTables T) {
+    extern __shared__ resample::c64 lp_lds[];
+    const int clip = blockIdx.y;
+    const int nseg = hdr[4 * clip];
+    if (nseg <= 0) return;
+    const Seg* S = segs + (int64_t)clip * max_seg;
+    const ClipInfo c = ci[clip];
+    const int total = (int)S[nseg - 1].item_off + lp_items((int)S[nseg - 1].lg);
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const Seg s = S[find_seg<13>(S, nseg, w)];
+        resample::LpSig sg;
+        sg.in_off = c.sample_off + (int64_t)s.ix1;
+        sg.out_off = c.sample_off - lp_origin + (int64_t)s.ix1;
+        sg.work_off = (int64_t)clip * cap_work + (int64_t)s.work_off;
+        sg.n = (int)s.m_in;
+        sg.lg = (int)s.lg;
+        const int bx = w - (int)s.item_off;
+        if (PASS == 0) resample::lp_cols_body<false>(wav, work, lowpassed, sg, bx, T, lp_lds);
+        else if (PASS == 1) resample::lp_rows_body(work, sg, bx, FS_OUT * DXS, T, lp_lds);
+        else resample::lp_cols_body<true>(wav, work, lowpassed, sg, bx, T, lp_lds);
+        __syncthreads();                                                     // the next item reuses the LDS buffer
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_kernel(const double* __restrict__ lowpassed, int64_t lp_origin,
+                                                       const ClipInfo* __restrict__ ci, const Seg* __restrict__ segs, int max_seg,
+                                                       const int* __restrict__ hdr, int cap_res, double* __restrict__ res) {
     const int clip = blockIdx.y;
     const int nseg = hdr[4 * clip], total = hdr[4 * clip + 3];
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -161,41 +210,10 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     const Seg* S = segs + (int64_t)clip * max_seg;
     const Seg s = S[find_seg<3>(S, nseg, g)];
     const ClipInfo c = ci[clip];
-    const float* x = wav + c.sample_off;
+    const double* y = lowpassed + (c.sample_off - lp_origin) + (int64_t)s.ix1;   // the extracted part, low-passed
     const int i = g - (int)s.res_off;
-    const double pos = (s.x1o + (double)i * DXO - s.x1_seg) / DXS;       // real index into the extracted part
-    const double base = floor(pos);
-    const double frac = pos - base;                                         // in [0, 1)
-    const int64_t j0 = (int64_t)s.ix1 + (int64_t)base - DEPTH;            // clip sample of tap k = -DEPTH
-    const int m_in = (int)s.m_in;
-    const int64_t part_lo = (int64_t)s.ix1, part_hi = part_lo + m_in - 1;
-    const double ratio = FS_OUT / 16000.0;
-    // tap k = -DEPTH .. DEPTH: d = frac - k ; start at d0 = frac + DEPTH and step -1
-    const double d0 = frac + (double)DEPTH;
-    double ss, sc, ws, wc;
-    sincos(PI * ratio * d0, &ss, &sc);                  // sin/cos(pi ratio d)
-    sincos(PI * d0 / (DEPTH + 1.0), &ws, &wc);          // sin/cos(pi d / (DEPTH + 1))
-    double rs, rc, vs, vc;
-    sincos(PI * ratio, &rs, &rc);
-    sincos(PI / (DEPTH + 1.0), &vs, &vc);
-    double acc = 0.0;
-    for (int k = 0; k <= 2 * DEPTH; ++k) {
-        const double d = d0 - (double)k;
-        const int64_t j = j0 + k;
-        // the tap next to the position takes sin() directly (the rotated value's ~1e-15 absolute error would be
-        // blown up by the division by a tiny d)
-        const double sn = (k == DEPTH || k == DEPTH + 1) ? sin(PI * ratio * d) : ss;
-        double w = d == 0.0 ? ratio : sn / (PI * d);
-        w *= 0.5 + 0.5 * wc;
-        const bool ok = j >= part_lo && j <= part_hi && j >= 0 && j < c.n_samples && fabs(d) <= DEPTH + 1.0;
-        if (ok) acc += (double)x[j] * w;
-        // rotate both angles by one tap backwards
-        const double s2 = ss * rc - sc * rs, c2 = sc * rc + ss * rs;
-        ss = s2; sc = c2;
-        const double w2 = ws * vc - wc * vs, u2 = wc * vc + ws * vs;
-        ws = w2; wc = u2;
-    }
-    res[(int64_t)clip * cap_res + g] = acc;
+    const double pos = (s.x1o + (double)i * DXO - s.x1_seg) / DXS;       // real 0-based index into the extracted part
+    res[(int64_t)clip * cap_res + g] = praat_interpolate_sinc(y, (int64_t)s.m_in, pos + 1.0, DEPTH);
 }
 
 // ---- 3. power cepstrum of every frame ----------------------------------------------------------------------
@@ -543,25 +561,46 @@ int rsaf_mshds_cpp_seg_doubles(void) { return SEG_DOUBLES; }
 int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const double* pulses, int max_pulses,
                    const int* n_pulses, const double* window1000, const double* twiddle1024, int max_seg, int cap_res,
                    int cap_frames, void* seg_table, int* hdr, double* resampled, double* cepstrogram, double* cpp_frames,
-                   double* out, rsaf_stream_t stream) {
+                   double* lowpassed, int64_t lp_origin, void* lp_work, int64_t cap_work, int lg_max, double* out,
+                   rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_pulses >= 0, "bad clip/pulse count");
     if (n_clips == 0) return RSAF_OK;
     RSAF_CHECK_ARG(wav && clip_info && pulses && n_pulses && window1000 && twiddle1024 && seg_table && hdr && resampled &&
-                   cepstrogram && cpp_frames && out, "NULL pointer");
-    RSAF_CHECK_ARG(max_seg >= 1 && cap_res >= 1 && cap_frames >= 1 && cap_frames <= 65535 * 32, "bad capacities");
+                   cepstrogram && cpp_frames && lowpassed && lp_work && out, "NULL pointer");
+    RSAF_CHECK_ARG(max_seg >= 1 && cap_res >= 1 && cap_frames >= 1 && cap_frames <= 65535 * 32 && cap_work >= 1024 &&
+                   lg_max >= 11 && lg_max <= 24, "bad capacities");
     hipStream_t s = (hipStream_t)stream;
     const ClipInfo* ci = (const ClipInfo*)clip_info;
     Seg* segs = (Seg*)seg_table;
     {
         ProfScope prof("mshds_cpp_segments", s, 0.0, 0.0);
         hipLaunchKernelGGL(segments_kernel, dim3(n_clips), dim3(64), 0, s, ci, pulses, max_pulses, n_pulses, 0.02, 0.1, 60.0,
-                           segs, max_seg, cap_res, cap_frames, hdr);
+                           segs, max_seg, cap_res, cap_frames, cap_work, lg_max, hdr);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     {
         ProfScope prof("mshds_cpp_resample", s, 0.0, 0.0);
-        hipLaunchKernelGGL(resample_kernel, dim3((cap_res + 255) / 256, n_clips), dim3(256), 0, s, wav, ci, segs, max_seg, hdr,
-                           cap_res, resampled);
+        resample::LpTables T;
+        const int rc = resample::lp_tables((int64_t)1 << lg_max, &T);
+        if (rc != RSAF_OK) return rc;
+        T.lg_max = lg_max;
+        size_t lds = 0;
+        for (int lg = 11; lg <= lg_max; ++lg) {
+            const resample::LpGeom g = resample::lp_geom(lg);
+            lds = std::max(lds, std::max(((size_t)g.C << g.log1), ((size_t)2 << g.log2)) * sizeof(resample::c64));
+        }
+        if (lds > 48 * 1024) {
+            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        const dim3 grid(64, n_clips);                                        // 64 workgroups walk the items of a clip
+        resample::c64* wk = (resample::c64*)lp_work;
+        hipLaunchKernelGGL(seg_lowpass_kernel<0>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, T);
+        hipLaunchKernelGGL(seg_lowpass_kernel<1>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, T);
+        hipLaunchKernelGGL(seg_lowpass_kernel<2>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, T);
+        hipLaunchKernelGGL(resample_kernel, dim3((cap_res + 255) / 256, n_clips), dim3(256), 0, s, (const double*)lowpassed, lp_origin,
+                           ci, segs, max_seg, hdr, cap_res, resampled);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     {

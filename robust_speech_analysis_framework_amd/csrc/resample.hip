@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "praat_interp.h"
+#include "praat_lowpass.h"
 #include "rsaf_common.h"
 
 namespace rsaf {
@@ -43,245 +44,19 @@ __global__ __launch_bounds__(256) void sinc_hann_kernel(const float* __restrict_
 
 constexpr double PI = 3.14159265358979323846;
 
-// ---- whole-sound FFT low-pass (Praat Sound_resample, anti-aliasing branch) -------------------------------------
-// The nfft real samples (1 000 zeros, the sound, zeros) are the M = nfft / 2 complex numbers z[n] = (d[2n], d[2n+1]),
-// n = n1 N2 + n2.  Forward: column transforms over n1 (decimation in frequency, in place in LDS, output row r holds
-// k1 = bitrev(r)), times W_M^(n2 k1); then row transforms over n2 (same scheme, LDS position p holds k2 = bitrev(p)):
-// Z[k1 + N1 k2].  The real-transform bins X[k], X[M - k] come from Z[k], Z[M - k], which live in rows k1 and N1 - k1: one
-// workgroup owns both rows, clears what Praat clears, folds back to Z' and runs the inverse row transforms (decimation
-// in time: bit-reversed in, natural out).  The inverse column pass undoes the first one.  No pass reorders memory.
-typedef double2 c64;
-constexpr int TW_LOG = 12, TW_N = 1 << TW_LOG;        // W_4096^j: butterflies of every LDS transform (length <= 4096)
-constexpr int ANTI_TURN_AROUND = 1000;
-
-__device__ __forceinline__ c64 cmul(c64 a, c64 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ c64 cmulc(c64 a, c64 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
-__device__ __forceinline__ c64 cadd(c64 a, c64 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ c64 csub(c64 a, c64 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ c64 cconj(c64 a) { return make_double2(a.x, -a.y); }
-__device__ __forceinline__ c64 mul_mi(c64 a) { return make_double2(a.y, -a.x); }    // a * (-i)
-__device__ __forceinline__ c64 mul_pi(c64 a) { return make_double2(-a.y, a.x); }    // a * (+i)
-__device__ __forceinline__ int bitrev(int v, int bits) { return bits ? (int)(__brev((unsigned)v) >> (32 - bits)) : 0; }
-
-struct LpTables {
-    const c64* tw;      // [4096]  e^(-2 pi i j / 4096)
-    const c64* lo;      // [4096]  e^(-2 pi i j / nfft_max)
-    const c64* hi;      // [nfft_max / 4096 or 1]  e^(-2 pi i 4096 j / nfft_max)
-    int lg_max;         // the tables belong to nfft_max = 2^lg_max; a shorter transform strides through them
-};
-
-// one sound of a batch: n samples at in + in_off -> out + out_off, transform of 2^lg samples in work + work_off
-struct LpSig {
-    int64_t in_off, out_off, work_off;
-    int n, lg;
-};
-static_assert(sizeof(LpSig) == 32, "LpSig layout");
-struct LpBatch {
-    const LpSig* sigs;  // device array indexed by blockIdx.y, or nullptr: `one`
-    LpSig one;
-    double upfactor;
-};
-
-struct LpGeom { int log1, log2, C; };
-__host__ __device__ inline LpGeom lp_geom(int lg) {
-    LpGeom g;
-    const int logM = lg - 1;                            // lg >= 11
-    g.log2 = logM - 1 < 11 ? logM - 1 : 11;             // rows of at most 2 048 points, at least 2 rows
-    g.log1 = logM - g.log2;
-    g.C = 8;
-    while (g.C > 1 && ((int64_t)g.C << g.log1) > 4096) g.C >>= 1;
-    return g;
-}
-
-// e^(-2 pi i p / 2^lg), 0 <= p < 2^lg
-__device__ __forceinline__ c64 w_nfft(const LpTables& T, int64_t p, int lg) {
-    p <<= T.lg_max - lg;
-    return cmul(T.lo[p & (TW_N - 1)], T.hi[p >> TW_LOG]);
-}
-
-// nseq interleaved sequences of length 2^logL in LDS (element e of sequence q at buf[e * es + q * ss]); INV = false:
-// decimation in frequency, forward twiddles, natural in / bit-reversed out; INV = true: decimation in time, conjugate
-// twiddles, bit-reversed in / natural out, unnormalised.  Two butterfly layers per barrier.
-template <bool INV>
-__device__ void lds_fft(c64* buf, int logL, int nseq, int es, int ss, const c64* __restrict__ tw) {
-    const int L = 1 << logL;
-    if (INV && (logL & 1)) {
-        for (int t = threadIdx.x; t < nseq * (L >> 1); t += blockDim.x) {
-            const int q = t / (L >> 1), u = t - q * (L >> 1);
-            c64* p = buf + q * ss + (2 * u) * es;
-            const c64 a = p[0], b = p[es];
-            p[0] = cadd(a, b);
-            p[es] = csub(a, b);
-        }
-        __syncthreads();
-    }
-    const int first = INV ? (2 + (logL & 1)) : logL, last = INV ? logL : (2 + (logL & 1));
-    for (int sl = first; INV ? sl <= last : sl >= last; sl += INV ? 2 : -2) {
-        const int ql = sl - 2, qn = 1 << ql;
-        for (int t = threadIdx.x; t < nseq * (L >> 2); t += blockDim.x) {
-            const int q = t / (L >> 2), u = t - q * (L >> 2);
-            const int blk = u >> ql, j = u & (qn - 1);
-            c64* p = buf + q * ss + ((blk << sl) + j) * es;
-            const int st = qn * es;
-            const c64 w1 = tw[j << (TW_LOG - sl)], w2 = tw[(2 * j) << (TW_LOG - sl)];
-            const c64 a0 = p[0], a1 = p[st], a2 = p[2 * st], a3 = p[3 * st];
-            if (!INV) {
-                const c64 b0 = cadd(a0, a2), b2 = cmul(csub(a0, a2), w1);
-                const c64 b1 = cadd(a1, a3), b3 = cmul(mul_mi(csub(a1, a3)), w1);
-                p[0] = cadd(b0, b1);
-                p[st] = cmul(csub(b0, b1), w2);
-                p[2 * st] = cadd(b2, b3);
-                p[3 * st] = cmul(csub(b2, b3), w2);
-            } else {
-                const c64 t1 = cmulc(a1, w2), t3 = cmulc(a3, w2);
-                const c64 b0 = cadd(a0, t1), b1 = csub(a0, t1), b2 = cadd(a2, t3), b3 = csub(a2, t3);
-                const c64 u2 = cmulc(b2, w1), u3 = mul_pi(cmulc(b3, w1));
-                p[0] = cadd(b0, u2);
-                p[2 * st] = csub(b0, u2);
-                p[st] = cadd(b1, u3);
-                p[3 * st] = csub(b1, u3);
-            }
-        }
-        __syncthreads();
-    }
-    if (!INV && (logL & 1)) {
-        for (int t = threadIdx.x; t < nseq * (L >> 1); t += blockDim.x) {
-            const int q = t / (L >> 1), u = t - q * (L >> 1);
-            c64* p = buf + q * ss + (2 * u) * es;
-            const c64 a = p[0], b = p[es];
-            p[0] = cadd(a, b);
-            p[es] = csub(a, b);
-        }
-        __syncthreads();
-    }
-}
-
-// Column pass.  Forward: samples -> LDS [N1][C] -> transform over n1 -> times W_M^(n2 k1) -> work.  Inverse: work times
-// the conjugate twiddle -> inverse transform -> samples (scaled by 1 / M) to `out`.  grid = (N2 / C), C columns each.
+// ---- whole-sound FFT low-pass: the three passes (praat_lowpass.h) over a batch, one sound per y index -----------
 template <bool INV>
 __global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ in, c64* __restrict__ work_base,
                                                       double* __restrict__ out_base, LpBatch B, LpTables T) {
     extern __shared__ c64 lp_lds[];
     const LpSig sg = B.sigs ? B.sigs[blockIdx.y] : B.one;
-    const LpGeom g = lp_geom(sg.lg);
-    const int log1 = g.log1, log2 = g.log2, C = g.C;
-    const int N1 = 1 << log1, N2 = 1 << log2;
-    const int c0 = blockIdx.x * C;
-    if (c0 >= N2) return;
-    const float* x = in + sg.in_off;
-    c64* work = work_base + sg.work_off;
-    double* out = out_base + sg.out_off;
-    const int64_t nx = sg.n;
-    const double scale = 1.0 / (double)((int64_t)N1 << log2);
-    for (int e = threadIdx.x; e < N1 * C; e += 256) {
-        const int r = e / C, c = e - r * C, n2 = c0 + c;
-        if (!INV) {
-            const int64_t i0 = 2 * (((int64_t)r << log2) + n2) - ANTI_TURN_AROUND;
-            c64 v;
-            v.x = (i0 >= 0 && i0 < nx) ? (double)x[i0] : 0.0;
-            v.y = (i0 + 1 >= 0 && i0 + 1 < nx) ? (double)x[i0 + 1] : 0.0;
-            lp_lds[e] = v;
-        } else {
-            const int64_t k1 = bitrev(r, log1);
-            lp_lds[e] = cmulc(work[((int64_t)r << log2) + n2], w_nfft(T, 2 * k1 * n2, sg.lg));
-        }
-    }
-    __syncthreads();
-    lds_fft<INV>(lp_lds, log1, C, C, 1, T.tw);
-    for (int e = threadIdx.x; e < N1 * C; e += 256) {
-        const int r = e / C, c = e - r * C, n2 = c0 + c;
-        if (!INV) {
-            const int64_t k1 = bitrev(r, log1);
-            work[((int64_t)r << log2) + n2] = cmul(lp_lds[e], w_nfft(T, 2 * k1 * n2, sg.lg));
-        } else {
-            const int64_t i0 = 2 * (((int64_t)r << log2) + n2) - ANTI_TURN_AROUND;
-            const c64 v = lp_lds[e];
-            if (i0 >= 0 && i0 < nx) out[i0] = v.x * scale;
-            if (i0 + 1 >= 0 && i0 + 1 < nx) out[i0 + 1] = v.y * scale;
-        }
-    }
+    lp_cols_body<INV>(in, work_base, out_base, sg, (int)blockIdx.x, T, lp_lds);
 }
 
-// bins k and M - k of the real transform from Z[k], Z[M - k]; Praat's clearing of the packed array (1-based position
-// 2k + 1 = real part, 2k + 2 = imaginary part of bin k, cleared from position `first_cleared`); back to Z'[k], Z'[M - k]
-__device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int64_t M, int64_t first_cleared, const LpTables& T, int lg) {
-    const c64 w = w_nfft(T, k, lg);
-    const c64 E = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-    const c64 O = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
-    const c64 Tt = mul_pi(cmul(w, O));
-    c64 xk = csub(E, Tt), xm = cconj(cadd(E, Tt));
-    const int64_t m = M - k;
-    if (2 * k + 1 >= first_cleared) xk.x = 0.0;
-    if (2 * k + 2 >= first_cleared) xk.y = 0.0;
-    if (2 * m + 1 >= first_cleared) xm.x = 0.0;
-    if (2 * m + 2 >= first_cleared) xm.y = 0.0;
-    const c64 s1 = cadd(xk, cconj(xm)), d1 = csub(xk, cconj(xm));
-    const c64 s2 = cadd(xm, cconj(xk)), d2 = csub(xm, cconj(xk));
-    const c64 r1 = mul_pi(cmulc(d1, w)), r2 = mul_pi(cmul(d2, w));
-    zk = make_double2(0.5 * (s1.x + r1.x), 0.5 * (s1.y + r1.y));
-    zm = make_double2(0.5 * (s2.x - r2.x), 0.5 * (s2.y - r2.y));
-}
-
-// Row pass: workgroup b owns the logical rows k1 = b and N1 - b (stored at their bit-reversed positions), b = 0 .. N1 / 2.
-__global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work_base, LpBatch batch, LpTables T) {
+__global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work_base, LpBatch B, LpTables T) {
     extern __shared__ c64 lp_lds[];
-    const LpSig sg = batch.sigs ? batch.sigs[blockIdx.y] : batch.one;
-    const LpGeom g = lp_geom(sg.lg);
-    const int log1 = g.log1, log2 = g.log2, lg = sg.lg;
-    const int N1 = 1 << log1, N2 = 1 << log2;
-    if ((int)blockIdx.x > N1 / 2) return;
-    c64* work = work_base + sg.work_off;
-    const int64_t M = (int64_t)N1 << log2;
-    const int64_t first_cleared = (int64_t)floor(batch.upfactor * (double)((int64_t)1 << lg));   // Praat: floor(upfactor * nfft)
-    const int ka = blockIdx.x, kb = (N1 - ka) & (N1 - 1);
-    const bool two = ka != kb;
-    c64* rowA = work + ((int64_t)bitrev(ka, log1) << log2);
-    c64* rowB = work + ((int64_t)bitrev(kb, log1) << log2);
-    c64* A = lp_lds;
-    c64* B = two ? lp_lds + N2 : lp_lds;
-    for (int e = threadIdx.x; e < N2; e += 256) {
-        A[e] = rowA[e];
-        if (two) B[e] = rowB[e];
-    }
-    __syncthreads();
-    lds_fft<false>(lp_lds, log2, two ? 2 : 1, 1, N2, T.tw);
-    if (two) {
-        for (int k2 = threadIdx.x; k2 < N2; k2 += 256) {
-            const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
-            c64 zk = A[pa], zm = B[pb];
-            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
-            A[pa] = zk;
-            B[pb] = zm;
-        }
-    } else if (ka != 0) {                              // k1 = N1 / 2: the partner of k2 is N2 - 1 - k2 in the same row
-        for (int k2 = threadIdx.x; k2 < N2 / 2; k2 += 256) {
-            const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
-            c64 zk = A[pa], zm = A[pb];
-            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
-            A[pa] = zk;
-            A[pb] = zm;
-        }
-    } else {                                           // k1 = 0: partner N2 - k2; k2 = 0 holds DC and Nyquist, k2 = N2 / 2 is its own partner
-        for (int k2 = threadIdx.x; k2 <= N2 / 2; k2 += 256) {
-            if (k2 == 0) {
-                const c64 z = A[0];
-                const double dc = first_cleared > 1 ? z.x + z.y : 0.0;   // position 1; position 2 (Nyquist) is always cleared
-                A[0] = make_double2(0.5 * dc, 0.5 * dc);
-            } else {
-                const int pa = bitrev(k2, log2), pb = bitrev(N2 - k2, log2);
-                c64 zk = A[pa], zm = A[pb];
-                lp_filter_pair(zk, zm, (int64_t)k2 << log1, M, first_cleared, T, lg);
-                A[pa] = zk;
-                if (pb != pa) A[pb] = zm;
-            }
-        }
-    }
-    __syncthreads();
-    lds_fft<true>(lp_lds, log2, two ? 2 : 1, 1, N2, T.tw);
-    for (int e = threadIdx.x; e < N2; e += 256) {
-        rowA[e] = A[e];
-        if (two) rowB[e] = B[e];
-    }
+    const LpSig sg = B.sigs ? B.sigs[blockIdx.y] : B.one;
+    lp_rows_body(work_base, sg, (int)blockIdx.x, B.upfactor, T, lp_lds);
 }
 
 // ---- NUM_interpolate_sinc on the re-centred grid -------------------------------------------------------------
@@ -305,7 +80,7 @@ namespace rsaf {
 namespace resample {
 
 // device tables of the low-pass transform of nfft samples, cached per (device, nfft); angles reduced on the host
-static int lp_tables(int64_t nfft, LpTables* out) {
+int lp_tables(int64_t nfft, LpTables* out) {
     static std::mutex mu;
     static std::map<std::pair<int, int64_t>, c64*> cache;
     int dev = 0;

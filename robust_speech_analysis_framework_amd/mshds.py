@@ -487,6 +487,10 @@ class MshdsEngine:
         max_seg = int(dur / 0.02) + 2
         cap_res = int(dur * 10000.0) + max_seg + 16
         cap_frames = int(dur / 0.002) + max_seg
+        # Sound_resample of every extracted part: transforms of the first power of two >= part + 2000 samples, i.e. fewer
+        # than part + 2000 complex numbers each
+        cap_work = int(max(lengths)) + 2000 * max_seg
+        lg_max = max(11, int(max(lengths) + 2000 - 1).bit_length())
         segd = int(lib.rsaf_mshds_cpp_seg_doubles())
         ci_all = p["ci"]
         # clips per launch group: bound the cepstrogram workspace (cap_frames x 513 doubles per clip) to ~3 GB
@@ -500,10 +504,15 @@ class MshdsEngine:
             res = torch.empty(m * cap_res, dtype=torch.float64, device=dev)
             ceps = torch.empty(m * cap_frames * 513, dtype=torch.float64, device=dev)
             cppf = torch.empty(m * cap_frames, dtype=torch.float64, device=dev)
+            lp_origin = int(min(int(r["sample_off"]) for r in ci_all[c0:c1]))
+            lp_end = int(max(int(r["sample_off"]) + int(r["n_samples"]) for r in ci_all[c0:c1]))
+            lp = torch.empty(max(lp_end - lp_origin, 1), dtype=torch.float64, device=dev)
+            lpw = torch.empty(m * cap_work * 2, dtype=torch.float64, device=dev)
             _lib.check(lib.rsaf_mshds_cpp(_lib.ptr(wav), _lib.ptr(ci_d), m, _lib.c_void_p_off(pulses, c0 * max_pulses),
                                           max_pulses, _lib.c_void_p_off(npul, c0), _lib.ptr(win), _lib.ptr(tw), max_seg,
                                           cap_res, cap_frames, _lib.ptr(segs), _lib.ptr(hdr), _lib.ptr(res), _lib.ptr(ceps),
-                                          _lib.ptr(cppf), _lib.c_void_p_off(out, c0), _lib.stream_ptr(stream)),
+                                          _lib.ptr(cppf), _lib.ptr(lp), lp_origin, _lib.ptr(lpw), cap_work, lg_max,
+                                          _lib.c_void_p_off(out, c0), _lib.stream_ptr(stream)),
                        "rsaf_mshds_cpp")
             self._last_cpp = {"segs": segs, "hdr": hdr, "res": res, "ceps": ceps, "cpp_frames": cppf, "max_seg": max_seg,
                               "cap_res": cap_res, "cap_frames": cap_frames, "seg_doubles": segd, "pulses": pulses,

@@ -307,7 +307,7 @@ def test_cpp_voiced_intervals_cepstrogram_and_cpps(eng):
             x1_seg = 0.5 * mo.DX + ix1 * mo.DX - tmin
             S = segs[i, k]
             assert int(S[0]) == ix1 and int(S[1]) == len(seg)                         # integers exact
-            y, x1o, _ = mo.resample_windowed_sinc(seg, x1_seg, tmax - tmin, mo.CPP_FS, mo.CPP_DEPTH)
+            y, x1o, _ = mo.resample_part(seg, x1_seg, tmax - tmin, mo.CPP_FS, mo.CPP_DEPTH)
             assert int(S[2]) == len(y) and abs(S[7] - x1o) < 1e-15
             r0 = int(S[3])
             assert np.abs(res[i, r0:r0 + len(y)] - y).max() < 1e-9 * max(1.0, np.abs(y).max())
