@@ -1691,9 +1691,10 @@ __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict
     o[4] = n_pauses > 0 ? (original_dur - phonation) / n_pauses : 0.0;
 }
 
-// ---- 16 kHz -> 10 kHz band-limited resampling (front end of To Formant (burg)) ----------------------------
-// out[m] = sum_k x[base + k] * W[phase][k + D]: the ratio 5/8 gives 5 distinct fractional offsets, whose
-// windowed-sinc weights (half-width D input samples) the host tabulates in float64.
+// ---- 16 kHz -> 10 kHz resampling (Sound_resample (10000, 500) at the head of To Formant (burg)) -----------------
+// Input: the clip after Praat's FFT low-pass (rsaf_praat_lowpass_batch).  out[m] = sum_k x[base + k] * W[phase][k + D]:
+// the ratio 5/8 gives 5 distinct fractional offsets, whose NUM_interpolate_sinc weights at full depth D the host
+// tabulates in float64.
 struct ResampleInfo {        // per clip (host-built), 48 bytes
     int64_t sample_off;      // into wav
     int64_t out_off;         // into the 10 kHz buffer
@@ -1705,7 +1706,8 @@ struct ResampleInfo {        // per clip (host-built), 48 bytes
 };
 
 // 320-thread workgroup = 64 consecutive q x 5 phases (wave r owns phase r, so its weight row is a wave-
-// uniform LDS broadcast); the tile of the low-passed sound is staged once in LDS.  The tables hold NUM_interpolate_sinc's
+// uniform LDS broadcast); the tile of the low-passed sound is staged once in LDS with a 9/8 skew, so that the stride-8
+// reads of a wave (64 B apart) spread over all banks.  The tables hold NUM_interpolate_sinc's
 // weights at full depth for the five fractional positions of the 8 : 5 grid; outputs whose depth Praat clips (within
 // `depth` input samples of either end) are recomputed by resample_edge_kernel.
 constexpr int RS_QT = 64;
@@ -1731,7 +1733,7 @@ __global__ __launch_bounds__(320) void resample_kernel(const double* __restrict_
     const double* x = lp + c.sample_off;
     for (int i = tid; i < span; i += 320) {
         const int j = lo + i;
-        xs[i] = (j >= 0 && j < c.n_in) ? x[j] : 0.0;
+        xs[i + (i >> 3)] = (j >= 0 && j < c.n_in) ? x[j] : 0.0;
     }
     __syncthreads();
     const int r = tid >> 6, ql = tid & 63;
@@ -1739,7 +1741,10 @@ __global__ __launch_bounds__(320) void resample_kernel(const double* __restrict_
     const double* w = wl + r * taps;
     const int i0 = 8 * ql + pb[r] - bmin;                             // tile index of tap 0
     double acc = 0.0;
-    for (int k = 0; k < taps; ++k) acc += xs[i0 + k] * w[k];
+    for (int k = 0; k < taps; ++k) {
+        const int i = i0 + k;
+        acc += xs[i + (i >> 3)] * w[k];
+    }
     if (m < c.n_out) out[c.out_off + m] = acc;
 }
 
@@ -2731,7 +2736,7 @@ int rsaf_mshds_resample10k(const double* lowpassed, const void* resample_info, i
     hipStream_t s = (hipStream_t)stream;
     const int taps = 2 * depth + 1;
     const int span = 8 * (RS_QT - 1) + 8 + taps;                       // phase bases differ by < 8
-    const size_t lds = (size_t)5 * taps * sizeof(double) + (size_t)(span + 2) * sizeof(double);
+    const size_t lds = (size_t)5 * taps * sizeof(double) + (size_t)(span + span / 8 + 2) * sizeof(double);
     RSAF_CHECK_ARG(lds <= 150 * 1024, "resampler depth too large for LDS");
     if (lds > 48 * 1024)
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

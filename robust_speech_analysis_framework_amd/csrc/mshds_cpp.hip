@@ -171,12 +171,14 @@ __device__ __forceinline__ int find_seg(const Seg* __restrict__ s, int nseg, int
 // FFT low-pass of the extracted part (its own transform length), then NUM_interpolate_sinc on the grid centred in the
 // part's domain.  The intervals are found on the device, so the three transform passes run as loops over work items:
 // item w of a clip = workgroup (w - item_off) of the interval that owns it; every pass uses the same item count.
+// Each pass is launched once for the short transforms (up to 2^14 samples: 8 KB of LDS, full occupancy) and once for the
+// long ones (LDS for a whole clip); a launch skips the items of the other class.
 template <int PASS>
 __global__ __launch_bounds__(256) void seg_lowpass_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                           const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
                                                           resample::c64* __restrict__ work, int64_t cap_work,
                                                           double* __restrict__ lowpassed, int64_t lp_origin,
-                                                          resample::LpTables T) {
+                                                          int lg_lo, int lg_hi, resample::LpTables T) {
     extern __shared__ resample::c64 lp_lds[];
     const int clip = blockIdx.y;
     const int nseg = hdr[4 * clip];
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(256) void seg_lowpass_kernel(const float* __restric
     const int total = (int)S[nseg - 1].item_off + lp_items((int)S[nseg - 1].lg);
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const Seg s = S[find_seg<13>(S, nseg, w)];
+        if ((int)s.lg < lg_lo || (int)s.lg > lg_hi) continue;               // the other launch's class (same for the whole workgroup)
         resample::LpSig sg;
         sg.in_off = c.sample_off + (int64_t)s.ix1;
         sg.out_off = c.sample_off - lp_origin + (int64_t)s.ix1;
@@ -584,21 +587,30 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
         const int rc = resample::lp_tables((int64_t)1 << lg_max, &T);
         if (rc != RSAF_OK) return rc;
         T.lg_max = lg_max;
-        size_t lds = 0;
-        for (int lg = 11; lg <= lg_max; ++lg) {
-            const resample::LpGeom g = resample::lp_geom(lg);
-            lds = std::max(lds, std::max(((size_t)g.C << g.log1), ((size_t)2 << g.log2)) * sizeof(resample::c64));
-        }
-        if (lds > 48 * 1024) {
-            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        const dim3 grid(64, n_clips);                                        // 64 workgroups walk the items of a clip
+        auto lds_for = [](int lg_a, int lg_b) {
+            size_t lds = 0;
+            for (int lg = lg_a; lg <= lg_b; ++lg) {
+                const resample::LpGeom g = resample::lp_geom(lg);
+                lds = std::max(lds, std::max(((size_t)g.C << g.log1), ((size_t)2 << g.log2)) * sizeof(resample::c64));
+            }
+            return lds;
+        };
+        constexpr int LG_SHORT = 14;
         resample::c64* wk = (resample::c64*)lp_work;
-        hipLaunchKernelGGL(seg_lowpass_kernel<0>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, T);
-        hipLaunchKernelGGL(seg_lowpass_kernel<1>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, T);
-        hipLaunchKernelGGL(seg_lowpass_kernel<2>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, T);
+        for (int cls = 0; cls < 2; ++cls) {
+            const int lg_lo = cls == 0 ? 11 : LG_SHORT + 1, lg_hi = cls == 0 ? std::min(LG_SHORT, lg_max) : lg_max;
+            if (lg_lo > lg_hi) continue;
+            const size_t lds = lds_for(lg_lo, lg_hi);
+            if (lds > 48 * 1024) {
+                RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            const dim3 grid(cls == 0 ? 128 : 64, n_clips);                   // workgroups that walk the items of a clip
+            hipLaunchKernelGGL(seg_lowpass_kernel<0>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);
+            hipLaunchKernelGGL(seg_lowpass_kernel<1>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);
+            hipLaunchKernelGGL(seg_lowpass_kernel<2>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);
+        }
         hipLaunchKernelGGL(resample_kernel, dim3((cap_res + 255) / 256, n_clips), dim3(256), 0, s, (const double*)lowpassed, lp_origin,
                            ci, segs, max_seg, hdr, cap_res, resampled);
         RSAF_CHECK_HIP(hipGetLastError());

@@ -58,6 +58,37 @@ def test_praat_resample_sizes_and_depths(rsaf_lib, fs, n, depth):
     assert len(ref) == 0 or np.abs(got - ref).max() <= 3e-7, np.abs(got - ref).max()
 
 
+def test_praat_lowpass_batch_of_ragged_sounds_matches_restatement(rsaf_lib):
+    """The batched low-pass behind To Formant (burg): sounds of different transform lengths in one launch (the shorter ones
+    stride through the twiddle tables of the longest), packed back to back like the clips of the MSHDS engine."""
+    import torch
+    from robust_speech_analysis_framework_amd import _lib
+    from robust_speech_analysis_framework_amd.mshds import LP_SIG, _dev
+    lib = _lib.load()
+    lengths = [49, 2049, 6193, 30000, 14385, 140001, 1]
+    rng = np.random.Generator(np.random.PCG64(17))
+    x = (0.4 * rng.standard_normal(sum(lengths))).astype(np.float32)
+    sigs = np.zeros(len(lengths), dtype=LP_SIG)
+    off = work = 0
+    for i, n in enumerate(lengths):
+        lg = max(11, int(n + 2000 - 1).bit_length())
+        assert (1 << lg) >= n + 2000 and (lg == 11 or (1 << (lg - 1)) < n + 2000)
+        sigs[i] = (off, off, work, n, lg)
+        off += n
+        work += 1 << (lg - 1)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.full((len(x),), float("nan"), dtype=torch.float64, device="cuda")
+    wk = torch.empty(2 * work, dtype=torch.float64, device="cuda")
+    _lib.check(lib.rsaf_praat_lowpass_batch(_lib.ptr(xd), _lib.ptr(_dev(sigs, "cuda")), len(lengths), int(sigs["lg"].max()), 0.625,
+                                            _lib.ptr(wk), work, _lib.ptr(out), _lib.stream_ptr(None)), "rsaf_praat_lowpass_batch")
+    got = out.cpu().numpy()
+    off = 0
+    for n in lengths:
+        ref = ro.praat_fft_lowpass(x[off:off + n].astype(np.float64), 0.625)
+        assert np.abs(got[off:off + n] - ref).max() <= 1e-13, n
+        off += n
+
+
 def test_praat_resample_rejects_missing_workspace(rsaf_lib):
     import torch
     from robust_speech_analysis_framework_amd import _lib

@@ -1,4 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r02/rs
-timeout -k 10 900 python -m pytest tests/test_resample_gpu.py tests/test_mshds_gpu.py -q -x > gpurun_out/r02/rs/test2.log 2>&1
+export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace -d gpurun_out/r02/rs/kt -o kt --output-format csv -- python3 bench.py --config C2 --no-cpu-baseline --no-inclusive --steps 1 --warmup 1 > gpurun_out/r02/rs/kt_bench.json 2> gpurun_out/r02/rs/kt_bench.err
+ls -la gpurun_out/r02/rs/kt | head
