@@ -89,6 +89,28 @@ def test_praat_lowpass_batch_of_ragged_sounds_matches_restatement(rsaf_lib):
         off += n
 
 
+@pytest.mark.parametrize("n", [4_800_001, 9_000_000])
+def test_praat_lowpass_of_a_five_and_a_nine_minute_sound(rsaf_lib, n):
+    """The two longest transform shapes: 2^23 samples (2 048 x 2 048 complex points, two columns per workgroup) and 2^24
+    (4 096-point column transforms, one column per workgroup)."""
+    import torch
+    from robust_speech_analysis_framework_amd import _lib
+    from robust_speech_analysis_framework_amd.mshds import LP_SIG, _dev
+    lib = _lib.load()
+    rng = np.random.Generator(np.random.PCG64(n))
+    x = (0.4 * rng.standard_normal(n)).astype(np.float32)
+    lg = int(n + 2000 - 1).bit_length()
+    sigs = np.zeros(1, dtype=LP_SIG)
+    sigs[0] = (0, 0, 0, n, lg)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    wk = torch.empty(2 << (lg - 1), dtype=torch.float64, device="cuda")
+    _lib.check(lib.rsaf_praat_lowpass_batch(_lib.ptr(xd), _lib.ptr(_dev(sigs, "cuda")), 1, lg, 0.625, _lib.ptr(wk), 1 << (lg - 1),
+                                            _lib.ptr(out), _lib.stream_ptr(None)), "rsaf_praat_lowpass_batch")
+    ref = ro.praat_fft_lowpass(x.astype(np.float64), 0.625)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-12
+
+
 def test_praat_resample_rejects_missing_workspace(rsaf_lib):
     import torch
     from robust_speech_analysis_framework_amd import _lib
