@@ -299,14 +299,16 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
  * then F1,B1,F2,B2 linearly interpolated at every pulse -> mean and sample SD.
  * resample_info: device array of {int64 sample_off; int64 out_off; double pos0; double x1o; int32 n_in;
  * int32 n_out; int32 table; int32 pad} (48 bytes).  The 10 kHz resampling is Praat's Sound_resample(10000, 500):
- * `lowpassed` = the clips after rsaf_praat_lowpass_batch (same layout as wav, float64); tables: [n_tables][5][2*depth+1]
- * float64 NUM_interpolate_sinc weights at full depth (tap k belongs to input base + k - depth); phase_base:
+ * `lowpassed` = the clips after rsaf_praat_lowpass_batch (same layout as wav, float64); tables: [n_tables][5][table_stride]
+ * float64 NUM_interpolate_sinc weights at full depth (tap k < 2*depth+1 belongs to input base + k - depth; zeros up to
+ * table_stride >= rsaf_mshds_resample10k_table_stride(depth)); phase_base:
  * [n_tables][5] int32 = floor(pos0 + 1.6 r) (output m = 5q + r reads input 8q + base); outputs whose depth Praat
  * clips at the ends of the sound are evaluated directly.
  * frames_out: per frame {double f[5]; double b[5]} (NaN padded); pulses: [n_clips][max_pulses] times (unsorted);
  * stats out[clip][8] = mean/SD of F1, B1, F2, B2 in the reference's column order. */
+int rsaf_mshds_resample10k_table_stride(int depth);
 int rsaf_mshds_resample10k(const double* lowpassed, const void* resample_info, int n_clips, int max_out,
-                           const double* tables, const int* phase_base, int depth, double* out,
+                           const double* tables, int table_stride, const int* phase_base, int depth, double* out,
                            rsaf_stream_t stream);
 int rsaf_mshds_formants(const double* y10, const void* resample_info, const void* clip_info, int n_clips,
                         int max_frames, const double* window, int nsamp_window, double time_step, double dx_out,

@@ -69,7 +69,8 @@ SIGNATURES = {
                                    C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "rsaf_mshds_speechrate_workspace_doubles": (_L, [_I]),
     "rsaf_mshds_speechrate": (_I, [_P, _P, _I, _I, C.c_double, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
-    "rsaf_mshds_resample10k": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P]),
+    "rsaf_mshds_resample10k_table_stride": (_I, [_I]),
+    "rsaf_mshds_resample10k": (_I, [_P, _P, _I, _I, _P, _I, _P, _I, _P, _P]),
     "rsaf_mshds_formants": (_I, [_P, _P, _P, _I, _I, _P, _I, C.c_double, C.c_double, C.c_double, _P, _P]),
     "rsaf_mshds_pulses_workspace_bytes": (_L, [_I, _I, C.c_double, C.c_double]),
     "rsaf_mshds_pulses": (_I, [_P, _P, _I, _I, _P, C.c_double, C.c_double, _P, _L, _P, _I, _P, _P]),

@@ -1705,14 +1705,17 @@ struct ResampleInfo {        // per clip (host-built), 48 bytes
     int pad;
 };
 
-// 320-thread workgroup = 64 consecutive q x 5 phases (wave r owns phase r, so its weight row is a wave-
-// uniform LDS broadcast); the tile of the low-passed sound is staged once in LDS with a 9/8 skew, so that the stride-8
-// reads of a wave (64 B apart) spread over all banks.  The tables hold NUM_interpolate_sinc's
-// weights at full depth for the five fractional positions of the 8 : 5 grid; outputs whose depth Praat clips (within
-// `depth` input samples of either end) are recomputed by resample_edge_kernel.
-constexpr int RS_QT = 64;
+// 320-thread workgroup = 5 phases x 256 consecutive q: wave r owns phase r, so its weight row is wave-uniform and comes
+// through the scalar cache into SGPRs (no LDS traffic for the weights); a lane owns 4 consecutive q, whose tap windows
+// are 8 samples apart: every sample it reads from the LDS tile feeds 4 FMAs (taps k, k - 8, k - 16, k - 24 of its four
+// outputs), which balances the LDS read rate against the fp64 FMA rate.  Lanes are 32 samples apart in the tile; a
+// 33/32 skew puts the 8-byte reads of a half wave on distinct banks.  The tables hold NUM_interpolate_sinc's weights at
+// full depth for the five fractional positions of the 8 : 5 grid, rows zero-padded to `wstride` doubles; outputs whose
+// depth Praat clips (within `depth` input samples of either end) are recomputed by resample_edge_kernel.
+constexpr int RS_QL = 4;                  // consecutive q per lane
+constexpr int RS_QT = 64 * RS_QL;         // q per workgroup
 __global__ __launch_bounds__(320) void resample_kernel(const double* __restrict__ lp, const ResampleInfo* __restrict__ ri,
-                                                       const double* __restrict__ tables,
+                                                       const double* __restrict__ tables, int wstride,
                                                        const int* __restrict__ phase_base, int depth,
                                                        double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1720,32 +1723,49 @@ __global__ __launch_bounds__(320) void resample_kernel(const double* __restrict_
     const int q0 = blockIdx.x * RS_QT;
     if (5 * q0 >= c.n_out) return;
     const int taps = 2 * depth + 1;
-    double* wl = reinterpret_cast<double*>(smem_raw);                 // [5][taps]
-    double* xs = wl + 5 * taps;                                       // input tile
+    double* xs = reinterpret_cast<double*>(smem_raw);                 // input tile
     const int tid = threadIdx.x;
     const int* pb = phase_base + c.table * 5;
     int bmin = pb[0], bmax = pb[0];
     for (int r = 1; r < 5; ++r) { bmin = min(bmin, pb[r]); bmax = max(bmax, pb[r]); }
     const int lo = 8 * q0 + bmin - depth;                             // first input index of the tile
-    const int span = 8 * (RS_QT - 1) + (bmax - bmin) + taps;
-    const double* wg = tables + (int64_t)c.table * 5 * taps;
-    for (int i = tid; i < 5 * taps; i += 320) wl[i] = wg[i];
+    const int nkb = (taps + 8 * (RS_QL - 1) + 7) / 8;                 // tap blocks of 8; the rows are zero beyond `taps`
+    const int span = 8 * RS_QL * 63 + (bmax - bmin) + 8 * nkb;        // every index the tap loop reads
     const double* x = lp + c.sample_off;
     for (int i = tid; i < span; i += 320) {
         const int j = lo + i;
-        xs[i + (i >> 3)] = (j >= 0 && j < c.n_in) ? x[j] : 0.0;
+        xs[i + (i >> 5)] = (j >= 0 && j < c.n_in) ? x[j] : 0.0;
     }
     __syncthreads();
-    const int r = tid >> 6, ql = tid & 63;
-    const int m = 5 * (q0 + ql) + r;
-    const double* w = wl + r * taps;
-    const int i0 = 8 * ql + pb[r] - bmin;                             // tile index of tap 0
-    double acc = 0.0;
-    for (int k = 0; k < taps; ++k) {
-        const int i = i0 + k;
-        acc += xs[i + (i >> 3)] * w[k];
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6), ql = tid & 63;
+    const double* __restrict__ w = tables + ((int64_t)c.table * 5 + r) * wstride;   // wave-uniform
+    const int i0 = 8 * RS_QL * ql + pb[r] - bmin;                     // tile index of tap 0 of the lane's first output
+    double acc[RS_QL] = {0.0, 0.0, 0.0, 0.0};
+    double wq[RS_QL][8];                                              // weights k = 8 (kb - j) + t of output j
+#pragma unroll
+    for (int j = 0; j < RS_QL; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) wq[j][t] = 0.0;
+    for (int kb = 0; kb < nkb; ++kb) {
+#pragma unroll
+        for (int j = RS_QL - 1; j > 0; --j)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) wq[j][t] = wq[j - 1][t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) wq[0][t] = w[8 * kb + t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = i0 + 8 * kb + t;
+            const double xv = xs[i + (i >> 5)];
+#pragma unroll
+            for (int j = 0; j < RS_QL; ++j) acc[j] = fma(xv, wq[j][t], acc[j]);
+        }
     }
-    if (m < c.n_out) out[c.out_off + m] = acc;
+#pragma unroll
+    for (int j = 0; j < RS_QL; ++j) {
+        const int m = 5 * (q0 + RS_QL * ql + j) + r;
+        if (m < c.n_out) out[c.out_off + m] = acc[j];
+    }
 }
 
 // the first and last `n_edge` output samples of every clip by the general routine when their depth is clipped (or the
@@ -2728,22 +2748,25 @@ int rsaf_mshds_speechrate(const double* intensity_db, const void* clip_info, int
     return RSAF_OK;
 }
 
+int rsaf_mshds_resample10k_table_stride(int depth) { return (2 * depth + 1 + 8 * (RS_QL - 1) + 7) / 8 * 8 + 8; }
+
 int rsaf_mshds_resample10k(const double* lowpassed, const void* resample_info, int n_clips, int max_out, const double* tables,
-                           const int* phase_base, int depth, double* out, rsaf_stream_t stream) {
+                           int table_stride, const int* phase_base, int depth, double* out, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535 && max_out >= 0 && depth >= 3, "bad argument");
     if (n_clips == 0 || max_out == 0) return RSAF_OK;
     RSAF_CHECK_ARG(lowpassed && resample_info && tables && phase_base && out, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     const int taps = 2 * depth + 1;
-    const int span = 8 * (RS_QT - 1) + 8 + taps;                       // phase bases differ by < 8
-    const size_t lds = (size_t)5 * taps * sizeof(double) + (size_t)(span + span / 8 + 2) * sizeof(double);
+    RSAF_CHECK_ARG(table_stride >= rsaf_mshds_resample10k_table_stride(depth), "weight rows shorter than rsaf_mshds_resample10k_table_stride");
+    const int span = 8 * (RS_QT - 1) + 8 + taps + 8 * RS_QL + 8;       // phase bases differ by < 8; the tap loop runs past `taps`
+    const size_t lds = (size_t)(span + span / 32 + 2) * sizeof(double);
     RSAF_CHECK_ARG(lds <= 150 * 1024, "resampler depth too large for LDS");
     if (lds > 48 * 1024)
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof("mshds_resample10k", s, 0.0, 0.0);
     const int nq = (max_out + 4) / 5;
     hipLaunchKernelGGL(resample_kernel, dim3((nq + RS_QT - 1) / RS_QT, n_clips), dim3(320), lds, s, lowpassed,
-                       (const ResampleInfo*)resample_info, tables, phase_base, depth, out);
+                       (const ResampleInfo*)resample_info, tables, table_stride, phase_base, depth, out);
     RSAF_CHECK_HIP(hipGetLastError());
     const int n_edge = (int)((double)(depth + 2) * 0.625) + 3;         // output samples within depth + 2 input samples of an end
     hipLaunchKernelGGL(resample_edge_kernel, dim3((2 * n_edge + 255) / 256, n_clips), dim3(256), 0, s, lowpassed,

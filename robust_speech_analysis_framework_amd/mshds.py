@@ -373,7 +373,10 @@ class MshdsEngine:
         if n == 0:
             return out[:0]
         ri_d = _dev(ri, dev)
-        tab_d = torch.from_numpy(np.ascontiguousarray(np.stack(tabs)).reshape(-1)).to(dev)
+        wstride = int(lib.rsaf_mshds_resample10k_table_stride(RS_DEPTH))   # rows zero-padded for the kernel's tap blocks
+        tab = np.zeros((len(tabs), 5, wstride))
+        tab[:, :, :2 * RS_DEPTH + 1] = np.stack(tabs)
+        tab_d = torch.from_numpy(tab.reshape(-1)).to(dev)
         base_d = torch.from_numpy(np.asarray(bases, dtype=np.int32).reshape(-1)).to(dev)
         # Sound_resample(10000, 500): whole-sound FFT low-pass (16 kHz -> 10 kHz goes down), then sinc interpolation
         lp = torch.empty(int(wav.numel()), dtype=torch.float64, device=dev)
@@ -381,7 +384,7 @@ class MshdsEngine:
         _lib.check(lib.rsaf_praat_lowpass_batch(_lib.ptr(wav), _lib.ptr(_dev(lps, dev)), n, int(lps["lg"].max()), RS_RATE * DX,
                                                 _lib.ptr(work), work_off, _lib.ptr(lp), _lib.stream_ptr(stream)),
                    "rsaf_praat_lowpass_batch")
-        _lib.check(lib.rsaf_mshds_resample10k(_lib.ptr(lp), _lib.ptr(ri_d), n, max_out, _lib.ptr(tab_d), _lib.ptr(base_d),
+        _lib.check(lib.rsaf_mshds_resample10k(_lib.ptr(lp), _lib.ptr(ri_d), n, max_out, _lib.ptr(tab_d), wstride, _lib.ptr(base_d),
                                               RS_DEPTH, _lib.ptr(y10), _lib.stream_ptr(stream)), "rsaf_mshds_resample10k")
         del work
         # Formant (burg): 5 ms, 5 formants, 5 kHz, 25 ms half-window, pre-emphasis from 50 Hz  (:319)
