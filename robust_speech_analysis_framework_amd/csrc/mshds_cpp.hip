@@ -171,8 +171,8 @@ __device__ __forceinline__ int find_seg(const Seg* __restrict__ s, int nseg, int
 // FFT low-pass of the extracted part (its own transform length), then NUM_interpolate_sinc on the grid centred in the
 // part's domain.  The intervals are found on the device, so the three transform passes run as loops over work items:
 // item w of a clip = workgroup (w - item_off) of the interval that owns it; every pass uses the same item count.
-// Each pass is launched once for the short transforms (up to 2^14 samples: 8 KB of LDS, full occupancy) and once for the
-// long ones (LDS for a whole clip); a launch skips the items of the other class.
+// Those launches take the long intervals only (transforms above 2^14 samples); a shorter interval is low-passed by one
+// workgroup inside LDS (seg_lowpass_lds_kernel).
 template <int PASS>
 __global__ __launch_bounds__(256) void seg_lowpass_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
                                                           const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
@@ -200,6 +200,25 @@ __global__ __launch_bounds__(256) void seg_lowpass_kernel(const float* __restric
         else if (PASS == 1) resample::lp_rows_body(work, sg, bx, FS_OUT * DXS, T, lp_lds);
         else resample::lp_cols_body<true>(wav, work, lowpassed, sg, bx, T, lp_lds);
         __syncthreads();                                                     // the next item reuses the LDS buffer
+    }
+}
+
+// intervals whose whole transform fits LDS (up to 2^14 samples = 8 192 complex numbers = 128 KB): one workgroup per interval,
+// samples in, low-passed samples out, nothing through the work buffer
+__global__ __launch_bounds__(1024) void seg_lowpass_lds_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                               const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                               double* __restrict__ lowpassed, int64_t lp_origin, int lg_hi,
+                                                               resample::LpTables T) {
+    extern __shared__ resample::c64 lp_lds[];
+    const int clip = blockIdx.y;
+    const int nseg = hdr[4 * clip];
+    const Seg* S = segs + (int64_t)clip * max_seg;
+    const ClipInfo c = ci[clip];
+    for (int k = blockIdx.x; k < nseg; k += gridDim.x) {
+        const Seg s = S[k];
+        if ((int)s.lg > lg_hi) continue;                                     // a long interval: the three-pass launches
+        resample::lp_whole_in_lds(wav + c.sample_off + (int64_t)s.ix1, lowpassed + (c.sample_off - lp_origin) + (int64_t)s.ix1,
+                                  (int)s.m_in, (int)s.lg, FS_OUT * DXS, T, lp_lds);
     }
 }
 
@@ -595,18 +614,25 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
             }
             return lds;
         };
-        constexpr int LG_SHORT = 14;
+        constexpr int LG_LDS = 14;                                           // 2^13 complex numbers = 128 KB of LDS
         resample::c64* wk = (resample::c64*)lp_work;
-        for (int cls = 0; cls < 2; ++cls) {
-            const int lg_lo = cls == 0 ? 11 : LG_SHORT + 1, lg_hi = cls == 0 ? std::min(LG_SHORT, lg_max) : lg_max;
-            if (lg_lo > lg_hi) continue;
+        {
+            const int lg_hi = std::min(LG_LDS, lg_max);
+            const size_t lds = ((size_t)1 << (lg_hi - 1)) * sizeof(resample::c64);
+            if (lds > 48 * 1024)
+                RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(seg_lowpass_lds_kernel, dim3(32, n_clips), dim3(1024), lds, s, wav, ci, segs, max_seg, hdr, lowpassed,
+                               lp_origin, lg_hi, T);
+        }
+        if (lg_max > LG_LDS) {
+            const int lg_lo = LG_LDS + 1, lg_hi = lg_max;
             const size_t lds = lds_for(lg_lo, lg_hi);
             if (lds > 48 * 1024) {
                 RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)seg_lowpass_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             }
-            const dim3 grid(cls == 0 ? 128 : 64, n_clips);                   // workgroups that walk the items of a clip
+            const dim3 grid(64, n_clips);                                    // workgroups that walk the items of a clip
             hipLaunchKernelGGL(seg_lowpass_kernel<0>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);
             hipLaunchKernelGGL(seg_lowpass_kernel<1>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);
             hipLaunchKernelGGL(seg_lowpass_kernel<2>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);

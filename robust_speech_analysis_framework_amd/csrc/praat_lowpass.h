@@ -48,14 +48,15 @@ struct LpBatch {
     double upfactor;
 };
 
-struct LpGeom { int log1, log2, C; };
+struct LpGeom { int log1, log2, C, logC; };
 __host__ __device__ inline LpGeom lp_geom(int lg) {
     LpGeom g;
     const int logM = lg - 1;                            // lg >= 11
     g.log2 = (logM + 1) / 2 < 11 ? (logM + 1) / 2 : 11; // about square; rows of at most 2 048 points
     g.log1 = logM - g.log2;
     g.C = 8;
-    while (g.C > 1 && ((int64_t)g.C << g.log1) > 4096) g.C >>= 1;
+    g.logC = 3;
+    while (g.C > 1 && ((int64_t)g.C << g.log1) > 4096) { g.C >>= 1; --g.logC; }
     return g;
 }
 
@@ -65,27 +66,34 @@ __device__ __forceinline__ c64 w_nfft(const LpTables& T, int64_t p, int lg) {
     return cmul(T.lo[p & (TW_N - 1)], T.hi[p >> TW_LOG]);
 }
 
-// nseq interleaved sequences of length 2^logL in LDS (element e of sequence q at buf[e * es + q * ss]); INV = false:
+// 2^lognseq interleaved sequences of length 2^logL in LDS (element e of sequence q at buf[e * es + q * ss]); INV = false:
 // decimation in frequency, forward twiddles, natural in / bit-reversed out; INV = true: decimation in time, conjugate
-// twiddles, bit-reversed in / natural out, unnormalised.  Two butterfly layers per barrier.
+// twiddles, bit-reversed in / natural out, unnormalised.  Two butterfly layers per barrier.  Consecutive threads take
+// consecutive sequences when those lie closer together than the elements of one sequence (column transforms), else
+// consecutive butterflies of one sequence: neighbouring lanes stay 16 bytes apart either way.
 template <bool INV>
-__device__ inline void lds_fft(c64* buf, int logL, int nseq, int es, int ss, const c64* __restrict__ tw) {
+__device__ inline void lds_fft(c64* buf, int logL, int lognseq, int es, int ss, const c64* __restrict__ tw) {
     const int L = 1 << logL;
-    if (INV && (logL & 1)) {
-        for (int t = threadIdx.x; t < nseq * (L >> 1); t += blockDim.x) {
-            const int q = t / (L >> 1), u = t - q * (L >> 1);
+    const bool seq_fast = ss < es;
+    const int qmask = (1 << lognseq) - 1;
+    auto radix2 = [&]() {
+        const int lc = logL - 1;                                      // log2 of the butterflies per sequence
+        for (int t = threadIdx.x; t < (1 << (lognseq + lc)); t += blockDim.x) {
+            const int q = seq_fast ? (t & qmask) : (t >> lc), u = seq_fast ? (t >> lognseq) : (t & ((1 << lc) - 1));
             c64* p = buf + q * ss + (2 * u) * es;
             const c64 a = p[0], b = p[es];
             p[0] = cadd(a, b);
             p[es] = csub(a, b);
         }
         __syncthreads();
-    }
+    };
+    if (INV && (logL & 1)) radix2();
     const int first = INV ? (2 + (logL & 1)) : logL, last = INV ? logL : (2 + (logL & 1));
     for (int sl = first; INV ? sl <= last : sl >= last; sl += INV ? 2 : -2) {
         const int ql = sl - 2, qn = 1 << ql;
-        for (int t = threadIdx.x; t < nseq * (L >> 2); t += blockDim.x) {
-            const int q = t / (L >> 2), u = t - q * (L >> 2);
+        const int lc = logL - 2;
+        for (int t = threadIdx.x; t < (1 << (lognseq + lc)); t += blockDim.x) {
+            const int q = seq_fast ? (t & qmask) : (t >> lc), u = seq_fast ? (t >> lognseq) : (t & ((1 << lc) - 1));
             const int blk = u >> ql, j = u & (qn - 1);
             c64* p = buf + q * ss + ((blk << sl) + j) * es;
             const int st = qn * es;
@@ -110,16 +118,7 @@ __device__ inline void lds_fft(c64* buf, int logL, int nseq, int es, int ss, con
         }
         __syncthreads();
     }
-    if (!INV && (logL & 1)) {
-        for (int t = threadIdx.x; t < nseq * (L >> 1); t += blockDim.x) {
-            const int q = t / (L >> 1), u = t - q * (L >> 1);
-            c64* p = buf + q * ss + (2 * u) * es;
-            const c64 a = p[0], b = p[es];
-            p[0] = cadd(a, b);
-            p[es] = csub(a, b);
-        }
-        __syncthreads();
-    }
+    if (!INV && (logL & 1)) radix2();
 }
 
 // Column pass.  Forward: samples -> LDS [N1][C] -> transform over n1 -> times W_M^(n2 k1) -> work.  Inverse: work times
@@ -152,7 +151,7 @@ __device__ void lp_cols_body(const float* __restrict__ in, c64* __restrict__ wor
         }
     }
     __syncthreads();
-    lds_fft<INV>(lp_lds, log1, C, C, 1, T.tw);
+    lds_fft<INV>(lp_lds, log1, g.logC, C, 1, T.tw);
     for (int e = threadIdx.x; e < N1 * C; e += blockDim.x) {
         const int r = e / C, c = e - r * C, n2 = c0 + c;
         if (!INV) {
@@ -187,6 +186,42 @@ __device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int6
     zm = make_double2(0.5 * (s2.x - r2.x), 0.5 * (s2.y - r2.y));
 }
 
+// the filter step for element k2 of the logical row ka (A) and its partner in row N1 - ka (B; B == A when the row is its own
+// partner); both rows hold their transform in bit-reversed positions
+__device__ __forceinline__ void lp_filter_at(c64* A, c64* B, int ka, int k2, int log1, int log2, int64_t first_cleared,
+                                             const LpTables& T, int lg) {
+    const int N1 = 1 << log1, N2 = 1 << log2;
+    const int64_t M = (int64_t)N1 << log2;
+    const bool two = ka != ((N1 - ka) & (N1 - 1));
+    if (two) {
+        const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
+        c64 zk = A[pa], zm = B[pb];
+        lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
+        A[pa] = zk;
+        B[pb] = zm;
+    } else if (ka != 0) {                              // k1 = N1 / 2: the partner of k2 is N2 - 1 - k2 in the same row
+        if (k2 >= N2 / 2) return;
+        const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
+        c64 zk = A[pa], zm = A[pb];
+        lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
+        A[pa] = zk;
+        A[pb] = zm;
+    } else {                                           // k1 = 0: partner N2 - k2; k2 = 0 holds DC and Nyquist, k2 = N2 / 2 is its own partner
+        if (k2 > N2 / 2) return;
+        if (k2 == 0) {
+            const c64 z = A[0];
+            const double dc = first_cleared > 1 ? z.x + z.y : 0.0;   // position 1; position 2 (Nyquist) is always cleared
+            A[0] = make_double2(0.5 * dc, 0.5 * dc);
+        } else {
+            const int pa = bitrev(k2, log2), pb = bitrev(N2 - k2, log2);
+            c64 zk = A[pa], zm = A[pb];
+            lp_filter_pair(zk, zm, (int64_t)k2 << log1, M, first_cleared, T, lg);
+            A[pa] = zk;
+            if (pb != pa) A[pb] = zm;
+        }
+    }
+}
+
 // Row pass: workgroup b owns the logical rows k1 = b and N1 - b (stored at their bit-reversed positions), b = 0 .. N1 / 2.
 __device__ inline void lp_rows_body(c64* __restrict__ work_base, const LpSig& sg, int bx, double upfactor, const LpTables& T,
                                     c64* lp_lds) {
@@ -208,44 +243,62 @@ __device__ inline void lp_rows_body(c64* __restrict__ work_base, const LpSig& sg
         if (two) B[e] = rowB[e];
     }
     __syncthreads();
-    lds_fft<false>(lp_lds, log2, two ? 2 : 1, 1, N2, T.tw);
-    if (two) {
-        for (int k2 = threadIdx.x; k2 < N2; k2 += blockDim.x) {
-            const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
-            c64 zk = A[pa], zm = B[pb];
-            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
-            A[pa] = zk;
-            B[pb] = zm;
-        }
-    } else if (ka != 0) {                              // k1 = N1 / 2: the partner of k2 is N2 - 1 - k2 in the same row
-        for (int k2 = threadIdx.x; k2 < N2 / 2; k2 += blockDim.x) {
-            const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
-            c64 zk = A[pa], zm = A[pb];
-            lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
-            A[pa] = zk;
-            A[pb] = zm;
-        }
-    } else {                                           // k1 = 0: partner N2 - k2; k2 = 0 holds DC and Nyquist, k2 = N2 / 2 is its own partner
-        for (int k2 = threadIdx.x; k2 <= N2 / 2; k2 += blockDim.x) {
-            if (k2 == 0) {
-                const c64 z = A[0];
-                const double dc = first_cleared > 1 ? z.x + z.y : 0.0;   // position 1; position 2 (Nyquist) is always cleared
-                A[0] = make_double2(0.5 * dc, 0.5 * dc);
-            } else {
-                const int pa = bitrev(k2, log2), pb = bitrev(N2 - k2, log2);
-                c64 zk = A[pa], zm = A[pb];
-                lp_filter_pair(zk, zm, (int64_t)k2 << log1, M, first_cleared, T, lg);
-                A[pa] = zk;
-                if (pb != pa) A[pb] = zm;
-            }
-        }
-    }
+    lds_fft<false>(lp_lds, log2, two ? 1 : 0, 1, N2, T.tw);
+    for (int k2 = threadIdx.x; k2 < N2; k2 += blockDim.x) lp_filter_at(A, B, ka, k2, log1, log2, first_cleared, T, lg);
     __syncthreads();
-    lds_fft<true>(lp_lds, log2, two ? 2 : 1, 1, N2, T.tw);
+    lds_fft<true>(lp_lds, log2, two ? 1 : 0, 1, N2, T.tw);
     for (int e = threadIdx.x; e < N2; e += blockDim.x) {
         rowA[e] = A[e];
         if (two) rowB[e] = B[e];
     }
+}
+
+// The whole low-pass of one short sound inside LDS (2^(lg-1) complex numbers: 64 KB at lg = 13, 128 KB at lg = 14): the same
+// column / row / filter / row / column sequence without the trips through the work buffer.  Called by every thread of the
+// workgroup; x = the sound's samples, out = its low-passed samples.
+__device__ inline void lp_whole_in_lds(const float* __restrict__ x, double* __restrict__ out, int n, int lg, double upfactor,
+                                       const LpTables& T, c64* buf) {
+    const LpGeom g = lp_geom(lg);
+    const int log1 = g.log1, log2 = g.log2;
+    const int N1 = 1 << log1, N2 = 1 << log2, M = N1 << log2;
+    const int64_t first_cleared = (int64_t)floor(upfactor * (double)((int64_t)1 << lg));
+    for (int e = threadIdx.x; e < M; e += blockDim.x) {
+        const int i0 = 2 * e - ANTI_TURN_AROUND;
+        c64 v;
+        v.x = (i0 >= 0 && i0 < n) ? (double)x[i0] : 0.0;
+        v.y = (i0 + 1 >= 0 && i0 + 1 < n) ? (double)x[i0 + 1] : 0.0;
+        buf[e] = v;
+    }
+    __syncthreads();
+    lds_fft<false>(buf, log1, log2, N2, 1, T.tw);                      // columns: element r of column c at buf[r N2 + c]
+    for (int e = threadIdx.x; e < M; e += blockDim.x) {
+        const int r = e >> log2, n2 = e & (N2 - 1);
+        buf[e] = cmul(buf[e], w_nfft(T, 2 * (int64_t)bitrev(r, log1) * n2, lg));
+    }
+    __syncthreads();
+    lds_fft<false>(buf, log2, log1, 1, N2, T.tw);                      // rows
+    for (int e = threadIdx.x; e < (N1 / 2 + 1) * N2; e += blockDim.x) {
+        const int ka = e >> log2, k2 = e & (N2 - 1);
+        const int kb = (N1 - ka) & (N1 - 1);
+        lp_filter_at(buf + ((int64_t)bitrev(ka, log1) << log2), buf + ((int64_t)bitrev(kb, log1) << log2), ka, k2, log1, log2,
+                     first_cleared, T, lg);
+    }
+    __syncthreads();
+    lds_fft<true>(buf, log2, log1, 1, N2, T.tw);
+    for (int e = threadIdx.x; e < M; e += blockDim.x) {
+        const int r = e >> log2, n2 = e & (N2 - 1);
+        buf[e] = cmulc(buf[e], w_nfft(T, 2 * (int64_t)bitrev(r, log1) * n2, lg));
+    }
+    __syncthreads();
+    lds_fft<true>(buf, log1, log2, N2, 1, T.tw);
+    const double scale = 1.0 / (double)M;
+    for (int e = threadIdx.x; e < M; e += blockDim.x) {
+        const int i0 = 2 * e - ANTI_TURN_AROUND;
+        const c64 v = buf[e];
+        if (i0 >= 0 && i0 < n) out[i0] = v.x * scale;
+        if (i0 + 1 >= 0 && i0 + 1 < n) out[i0 + 1] = v.y * scale;
+    }
+    __syncthreads();
 }
 
 // device tables of the transform of nfft samples, cached per (device, nfft) (resample.hip); the caller sets lg_max
