@@ -31,7 +31,7 @@ extern "C" {
 #define RSAF_ERR_HIP 2      /* a HIP runtime call failed */
 #define RSAF_ERR_WORKSPACE 3 /* workspace too small */
 
-#define RSAF_ABI_VERSION 2
+#define RSAF_ABI_VERSION 3   /* 3: workspace arguments of rsaf_resample_praat / rsaf_mshds_cpp, low-passed input of rsaf_mshds_resample10k */
 
 typedef void* rsaf_stream_t;
 

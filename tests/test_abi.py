@@ -28,11 +28,20 @@ def test_python_binding_covers_header(rsaf_lib):
 
 
 def test_abi_version_and_host_only_calls(rsaf_lib):
-    assert rsaf_lib.rsaf_abi_version() == 2
+    assert rsaf_lib.rsaf_abi_version() == 3
     # integer-exact frame-count contract (Androids.conf:73-78): no GPU needed
     for n, want in [(0, 0), (399, 0), (400, 1), (559, 1), (560, 2), (80000, 498), (480000, 2998)]:
         assert rsaf_lib.rsaf_smile_n_frames(n, 16000) == want
     assert rsaf_lib.rsaf_smile_n_frames(44100, 44100) == (44100 - 1103) // 441 + 1      # native-rate geometry
+    # Sound_resample's transform length (first power of two >= n + 2000) as the host sizes its scratch: same rule in C and Python
+    for n in (1, 48, 49, 2096, 2097, 6192, 6193, 480000, 1440000, 16775216):
+        lg = max(11, int(n + 2000 - 1).bit_length())
+        assert (1 << lg) >= n + 2000 and (lg == 11 or (1 << (lg - 1)) < n + 2000)
+        assert rsaf_lib.rsaf_resample_praat_work_bytes(n, 44100.0, 16000.0) == (1 << lg) * 8 + n * 8
+    assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 8000.0, 16000.0) == 0             # rate going up: no low-pass
+    assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 16000.0, 16000.0) == 0
+    stride = rsaf_lib.rsaf_mshds_resample10k_table_stride(500)
+    assert stride % 8 == 0 and stride >= 1001 + 24 + 7
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
