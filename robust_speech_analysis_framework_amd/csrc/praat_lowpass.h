@@ -73,7 +73,6 @@ __device__ __forceinline__ c64 w_nfft(const LpTables& T, int64_t p, int lg) {
 // consecutive butterflies of one sequence: neighbouring lanes stay 16 bytes apart either way.
 template <bool INV>
 __device__ inline void lds_fft(c64* buf, int logL, int lognseq, int es, int ss, const c64* __restrict__ tw) {
-    const int L = 1 << logL;
     const bool seq_fast = ss < es;
     const int qmask = (1 << lognseq) - 1;
     auto radix2 = [&]() {
@@ -230,7 +229,6 @@ __device__ inline void lp_rows_body(c64* __restrict__ work_base, const LpSig& sg
     const int N1 = 1 << log1, N2 = 1 << log2;
     if (bx > N1 / 2) return;
     c64* work = work_base + sg.work_off;
-    const int64_t M = (int64_t)N1 << log2;
     const int64_t first_cleared = (int64_t)floor(upfactor * (double)((int64_t)1 << lg));   // Praat: floor(upfactor * nfft)
     const int ka = bx, kb = (N1 - ka) & (N1 - 1);
     const bool two = ka != kb;

@@ -42,8 +42,6 @@ __global__ __launch_bounds__(256) void sinc_hann_kernel(const float* __restrict_
     out[o] = acc;
 }
 
-constexpr double PI = 3.14159265358979323846;
-
 // ---- whole-sound FFT low-pass: the three passes (praat_lowpass.h) over a batch, one sound per y index -----------
 template <bool INV>
 __global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ in, c64* __restrict__ work_base,
