@@ -402,6 +402,8 @@ def main():
             line["parity_vs_oracle"] = parity_vs_oracle(pipe, ref, stages, dev, model)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                                      # rank 0's post-run passes are done: every rank leaves together
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
