@@ -31,7 +31,7 @@ extern "C" {
 #define RSAF_ERR_HIP 2      /* a HIP runtime call failed */
 #define RSAF_ERR_WORKSPACE 3 /* workspace too small */
 
-#define RSAF_ABI_VERSION 3   /* 3: workspace arguments of rsaf_resample_praat / rsaf_mshds_cpp, low-passed input of rsaf_mshds_resample10k */
+#define RSAF_ABI_VERSION 4   /* 4: clip_info rows carry the sound's x1 / xmax (48 bytes); rsaf_resample_praat restates Sound_upsample for a rate ratio of 2 */
 
 typedef void* rsaf_stream_t;
 
@@ -249,9 +249,12 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
  * (ac) (:104,143,178,270,355), To Harmonicity (cc) (:36,221), to_spectrogram + spectrum moments
  * (:356-369) and the statistics taken from them (:144-160,179-180,199-202,222,370-373).
  * `clip_info`: device array of n_clips records {int64 sample_off; int64 frame_off; double t1;
- * int32 n_samples; int32 n_frames} (32 bytes) describing, for THIS analysis, where each clip's
+ * int32 n_samples; int32 n_frames; double x1; double xmax} (48 bytes) describing, for THIS analysis, where each clip's
  * samples start in `wav`, where its frames start in the per-frame output buffers, the time of its
- * first frame and its frame count (Praat's Sampled_shortTermAnalysis grid, computed by the host).
+ * first frame and its frame count (Praat's Sampled_shortTermAnalysis grid, computed by the host), and the
+ * sound's own time axis as Praat's Sound object carries it: x1 = time of the first sample (dx / 2 for a sound read
+ * from a file), [0, xmax] = its time domain (n dx for a file; after the Sound_resample of
+ * src/mshds_extractor.py:418-419 the ORIGINAL duration, with the new grid centred in it).
  * Window tables (`window`, `window_r` = normalised autocorrelation of the window, `twiddle`) are
  * device float64 arrays prepared by the host.  All outputs are float64.                          */
 int rsaf_mshds_frameout_doubles(void);   /* doubles per frame record: intensity, ncand, freq[16], strength[16] */

@@ -33,25 +33,45 @@ FEATURE_NAMES = [
 BUILT = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 
-# ---- Sampled helpers (Praat: x1 = 0.5 dx for a Sound read from file) ----------------------------
-def short_term_frames(n_samples, window_duration, time_step):
-    """Sampled_shortTermAnalysis: (number of frames, time of the first frame); frames are centred."""
+# ---- Sampled helpers ------------------------------------------------------------------------------
+# A Praat Sound carries its own time axis: x1 = time of the first sample, [xmin = 0, xmax] = its domain.  Read from a
+# file: x1 = 0.5 dx, xmax = n / fs.  After Sound_resample (src/mshds_extractor.py:418-419) the domain is still the
+# ORIGINAL file's [0, n_in / fs_in] and the 16 kHz grid is centred in it: nx = round(xmax * 16000),
+# x1 = (xmax - (nx - 1) dx) / 2, i.e. up to a quarter sample away from 0.5 dx, and xmax != nx dx.  Every analysis below
+# takes ``x1`` (and ``xmax`` where Praat uses the domain rather than the physical duration nx dx).
+X1_FILE = 0.5 * DX
+
+
+def short_term_frames(n_samples, window_duration, time_step, x1=X1_FILE):
+    """Sampled_shortTermAnalysis: (number of frames, time of the first frame); frames are centred in the PHYSICAL
+    extent of the samples (nx dx around x1 - dx/2 + nx dx / 2), whatever the domain."""
     duration = n_samples * DX
     if window_duration > duration:
         return 0, 0.0
     nf = int(np.floor((duration - window_duration) / time_step)) + 1
-    mid = 0.5 * duration
+    mid = x1 - 0.5 * DX + 0.5 * duration
     t1 = mid - 0.5 * nf * time_step + 0.5 * time_step
     return nf, t1
 
 
-def x_to_low_index(t):
-    """Sampled_xToLowIndex for the sound, 0-based: floor((t - x1)/dx)."""
-    return np.floor((np.asarray(t) - 0.5 * DX) / DX).astype(np.int64)
+def x_to_low_index(t, x1=X1_FILE):
+    """Sampled_xToLowIndex for the sound, 0-based.  Praat works on the 1-based real index (x - x1) / dx + 1 and frame
+    times sit on half-sample positions, where the last bit decides: the + 1.0 is kept as its own rounded operation."""
+    return np.floor((np.asarray(t) - x1) / DX + 1.0).astype(np.int64) - 1
 
 
-def x_to_nearest_index(t):
-    return np.floor((np.asarray(t) - 0.5 * DX) / DX + 0.5).astype(np.int64)
+def x_to_nearest_index(t, x1=X1_FILE):
+    """Sampled_xToNearestIndex, 0-based: Melder_iround (= floor (. + 0.5)) of the 1-based real index."""
+    return np.floor(((np.asarray(t) - x1) / DX + 1.0) + 0.5).astype(np.int64) - 1
+
+
+def x_to_high_index(t, x1=X1_FILE):
+    return np.ceil((np.asarray(t) - x1) / DX + 1.0).astype(np.int64) - 1
+
+
+def file_xmax(n_samples):
+    """Domain end of a sound of n samples read from a 16 kHz file (Praat: numberOfSamples / sampleRate)."""
+    return n_samples / FS
 
 
 # ---- Intensity (Praat manual "Sound: To Intensity...") -------------------------------------------
@@ -59,7 +79,7 @@ def _bessel_i0(x):
     return np.i0(x)
 
 
-def intensity(x, minimum_pitch, time_step, subtract_mean=True):
+def intensity(x, minimum_pitch, time_step, subtract_mean=True, x1=X1_FILE):
     """dB contour + first frame time.  Effective window 3.2/minimum_pitch (physical 6.4/minimum_pitch),
     Kaiser-20 window (sidelobes below -190 dB), per-frame mean subtracted, reference 4e-10 Pa^2."""
     x = np.asarray(x, dtype=np.float64)
@@ -72,11 +92,11 @@ def intensity(x, minimum_pitch, time_step, subtract_mean=True):
     i = np.arange(-half, half + 1)
     xx = i * DX / half_dur
     win = _bessel_i0((2.0 * np.pi * np.pi + 0.5) * np.sqrt(np.maximum(0.0, 1.0 - xx * xx)))
-    nf, t1 = short_term_frames(n, phys, time_step)
+    nf, t1 = short_term_frames(n, phys, time_step, x1)
     out = np.empty(nf)
     for f in range(nf):
         t = t1 + f * time_step
-        mid = int(x_to_nearest_index(t))
+        mid = int(x_to_nearest_index(t, x1))
         lo, hi = max(0, mid - half), min(n - 1, mid + half)
         seg = x[lo:hi + 1]
         w = win[lo - mid + half: hi - mid + half + 1]
@@ -372,7 +392,7 @@ def _hanning(n):
 
 def pitch_ac(x, time_step=0.0, pitch_floor=75.0, max_candidates=15, very_accurate=False, silence_threshold=0.03,
              voicing_threshold=0.45, octave_cost=0.01, octave_jump_cost=0.35, voiced_unvoiced_cost=0.14,
-             pitch_ceiling=600.0):
+             pitch_ceiling=600.0, x1=X1_FILE):
     """Sound: To Pitch (ac)... (Hanning window of 3 longest periods)."""
     if very_accurate:
         raise NotImplementedError("very_accurate (Gaussian window) is not used by the reference")
@@ -389,7 +409,7 @@ def pitch_ac(x, time_step=0.0, pitch_floor=75.0, max_candidates=15, very_accurat
     nsamp_window = half_window * 2
     min_lag = max(2, int(np.floor(1.0 / DX / ceiling)))
     max_lag = min(int(np.floor(nsamp_window / ppw)) + 2, nsamp_window)
-    nF, t1 = short_term_frames(n, dt_window, dt)
+    nF, t1 = short_term_frames(n, dt_window, dt, x1)
     interp_depth = 0.5
     brent_ixmax = int(np.floor(nsamp_window * interp_depth))
     nfft = 1
@@ -405,7 +425,7 @@ def pitch_ac(x, time_step=0.0, pitch_floor=75.0, max_candidates=15, very_accurat
         e = np.zeros((0, maxc))
         return PitchResult(t1, dt, ceiling, e, e.copy(), np.zeros(0, np.int64), np.zeros(0), np.zeros(0, np.int64))
     t = t1 + np.arange(nF) * dt
-    left = x_to_low_index(t)
+    left = x_to_low_index(t, x1)
     right = left + 1
     # local mean over one longest period to each side
     cs = np.concatenate([[0.0], np.cumsum(x)])
@@ -438,7 +458,7 @@ def pitch_ac(x, time_step=0.0, pitch_floor=75.0, max_candidates=15, very_accurat
 
 
 def pitch_cc(x, time_step, pitch_floor, periods_per_window, max_candidates, silence_threshold, voicing_threshold,
-             octave_cost, octave_jump_cost, voiced_unvoiced_cost, pitch_ceiling, accurate=False):
+             octave_cost, octave_jump_cost, voiced_unvoiced_cost, pitch_ceiling, accurate=False, x1=X1_FILE):
     """Forward cross-correlation pitch (Boersma 1993 §cc; Praat "To Pitch (cc)")."""
     x = np.asarray(x, dtype=np.float64)
     n = len(x)
@@ -453,7 +473,7 @@ def pitch_cc(x, time_step, pitch_floor, periods_per_window, max_candidates, sile
     nsamp_window = half_window * 2
     min_lag = max(2, int(np.floor(1.0 / DX / ceiling)))
     max_lag = min(int(np.floor(nsamp_window / ppw)) + 2, nsamp_window)
-    nF, t1 = short_term_frames(n, 1.0 / pitch_floor + dt_window, dt)
+    nF, t1 = short_term_frames(n, 1.0 / pitch_floor + dt_window, dt, x1)
     brent_ixmax = int(np.floor(nsamp_window * 1.0))
     maxc = max_candidates
     xm = x - x.mean()
@@ -462,14 +482,14 @@ def pitch_cc(x, time_step, pitch_floor, periods_per_window, max_candidates, sile
         e = np.zeros((0, maxc))
         return PitchResult(t1, dt, ceiling, e, e.copy(), np.zeros(0, np.int64), np.zeros(0), np.zeros(0, np.int64))
     t = t1 + np.arange(nF) * dt
-    left = x_to_low_index(t)
+    left = x_to_low_index(t, x1)
     right = left + 1
     cs = np.concatenate([[0.0], np.cumsum(x)])
     s0 = np.clip(right - nsamp_period, 0, n - 1)
     s1 = np.clip(left + nsamp_period, 0, n - 1)
     local_mean = (cs[s1 + 1] - cs[s0]) / (2 * nsamp_period)
     start_time = t - 0.5 * (1.0 / pitch_floor + dt_window)
-    start = np.maximum(x_to_low_index(start_time), 0)
+    start = np.maximum(x_to_low_index(start_time, x1), 0)
     span = np.minimum(max_lag + nsamp_window, n - start)
     loc_max_lag = span - nsamp_window
     L = max_lag
@@ -506,10 +526,10 @@ def pitch_cc(x, time_step, pitch_floor, periods_per_window, max_candidates, sile
     return PitchResult(t1, dt, ceiling, freq, stren, ncand, intens, sel)
 
 
-def harmonicity_cc(x, time_step=0.01, minimum_pitch=75.0, silence_threshold=0.1, periods_per_window=1.0):
+def harmonicity_cc(x, time_step=0.01, minimum_pitch=75.0, silence_threshold=0.1, periods_per_window=1.0, x1=X1_FILE):
     """Sound: To Harmonicity (cc): dB per frame, -200 for unvoiced frames."""
     p = pitch_cc(x, time_step, minimum_pitch, periods_per_window, 15, silence_threshold, 0.0, 0.0, 0.0, 0.0,
-                 0.5 / DX, accurate=True)
+                 0.5 / DX, accurate=True, x1=x1)
     f = p.frequency()
     s = p.strength[np.arange(p.n_frames), p.selected] if p.n_frames else np.zeros(0)
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -518,7 +538,7 @@ def harmonicity_cc(x, time_step=0.01, minimum_pitch=75.0, silence_threshold=0.1,
 
 
 # ---- Spectrogram + spectral moments (Praat manual "Sound: To Spectrogram...", "Spectrum: Get ...") ---
-def spectrogram_power(x, window_length=0.005, maximum_frequency=5000.0, time_step=0.002, frequency_step=20.0):
+def spectrogram_power(x, window_length=0.005, maximum_frequency=5000.0, time_step=0.002, frequency_step=20.0, x1=X1_FILE):
     """Gaussian-window spectrogram: (power density [nF, nBins], t1, time step, frequency step)."""
     x = np.asarray(x, dtype=np.float64)
     n = len(x)
@@ -535,7 +555,7 @@ def spectrogram_power(x, window_length=0.005, maximum_frequency=5000.0, time_ste
     if phys > duration or half < 1:
         return np.zeros((0, 0)), 0.0, tstep, fstep
     nT = 1 + int(np.floor((duration - phys) / tstep))
-    t1 = 0.5 * DX + 0.5 * ((n - 1) * DX - (nT - 1) * tstep)
+    t1 = x1 + 0.5 * ((n - 1) * DX - (nT - 1) * tstep)
     fmax = maximum_frequency if 0 < maximum_frequency <= nyq else nyq
     nfreq = int(np.floor(fmax / fstep))
     nfft = 1
@@ -551,7 +571,7 @@ def spectrogram_power(x, window_length=0.005, maximum_frequency=5000.0, time_ste
     win = (np.exp(-48.0 * phase * phase) - edge) / (1.0 - edge)
     one_by = 1.0 / np.sum(win * win) / bw_samples
     t = t1 + np.arange(nT) * tstep
-    left = x_to_low_index(t)
+    left = x_to_low_index(t, x1)
     start = left + 1 - half
     idx = start[:, None] + np.arange(nsamp)[None, :]
     frames = x[np.clip(idx, 0, n - 1)] * win[None, :]
@@ -580,10 +600,10 @@ def spectral_moments(power, fstep):
 
 
 # ---- the reference's helpers ----------------------------------------------------------------------------
-def pitch_values(x):
+def pitch_values(x, x1=X1_FILE):
     """``_pitch_values`` (src/mshds_extractor.py:127-162) -> (floor, ceiling)."""
     try:
-        p = pitch_ac(x, time_step=0.005, pitch_floor=50.0, pitch_ceiling=600.0)              # :143
+        p = pitch_ac(x, time_step=0.005, pitch_floor=50.0, pitch_ceiling=600.0, x1=x1)       # :143
         v = p.frequency()
         v = v[v != 0]
         if len(v) == 0:
@@ -597,9 +617,9 @@ def pitch_values(x):
         return 75, 500
 
 
-def extract_pitch(x, floor, ceiling, frame_shift=0.005, pitch=None):
+def extract_pitch(x, floor, ceiling, frame_shift=0.005, pitch=None, x1=X1_FILE):
     """``_extract_pitch`` (:164-183): mean F0 (Hz), SD in semitones re 100 Hz (sample SD)."""
-    p = pitch if pitch is not None else pitch_ac(x, time_step=frame_shift, pitch_floor=floor, pitch_ceiling=ceiling)
+    p = pitch if pitch is not None else pitch_ac(x, time_step=frame_shift, pitch_floor=floor, pitch_ceiling=ceiling, x1=x1)
     v = p.voiced_values()
     mean = np.mean(v) if len(v) else np.nan
     st = 12.0 * np.log2(v / 100.0)
@@ -607,9 +627,9 @@ def extract_pitch(x, floor, ceiling, frame_shift=0.005, pitch=None):
     return mean, sd
 
 
-def extract_intensity(x, floor, frame_shift=0.005):
+def extract_intensity(x, floor, frame_shift=0.005, x1=X1_FILE):
     """``_extract_intensity`` (:185-205): energy-mean dB and max/min ratio of dB values."""
-    db, _, _ = intensity(x, floor, frame_shift, True)
+    db, _, _ = intensity(x, floor, frame_shift, True, x1)
     if len(db) == 0:
         return np.nan, np.nan
     mean_db = 10.0 * np.log10(np.mean(10.0 ** (db / 10.0)))
@@ -618,18 +638,18 @@ def extract_intensity(x, floor, frame_shift=0.005):
     return mean_db, (mx / mn if mn != 0 else np.nan)
 
 
-def extract_harmonicity(x, floor, ceiling, frame_shift=0.005):
+def extract_harmonicity(x, floor, ceiling, frame_shift=0.005, x1=X1_FILE):
     """``_extract_harmonicity`` (:207-225): mean HNR over voiced frames."""
-    h = harmonicity_cc(x, frame_shift, floor, 0.1, 4.5)
+    h = harmonicity_cc(x, frame_shift, floor, 0.1, 4.5, x1)
     v = h[h != -200.0]
     return np.mean(v) if len(v) else np.nan
 
 
-def extract_spectral_moments(x, floor, ceiling, window_size=0.025, frame_shift=0.005, pitch=None):
+def extract_spectral_moments(x, floor, ceiling, window_size=0.025, frame_shift=0.005, pitch=None, x1=X1_FILE):
     """``_extract_Spectral_Moments`` (:340-376): mean of the 4 moments over frames whose time has a
     defined pitch value."""
-    p = pitch if pitch is not None else pitch_ac(x, time_step=frame_shift, pitch_floor=floor, pitch_ceiling=ceiling)
-    pw, t1, tstep, fstep = spectrogram_power(x, window_size, 5000.0, frame_shift, 20.0)
+    p = pitch if pitch is not None else pitch_ac(x, time_step=frame_shift, pitch_floor=floor, pitch_ceiling=ceiling, x1=x1)
+    pw, t1, tstep, fstep = spectrogram_power(x, window_size, 5000.0, frame_shift, 20.0, x1)
     if pw.shape[0] == 0:
         return (np.nan,) * 4
     t = t1 + np.arange(pw.shape[0]) * tstep
@@ -734,7 +754,7 @@ def detect_silences(db, t1, dt, xmin, xmax, silence_threshold_db, min_silence, m
     return iv
 
 
-def speechrate(x):
+def speechrate(x, x1=X1_FILE, xmax=None):
     """``_speechrate`` (:11-125) -> (Speaking_Rate, Articulation_Rate, Phonation_Ratio, Pause_Rate,
     Mean_Pause_Dur).  The harmonicity call of :36-38 is not evaluated, and that changes nothing: (1) its value
     only feeds a no-op (mindip = 2 either way; an undefined mean compares False); (2) its failure path (:123-124,
@@ -745,11 +765,11 @@ def speechrate(x):
     nan5 = (np.nan,) * 5
     x = np.asarray(x, dtype=np.float64)
     silencedb, mindip, minpause = -25.0, 2.0, 0.3
-    db, t1, dt = intensity(x, 50.0, 0.016, True)                                   # :41
+    db, t1, dt = intensity(x, 50.0, 0.016, True, x1)                               # :41
     n = len(db)
     if n == 0:
         return nan5                                                                # Praat raises -> :124
-    duration = len(x) * DX
+    duration = file_xmax(len(x)) if xmax is None else xmax                         # the Intensity keeps the sound's domain
     min_int = vector_extremum_parabolic(db, False)                                 # :42
     max_int = vector_extremum_parabolic(db, True)                                  # :43
     q99 = quantile_sorted(np.sort(db), 0.99)                                       # :47
@@ -790,7 +810,7 @@ def speechrate(x):
                 validtime.append(timepeaks[p])
             currenttime = nxt
             currentint = value_cubic(db, (nxt - t1) / dt)
-    pitch = pitch_ac(x, 0.02, 30.0, 4, False, 0.03, 0.25, 0.01, 0.35, 0.25, 450.0)   # :104
+    pitch = pitch_ac(x, 0.02, 30.0, 4, False, 0.03, 0.25, 0.01, 0.35, 0.25, 450.0, x1=x1)   # :104
     nsyll = 0
     for tm in validtime:                                                           # :106-111
         lab = None
@@ -846,11 +866,11 @@ def pitch_value_at(p, t):
     return fn + phase * (ff - fn)
 
 
-def _find_extremum(x, tmin, tmax):
+def _find_extremum(x, tmin, tmax, x1=X1_FILE):
     """Sound_findExtremum (absolute extremum, parabolic position)."""
     n = len(x)
-    imin = max(0, int(x_to_low_index(tmin)))
-    imax = min(n - 1, int(np.ceil((tmax - 0.5 * DX) / DX)))
+    imin = max(0, int(x_to_low_index(tmin, x1)))
+    imax = min(n - 1, int(x_to_high_index(tmax, x1)))
     cnt = imax - imin + 1
     if cnt <= 0:
         return 0.5 * (tmin + tmax)
@@ -874,17 +894,17 @@ def _find_extremum(x, tmin, tmax):
             else:
                 vm, vl, vr = seg[j], seg[j - 1], seg[j + 1]
                 ie = (j + 1) + 0.5 * (vr - vl) / (2.0 * vm - vl - vr)
-    return 0.5 * DX + (imin + ie - 1.0) * DX
+    return x1 + (imin + ie - 1.0) * DX
 
 
-def _max_correlation(x, t1, window, tmin2, tmax2):
+def _max_correlation(x, t1, window, tmin2, tmax2, x1=X1_FILE):
     """Sound_findMaximumCorrelation -> (correlation, tout, peak)."""
     n = len(x)
     half = 0.5 * window
-    ileft1 = int(x_to_nearest_index(t1 - half))
-    iright1 = int(x_to_nearest_index(t1 + half))
-    ileft2min = int(x_to_low_index(tmin2 - half))
-    ileft2max = int(np.ceil((tmax2 - half - 0.5 * DX) / DX))
+    ileft1 = int(x_to_nearest_index(t1 - half, x1))
+    iright1 = int(x_to_nearest_index(t1 + half, x1))
+    ileft2min = int(x_to_low_index(tmin2 - half, x1))
+    ileft2max = int(x_to_high_index(tmax2 - half, x1))
     best, r1, r2, r3 = -1.0, 0.0, 0.0, 0.0
     r1b = r3b = 0.0
     ir = 0.0
@@ -913,11 +933,12 @@ def _max_correlation(x, t1, window, tmin2, tmax2):
     return best, tout, peak
 
 
-def point_process_cc(x, p):
-    """Pulse times (Praat Sound_Pitch_to_PointProcess_cc)."""
+def point_process_cc(x, p, x1=X1_FILE, xmax=None):
+    """Pulse times (Praat Sound_Pitch_to_PointProcess_cc).  The voiced stretches are clipped to the Pitch's domain, which
+    is the sound's [0, xmax]."""
     x = np.asarray(x, dtype=np.float64)
     n = len(x)
-    duration = n * DX
+    duration = file_xmax(n) if xmax is None else xmax
     f = p.frequency()
     voiced = (f > 0.0) & (f < p.ceiling)
     nF = p.n_frames
@@ -946,14 +967,14 @@ def point_process_cc(x, p):
         if np.isnan(f0mid):
             t = tright
             continue
-        tmax = _find_extremum(x, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid)
+        tmax = _find_extremum(x, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid, x1)
         pts.append(tmax)
         tsave = tmax
         while True:                                              # to the left
             f0 = pitch_value_at(p, tmax)
             if np.isnan(f0):
                 break
-            corr, tmax, peak = _max_correlation(x, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0)
+            corr, tmax, peak = _max_correlation(x, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, x1)
             if corr == -1.0:
                 tmax -= 1.0 / f0
             if tmax < tleft:
@@ -968,7 +989,7 @@ def point_process_cc(x, p):
             f0 = pitch_value_at(p, tmax)
             if np.isnan(f0):
                 break
-            corr, tmax, peak = _max_correlation(x, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0)
+            corr, tmax, peak = _max_correlation(x, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, x1)
             if corr == -1.0:
                 tmax += 1.0 / f0
             if tmax > tright:
@@ -988,13 +1009,13 @@ RS_DEPTH = 500          # Praat resamples with sinc precision 500 for formant an
 RS_RATE = 10000.0
 
 
-def resample_10k(x):
+def resample_10k(x, x1=X1_FILE, xmax=None):
     """``Sound_resample (me, 10000, 500)`` at the head of Praat's ``Sound_to_Formant_burg``: whole-sound FFT brick-wall
     low-pass, new sample grid centred in the sound's domain, ``NUM_interpolate_sinc`` of depth 500
     (``resample_oracle.sound_resample``)."""
     from .resample_oracle import sound_resample
     x = np.asarray(x, dtype=np.float64)
-    return sound_resample(x, 0.5 * DX, DX, 0.0, len(x) * DX, RS_RATE, RS_DEPTH)
+    return sound_resample(x, x1, DX, 0.0, file_xmax(len(x)) if xmax is None else xmax, RS_RATE, RS_DEPTH)
 
 
 def _burg(x, m):
@@ -1028,9 +1049,9 @@ def _burg(x, m):
 
 
 def formant_burg(x, time_step=0.005, n_formants=5, max_freq=5000.0, half_window=0.025, preemph_from=50.0,
-                 safety=50.0):
+                 safety=50.0, x1=X1_FILE, xmax=None):
     """Sound: To Formant (burg): returns (freq [nF, 5], bw [nF, 5] (NaN padded), t1, dt)."""
-    y, x1o, dxo = resample_10k(x)
+    y, x1o, dxo = resample_10k(x, x1, xmax)
     n = len(y)
     nyq = 0.5 / dxo
     npoles = 2 * n_formants
@@ -1096,12 +1117,12 @@ def sampled_value_linear(vals, t1, dt, t):
     return vals[inear] + phase * (vals[ifar] - vals[inear])
 
 
-def measure_formants(x, floor, ceiling, frame_shift=0.005):
+def measure_formants(x, floor, ceiling, frame_shift=0.005, x1=X1_FILE, xmax=None):
     """``_measureFormants`` (:303-338): F1, B1, F2, B2 at every glottal pulse -> mean and sample SD."""
     x = np.asarray(x, dtype=np.float64)
-    F, B, ft1, fdt = formant_burg(x, frame_shift, 5, 5000.0, 0.025, 50.0)                    # :319
-    p = pitch_cc(x, frame_shift, floor, 1.0, 15, 0.03, 0.45, 0.01, 0.35, 0.14, ceiling)      # :320
-    pulses = point_process_cc(x, p)                                                          # :321
+    F, B, ft1, fdt = formant_burg(x, frame_shift, 5, 5000.0, 0.025, 50.0, x1=x1, xmax=xmax)  # :319
+    p = pitch_cc(x, frame_shift, floor, 1.0, 15, 0.03, 0.45, 0.01, 0.35, 0.14, ceiling, x1=x1)   # :320
+    pulses = point_process_cc(x, p, x1, xmax)                                                # :321
     lists = [[], [], [], []]
     for t in pulses:                                                                         # :326-331
         for k, arr in enumerate((F[:, 0], B[:, 0], F[:, 1], B[:, 1])):
@@ -1117,7 +1138,7 @@ def measure_formants(x, floor, ceiling, frame_shift=0.005):
 
 # ---- Ltas (pitch-corrected), slope and tilt  (src/mshds_extractor.py:227-251) ---------------------------
 def ltas_pitch_corrected(x, floor, ceiling, max_freq=5000.0, bandwidth=100.0, shortest=0.0001, longest=0.02,
-                         max_factor=1.3):
+                         max_factor=1.3, x1=X1_FILE, xmax=None):
     """Praat "Sound: To Ltas (pitch-corrected)...": pulses from Sound_to_PointProcess_periodic_cc (AC pitch with
     the standard settings and the automatic time step, then the cc pulse train); every pulse whose two
     neighbouring intervals are plausible periods contributes the energy spectrum of the one period around
@@ -1126,8 +1147,8 @@ def ltas_pitch_corrected(x, floor, ceiling, max_freq=5000.0, bandwidth=100.0, sh
     (Praat raises -> the reference returns NaN, NaN)."""
     x = np.asarray(x, dtype=np.float64)
     n = len(x)
-    p = pitch_ac(x, 0.0, floor, pitch_ceiling=ceiling)
-    pulses = point_process_cc(x, p)
+    p = pitch_ac(x, 0.0, floor, pitch_ceiling=ceiling, x1=x1)
+    pulses = point_process_cc(x, p, x1, xmax)
     nb = int(max_freq / bandwidth)
     if len(pulses) - 2 < 1:
         return None
@@ -1140,8 +1161,8 @@ def ltas_pitch_corrected(x, floor, ceiling, max_freq=5000.0, bandwidth=100.0, sh
         if not (shortest <= left <= longest and shortest <= right <= longest and factor <= max_factor):
             continue
         t1, t2 = pulses[i] - 0.5 * left, pulses[i] + 0.5 * right
-        ix1 = int(np.ceil((t1 - 0.5 * DX) / DX))                 # 0-based; samples outside the sound are zero
-        ix2 = int(np.floor((t2 - 0.5 * DX) / DX))
+        ix1 = int(np.ceil((t1 - x1) / DX))                       # Sound_extractPart: 1 + ceil / 1 + floor of (t - x1) / dx,
+        ix2 = int(np.floor((t2 - x1) / DX))                      # 0-based here; samples outside the sound are zero
         if ix2 < ix1:
             return None                                           # "Extracted Sound would contain no samples"
         m = ix2 - ix1 + 1
@@ -1161,7 +1182,7 @@ def ltas_pitch_corrected(x, floor, ceiling, max_freq=5000.0, bandwidth=100.0, sh
         return None
     total = numbers.sum()
     z = np.full(nb, np.nan)
-    duration = n * DX
+    duration = file_xmax(n) if xmax is None else xmax            # PointProcess_Sound_to_Ltas: sound->xmax - sound->xmin
     for b in range(nb):
         if numbers[b] > 0:
             mean_e = energy[b] / numbers[b]
@@ -1229,23 +1250,23 @@ def line_fit_theil_incomplete(xv, yv):
     return quantile_sorted(slopes, 0.5)
 
 
-def extract_slope_tilt(x, floor, ceiling):
+def extract_slope_tilt(x, floor, ceiling, x1=X1_FILE, xmax=None):
     """src/mshds_extractor.py:227-251: Ltas "Get slope" 50-1000 vs 1000-4000 Hz in dB and the slope of the
     robust line fit over 100-5000 Hz (linear frequency) read from "Report spectral tilt"."""
-    z = ltas_pitch_corrected(x, floor, ceiling)
+    z = ltas_pitch_corrected(x, floor, ceiling, x1=x1, xmax=xmax)
     if z is None:
         return np.nan, np.nan
     bw = 100.0
-    x1 = 0.5 * bw
-    low = sampled_mean_rect(z, x1, bw, 50.0, 1000.0)
-    high = sampled_mean_rect(z, x1, bw, 1000.0, 4000.0)
+    f1 = 0.5 * bw
+    low = sampled_mean_rect(z, f1, bw, 50.0, 1000.0)
+    high = sampled_mean_rect(z, f1, bw, 1000.0, 4000.0)
     slope = high - low
     nb = len(z)
-    imin = max(1, 1 + int(np.ceil((100.0 - x1) / bw)))
-    imax = min(nb, 1 + int(np.floor((5000.0 - x1) / bw)))
+    imin = max(1, 1 + int(np.ceil((100.0 - f1) / bw)))
+    imax = min(nb, 1 + int(np.floor((5000.0 - f1) / bw)))
     if imax - imin + 1 < 2:
         return np.nan, np.nan                                      # the report raises -> both NaN in the reference
-    fx = x1 + (np.arange(imin, imax + 1) - 1) * bw
+    fx = f1 + (np.arange(imin, imax + 1) - 1) * bw
     tilt = line_fit_theil_incomplete(fx, z[imin - 1:imax])
     return slope, tilt
 
@@ -1387,26 +1408,27 @@ def cpps(z, dq=1e-4, time_window=0.01, quef_window=0.001, pitch_floor=60.0, pitc
     return float(np.mean(vals)) if vals else np.nan
 
 
-def extract_cpp(x, floor, ceiling, frame_shift=0.005):
+def extract_cpp(x, floor, ceiling, frame_shift=0.005, x1=X1_FILE, xmax=None):
     """_extract_CPP (:253-301): mean CPPS over the voiced intervals whose CPPS exceeds 4 dB."""
     x = np.asarray(x, dtype=np.float64)
     n = len(x)
-    p = pitch_ac(x, frame_shift, floor, voicing_threshold=0.3, pitch_ceiling=ceiling)      # :270
-    pulses = point_process_cc(x, p)                                                          # :271
+    xmax = file_xmax(n) if xmax is None else xmax
+    p = pitch_ac(x, frame_shift, floor, voicing_threshold=0.3, pitch_ceiling=ceiling, x1=x1)   # :270
+    pulses = point_process_cc(x, p, x1, xmax)                                                # :271
     vals = []
-    for (tmin, tmax) in vuv_intervals(pulses, 0.0, n * DX):                                  # :272
+    for (tmin, tmax) in vuv_intervals(pulses, 0.0, xmax):                                    # :272
         tmin, tmax = float(f"{tmin:.6f}"), float(f"{tmax:.6f}")                              # Down to Table, 6 decimals
         if tmin >= tmax:
             continue
-        ix1 = int(np.ceil((tmin - 0.5 * DX) / DX))
-        ix2 = int(np.floor((tmax - 0.5 * DX) / DX))
+        ix1 = int(np.ceil((tmin - x1) / DX))
+        ix2 = int(np.floor((tmax - x1) / DX))
         if ix2 < ix1:
             return np.nan                                        # extract_part raises outside the inner try -> NaN (:299-300)
         seg = np.zeros(ix2 - ix1 + 1)
         a, b = max(ix1, 0), min(ix2, n - 1)
         if b >= a:
             seg[a - ix1:b - ix1 + 1] = x[a:b + 1]
-        x1_seg = 0.5 * DX + ix1 * DX - tmin
+        x1_seg = x1 + ix1 * DX - tmin
         z = power_cepstrogram(seg, x1_seg, tmax - tmin)
         v = cpps(z)
         if not np.isnan(v) and v > 4:
@@ -1414,18 +1436,21 @@ def extract_cpp(x, floor, ceiling, frame_shift=0.005):
     return float(np.mean(vals)) if vals else np.nan
 
 
-def extract(x):
-    """One clip -> 25 features in the reference's column order (unbuilt helpers give NaN)."""
+def extract(x, x1=X1_FILE, xmax=None):
+    """One clip -> 25 features in the reference's column order.  ``x1`` / ``xmax``: the sound's time axis (first sample,
+    end of the domain); the defaults are those of a sound read from a 16 kHz file, ``resample_oracle.resample_praat_sound``
+    gives the ones of a file the reference resamples first (:418-419)."""
     x = np.asarray(x, dtype=np.float64)
+    xmax = file_xmax(len(x)) if xmax is None else xmax
     out = np.full(25, np.nan)
-    out[0:5] = speechrate(x)                                                         # :426
-    floor, ceiling = pitch_values(x)                                                 # :428
-    p = pitch_ac(x, time_step=0.005, pitch_floor=floor, pitch_ceiling=ceiling)       # :178 == :355
+    out[0:5] = speechrate(x, x1, xmax)                                               # :426
+    floor, ceiling = pitch_values(x, x1)                                             # :428
+    p = pitch_ac(x, time_step=0.005, pitch_floor=floor, pitch_ceiling=ceiling, x1=x1)   # :178 == :355
     out[5], out[6] = extract_pitch(x, floor, ceiling, 0.005, p)                      # :430
-    out[7], out[8] = extract_intensity(x, floor, 0.005)                              # :431
-    out[9] = extract_harmonicity(x, floor, ceiling, 0.005)                           # :432
-    out[10], out[11] = extract_slope_tilt(x, floor, ceiling)                         # :433
-    out[12] = extract_cpp(x, floor, ceiling, 0.005)                                  # :434
-    out[13:21] = measure_formants(x, floor, ceiling, 0.005)                          # :441
-    out[21:25] = extract_spectral_moments(x, floor, ceiling, 0.025, 0.005, p)        # :446
+    out[7], out[8] = extract_intensity(x, floor, 0.005, x1)                          # :431
+    out[9] = extract_harmonicity(x, floor, ceiling, 0.005, x1)                       # :432
+    out[10], out[11] = extract_slope_tilt(x, floor, ceiling, x1, xmax)               # :433
+    out[12] = extract_cpp(x, floor, ceiling, 0.005, x1, xmax)                        # :434
+    out[13:21] = measure_formants(x, floor, ceiling, 0.005, x1, xmax)                # :441
+    out[21:25] = extract_spectral_moments(x, floor, ceiling, 0.025, 0.005, p, x1)    # :446
     return out, (floor, ceiling)

@@ -8,7 +8,9 @@ PARITY UNPINNED: ``torchaudio`` (reference pin 2.5.1) and Praat are absent from 
   ``ceil(new * n / orig)`` samples.  Written as a direct double loop over (frame, phase), not as a convolution call.
 * ``resample_praat`` restates ``Sound.resample(16000, 50)`` (``src/mshds_extractor.py:419``) from Praat's published
   source: whole-sound FFT brick-wall low-pass when the rate goes down (``praat_fft_lowpass``), then
-  ``NUM_interpolate_sinc`` of depth 50 on the re-centred sample grid (``praat_interpolate_sinc``).
+  ``NUM_interpolate_sinc`` of depth 50 on the re-centred sample grid (``praat_interpolate_sinc``); a doubling of the
+  rate is ``Sound_upsample`` (``praat_upsample``).  ``resample_praat_sound`` also returns the time axis (x1, xmax) that
+  Praat gives the result and that every later analysis depends on.
 """
 from __future__ import annotations
 
@@ -131,13 +133,48 @@ def praat_interpolate_sinc(y, pos, depth: int):
     return out
 
 
+def praat_upsample(x):
+    """Praat's ``Sound_upsample`` (published source, ``fon/Sound.cpp``; ``Sound_resample`` hands it every request whose
+    rate ratio is within 1e-6 of 2): the sound goes into a zero buffer of 2 nfft samples behind 1 000 zeros (nfft = the
+    first power of two that holds it plus 2 000), ``NUMrealft`` of the first nfft samples, the packed array is scaled by a
+    linear ramp (nfft - i) / (nfft - imin) over its 1-based positions i > imin = (integer)(0.95 nfft) and cleared at
+    position 2 (the Nyquist bin, which the longer transform would read as ITS Nyquist bin), inverse ``NUMrealft`` of all
+    2 nfft positions, output sample i (1-based, 2 n of them) = data[i + 2000] / nfft.  Position 2k + 1 / 2k + 2 hold the
+    real / imaginary part of bin k, so the two parts of a bin on the ramp get different factors.  Output sample 2p (0-based)
+    is therefore the filtered sound AT input sample p, although the result is declared to start a quarter input period
+    before the first input sample (x1 - dx / 4): the labelling is Praat's, and it is kept."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    nfft = 1
+    while nfft < n + 2 * ANTI_TURN_AROUND:
+        nfft *= 2
+    data = np.zeros(nfft)
+    data[ANTI_TURN_AROUND:ANTI_TURN_AROUND + n] = x
+    spec = np.fft.rfft(data)                              # bins 0 .. nfft / 2
+    imin = int(nfft * 0.95)
+    k = np.arange(nfft // 2 + 1)
+
+    def ramp(pos):
+        return np.where(pos > imin, (nfft - pos) / float(nfft - imin), 1.0)
+    re = spec.real * ramp(2 * k + 1)
+    im = spec.imag * ramp(2 * k + 2)
+    im[0] = 0.0
+    re[-1] = im[-1] = 0.0                                 # position 2
+    big = np.zeros(nfft + 1, dtype=np.complex128)         # bins 0 .. nfft of the transform of 2 nfft samples
+    big[:nfft // 2 + 1] = re + 1j * im
+    y = np.fft.irfft(big, 2 * nfft) * 2.0                 # unnormalised inverse / nfft
+    return y[2 * ANTI_TURN_AROUND:2 * ANTI_TURN_AROUND + 2 * n]
+
+
 def sound_resample(x, x1_in: float, dx_in: float, xmin: float, xmax: float, fs_out: float, depth: int):
     """Praat's ``Sound_resample`` of the samples ``x`` (first sample at time ``x1_in``, period ``dx_in``, domain
     ``[xmin, xmax]``): FFT low-pass when the rate goes down, new sample grid centred in the domain, sinc
-    interpolation of the given depth.  Returns (samples float64, x1_out, dx_out).  Not restated: the special
-    case of a rate ratio of exactly 2 (``Sound_upsample``), which goes through the general branch here."""
+    interpolation of the given depth; a doubling of the rate is ``Sound_upsample`` (``praat_upsample``), an unchanged rate
+    a copy.  Returns (samples float64, x1_out, dx_out)."""
     x = np.asarray(x, dtype=np.float64)
     upfactor = fs_out * dx_in
+    if abs(upfactor - 2.0) < 1e-6:
+        return praat_upsample(x), x1_in - dx_in / 4.0, dx_in / 2.0
     m = int(np.floor((xmax - xmin) * fs_out + 0.5))
     dxo = 1.0 / fs_out
     x1o = 0.5 * (xmin + xmax - (m - 1) / fs_out)
@@ -148,10 +185,15 @@ def sound_resample(x, x1_in: float, dx_in: float, xmin: float, xmax: float, fs_o
     return praat_interpolate_sinc(src, pos, depth), x1o, dxo
 
 
-def resample_praat(x, fs_in: float, fs_out: float = 16000.0, depth: int = 50):
+def resample_praat_sound(x, fs_in: float, fs_out: float = 16000.0, depth: int = 50):
+    """``Sound(path).resample(fs_out, depth)`` (``src/mshds_extractor.py:415-419``) -> (samples float32, x1, xmax): a sound
+    read from a file has dx = 1 / fs, x1 = 0.5 / fs and the domain [0, n / fs]; the resampled one keeps the domain."""
     x = np.asarray(x, dtype=np.float64)
-    if fs_in == fs_out:
-        return x.astype(np.float32)
     dxi = 1.0 / fs_in
-    y, _, _ = sound_resample(x, 0.5 * dxi, dxi, 0.0, len(x) * dxi, fs_out, depth)
-    return y.astype(np.float32)
+    xmax = len(x) / fs_in
+    y, x1o, _ = sound_resample(x, 0.5 / fs_in, dxi, 0.0, xmax, fs_out, depth)
+    return y.astype(np.float32), x1o, xmax
+
+
+def resample_praat(x, fs_in: float, fs_out: float = 16000.0, depth: int = 50):
+    return resample_praat_sound(x, fs_in, fs_out, depth)[0]

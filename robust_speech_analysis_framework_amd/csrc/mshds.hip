@@ -44,6 +44,8 @@ struct ClipInfo {       // one entry per clip of a launch (host-built)
     double t1;          // time of the first frame
     int n_samples;
     int n_frames;
+    double x1;          // time of the first sample (0.5 dx for a sound read from a 16 kHz file; Praat's centred grid after Sound_resample)
+    double xmax;        // end of the sound's time domain [0, xmax] (n dx for a file; the ORIGINAL duration after Sound_resample)
 };
 
 struct PitchParams {
@@ -56,7 +58,11 @@ struct PitchParams {
     int debug_stop;         // profiling aid (env RSAF_PITCH_STOP): leave the frame kernel after phase k; 0 = run all
 };
 
-__device__ __forceinline__ int64_t low_index(double t) { return (int64_t)floor((t - 0.5 * DXS) / DXS); }
+// Sampled_xToLowIndex / xToNearestIndex / xToHighIndex of the sound (0-based), x1 = time of its first sample
+// (Praat rounds the 1-based real index (x - x1) / dx + 1; the + 1.0 stays a separately rounded operation: fp contract is off)
+__device__ __forceinline__ int64_t low_index(double t, double x1) { return (int64_t)floor((t - x1) / DXS + 1.0) - 1; }
+__device__ __forceinline__ int64_t nearest_index(double t, double x1) { return (int64_t)floor(((t - x1) / DXS + 1.0) + 0.5) - 1; }
+__device__ __forceinline__ int64_t high_index(double t, double x1) { return (int64_t)ceil((t - x1) / DXS + 1.0) - 1; }
 
 __device__ __forceinline__ double wave_max_f64(double v) {
 #pragma unroll
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void intensity_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const float* x = wav + c.sample_off;
     const double t = c.t1 + f * dt;
-    const int64_t mid = (int64_t)floor((t - 0.5 * DXS) / DXS + 0.5);
+    const int64_t mid = nearest_index(t, c.x1);
     const int64_t lo = mid - half < 0 ? 0 : mid - half;
     const int64_t hi = mid + half > c.n_samples - 1 ? c.n_samples - 1 : mid + half;
     double mean = 0.0;
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(256) void pitch_ac_kernel(const float* __restrict__
     for (int f = blockIdx.x * AC_FRAMES_PER_WG; f < (int)(blockIdx.x + 1) * AC_FRAMES_PER_WG && f < c.n_frames; ++f) {
     double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
     const double t = c.t1 + f * P.dt;
-    const int64_t left = low_index(t), right = left + 1;
+    const int64_t left = low_index(t, c.x1), right = left + 1;
     // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat)
     {
         int64_t s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(256) void pitch_cc_kernel(const float* __restrict__
     for (int f = blockIdx.x * CC_FRAMES_PER_WG; f < (int)(blockIdx.x + 1) * CC_FRAMES_PER_WG && f < c.n_frames; ++f) {
     double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
     const double t = c.t1 + f * P.dt;
-    const int64_t left = low_index(t), right = left + 1;
+    const int64_t left = low_index(t, c.x1), right = left + 1;
     // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat)
     {
         int64_t s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(256) void pitch_cc_kernel(const float* __restrict__
     {
         // Praat: startTime = t - 0.5 * (1 / minimumPitch + dt_window), dt_window = periods / minimumPitch
         const double start_time = t - 0.5 * (1.0 / P.min_pitch + P.dt_window);
-        int64_t start = low_index(start_time);
+        int64_t start = low_index(start_time, c.x1);
         if (start < 0) start = 0;
         int64_t span = L + nw;
         if (span > n - start) span = n - start;
@@ -1363,7 +1369,7 @@ __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restri
         }
     }
     const float* x = wav + c.sample_off;
-    const int64_t start = low_index(t) + 1 - half;
+    const int64_t start = low_index(t, c.x1) + 1 - half;
     // windowed frame, zero-padded to nfft.  Real input: one complex FFT of half the length over z[j] = x[2j] + i x[2j+1]
     // (stored bit-reversed for the in-place radix-2 passes), then X[k] = E + W^k O with E / O the even / odd parts.
     const int nthr = blockDim.x;
@@ -1579,7 +1585,7 @@ __global__ __launch_bounds__(64) void speechrate_kernel(const double* __restrict
     double* ivl = ivb + (n + 2);                               // 1 = sounding, 0 = silent
     double* tpk = ivl + (n + 2);                               // kept peak times
     double* vpk = tpk + peak_cap;                              // kept peak values
-    const double duration = c.n_samples * DXS;
+    const double duration = c.xmax;                            // the Intensity (and its TextGrid) keep the sound's domain [0, xmax]
     int niv = 0;
     {
         const double thr = max_int - fabs(silencedb_2);
@@ -1966,13 +1972,13 @@ __device__ double pitch_value_at(const double* __restrict__ f, int n, double t1,
 
 // Sound_findMaximumCorrelation with the shifts spread over the lanes; returns corr, *tout, *peak (uniform)
 constexpr int PULSE_LDS = 1536;
-__device__ double max_correlation_wave(const float* __restrict__ x, int n, double t1, double window, double tmin2,
+__device__ double max_correlation_wave(const float* __restrict__ x, int n, double x1, double t1, double window, double tmin2,
                                        double tmax2, int lane, double* tout, double* peak, float* ps1, float* ps2) {
     const double half = 0.5 * window;
-    const int64_t ileft1 = (int64_t)floor((t1 - half - 0.5 * DXS) / DXS + 0.5);
-    const int64_t iright1 = (int64_t)floor((t1 + half - 0.5 * DXS) / DXS + 0.5);
-    const int64_t l2min = low_index(tmin2 - half);
-    const int64_t l2max = (int64_t)ceil((tmax2 - half - 0.5 * DXS) / DXS);
+    const int64_t ileft1 = nearest_index(t1 - half, x1);
+    const int64_t iright1 = nearest_index(t1 + half, x1);
+    const int64_t l2min = low_index(tmin2 - half, x1);
+    const int64_t l2max = high_index(tmax2 - half, x1);
     double best = -1.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r1b = 0.0, r3b = 0.0, ir = 0.0, pk = 0.0;
     // stage the fixed window and the union of the shifted windows in LDS (float): every lane then reads
     // the fixed window as a broadcast and its own shifted window with unit stride
@@ -2042,8 +2048,8 @@ __device__ double max_correlation_wave(const float* __restrict__ x, int n, doubl
     return best;
 }
 
-__device__ double find_extremum_wave(const float* __restrict__ x, int n, double tmin, double tmax, int lane) {
-    int64_t imin = low_index(tmin), imax = (int64_t)ceil((tmax - 0.5 * DXS) / DXS);
+__device__ double find_extremum_wave(const float* __restrict__ x, int n, double x1, double tmin, double tmax, int lane) {
+    int64_t imin = low_index(tmin, x1), imax = high_index(tmax, x1);
     imin = imin < 0 ? 0 : imin;
     imax = imax > n - 1 ? n - 1 : imax;
     const int cnt = (int)(imax - imin + 1);
@@ -2080,7 +2086,7 @@ __device__ double find_extremum_wave(const float* __restrict__ x, int n, double 
             }
         }
     }
-    return 0.5 * DXS + ((double)imin + ie - 1.0) * DXS;
+    return x1 + ((double)imin + ie - 1.0) * DXS;
 }
 
 // ---- Sound & Pitch: To PointProcess (cc) -------------------------------------------------------------------
@@ -2163,7 +2169,7 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
     double2* L = left + (int64_t)clip * cap_slots + S.off;
     double* R = right + (int64_t)clip * cap_slots + S.off;
     const int cap = S.pad;
-    const double duration = n * DXS;
+    const double duration = c.xmax;                          // Pitch_getVoicedIntervalAfter works on the Pitch's domain = the sound's
     const double gp = abs_peak[clip];
     int nl = 0, nr = 0;
     double tleft = c.t1 + S.il * pdt - 0.5 * pdt, tright = c.t1 + S.irr * pdt + 0.5 * pdt;
@@ -2174,7 +2180,7 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
     const double f0mid = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmid);
     if (!(f0mid == f0mid)) skip = true;
     if (!skip) {
-        double tmax = find_extremum_wave(x, n, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid, lane);
+        double tmax = find_extremum_wave(x, n, c.x1, tmid - 0.5 / f0mid, tmid + 0.5 / f0mid, lane);
         if (lane == 0) L[0] = make_double2(tmax, 0.0);
         nl = 1;
         const double tsave = tmax;
@@ -2182,7 +2188,7 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
             const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
             if (!(f0 == f0)) break;
             double peak, tout;
-            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, lane, &tout, &peak, ps1, ps2);
+            const double corr = max_correlation_wave(x, n, c.x1, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, lane, &tout, &peak, ps1, ps2);
             tmax = tout;
             if (corr == -1.0) tmax -= 1.0 / f0;
             if (tmax < tleft) {
@@ -2196,7 +2202,7 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
             const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
             if (!(f0 == f0)) break;
             double peak, tout;
-            const double corr = max_correlation_wave(x, n, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, lane, &tout, &peak, ps1, ps2);
+            const double corr = max_correlation_wave(x, n, c.x1, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, lane, &tout, &peak, ps1, ps2);
             tmax = tout;
             if (corr == -1.0) tmax += 1.0 / f0;
             if (tmax > tright) {
@@ -2299,7 +2305,7 @@ __global__ __launch_bounds__(256) void ltas_kernel(const float* __restrict__ wav
         const double factor = left > right ? left / right : right / left;
         if (!(left >= shortest && left <= longest && right >= shortest && right <= longest && factor <= max_factor)) continue;
         const double t1 = tm - 0.5 * left, t2 = tm + 0.5 * right;
-        const int64_t ix1 = (int64_t)ceil((t1 - 0.5 * DXS) / DXS), ix2 = (int64_t)floor((t2 - 0.5 * DXS) / DXS);
+        const int64_t ix1 = (int64_t)ceil((t1 - c.x1) / DXS), ix2 = (int64_t)floor((t2 - c.x1) / DXS);   // Sound_extractPart
         if (ix2 < ix1 || ix2 - ix1 + 1 > LTAS_MAXN) { fail = 1; continue; }   // Praat: "no samples" aborts the analysis
         const int m = (int)(ix2 - ix1 + 1);
         for (int j = lane; j < m; j += 64) { const int64_t i = ix1 + j; s_x[wv][j] = (i >= 0 && i < n) ? x[i] : 0.0f; }
@@ -2362,7 +2368,7 @@ __global__ __launch_bounds__(256) void ltas_kernel(const float* __restrict__ wav
                 s_count[0][b] = (s_count[0][b] + s_count[1][b]) + (s_count[2][b] + s_count[3][b]);
                 total += s_count[0][b];
             }
-            const double duration = n * DXS;
+            const double duration = c.xmax;                      // PointProcess_Sound_to_Ltas divides by sound->xmax - sound->xmin
             bool any = false;
             for (int b = 0; b < LTAS_NB; ++b) {
                 if (s_count[0][b] > 0.0) {

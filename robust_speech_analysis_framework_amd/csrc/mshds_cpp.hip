@@ -35,12 +35,14 @@ constexpr int NFFT_MAX = 1024;            // 0.1 s window at 10 kHz = 1000 sampl
 constexpr int NQ_MAX = NFFT_MAX / 2 + 1;  // 513
 constexpr int SEG_DOUBLES = 15;
 
-struct ClipInfo {      // same 32-byte rows as csrc/mshds.hip
+struct ClipInfo {      // same 48-byte rows as csrc/mshds.hip
     int64_t sample_off;
     int64_t frame_off;
     double t1;
     int n_samples;
     int n_frames;
+    double x1;         // time of the first sample
+    double xmax;       // end of the sound's time domain
 };
 
 // one voiced interval (all fields double so that the table is one plain array)
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict
     const double* t = pulses + (int64_t)blockIdx.x * max_pulses;
     const int np_ = n_pulses[blockIdx.x];
     Seg* out = segs + (int64_t)blockIdx.x * max_seg;
-    const double xmax = c.n_samples * DXS, half = 0.5 * mean_period;
+    const double xmax = c.xmax, half = 0.5 * mean_period;         // PointProcess_to_TextGrid_vuv: the sound's domain
     int nseg = 0, fail = 0;
     int64_t res_off = 0, frame_off = 0, work_off = 0, item_off = 0;
     double begin_voiceless = 0.0;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict
         begin_voiceless = end_voiced;
         const double tmin = round6(begin_voiced), tmax = round6(end_voiced);
         if (tmin >= tmax) return;                                            // :284
-        const int64_t ix1 = (int64_t)ceil((tmin - 0.5 * DXS) / DXS), ix2 = (int64_t)floor((tmax - 0.5 * DXS) / DXS);
+        const int64_t ix1 = (int64_t)ceil((tmin - c.x1) / DXS), ix2 = (int64_t)floor((tmax - c.x1) / DXS);
         const double dur = tmax - tmin;
         const int64_t m_out = (int64_t)floor(dur * FS_OUT + 0.5);
         if (ix2 < ix1 || m_out < 1) { fail = 1; return; }                    // Praat raises outside the inner try -> NaN
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(64) void segments_kernel(const ClipInfo* __restrict
         const double my_duration = DXS * (double)m_in;
         if (window > my_duration) window = my_duration;
         const int64_t nf = (int64_t)floor((my_duration - window) / DT) + 1;
-        const double x1_seg = 0.5 * DXS + (double)ix1 * DXS - tmin;
+        const double x1_seg = c.x1 + (double)ix1 * DXS - tmin;
         const double mid = x1_seg - 0.5 * DXS + 0.5 * my_duration;
         const double t1 = mid - 0.5 * (double)nf * DT + 0.5 * DT;
         const int64_t nx = (int64_t)floor(window * FS_OUT + 0.5);

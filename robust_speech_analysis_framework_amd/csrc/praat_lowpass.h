@@ -42,10 +42,17 @@ struct LpSig {
     int n, lg;
 };
 static_assert(sizeof(LpSig) == 32, "LpSig layout");
+// what the row pass does to the spectrum between the forward and the inverse transform
+enum LpMode {
+    LP_LOWPASS = 0,         // Sound_resample, anti-aliasing branch: clear the packed array from floor(upfactor * nfft)
+    LP_UPSAMPLE_EVEN = 1,   // Sound_upsample: linear ramp to zero over the last 5 % of the packed array; the even output samples
+    LP_UPSAMPLE_ODD = 2     // ... and the odd ones: bin k also turned by e^(+i pi k / nfft) (half an input sample later)
+};
 struct LpBatch {
     const LpSig* sigs;  // device array indexed by the workgroup's y index, or nullptr: `one`
     LpSig one;
     double upfactor;
+    int mode;           // LpMode
 };
 
 struct LpGeom { int log1, log2, C, logC; };
@@ -167,17 +174,34 @@ __device__ void lp_cols_body(const float* __restrict__ in, c64* __restrict__ wor
 
 // bins k and M - k of the real transform from Z[k], Z[M - k]; Praat's clearing of the packed array (1-based position
 // 2k + 1 = real part, 2k + 2 = imaginary part of bin k, cleared from position `first_cleared`); back to Z'[k], Z'[M - k]
-__device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int64_t M, int64_t first_cleared, const LpTables& T, int lg) {
+// Sound_upsample (mode != LP_LOWPASS): instead of the clearing, the 1-based packed positions i > imin = (integer)(0.95 nfft)
+// are scaled by (nfft - i) / (nfft - imin) (real and imaginary part of a bin sit at different positions and get different
+// factors), the Nyquist position is cleared, and the array is transformed back at TWICE the length: output sample 2p is the
+// inverse transform of this spectrum at p, output sample 2p + 1 that of the spectrum with bin k turned by e^(+i pi k / nfft)
+// (the tables must then reach 2 nfft: T.lg_max >= lg + 1).
+__device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int64_t M, int64_t first_cleared, const LpTables& T, int lg,
+                                               int mode = LP_LOWPASS) {
     const c64 w = w_nfft(T, k, lg);
     const c64 E = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
     const c64 O = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
     const c64 Tt = mul_pi(cmul(w, O));
     c64 xk = csub(E, Tt), xm = cconj(cadd(E, Tt));
     const int64_t m = M - k;
-    if (2 * k + 1 >= first_cleared) xk.x = 0.0;
-    if (2 * k + 2 >= first_cleared) xk.y = 0.0;
-    if (2 * m + 1 >= first_cleared) xm.x = 0.0;
-    if (2 * m + 2 >= first_cleared) xm.y = 0.0;
+    if (mode == LP_LOWPASS) {
+        if (2 * k + 1 >= first_cleared) xk.x = 0.0;
+        if (2 * k + 2 >= first_cleared) xk.y = 0.0;
+        if (2 * m + 1 >= first_cleared) xm.x = 0.0;
+        if (2 * m + 2 >= first_cleared) xm.y = 0.0;
+    } else {
+        const int64_t nfft = 2 * M, imin = (int64_t)((double)nfft * 0.95);
+        auto ramp = [&](int64_t pos) -> double { return pos > imin ? (double)(nfft - pos) / (double)(nfft - imin) : 1.0; };
+        xk.x *= ramp(2 * k + 1); xk.y *= ramp(2 * k + 2);
+        xm.x *= ramp(2 * m + 1); xm.y *= ramp(2 * m + 2);
+        if (mode == LP_UPSAMPLE_ODD) {
+            xk = cmulc(xk, w_nfft(T, k, lg + 1));
+            xm = cmulc(xm, w_nfft(T, m, lg + 1));
+        }
+    }
     const c64 s1 = cadd(xk, cconj(xm)), d1 = csub(xk, cconj(xm));
     const c64 s2 = cadd(xm, cconj(xk)), d2 = csub(xm, cconj(xk));
     const c64 r1 = mul_pi(cmulc(d1, w)), r2 = mul_pi(cmul(d2, w));
@@ -188,33 +212,33 @@ __device__ __forceinline__ void lp_filter_pair(c64& zk, c64& zm, int64_t k, int6
 // the filter step for element k2 of the logical row ka (A) and its partner in row N1 - ka (B; B == A when the row is its own
 // partner); both rows hold their transform in bit-reversed positions
 __device__ __forceinline__ void lp_filter_at(c64* A, c64* B, int ka, int k2, int log1, int log2, int64_t first_cleared,
-                                             const LpTables& T, int lg) {
+                                             const LpTables& T, int lg, int mode = LP_LOWPASS) {
     const int N1 = 1 << log1, N2 = 1 << log2;
     const int64_t M = (int64_t)N1 << log2;
     const bool two = ka != ((N1 - ka) & (N1 - 1));
     if (two) {
         const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
         c64 zk = A[pa], zm = B[pb];
-        lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
+        lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg, mode);
         A[pa] = zk;
         B[pb] = zm;
     } else if (ka != 0) {                              // k1 = N1 / 2: the partner of k2 is N2 - 1 - k2 in the same row
         if (k2 >= N2 / 2) return;
         const int pa = bitrev(k2, log2), pb = bitrev(N2 - 1 - k2, log2);
         c64 zk = A[pa], zm = A[pb];
-        lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg);
+        lp_filter_pair(zk, zm, ka + ((int64_t)k2 << log1), M, first_cleared, T, lg, mode);
         A[pa] = zk;
         A[pb] = zm;
     } else {                                           // k1 = 0: partner N2 - k2; k2 = 0 holds DC and Nyquist, k2 = N2 / 2 is its own partner
         if (k2 > N2 / 2) return;
         if (k2 == 0) {
             const c64 z = A[0];
-            const double dc = first_cleared > 1 ? z.x + z.y : 0.0;   // position 1; position 2 (Nyquist) is always cleared
+            const double dc = (mode != LP_LOWPASS || first_cleared > 1) ? z.x + z.y : 0.0;   // position 1; position 2 (Nyquist) is always cleared
             A[0] = make_double2(0.5 * dc, 0.5 * dc);
         } else {
             const int pa = bitrev(k2, log2), pb = bitrev(N2 - k2, log2);
             c64 zk = A[pa], zm = A[pb];
-            lp_filter_pair(zk, zm, (int64_t)k2 << log1, M, first_cleared, T, lg);
+            lp_filter_pair(zk, zm, (int64_t)k2 << log1, M, first_cleared, T, lg, mode);
             A[pa] = zk;
             if (pb != pa) A[pb] = zm;
         }
@@ -223,7 +247,7 @@ __device__ __forceinline__ void lp_filter_at(c64* A, c64* B, int ka, int k2, int
 
 // Row pass: workgroup b owns the logical rows k1 = b and N1 - b (stored at their bit-reversed positions), b = 0 .. N1 / 2.
 __device__ inline void lp_rows_body(c64* __restrict__ work_base, const LpSig& sg, int bx, double upfactor, const LpTables& T,
-                                    c64* lp_lds) {
+                                    c64* lp_lds, int mode = LP_LOWPASS) {
     const LpGeom g = lp_geom(sg.lg);
     const int log1 = g.log1, log2 = g.log2, lg = sg.lg;
     const int N1 = 1 << log1, N2 = 1 << log2;
@@ -242,7 +266,7 @@ __device__ inline void lp_rows_body(c64* __restrict__ work_base, const LpSig& sg
     }
     __syncthreads();
     lds_fft<false>(lp_lds, log2, two ? 1 : 0, 1, N2, T.tw);
-    for (int k2 = threadIdx.x; k2 < N2; k2 += blockDim.x) lp_filter_at(A, B, ka, k2, log1, log2, first_cleared, T, lg);
+    for (int k2 = threadIdx.x; k2 < N2; k2 += blockDim.x) lp_filter_at(A, B, ka, k2, log1, log2, first_cleared, T, lg, mode);
     __syncthreads();
     lds_fft<true>(lp_lds, log2, two ? 1 : 0, 1, N2, T.tw);
     for (int e = threadIdx.x; e < N2; e += blockDim.x) {

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void lp_cols_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void lp_rows_kernel(c64* __restrict__ work_base, LpBatch B, LpTables T) {
     extern __shared__ c64 lp_lds[];
     const LpSig sg = B.sigs ? B.sigs[blockIdx.y] : B.one;
-    lp_rows_body(work_base, sg, (int)blockIdx.x, B.upfactor, T, lp_lds);
+    lp_rows_body(work_base, sg, (int)blockIdx.x, B.upfactor, T, lp_lds, B.mode);
 }
 
 // ---- NUM_interpolate_sinc on the re-centred grid -------------------------------------------------------------
@@ -64,11 +64,20 @@ __global__ __launch_bounds__(256) void praat_interp_kernel(const SRC* __restrict
                                                            int depth, float* __restrict__ out, int64_t n_out) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= n_out) return;
+    // a sound read from a file: dx = 1 / fs, x1 = 0.5 / fs, domain [0, n / fs]; the new grid is centred in that domain
     const double dx_in = 1.0 / fs_in, dx_out = 1.0 / fs_out;
-    const double duration = (double)n_in * dx_in;
-    const double x1o = 0.5 * (duration - (double)(n_out - 1) / fs_out);
-    const double x = (x1o + (double)o * dx_out - 0.5 * dx_in) / dx_in + 1.0;   // Praat's 1-based real index
+    const double xmax = (double)n_in / fs_in;
+    const double x1o = 0.5 * (xmax - (double)(n_out - 1) / fs_out);
+    const double x = (x1o + (double)o * dx_out - 0.5 / fs_in) / dx_in + 1.0;   // Praat's 1-based real index
     out[o] = (float)praat_interpolate_sinc(y, n_in, x, depth);
+}
+
+// Sound_upsample: output sample 2p = the ramp-filtered sound at p, 2p + 1 = the same spectrum half an input sample later
+__global__ __launch_bounds__(256) void upsample_interleave_kernel(const double* __restrict__ even, const double* __restrict__ odd,
+                                                                  int64_t n_in, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * n_in) return;
+    out[i] = (float)((i & 1) ? odd[i >> 1] : even[i >> 1]);
 }
 
 }  // namespace resample
@@ -134,25 +143,30 @@ int rsaf_resample_sinc_hann(const float* in, int64_t n_in, const float* taps, co
 }
 
 int64_t rsaf_resample_praat_work_bytes(int64_t n_in, double fs_in, double fs_out) {
-    if (n_in <= 0 || !(fs_in > 0.0) || !(fs_out > 0.0) || fs_out * (1.0 / fs_in) >= 1.0) return 0;
+    if (n_in <= 0 || !(fs_in > 0.0) || !(fs_out > 0.0)) return 0;
+    const double upfactor = fs_out * (1.0 / fs_in);
+    const bool doubling = fabs(upfactor - 2.0) < 1e-6;  // Sound_upsample
+    if (upfactor >= 1.0 && !doubling) return 0;
     int64_t nfft = 1;
     while (nfft < n_in + 2 * resample::ANTI_TURN_AROUND) nfft *= 2;
-    return nfft * 8 + n_in * 8;                         // nfft / 2 complex numbers + the low-passed sound (fp64)
+    // nfft / 2 complex numbers + the filtered sound (fp64): low-passed, or the even and the odd output samples
+    return nfft * 8 + n_in * 8 * (doubling ? 2 : 1);
 }
 
 }  // extern "C"
 
 // the three passes of the low-pass over a batch (sigs on the device, n_sigs of them) or over `one` sound
 static int launch_lowpass(const float* in, double* out, resample::c64* work, const resample::LpSig* sigs, int n_sigs,
-                          const resample::LpSig& one, int lg_max, double upfactor, hipStream_t s) {
+                          const resample::LpSig& one, int lg_max, double upfactor, hipStream_t s, int mode = resample::LP_LOWPASS) {
     using namespace resample;
     RSAF_CHECK_ARG(lg_max >= 11 && lg_max <= 24, "sound longer than 2^24 - 2000 samples: the low-pass transform does not fit its two LDS passes");
     LpTables T;
+    const int lg_tab = lg_max + (mode == LP_UPSAMPLE_ODD ? 1 : 0);   // the half-sample turn needs e^(-2 pi i k / (2 nfft))
     {
-        const int rc = lp_tables((int64_t)1 << lg_max, &T);
+        const int rc = lp_tables((int64_t)1 << lg_tab, &T);
         if (rc != RSAF_OK) return rc;
     }
-    T.lg_max = lg_max;
+    T.lg_max = lg_tab;
     unsigned gc = 1, gr = 1;
     size_t lds_c = 0, lds_r = 0;
     for (int lg = 11; lg <= lg_max; ++lg) {             // the batch may hold any shorter transform
@@ -172,6 +186,7 @@ static int launch_lowpass(const float* in, double* out, resample::c64* work, con
     B.sigs = sigs;
     B.one = one;
     B.upfactor = upfactor;
+    B.mode = mode;
     const unsigned ny = sigs ? (unsigned)n_sigs : 1u;
     hipLaunchKernelGGL(lp_cols_kernel<false>, dim3(gc, ny), dim3(256), lds_c, s, in, work, (double*)nullptr, B, T);
     hipLaunchKernelGGL(lp_rows_kernel, dim3(gr, ny), dim3(256), lds_r, s, work, B, T);
@@ -202,6 +217,29 @@ int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_o
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = (unsigned)((n_out + 255) / 256);
     const double upfactor = fs_out * (1.0 / fs_in);     // Praat: samplingFrequency * my dx
+    if (fabs(upfactor - 2.0) < 1e-6) {                  // Sound_resample hands a doubling of the rate to Sound_upsample
+        RSAF_CHECK_ARG(n_out == 2 * n_in, "Sound_upsample writes 2 n samples");
+        int64_t nfft = 1;
+        int lg = 0;
+        while (nfft < n_in + 2 * resample::ANTI_TURN_AROUND) { nfft *= 2; ++lg; }
+        RSAF_CHECK_ARG(lg <= 24, "sound longer than 2^24 - 2000 samples: the transform does not fit its two LDS passes");
+        RSAF_CHECK_ARG(work && work_bytes >= rsaf_resample_praat_work_bytes(n_in, fs_in, fs_out), "workspace missing or too small");
+        resample::c64* wk = (resample::c64*)work;
+        double* even = (double*)(wk + nfft / 2);
+        double* odd = even + n_in;
+        ProfScope prof("resample_praat", s, 4.0 * 2.5 * (double)nfft * (double)(lg - 1), 12.0 * 8.0 * (double)nfft + 4.0 * (double)(n_in + n_out));
+        resample::LpSig one{};
+        one.n = (int)n_in;
+        one.lg = lg;
+        int rc = launch_lowpass(in, even, wk, nullptr, 1, one, lg, 0.5, s, resample::LP_UPSAMPLE_EVEN);
+        if (rc != RSAF_OK) return rc;
+        rc = launch_lowpass(in, odd, wk, nullptr, 1, one, lg, 0.5, s, resample::LP_UPSAMPLE_ODD);
+        if (rc != RSAF_OK) return rc;
+        hipLaunchKernelGGL(resample::upsample_interleave_kernel, dim3(grid), dim3(256), 0, s, (const double*)even, (const double*)odd,
+                           n_in, out);
+        RSAF_CHECK_HIP(hipGetLastError());
+        return RSAF_OK;
+    }
     if (!(upfactor < 1.0)) {                            // rate going up: interpolation only
         ProfScope prof("resample_praat", s, 0.0, 4.0 * (double)(n_in + n_out));
         hipLaunchKernelGGL(resample::praat_interp_kernel<float>, dim3(grid), dim3(256), 0, s, in, n_in, fs_in, fs_out, precision,

@@ -36,8 +36,8 @@ FEATURE_NAMES = [
 BUILT_COLUMNS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24]
 
 CLIP_INFO = np.dtype([("sample_off", "<i8"), ("frame_off", "<i8"), ("t1", "<f8"),
-                      ("n_samples", "<i4"), ("n_frames", "<i4")])
-assert CLIP_INFO.itemsize == 32
+                      ("n_samples", "<i4"), ("n_frames", "<i4"), ("x1", "<f8"), ("xmax", "<f8")])
+assert CLIP_INFO.itemsize == 48
 RESAMPLE_INFO = np.dtype([("sample_off", "<i8"), ("out_off", "<i8"), ("pos0", "<f8"), ("x1o", "<f8"),
                           ("n_in", "<i4"), ("n_out", "<i4"), ("table", "<i4"), ("pad", "<i4")])
 assert RESAMPLE_INFO.itemsize == 48
@@ -72,23 +72,41 @@ def resample10k_tables(pos0: float, depth: int = RS_DEPTH):
     return np.stack(rows), bs
 
 
-def short_term_frames(n_samples: int, window_duration: float, time_step: float):
-    """Praat Sampled_shortTermAnalysis: (frames, time of first frame); integer-exact contract."""
+def short_term_frames(n_samples: int, window_duration: float, time_step: float, x1: float = 0.5 * DX):
+    """Praat Sampled_shortTermAnalysis of a sound of ``n_samples`` samples whose first sample lies at ``x1``:
+    (frames, time of first frame); integer-exact contract.  The physical duration is nx * dx (not the domain)."""
     duration = n_samples * DX
     if window_duration > duration:
         return 0, 0.0
     nf = int(math.floor((duration - window_duration) / time_step)) + 1
-    t1 = 0.5 * duration - 0.5 * nf * time_step + 0.5 * time_step
+    mid = x1 - 0.5 * DX + 0.5 * duration
+    t1 = mid - 0.5 * nf * time_step + 0.5 * time_step
     return nf, t1
 
 
-def _clip_info(sample_offs, lengths, grid):
-    """grid(n_samples) -> (n_frames, t1).  Returns (structured host array, total frames, max frames)."""
+class SoundDomain:
+    """Time domain of every clip of a packed batch, as Praat's Sound carries it: ``x1`` = time of the first sample,
+    ``xmax`` = end of the domain [0, xmax].  A sound read from a 16 kHz file has x1 = dx / 2 and xmax = n dx; after
+    ``Sound_resample`` the grid is centred in the ORIGINAL domain: xmax = n_in / fs_in, n = round(xmax * 16000),
+    x1 = (xmax - (n - 1) dx) / 2 (``src/mshds_extractor.py:418-419``)."""
+
+    def __init__(self, lengths, x1=None, xmax=None):
+        self.x1 = [0.5 * DX] * len(lengths) if x1 is None else [float(v) for v in x1]
+        self.xmax = [int(n) / FS for n in lengths] if xmax is None else [float(v) for v in xmax]
+        assert len(self.x1) == len(lengths) and len(self.xmax) == len(lengths)
+
+    def sub(self, ids):
+        return SoundDomain(ids, [self.x1[i] for i in ids], [self.xmax[i] for i in ids])
+
+
+def _clip_info(sample_offs, lengths, grid, dom=None):
+    """grid(n_samples, x1) -> (n_frames, t1).  Returns (structured host array, total frames, max frames)."""
+    dom = dom if dom is not None else SoundDomain(lengths)
     ci = np.zeros(len(lengths), dtype=CLIP_INFO)
     off = 0
     for i, (so, n) in enumerate(zip(sample_offs, lengths)):
-        nf, t1 = grid(int(n))
-        ci[i] = (int(so), off, t1, int(n), nf)
+        nf, t1 = grid(int(n), dom.x1[i])
+        ci[i] = (int(so), off, t1, int(n), nf, dom.x1[i], dom.xmax[i])
         off += nf
     return ci, off, int(ci["n_frames"].max()) if len(ci) else 0
 
@@ -140,10 +158,10 @@ class _PitchGeom:
         self.brent_ixmax = int(math.floor(self.nsamp_window * (1.0 if is_cc else 0.5)))
         self.frame_window = (1.0 / floor + self.dt_window) if is_cc else self.dt_window
 
-    def grid(self, n):
+    def grid(self, n, x1=0.5 * DX):
         if self.half_window < 2:
             return 0, 0.0
-        return short_term_frames(n, self.frame_window, self.dt)
+        return short_term_frames(n, self.frame_window, self.dt, x1)
 
     def tables(self):
         if self.is_cc:
@@ -183,13 +201,13 @@ class MshdsEngine:
     def pitch(self, wav, sample_offs, lengths, gpeak, *, time_step, floor, ceiling, max_candidates=15,
               silence_threshold=0.03, voicing_threshold=0.45, octave_cost=0.01, octave_jump_cost=0.35,
               voiced_unvoiced_cost=0.14, periods=3.0, is_cc=False, refine_depth=70, voicing_threshold2=None,
-              stream=None):
+              stream=None, dom=None):
         """One Sound: To Pitch (ac/cc) analysis.  ``voicing_threshold2``: also return (key ``second``) the same
         analysis with that voicing threshold; the frame kernel's correlation and refinement are shared."""
         import torch
         lib = _lib.load()
         g = _PitchGeom(time_step, floor, ceiling, periods, is_cc)
-        ci, total, mx = _clip_info(sample_offs, lengths, g.grid)
+        ci, total, mx = _clip_info(sample_offs, lengths, g.grid, dom)
         n = len(lengths)
         dev = self.device
         ci_d = _dev(ci, dev)
@@ -246,7 +264,7 @@ class MshdsEngine:
         return {"geom": g, "ci": ci, "ci_dev": ci_d, "sel_freq": sel_f, "sel_strength": sel_s, "stats": stats[:n],
                 "frame_out": frame_out, "total_frames": total, "max_frames": mx, "second": second}
 
-    def intensity(self, wav, sample_offs, lengths, minimum_pitch, time_step, subtract_mean=True, stream=None):
+    def intensity(self, wav, sample_offs, lengths, minimum_pitch, time_step, subtract_mean=True, stream=None, dom=None):
         import torch
         lib = _lib.load()
         phys = 6.4 / minimum_pitch
@@ -259,7 +277,7 @@ class MshdsEngine:
             xx = i * DX / half_dur
             return (np.i0((2.0 * np.pi * np.pi + 0.5) * np.sqrt(np.maximum(0.0, 1.0 - xx * xx))),)
         (win,) = self._table(("intensity", half, minimum_pitch), build)
-        ci, total, mx = _clip_info(sample_offs, lengths, lambda n: short_term_frames(n, phys, dt))
+        ci, total, mx = _clip_info(sample_offs, lengths, lambda n, x1: short_term_frames(n, phys, dt, x1), dom)
         n = len(lengths)
         db = torch.empty(max(total, 1), dtype=torch.float64, device=self.device)
         stats = torch.empty((max(n, 1), 2), dtype=torch.float64, device=self.device)
@@ -269,16 +287,16 @@ class MshdsEngine:
                                                 _lib.stream_ptr(stream)), "rsaf_mshds_intensity")
         return {"db": db, "ci": ci, "ci_dev": _dev(ci, self.device), "stats": stats[:n], "dt": dt, "max_frames": mx}
 
-    def speechrate(self, wav, sample_offs, lengths, gpeak, stream=None):
+    def speechrate(self, wav, sample_offs, lengths, gpeak, stream=None, dom=None):
         """``_speechrate`` (:11-125): intensity(50 Hz, 16 ms) + the 4-candidate pitch pass of :104 ->
         float64 [n, 5].  (The harmonicity call of :36-38 is not evaluated: its value only feeds a no-op and its failure path - clips shorter than 26.7 ms - lies inside the failure path of the intensity call of :41 - clips shorter than 128 ms -, which gives the same five NaN; tests/test_mshds_oracle.py checks the containment.)"""
         import torch
         lib = _lib.load()
         n = len(lengths)
-        inten = self.intensity(wav, sample_offs, lengths, 50.0, 0.016, True, stream)                 # :41
+        inten = self.intensity(wav, sample_offs, lengths, 50.0, 0.016, True, stream, dom)            # :41
         p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.02, floor=30.0, ceiling=450.0,
                        max_candidates=4, silence_threshold=0.03, voicing_threshold=0.25, octave_cost=0.01,
-                       octave_jump_cost=0.35, voiced_unvoiced_cost=0.25, stream=stream)            # :104
+                       octave_jump_cost=0.35, voiced_unvoiced_cost=0.25, stream=stream, dom=dom)   # :104
         out = torch.empty((max(n, 1), 5), dtype=torch.float64, device=self.device)
         if n:
             wsd = int(lib.rsaf_mshds_speechrate_workspace_doubles(inten["max_frames"]))
@@ -290,7 +308,7 @@ class MshdsEngine:
         return out[:n]
 
     def spectral_moments(self, wav, sample_offs, lengths, pitch, window_length=0.025, time_step=0.005,
-                         maximum_frequency=5000.0, frequency_step=20.0, stream=None):
+                         maximum_frequency=5000.0, frequency_step=20.0, stream=None, dom=None):
         import torch
         lib = _lib.load()
         nyq = 0.5 / DX
@@ -322,13 +340,13 @@ class MshdsEngine:
             return win, tw.reshape(-1)
         win, tw = self._table(("spec", nsamp, nfft), build)
 
-        def grid(n):
+        def grid(n, x1):
             duration = n * DX
             if phys > duration or half < 1:
                 return 0, 0.0
             nt = 1 + int(math.floor((duration - phys) / tstep))
-            return nt, 0.5 * DX + 0.5 * ((n - 1) * DX - (nt - 1) * tstep)
-        ci, total, mx = _clip_info(sample_offs, lengths, grid)
+            return nt, x1 + 0.5 * ((n - 1) * DX - (nt - 1) * tstep)
+        ci, total, mx = _clip_info(sample_offs, lengths, grid, dom)
         n = len(lengths)
         mom = torch.empty(max(total, 1) * 5, dtype=torch.float64, device=self.device)
         stats = torch.empty((max(n, 1), 4), dtype=torch.float64, device=self.device)
@@ -340,12 +358,13 @@ class MshdsEngine:
                 "rsaf_mshds_spectral_moments")
         return {"stats": stats[:n], "moments": mom, "ci": ci, "fstep": fstep, "tstep": tstep}
 
-    def formants(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None):
+    def formants(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None, dom=None):
         """``_measureFormants`` (:303-338) -> float64 [n, 8] (mean/SD of F1, B1, F2, B2 at the pulses)."""
         import torch
         lib = _lib.load()
         n = len(lengths)
         dev = self.device
+        dom = dom if dom is not None else SoundDomain(lengths)
         dxo = 1.0 / RS_RATE
         ratio = RS_RATE / FS
         ri = np.zeros(n, dtype=RESAMPLE_INFO)
@@ -353,10 +372,11 @@ class MshdsEngine:
         tabs, bases, key_to_table = [], [], {}
         out_off = work_off = 0
         for i, (so, nn) in enumerate(zip(sample_offs, lengths)):
-            duration = nn * DX
-            m = int(math.floor(duration * RS_RATE + 0.5))
-            x1o = 0.5 * (duration - (m - 1) / RS_RATE)
-            pos0 = (x1o - 0.5 * DX) / DX
+            # Sound_resample: round((xmax - xmin) fs) samples on a grid centred in the sound's DOMAIN; output sample j sits at
+            # the real input index (x1o + j dxo - x1) / dx
+            m = int(math.floor(dom.xmax[i] * RS_RATE + 0.5))
+            x1o = 0.5 * (dom.xmax[i] - (m - 1) / RS_RATE)
+            pos0 = (x1o - dom.x1[i]) / DX
             if pos0 not in key_to_table:
                 key_to_table[pos0] = len(tabs)
                 rows, bs = resample10k_tables(pos0)
@@ -406,7 +426,7 @@ class MshdsEngine:
             else:
                 nf = int(math.floor((duration - dt_window) / frame_shift)) + 1
                 t1 = x1o - 0.5 * dxo + 0.5 * duration - 0.5 * nf * frame_shift + 0.5 * frame_shift
-            ci[i] = (int(ri[i]["out_off"]), foff, t1, m, nf)
+            ci[i] = (int(ri[i]["out_off"]), foff, t1, m, nf, x1o, dom.xmax[i])
             foff += nf
         mxf = int(ci["n_frames"].max())
         frames = torch.empty(max(foff, 1) * 10, dtype=torch.float64, device=dev)
@@ -416,7 +436,7 @@ class MshdsEngine:
                                            _lib.stream_ptr(stream)), "rsaf_mshds_formants")
         # To Pitch (cc) with parselmouth's defaults (:320) and the pulses (:321)
         p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=frame_shift, floor=floor, ceiling=ceiling,
-                       periods=1.0, is_cc=True, refine_depth=70, stream=stream)
+                       periods=1.0, is_cc=True, refine_depth=70, stream=stream, dom=dom)
         pulses, npul, max_pulses = self.pulses(wav, lengths, p, stream)
         _lib.check(lib.rsaf_mshds_formant_stats(_lib.ptr(frames), _lib.ptr(ci_d), n, frame_shift, _lib.ptr(pulses),
                                                 max_pulses, _lib.ptr(npul), _lib.ptr(out), _lib.stream_ptr(stream)),
@@ -443,7 +463,7 @@ class MshdsEngine:
                                              _lib.ptr(npul), _lib.stream_ptr(stream)), "rsaf_mshds_pulses")
         return pulses, npul, max_pulses
 
-    def slope_tilt(self, wav, sample_offs, lengths, gpeak, floor, ceiling, stream=None):
+    def slope_tilt(self, wav, sample_offs, lengths, gpeak, floor, ceiling, stream=None, dom=None):
         """_extract_Slope_Tilt (src/mshds_extractor.py:227-251) -> float64 [n, 2] = (Spectral_Slope, Spectral_Tilt).
         "To Ltas (pitch-corrected)" finds its own pulses: To Pitch (ac) with the standard settings and the
         automatic time step 0.75 / floor, then the cc pulse train."""
@@ -452,7 +472,7 @@ class MshdsEngine:
         out = torch.full((max(n, 1), 2), float("nan"), dtype=torch.float64, device=self.device)
         if n == 0:
             return out[:0]
-        p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.0, floor=floor, ceiling=ceiling, stream=stream)
+        p = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.0, floor=floor, ceiling=ceiling, stream=stream, dom=dom)
         pulses, npul, max_pulses = self.pulses(wav, lengths, p, stream)
         _lib.check(_lib.load().rsaf_mshds_ltas_slope_tilt(_lib.ptr(wav), _lib.ptr(p["ci_dev"]), n, _lib.ptr(pulses),
                                                           max_pulses, _lib.ptr(npul), 0.0001, 0.02, 1.3, _lib.ptr(out),
@@ -463,7 +483,7 @@ class MshdsEngine:
     pitch_ws_cap_bytes = 4.0e9   # cap of the correlation-row workspace between the two pitch kernels (clips run in groups)
     CPP_CHUNK = 48          # most clips per launch group (the cepstrogram workspace is ~68 MB per 30 s clip)
 
-    def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None, pitch=None):
+    def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None, pitch=None, dom=None):
         """_extract_CPP (src/mshds_extractor.py:253-301) -> float64 [n] mean CPPS of the voiced intervals."""
         import torch
         lib = _lib.load()
@@ -473,7 +493,7 @@ class MshdsEngine:
         if n == 0:
             return out[:0]
         p = pitch if pitch is not None else self.pitch(wav, sample_offs, lengths, gpeak, time_step=frame_shift, floor=floor,
-                                                       ceiling=ceiling, voicing_threshold=0.3, stream=stream)   # :270
+                                                       ceiling=ceiling, voicing_threshold=0.3, stream=stream, dom=dom)   # :270
         pulses, npul, max_pulses = self.pulses(wav, lengths, p, stream)                                  # :271
 
         def build_win():
@@ -535,7 +555,7 @@ class MshdsEngine:
     def clip_peaks(self, wav, sample_offs, lengths, stream=None):
         import torch
         n = len(lengths)
-        ci, _, _ = _clip_info(sample_offs, lengths, lambda k: (0, 0.0))
+        ci, _, _ = _clip_info(sample_offs, lengths, lambda k, x1: (0, 0.0))
         gp = torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)
         if n:
             _lib.check(_lib.load().rsaf_mshds_clip_peak(_lib.ptr(wav), _lib.ptr(_dev(ci, self.device)), n, _lib.ptr(gp),
@@ -543,9 +563,10 @@ class MshdsEngine:
         return gp
 
     # ---- the reference's orchestration for a packed batch ----
-    def extract_packed(self, wav, sample_offs, lengths, stream=None):
+    def extract_packed(self, wav, sample_offs, lengths, stream=None, x1=None, xmax=None):
         """wav: 1-D float32 device tensor with the clips back to back -> (float64 [n, 25] device tensor,
-        list of (floor, ceiling) per clip)."""
+        list of (floor, ceiling) per clip).  ``x1`` / ``xmax`` (per clip, seconds): time of the first sample and end of the
+        time domain of each sound as Praat carries them (``SoundDomain``); default = sounds read from 16 kHz files."""
         import torch
         n = len(lengths)
         out = torch.full((n, 25), float("nan"), dtype=torch.float64, device=self.device)
@@ -553,6 +574,7 @@ class MshdsEngine:
             return out, []
         sample_offs = [int(v) for v in sample_offs]
         lengths = [int(v) for v in lengths]
+        dom = SoundDomain(lengths, x1, xmax)
         gpeak = self.clip_peaks(wav, sample_offs, lengths, stream)
         # Two HIP streams when the caller leaves the stream choice to us: the analyses of a clip are independent once the
         # speaker range is known, and several of them are latency-bound (path finder, pulse walk, speech-rate scan: one
@@ -579,9 +601,9 @@ class MshdsEngine:
                 for t in tensors:
                     t.record_stream(main)
 
-        sr = side(lambda: self.speechrate(wav, sample_offs, lengths, gpeak, stream))                # :426
+        sr = side(lambda: self.speechrate(wav, sample_offs, lengths, gpeak, stream, dom))           # :426
         # _pitch_values (:127-162): wide search, outlier-trimmed mean -> speaker range
-        wide = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.005, floor=50.0, ceiling=600.0, stream=stream)
+        wide = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.005, floor=50.0, ceiling=600.0, stream=stream, dom=dom)
         st = wide["stats"].cpu().numpy()                       # one small D2H per batch
         join(sr)
         out[:, 0:5] = sr
@@ -595,28 +617,29 @@ class MshdsEngine:
             ids = [i for i in range(n) if ranges[i] == rng]
             so = [sample_offs[i] for i in ids]
             ln = [lengths[i] for i in ids]
+            dm = dom.sub(ids)
             idx = torch.tensor(ids, dtype=torch.long, device=self.device)
             gp = gpeak[idx].contiguous()
             floor, ceiling = float(rng[0]), float(rng[1])
 
             def branch_hnr():
-                inten = self.intensity(wav, so, ln, floor, 0.005, True, stream)                              # :198
+                inten = self.intensity(wav, so, ln, floor, 0.005, True, stream, dm)                          # :198
                 cc = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=0.5 / DX, max_candidates=15,
                                 silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
-                                voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700, stream=stream)  # :221
+                                voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700, stream=stream, dom=dm)  # :221
                 return inten["stats"], self.hnr_mean(cc, stream)
 
             def branch_pulses():
-                fm = self.formants(wav, so, ln, gp, floor, ceiling, 0.005, stream)                           # :441
-                return fm, self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream)                          # :433
+                fm = self.formants(wav, so, ln, gp, floor, ceiling, 0.005, stream, dm)                       # :441
+                return fm, self.slope_tilt(wav, so, ln, gp, floor, ceiling, stream, dm)                      # :433
 
             i_stats, hnr = side(branch_hnr, 0)
             fm, sl = side(branch_pulses, 1)
             # :178 == :355, and :270 (voicing threshold 0.3, everything else equal) from the same frame kernel
             p = self.pitch(wav, so, ln, gp, time_step=0.005, floor=floor, ceiling=ceiling, voicing_threshold2=0.3,
-                           stream=stream)
-            sm = self.spectral_moments(wav, so, ln, p, 0.025, 0.005, stream=stream)                          # :356
-            cppv = self.cpp(wav, so, ln, gp, floor, ceiling, 0.005, stream, pitch=p["second"])               # :434
+                           stream=stream, dom=dm)
+            sm = self.spectral_moments(wav, so, ln, p, 0.025, 0.005, stream=stream, dom=dm)                  # :356
+            cppv = self.cpp(wav, so, ln, gp, floor, ceiling, 0.005, stream, pitch=p["second"], dom=dm)       # :434
             join(i_stats, hnr, fm, sl)
             out[idx, 5] = p["stats"][:, 5]
             out[idx, 6] = p["stats"][:, 6]
@@ -651,18 +674,21 @@ def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True,
     paths = list(input_df[audio_file_column])
     for b0 in range(0, len(paths), batch_files):
         batch = paths[b0:b0 + batch_files]
-        clips, ok_idx = [], []
+        clips, ok_idx, x1s, xmaxs = [], [], [], []
         for j, pth in enumerate(batch):
             filename = os.path.basename(pth)
             try:
                 x, fs, n_in = read_wav_mono_device(pth, device=eng.device)     # :415-416 Sound(path), convert_to_mono
+                x1, xmax = 0.5 / fs, int(x.numel()) / fs                      # a Sound read from a file
                 if fs != SAMPLE_RATE:                                         # :418-419 snd.resample(16000, 50)
-                    from .resample import resample_praat
-                    x = resample_praat(x, fs, SAMPLE_RATE, 50, device=eng.device)
+                    from .resample import resample_praat_sound
+                    x, x1, xmax = resample_praat_sound(x, fs, SAMPLE_RATE, 50, device=eng.device)
                 if int(x.numel()) == 0:
                     raise ValueError("empty file")
                 clips.append(x)
                 ok_idx.append(j)
+                x1s.append(x1)
+                xmaxs.append(xmax)
             except Exception as e:
                 if verbose:
                     print(f"ERROR processing file '{filename}': {e}. Appending NaNs.")
@@ -673,7 +699,7 @@ def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True,
             offs[1:] = np.cumsum(lengths)
             wav = torch.cat(clips) if len(clips) > 1 else clips[0].contiguous()
             try:
-                vals, _ = eng.extract_packed(wav, offs[:-1], lengths)
+                vals, _ = eng.extract_packed(wav, offs[:-1], lengths, x1=x1s, xmax=xmaxs)
                 torch.cuda.synchronize()
                 feats[ok_idx] = vals.cpu().numpy()
             except _lib.RsafError as e:
@@ -681,9 +707,9 @@ def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True,
                 # only the offending files the reference's per-file NaN row (:450-457)
                 if verbose:
                     print(f"WARNING: batch of {len(clips)} files failed ({e}); retrying file by file.")
-                for j, c in zip(ok_idx, clips):
+                for k, (j, c) in enumerate(zip(ok_idx, clips)):
                     try:
-                        v1, _ = eng.extract_packed(c.contiguous(), [0], [int(c.numel())])
+                        v1, _ = eng.extract_packed(c.contiguous(), [0], [int(c.numel())], x1=x1s[k:k + 1], xmax=xmaxs[k:k + 1])
                         torch.cuda.synchronize()
                         feats[j] = v1.cpu().numpy()[0]
                     except _lib.RsafError as e1:

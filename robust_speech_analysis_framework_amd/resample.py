@@ -73,21 +73,43 @@ def resample_sinc_hann(x, orig: int, new: int, device="cuda", stream=None):
     return out[:n_out]
 
 
+def praat_resampled_grid(n_in: int, fs_in: float, fs_out: float):
+    """Time axis of ``Sound.resample(fs_out, ...)`` applied to a sound of ``n_in`` samples read from a file at ``fs_in`` ->
+    (n_out, x1, xmax): Praat keeps the domain [0, xmax = n_in / fs_in], writes round(xmax * fs_out) samples and centres the
+    new grid in the domain: x1 = (xmax - (n_out - 1) / fs_out) / 2 (``Sound_resample``; ``Sound_upsample`` for a doubling of
+    the rate: 2 n_in samples from x1 - dx / 4, the same numbers).  Unchanged rate: the file's own axis."""
+    xmax = n_in / float(fs_in)
+    if abs(float(fs_out) * (1.0 / float(fs_in)) - 1.0) < 1e-6:
+        return int(n_in), 0.5 / float(fs_in), xmax
+    if abs(float(fs_out) * (1.0 / float(fs_in)) - 2.0) < 1e-6:
+        return 2 * int(n_in), 0.5 / float(fs_in) - (1.0 / float(fs_in)) / 4.0, xmax
+    n_out = int(math.floor(xmax * float(fs_out) + 0.5))
+    return n_out, 0.5 * (xmax - (n_out - 1) / float(fs_out)), xmax
+
+
+def resample_praat_sound(x, fs_in: float, fs_out: float = 16000.0, precision: int = 50, device="cuda", stream=None):
+    """``resample_praat`` together with the time axis Praat gives the result -> (samples, x1, xmax); the MSHDS analyses
+    take x1 / xmax through ``MshdsEngine.extract_packed(..., x1=, xmax=)``."""
+    n_out, x1, xmax = praat_resampled_grid(int(getattr(x, "numel", lambda: len(x))()), fs_in, fs_out)
+    return resample_praat(x, fs_in, fs_out, precision, device, stream), x1, xmax
+
+
 def resample_praat(x, fs_in: float, fs_out: float = 16000.0, precision: int = 50, device="cuda", stream=None):
     """Praat ``Sound.resample(fs_out, precision)`` of one mono clip -> torch float32 [round(n/fs_in*fs_out)] on the device.
 
-    Praat's own two steps: whole-sound FFT brick-wall low-pass when the rate goes down, then ``NUM_interpolate_sinc`` on
-    the new sample grid centred in the old time domain.  The result is handed to the MSHDS kernels as if it had been read
-    from a 16 kHz file (first sample at half a sample period): the offset of the centred grid against that, less than a
-    quarter sample, is not carried into the analyses."""
+    Praat's own steps (``Sound_resample``): whole-sound FFT brick-wall low-pass when the rate goes down, then
+    ``NUM_interpolate_sinc`` on the new sample grid centred in the old time domain; a doubling of the rate goes to
+    ``Sound_upsample`` instead (spectrum ramped to zero over its last 5 %, inverse transform of twice the length).  The
+    samples alone do not say where the grid lies: ``resample_praat_sound`` returns x1 and the domain with them.  Praat
+    keeps the resampled sound in float64; it is stored as float32 here like every other clip (one rounding of 6e-8 relative)."""
     import torch
     lib = _lib.load()
     _lib.require_gpu()
     xd = torch.as_tensor(x, dtype=torch.float32, device=device).contiguous()
-    if float(fs_in) == float(fs_out):
+    if abs(float(fs_out) * (1.0 / float(fs_in)) - 1.0) < 1e-6:           # Sound_resample: a copy
         return xd
     n_in = int(xd.numel())
-    n_out = int(math.floor(n_in / float(fs_in) * float(fs_out) + 0.5))
+    n_out = praat_resampled_grid(n_in, fs_in, fs_out)[0]
     out = torch.empty(max(n_out, 1), dtype=torch.float32, device=xd.device)
     wb = int(lib.rsaf_resample_praat_work_bytes(n_in, float(fs_in), float(fs_out)))
     work = torch.empty(max(wb, 8) // 8, dtype=torch.float64, device=xd.device)

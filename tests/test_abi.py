@@ -28,7 +28,7 @@ def test_python_binding_covers_header(rsaf_lib):
 
 
 def test_abi_version_and_host_only_calls(rsaf_lib):
-    assert rsaf_lib.rsaf_abi_version() == 3
+    assert rsaf_lib.rsaf_abi_version() == 4
     # integer-exact frame-count contract (Androids.conf:73-78): no GPU needed
     for n, want in [(0, 0), (399, 0), (400, 1), (559, 1), (560, 2), (80000, 498), (480000, 2998)]:
         assert rsaf_lib.rsaf_smile_n_frames(n, 16000) == want
@@ -38,7 +38,8 @@ def test_abi_version_and_host_only_calls(rsaf_lib):
         lg = max(11, int(n + 2000 - 1).bit_length())
         assert (1 << lg) >= n + 2000 and (lg == 11 or (1 << (lg - 1)) < n + 2000)
         assert rsaf_lib.rsaf_resample_praat_work_bytes(n, 44100.0, 16000.0) == (1 << lg) * 8 + n * 8
-    assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 8000.0, 16000.0) == 0             # rate going up: no low-pass
+    assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 8000.0, 16000.0) == 4096 * 8 + 2 * 1000 * 8   # Sound_upsample: even + odd samples
+    assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 11025.0, 16000.0) == 0            # rate going up: no low-pass
     assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 16000.0, 16000.0) == 0
     stride = rsaf_lib.rsaf_mshds_resample10k_table_stride(500)
     assert stride % 8 == 0 and stride >= 1001 + 24 + 7

@@ -419,3 +419,83 @@ def test_config_c2_mshds_30s_clips_match_oracle(eng):
     for i, (_, rng) in enumerate(refs):
         assert tuple(ranges[i]) == rng
     _check_rows(out.cpu().numpy(), refs)
+
+
+# ---- files that the reference resamples first (src/mshds_extractor.py:418-419): the 16 kHz sound then carries Praat's
+# centred time axis (x1 != dx / 2, xmax = the ORIGINAL duration) through every analysis -------------------------------
+def _oracle_extract_resampled(args):
+    k, seconds, fs = args
+    from oracle import mshds_oracle, resample_oracle
+    from robust_speech_analysis_framework_amd import synth as sy
+    y, x1, xmax = resample_oracle.resample_praat_sound(sy.synth_clip(k, seconds, fs=fs), float(fs), 16000.0, 50)
+    r, rng = mshds_oracle.extract(y, x1, xmax)
+    return r, tuple(rng), y, x1, xmax
+
+
+def _oracle_pool_resampled(jobs):
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    with cf.ProcessPoolExecutor(max_workers=min(8, len(jobs)), mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_oracle_extract_resampled, jobs))
+
+
+RESAMPLED_JOBS = [(20260300, 5.0, 44100), (20260301, 5.0, 8000), (20260302, 3.70001, 44100), (20260303, 2.0, 22050),
+                  (20260304, 2.5, 48000), (20260305, 1.3001, 11025)]
+
+
+@pytest.fixture(scope="module")
+def resampled_refs():
+    return _oracle_pool_resampled(RESAMPLED_JOBS)
+
+
+def test_extract_packed_with_praats_resampled_time_axis(eng, resampled_refs):
+    """The SAME float32 samples through both paths (the oracle's resampled sounds), with the time axis Praat gives them:
+    all 25 columns, the NaN pattern and the speaker range; and the axis matters: x1 differs from dx / 2 for these files."""
+    import torch
+    clips = [r[2] for r in resampled_refs]
+    x1s, xmaxs = [r[3] for r in resampled_refs], [r[4] for r in resampled_refs]
+    assert max(abs(x1 - 0.5 / 16000.0) for x1 in x1s) > 1e-6                    # off the file grid by up to a quarter sample
+    assert max(abs(xm - len(c) / 16000.0) for xm, c in zip(xmaxs, clips)) > 1e-6  # the domain is not nx dx
+    wav, offs, lens = _pack(clips)
+    out, ranges = eng.extract_packed(wav, offs, lens, x1=x1s, xmax=xmaxs)
+    torch.cuda.synchronize()
+    for i, r in enumerate(resampled_refs):
+        assert tuple(ranges[i]) == r[1]
+    _check_rows(out.cpu().numpy(), [(r[0], r[1]) for r in resampled_refs])
+
+
+def test_dropin_on_44k1_and_8k_files_matches_resample_then_extract(eng, tmp_path, resampled_refs):
+    """src.mshds_extractor on WAV files at 44.1 kHz (the Androids corpus rate, Androids.conf:70), 8 kHz (Sound_upsample),
+    22.05 / 48 / 11.025 kHz: device decode -> device Sound_resample -> analyses on Praat's centred grid, against
+    resample_oracle -> mshds_oracle(x1, xmax).  All 25 columns + the NaN pattern."""
+    import pandas as pd
+    from src.mshds_extractor import extract_mshds_features
+    paths = []
+    for k, seconds, fs in RESAMPLED_JOBS:
+        p = str(tmp_path / f"clip_{k}_{fs}.wav")
+        synth.write_wav(p, synth.synth_clip_int16(k, seconds, fs), fs=fs)
+        paths.append(p)
+    out = extract_mshds_features(pd.DataFrame({"filepath": paths}), verbose=False)
+    assert len(out) == len(paths)
+    _check_rows(out.iloc[:, 1:].to_numpy(dtype=np.float64), [(r[0], r[1]) for r in resampled_refs])
+
+
+def test_time_axis_shifts_times_but_not_windows(eng):
+    """A sound whose axis is shifted by a constant (x1 and xmax moved together) has the same sample windows in every
+    analysis: time-free features are unchanged, and the default axis equals the explicit file axis bit for bit."""
+    import torch
+    c = synth.synth_clip(146, 1.5)
+    wav, offs, lens = _pack([c, c, c])
+    d = 0.2 / 16000.0
+    out, _ = eng.extract_packed(wav, offs, lens, x1=[0.5 / 16000.0, 0.5 / 16000.0 + d, 0.5 / 16000.0 - d],
+                                xmax=[len(c) / 16000.0, len(c) / 16000.0 + d, len(c) / 16000.0 - d])
+    ref, _ = eng.extract_packed(wav[:len(c)].contiguous(), [0], [len(c)])
+    torch.cuda.synchronize()
+    g, r = out.cpu().numpy(), ref.cpu().numpy()[0]
+    assert np.array_equal(g[0], r, equal_nan=True)
+    # mean F0 / SD, HNR, spectral moments take the LOW sample index of half-sample frame times (robust); intensity and the
+    # pulse walker take the NEAREST sample of exact ties, where the last bit of (t - x1) / dx decides as it does in Praat
+    cols = [5, 6, 9, 21, 22, 23, 24]
+    for i in (1, 2):
+        assert np.array_equal(np.isnan(g[i]), np.isnan(r))
+        assert (np.abs(g[i][cols] - r[cols]) <= 1e-9 * np.maximum(np.abs(r[cols]), 1e-3)).all(), (g[i], r)

@@ -156,3 +156,24 @@ def test_speechrate_harmonicity_call_cannot_change_the_result():
     assert mo.short_term_frames(426, 2.0 / 75.0, 0.01)[0] == 0 and mo.short_term_frames(427, 2.0 / 75.0, 0.01)[0] == 1
     short = np.zeros(427, dtype=np.float32)                      # harmonicity would succeed, intensity cannot
     assert all(np.isnan(v) for v in mo.speechrate(short))
+
+
+def test_time_axis_is_carried_by_every_analysis():
+    """x1 / xmax of the sound (Praat's centred grid after Sound_resample): a constant shift of the axis moves frame times
+    and nothing else; the default axis is the file axis."""
+    from robust_speech_analysis_framework_amd import synth
+    x = synth.synth_clip(146, 0.8)
+    d = 0.2 * mo.DX
+    a = mo.pitch_ac(x, 0.005, 75.0, pitch_ceiling=500.0)
+    b = mo.pitch_ac(x, 0.005, 75.0, pitch_ceiling=500.0, x1=mo.X1_FILE + d)
+    assert abs((b.t1 - a.t1) - d) < 1e-15 and np.array_equal(a.frequency(), b.frequency())
+    # (analyses that take the NEAREST sample - intensity, the pulse walker - sit on exact ties at these frame times, where
+    # the last bit of (t - x1) / dx decides as it does in Praat: no invariance to assert there)
+    ia, t1a, _ = mo.intensity(x, 100.0, 0.005, True)
+    ib, t1b, _ = mo.intensity(x, 100.0, 0.005, True, mo.X1_FILE - d)
+    assert abs((t1a - t1b) - d) < 1e-15 and len(ia) == len(ib)
+    ra, _ = mo.extract(x)
+    rb, _ = mo.extract(x, mo.X1_FILE, mo.file_xmax(len(x)))
+    assert np.array_equal(ra, rb, equal_nan=True)
+    nf, t1 = mo.short_term_frames(12800, 0.06, 0.005, x1=0.7 * mo.DX)
+    assert nf == int(np.floor((0.8 - 0.06) / 0.005)) + 1 and abs(t1 - (0.2 * mo.DX + 0.4 - 0.5 * nf * 0.005 + 0.0025)) < 1e-15

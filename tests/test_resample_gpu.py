@@ -118,7 +118,8 @@ def test_praat_resample_rejects_missing_workspace(rsaf_lib):
     x = torch.zeros(4000, device="cuda")
     out = torch.zeros(2000, device="cuda")
     assert lib.rsaf_resample_praat_work_bytes(4000, 32000.0, 16000.0) == 8192 * 8 + 4000 * 8
-    assert lib.rsaf_resample_praat_work_bytes(4000, 8000.0, 16000.0) == 0
+    assert lib.rsaf_resample_praat_work_bytes(4000, 11025.0, 16000.0) == 0
+    assert lib.rsaf_resample_praat_work_bytes(4000, 8000.0, 16000.0) == 8192 * 8 + 2 * 4000 * 8      # Sound_upsample
     rc = lib.rsaf_resample_praat(_lib.ptr(x), 4000, 32000.0, 16000.0, 50, _lib.ptr(out), 2000, None, 0, _lib.stream_ptr(None))
     assert rc != 0 and b"workspace" in lib.rsaf_last_error()
 
@@ -132,8 +133,8 @@ def test_mshds_dropin_accepts_44k1_files(rsaf_lib, tmp_path):
     synth.write_wav(path, pcm, fs=44100)
     df = extract_mshds_features(pd.DataFrame({"filepath": [path]}), verbose=False)
     assert list(df.columns) == ["filename"] + FEATURE_NAMES and len(df) == 1
-    x16 = ro.resample_praat(pcm.astype(np.float32) / np.float32(32768.0), 44100.0, 16000.0, 50)
-    ref, _ = mo.extract(x16)
+    x16, x1, xmax = ro.resample_praat_sound(pcm.astype(np.float32) / np.float32(32768.0), 44100.0, 16000.0, 50)
+    ref, _ = mo.extract(x16, x1, xmax)
     got = df[FEATURE_NAMES].to_numpy(dtype=np.float64)[0]
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     ok = ~np.isnan(ref)
@@ -163,3 +164,39 @@ def test_pcm_decode_and_mixdown_on_device_is_bit_identical_to_the_host_reader(rs
     dev, fs2, nfr = read_wav_mono_device(path)
     assert fs == fs2 == 22050 and nfr == n == len(host)
     assert np.array_equal(dev.cpu().numpy(), host)                      # same float32 operations in the same order
+
+
+def test_praat_resampled_sound_keeps_its_time_axis(rsaf_lib):
+    """Known answer: a windowed tone resampled from 44.1 kHz keeps its phase at t = 0 when the samples are read on the
+    axis (x1, dx) that comes back with them; read as if x1 were dx / 2 the phase is off by x1 - dx / 2.  A doubling of the
+    rate is Praat's Sound_upsample: sample 2p IS input sample p (filtered), declared a quarter input period earlier."""
+    from robust_speech_analysis_framework_amd.resample import resample_praat_sound
+    f0, ph = 440.0, 0.7
+
+    def phase_at_zero(y, x1):
+        m = len(y)
+        ty = x1 + np.arange(m) / 16000.0
+        sl = slice(m // 4, 3 * m // 4)
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * ty[sl] / 0.5)
+        A = np.stack([np.sin(2 * np.pi * f0 * ty[sl]), np.cos(2 * np.pi * f0 * ty[sl])], 1) * w[:, None]
+        c = np.linalg.lstsq(A, y[sl].astype(np.float64), rcond=None)[0]
+        return np.arctan2(c[1], c[0])
+    for fs in (44100.0, 48000.0, 22050.0):
+        n = int(fs * 0.5) + 7                                          # 0.5 s and a bit: the new grid is off the file grid
+        t = (np.arange(n) + 0.5) / fs
+        x = (np.sin(2 * np.pi * f0 * t + ph) * (0.5 - 0.5 * np.cos(2 * np.pi * t / 0.5))).astype(np.float32)
+        y, x1, xmax = resample_praat_sound(x, fs, 16000.0, 50)
+        yo, x1o, xmaxo = ro.resample_praat_sound(x, fs, 16000.0, 50)
+        assert x1 == x1o and xmax == xmaxo == n / fs and len(y) == len(yo)
+        assert abs(x1 - 0.5 / 16000.0) > 1e-7
+        y = y.cpu().numpy()
+        assert abs(phase_at_zero(y, x1) - ph) / (2 * np.pi * f0) <= 1e-9                  # seconds
+        assert abs(abs(phase_at_zero(y, 0.5 / 16000.0) - ph) / (2 * np.pi * f0) - abs(x1 - 0.5 / 16000.0)) <= 1e-9
+    n = 4000
+    t = (np.arange(n) + 0.5) / 8000.0
+    x = (np.sin(2 * np.pi * f0 * t + ph) * (0.5 - 0.5 * np.cos(2 * np.pi * t / 0.5))).astype(np.float32)
+    y, x1, xmax = resample_praat_sound(x, 8000.0, 16000.0, 50)
+    assert len(y) == 2 * n and x1 == 0.5 / 8000.0 - 0.25 / 8000.0 and xmax == 0.5
+    y = y.cpu().numpy()
+    assert np.abs(y[0::2][100:-100] - x[100:-100]).max() <= 1e-5                           # 440 Hz lies far below the ramp
+    assert abs((phase_at_zero(y, x1) - ph) / (2 * np.pi * f0) - 0.25 / 8000.0) <= 1e-8       # Praat's labelling, kept

@@ -137,3 +137,44 @@ def test_formant_resampler_tables_are_the_full_depth_interpolation_weights():
             assert abs(float(np.dot(rows[r], y[lo:lo + 2 * depth + 1])) - ref[mm]) <= 1e-9
             checked += 1
         assert checked > m // 2
+
+
+def test_resampled_sound_time_axis_known_answers():
+    """Sound_resample centres the new grid in the ORIGINAL domain: a tone keeps its phase at t = 0 when read on the
+    returned axis.  Sound_upsample (rate ratio 2): even output samples are the input samples (below the 5 % ramp), on a
+    grid declared a quarter input period early; the general branch is NOT what a doubling goes through."""
+    f0, ph = 440.0, 0.7
+
+    def phase_at_zero(y, x1):
+        m = len(y)
+        ty = x1 + np.arange(m) / 16000.0
+        sl = slice(m // 4, 3 * m // 4)
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * ty[sl] / 0.5)
+        A = np.stack([np.sin(2 * np.pi * f0 * ty[sl]), np.cos(2 * np.pi * f0 * ty[sl])], 1) * w[:, None]
+        c = np.linalg.lstsq(A, y[sl].astype(np.float64), rcond=None)[0]
+        return np.arctan2(c[1], c[0])
+    for fs in (44100.0, 22050.0):
+        n = int(fs * 0.5) + 7
+        t = (np.arange(n) + 0.5) / fs
+        x = np.sin(2 * np.pi * f0 * t + ph) * (0.5 - 0.5 * np.cos(2 * np.pi * t / 0.5))
+        y, x1, xmax = ro.resample_praat_sound(x, fs, 16000.0, 50)
+        m = len(y)
+        assert m == int(np.floor(n / fs * 16000.0 + 0.5)) and xmax == n / fs
+        assert x1 == 0.5 * (xmax - (m - 1) / 16000.0) and abs(x1 - 0.5 / 16000.0) > 1e-7
+        assert abs(phase_at_zero(y, x1) - ph) / (2 * np.pi * f0) <= 1e-9
+    n = 4000
+    t = (np.arange(n) + 0.5) / 8000.0
+    x = np.sin(2 * np.pi * f0 * t + ph) * (0.5 - 0.5 * np.cos(2 * np.pi * t / 0.5))
+    y, x1, xmax = ro.resample_praat_sound(x, 8000.0, 16000.0, 50)
+    assert len(y) == 2 * n and x1 == 0.25 / 8000.0 and xmax == 0.5
+    assert np.abs(y[0::2][100:-100] - x[100:-100]).max() <= 1e-5
+    # white noise: the ramp over the last 5 % of the packed spectrum removes energy that the general branch (pure sinc
+    # interpolation, no filter when the rate goes up) would keep
+    rng = np.random.Generator(np.random.PCG64(5))
+    wn = rng.standard_normal(3000)
+    up = ro.praat_upsample(wn)
+    assert len(up) == 6000
+    spec = np.abs(np.fft.rfft(up * np.hanning(6000)))
+    f = np.fft.rfftfreq(6000, 1.0 / 16000.0)
+    assert spec[(f > 4100) & (f < 7900)].max() <= 1e-6 * spec[f < 3000].max()           # nothing above the old Nyquist
+    assert spec[(f > 3950) & (f < 4000)].mean() < 0.25 * spec[(f > 3000) & (f < 3700)].mean()   # the ramp
