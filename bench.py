@@ -10,6 +10,7 @@ N > 1.  Rank 0 prints ONE JSON line.
     python bench.py --total-clips 10000 --gpus 8      # BASELINE config C5 (strong scaling: 1 250 clips per rank)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...                      # no torchrun around it: starts that torchrun itself (launch_ranks)
 """
 from __future__ import annotations
 
@@ -51,7 +52,72 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true",
                     help="run the MSHDS stage on a second HIP stream beside Wav2Vec2 (per-kernel event times then include "
                          "time-sharing, so the roofline object is only clean without it)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU work and NOT a measurement: every rank fabricates its shard's rows on the CPU (gloo), the ranks "
+                         "run the sharding plan, the all-gather, the barriers and the MAX-over-ranks timing of the real run; "
+                         "exercises `bench.py --gpus N` -> torchrun -> rank 0's JSON line where no GPU exists (tests/)")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside any launcher: start the N ranks as ONE child process tree
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`,
+    the command the driver itself uses) BEFORE this process has made any GPU call, let the child own stdout / stderr
+    (rank 0 prints the JSON line) and return its exit code.  Under an existing torchrun (WORLD_SIZE set) this is not called."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"--gpus {args.gpus} without a launcher: starting {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(args) -> None:
+    """The control flow of main() around a fabricated CPU 'pipeline' (row of global clip g = g * 10 + column): sharding plan,
+    warm-up, barrier-bracketed timed steps, all-gather of the rows in global order, MAX over ranks, rank 0's line."""
+    import torch
+    import torch.distributed as dist
+    from robust_speech_analysis_framework_amd import benchlib
+    from robust_speech_analysis_framework_amd.dist import gather_rows
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    first, n_local, n_total, scaling = benchlib.shard_plan(rank, world, args.clips if args.clips is not None else 5, args.total_clips)
+    width = 940
+
+    def step():
+        idx = torch.arange(first, first + n_local, dtype=torch.float32)[:, None]
+        return gather_rows(idx * 10.0 + torch.arange(width, dtype=torch.float32)[None, :], n_total)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    want = torch.arange(n_total, dtype=torch.float32)[:, None] * 10.0 + torch.arange(width, dtype=torch.float32)[None, :]
+    assert torch.equal(out, want), "gathered rows are not in global clip order"
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest: NOT a measurement (no GPU work, fabricated rows on the CPU, gloo)",
+                          "value": None, "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * dt / max(args.steps, 1), 3), "scaling": scaling, "data": "none",
+                          "config": {"workload": "launcher selftest", "clips_total": n_total, "clips_per_rank": n_local}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def log(msg):
@@ -248,6 +314,10 @@ def attach_traffic(roof, args, n_local):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))                         # nothing has touched the GPU (or imported torch) yet
+    if args.launcher_selftest:
+        return launcher_selftest(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -260,9 +330,18 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_collective = os.environ.get("RSAF_FORCE_COLLECTIVE", "0") == "1"
+    if world > 1 or force_collective:
+        # RSAF_FORCE_COLLECTIVE=1 at N = 1: a one-rank RCCL group, so that the terminal all-gather really executes
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from robust_speech_analysis_framework_amd import _lib, benchlib, pipeline, synth
     from robust_speech_analysis_framework_amd.dist import gather_rows
@@ -391,6 +470,7 @@ def main():
             "roofline": roof, "other_rooflines": roofs[1:],
             "inclusive_of_pcie_and_decode": inclusive,
             "checks": {"finite": True, "duplicate_clips_bit_identical": dup_ok,
+                       "rccl_all_gather_executed": bool(world > 1 or force_collective),
                        "note": "parity vs the CPU oracle is asserted by tests/ (-m gpu) and smoke(); parity_vs_oracle below reports it "
                                "for the cpu_baseline sample, outside the timed run"},
             "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
@@ -401,7 +481,7 @@ def main():
             ref, line["cpu_baseline"] = cpu_baseline(args.config, stages, args.seconds, args.cpu_sample_clips)
             line["parity_vs_oracle"] = parity_vs_oracle(pipe, ref, stages, dev, model)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_collective:
         dist.barrier()                                      # rank 0's post-run passes are done: every rank leaves together
         torch.cuda.synchronize()
         dist.destroy_process_group()

@@ -447,11 +447,10 @@ int launch_gemm_bf16x6(const Gemm6Params& p, hipStream_t stream, const char* tag
                    "two-level batches: fp32 output only, no residual, A row-major, nz a multiple of nz2");
 #define G6_LAUNCH_CFG(CFG, ACT, F32, PL, HR)                                                                            \
     do {                                                                                                                \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
+        static DeviceOnce attr_once;                                                                                    \
+        if (attr_once.first()) {                                                                                        \
             RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x6_kernel<CFG, ACT, F32, PL, HR>,                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES));             \
-            attr_set = true;                                                                                            \
         }                                                                                                               \
         const int64_t tiles = (int64_t)((p.N + CFG::BN - 1) / CFG::BN) * ((p.M + CFG::BM - 1) / CFG::BM);               \
         RSAF_CHECK_ARG(tiles <= 0x7fffffffLL, "too many tiles");                                                        \

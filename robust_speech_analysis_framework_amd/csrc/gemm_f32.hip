@@ -442,11 +442,10 @@ static int launch_glds_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
     const int lds = 2 * (BM + BN) * 32 * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f32_glds_kernel<BM, BN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN>), dim3((unsigned)tiles, (unsigned)p.nz), dim3(THREADS), lds, s, p);
     RSAF_CHECK_HIP(hipGetLastError());

@@ -864,11 +864,10 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         if (fused_attn && hd == 64 && Tt <= 256) {
             // 2 x 2 T^2 hd flops per (chunk, head)
             ProfScope prof("w2v2_attn_fused", s, 4.0 * (double)n * c.NH * (double)Tt * Tt * hd, 0.0);
-            static bool attn_attr = false;
-            if (!attn_attr) {
+            static DeviceOnce attn_once;
+            if (attn_once.first()) {
                 RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    2 * 128 * 64 * (int)sizeof(float)));
-                attn_attr = true;
             }
             hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256),
                                2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, rows, Tt, c.NH, Hd, scale);

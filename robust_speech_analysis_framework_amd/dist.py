@@ -24,9 +24,14 @@ def gather_rows(rows, n_total: int, group=None):
 
     rows: [n_local, width] of this rank's shard_bounds() block.  Shards are padded to equal counts
     for the collective and the padding is trimmed afterwards."""
+    import os
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return rows
+    # a one-rank group has nothing to exchange; RSAF_FORCE_COLLECTIVE=1 runs the collective anyway (a 1-GPU box can then
+    # show that the RCCL call executes on these buffers; bench.py creates the one-rank group for it)
+    if dist.get_world_size(group) == 1 and os.environ.get("RSAF_FORCE_COLLECTIVE", "0") != "1":
         return rows
     world = dist.get_world_size(group)
     per = math.ceil(n_total / world)

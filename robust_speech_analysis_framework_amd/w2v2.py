@@ -236,9 +236,10 @@ def extract_wav2vec2_sequences(input_df, model_name="facebook/wav2vec2-base-960h
                 a, b = int(frame_off[i]), int(frame_off[i + 1])
                 if b > a:                                                      # :123 (no chunk survived)
                     sequences[fn] = host[a:b].copy()
-        except (_lib.RsafError, RuntimeError) as e:
+        except (_lib.RsafError, torch.cuda.OutOfMemoryError) as e:
             # one bad file (or an allocation failure of the whole batch) must not take the other files of the batch or
-            # the files already done with it: the reference skips only the offending file (:127-129)
+            # the files already done with it: the reference skips only the offending file (:127-129).  Any other
+            # RuntimeError (a HIP fault surfacing at the synchronize) is NOT retried on the poisoned context: it propagates.
             if verbose:
                 print(f"WARNING: batch of {len(clips)} files failed ({e}); retrying file by file.")
             for fn, c in zip(names, clips):
@@ -246,7 +247,7 @@ def extract_wav2vec2_sequences(input_df, model_name="facebook/wav2vec2-base-960h
                     host, frame_off = run([c])
                     if int(frame_off[1]) > 0:
                         sequences[fn] = host[:int(frame_off[1])].copy()
-                except (_lib.RsafError, RuntimeError) as e1:
+                except (_lib.RsafError, torch.cuda.OutOfMemoryError) as e1:
                     if verbose:
                         print(f"FATAL ERROR processing file '{fn}': {e1}. Skipping.")
     return sequences

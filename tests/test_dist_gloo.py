@@ -137,3 +137,38 @@ def test_shard_plan_c5_shape():
     assert benchlib.duplicates_bit_identical(rows, [0, 1, 0])
     rows[2, 0] = 1.5
     assert not benchlib.duplicates_bit_identical(rows, [0, 1, 0])
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form of the driver's N = 1 command) must start two
+    ranks itself - torchrun as a child process, before anything touches a GPU - and relay rank 0's JSON line; run here
+    with the fabricated-rows selftest (gloo, no GPU work), strong and weak plans, and an uneven shard."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for extra, n_total in ((["--clips", "3"], 6), (["--total-clips", "7"], 7)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                            "--launcher-selftest", *extra], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout                                    # ONE JSON line, from rank 0
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+        assert line["config"]["clips_total"] == n_total and line["value"] is None
+        assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+
+
+def test_bench_under_an_existing_launcher_does_not_spawn_again():
+    """With WORLD_SIZE in the environment (torchrun's) bench.py is a rank, not a launcher."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--launcher-selftest"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "torch.distributed.run" not in r.stderr
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1

@@ -95,12 +95,22 @@ VARIANTS = {"head_interleaved": head_interleaved, "base": lambda s: s, "nodma": 
             "nodma_nolds_nobar": lambda s: nobar(nolds(nodma(s))), "halfdma": halfdma, "samek": samek, "nowait": nowait,
             "nostagger": nostagger, "head_split": head_split, "head_after_mt0": head_after_mt0}
 which = sys.argv[1:] or list(VARIANTS)
+BUILD = [sys.executable, "-c", "from robust_speech_analysis_framework_amd import build; build.build_library(verbose=False)"]
+
+
+def restore():
+    """Whatever happened (failed build, interrupt): the product source and the built library are the real kernel again."""
+    open(SRC, "w").write(orig)
+    subprocess.run(BUILD, check=False, cwd=ROOT)
+
+
+import atexit
+atexit.register(restore)
 for name in which:
     src = VARIANTS[name](orig)
     assert name == "base" or src != orig, name
     open(SRC, "w").write(src)
-    subprocess.run([sys.executable, "-c", "from robust_speech_analysis_framework_amd import build; build.build_library(verbose=False)"],
-                   check=True, cwd=ROOT)
+    subprocess.run(BUILD, check=True, cwd=ROOT)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm6_bench.py")], capture_output=True, text=True, cwd=ROOT)
     for line in r.stdout.splitlines():
         if line.startswith(("qkv", "ffn2", "out-proj")):
@@ -109,4 +119,3 @@ for name in which:
             print(f"{name:20s} {line.split()[0]:10s} row-major {m.group(1)} ms {m.group(2)} TF-eq | as used {u.group(1)} ms {u.group(2)} TF-eq", flush=True)
     if r.returncode != 0:
         print(r.stderr[-2000:])
-open(SRC, "w").write(orig)
