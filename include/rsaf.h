@@ -31,7 +31,7 @@ extern "C" {
 #define RSAF_ERR_HIP 2      /* a HIP runtime call failed */
 #define RSAF_ERR_WORKSPACE 3 /* workspace too small */
 
-#define RSAF_ABI_VERSION 4   /* 4: clip_info rows carry the sound's x1 / xmax (48 bytes); rsaf_resample_praat restates Sound_upsample for a rate ratio of 2 */
+#define RSAF_ABI_VERSION 5   /* 4: clip_info rows carry the sound's x1 / xmax (48 bytes); rsaf_resample_praat restates Sound_upsample for a rate ratio of 2.  5: the openSMILE-style chain is float64 end to end (lld / cand / functionals buffers are double) */
 
 typedef void* rsaf_stream_t;
 
@@ -63,7 +63,9 @@ int rsaf_prof_end(rsaf_prof_record* records_host, int cap, int* n_records_host);
  * samples [clip_off[c], clip_off[c+1]).  rsaf_smile_geometry gives frame = round(0.025 fs), hop =
  * round(0.010 fs) (floor(x + 0.5)) and the FFT length (next power of two: 256 / 512 / 1024 / 2048).
  * Frames: n_frames(n) = n < frame ? 0 : (n-frame)/hop + 1, frame_off is their exclusive prefix sum.
- * LLDs are written contour-major: lld[i * total_frames + frame_off[c] + t], i in [0, RSAF_SMILE_NLLD). */
+ * LLDs are written contour-major: lld[i * total_frames + frame_off[c] + t], i in [0, RSAF_SMILE_NLLD).
+ * The whole chain computes, stores and hands over FLOAT64 (ABI 5): its decisions (peak enhancement, candidate ranking,
+ * Viterbi path, jitter lags, roll-off crossings, maxPos / minPos) then coincide with the float64 CPU restatement. */
 #define RSAF_SMILE_FRAME 400   /* at 16 kHz */
 #define RSAF_SMILE_HOP 160     /* at 16 kHz */
 #define RSAF_SMILE_NLLD 38
@@ -73,28 +75,28 @@ int rsaf_smile_geometry(int sample_rate, int* frame_host, int* hop_host, int* nf
 int64_t rsaf_smile_n_frames(int64_t n_samples, int sample_rate);
 /* Androids.conf:73-186,258-280: framer, pre-emphasis, Hamming, FFT magnitude, mel/MFCC, RMS energy, ZCR,
  * intensity/loudness, 16 spectral descriptors (32 LLD rows), and cSpecScale + cPitchShs: per frame the
- * NCAND best sub-harmonic-summation candidates as (f0 Hz, voicing) float pairs, best score first, zeros in
- * empty slots -> cand[frame][NCAND][2] (caller-owned, 48 bytes per frame).  The six remaining LLD rows
+ * NCAND best sub-harmonic-summation candidates as (f0 Hz, voicing) double pairs, best score first, zeros in
+ * empty slots -> cand[frame][NCAND][2] (caller-owned, 96 bytes per frame).  The six remaining LLD rows
  * (F0final, voicingFinalUnclipped, jitterLocal, jitterDDP, shimmerLocal, logHNR) are filled by
  * rsaf_smile_pitch_track.  octave_spectrum (may be NULL): the cSpecScale output ('hps' level of the config),
- * [total_frames][nfft/2 + 1] float32. */
+ * [total_frames][nfft/2 + 1] float64. */
 int rsaf_smile_lld_batch(const float* wav, const int64_t* clip_off, const int64_t* frame_off,
                          int n_clips, int64_t max_clip_frames, int64_t total_frames, int sample_rate,
-                         float* lld, float* cand, float* octave_spectrum, rsaf_stream_t stream);
+                         double* lld, double* cand, double* octave_spectrum, rsaf_stream_t stream);
 /* Androids.conf:190-255: cPitchSmootherViterbi (fixed lag 30 frames) over the candidates, cValbasedSelector
  * (pitch zeroed where pcm_RMSenergy < 0.001: reads LLD row 0), cPitchJitter (waveform-matched periods on `wav`
  * driven by F0final) -> LLD rows 14, 15, 18..21.  back_workspace: 8 bytes per frame.
  * rsaf_smile_workspace_bytes(total_frames) covers cand + back_workspace when carved from one buffer. */
 int64_t rsaf_smile_workspace_bytes(int64_t total_frames);
 int rsaf_smile_pitch_track(const float* wav, const int64_t* clip_off, const int64_t* frame_off, int n_clips,
-                           int64_t total_frames, int sample_rate, const float* cand, void* back_workspace,
-                           float* lld, rsaf_stream_t stream);
+                           int64_t total_frames, int sample_rate, const double* cand, void* back_workspace,
+                           double* lld, rsaf_stream_t stream);
 /* Androids.conf:284-368 (sma3, delta regression W=2, 12 functionals).  window_frames = 0: statistics over the
  * whole clip; > 0: over the first window_frames frames of the full-length contours (the literal reading of
  * frameSize=0.025 / frameStep=0 at :355-356 keeps row 0 of a 3-frame-window output; see oracle/smile_oracle.py).
- * out: [n_clips, RSAF_SMILE_NFEAT] float32 in cCsvSink column order. */
-int rsaf_smile_functionals(const float* lld, const int64_t* frame_off, int n_clips,
-                           int64_t total_frames, int window_frames, float* out, rsaf_stream_t stream);
+ * out: [n_clips, RSAF_SMILE_NFEAT] float64 in cCsvSink column order. */
+int rsaf_smile_functionals(const double* lld, const int64_t* frame_off, int n_clips,
+                           int64_t total_frames, int window_frames, double* out, rsaf_stream_t stream);
 
 /* ---- exact-fp32 MFMA GEMM building block ---------------------------------------------------------
  * C[z][m][n] = act(alpha * sum_k A[z][m][k] * B[z](k,n) + bias[n] + R[z][m][n]).

@@ -9,7 +9,8 @@ Hermes 1988 and the Praat manual's "Sound: To Pitch (shs)" for the sub-harmonic 
 cSpecScale + cPitchShs implement).  Where a detail is a free choice it is fixed here, documented
 (search for "free choice"), and mirrored in ``csrc/smile_*.hip``.
 
-Arithmetic: float64 on the float32 samples (openSMILE itself is float32).
+Arithmetic: float64 on the float32 samples (openSMILE itself is float32).  The HIP chain is float64 as well since round 3
+(``csrc/smile_lld.hip``): every decision of the chain then coincides with this restatement's.
 
 All 38 low-level descriptors are built.  The analysis runs at the FILE'S OWN sample rate
 (``Params(fs)``): cFramer's frameSize / frameStep are seconds (``Androids.conf:73-78``) and the
@@ -615,7 +616,10 @@ def lld(x: np.ndarray, P: Params = _P16) -> np.ndarray:
     pk = np.sum(np.maximum(mid - 0.5 * (mag[:, :-2] + mag[:, 2:]), 0.0), axis=1)
     msum = np.sum(mag, axis=1)
     out[36] = pk / np.where(msum > 0, msum, 1.0)                 # harmonicity proxy (free choice)
-    out[37] = np.exp(np.mean(np.log(np.maximum(Pw, 1e-30)), axis=1)) / np.maximum(tot / NB, 1e-30)
+    # geometric / arithmetic mean of the power spectrum; an all-zero frame takes the limit value 1 EXACTLY (free choice:
+    # the formula itself gives 1 +- 1e-14 there, and which of several silent frames holds the contour's maximum would
+    # then be rounding noise - maxPos must not depend on that)
+    out[37] = np.where(tot > 0, np.exp(np.mean(np.log(np.maximum(Pw, 1e-30)), axis=1)) / np.maximum(tot / NB, 1e-30), 1.0)
     # --- cSpecScale .. cPitchJitter (Androids.conf:142-255)
     rows, _ = pitch_chain(np.asarray(x, dtype=np.float64), mag, out[0], P)
     out[I_F0], out[I_VOICE] = rows[0], rows[1]

@@ -1,4 +1,4 @@
-// openSMILE-style low-level descriptors for gfx950 (wave64), at the file's own sample rate.
+// openSMILE-style low-level descriptors for gfx950 (wave64), at the file's own sample rate, in FLOAT64.
 //
 // One fused kernel for Androids.conf:73-186 and :258-280 of the reference
 // (cFramer -> cVectorPreemphasis -> cWindower -> cTransformFFT -> cFFTmagphase ->
@@ -6,24 +6,29 @@
 // chain by spawning SMILExtract once per file (src/opensmile_extractor.py:62-75).  The sequential tail of the
 // pitch chain (cPitchSmootherViterbi, cValbasedSelector, cPitchJitter) is csrc/smile_pitch.hip.
 //
-// Mapping.  A wave owns PAIRS of consecutive frames and keeps the two frames in the two halves of packed
-// float2 registers: every elementwise step (pre-emphasis, window, FFT butterflies, spectral descriptors,
-// spline, sub-harmonic summation) is then v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on both frames at once,
-// and every LDS access moves 8 or 16 bytes per lane.  The kernel is VALU-issue bound (profiles/r02), so this is
-// the lever: half the vector instructions per frame.  A workgroup of 8 waves (4 for the 2048-point FFT) shares
-// one LDS copy of the constant tables (twiddles, Hamming, mel weights, spline / octave-scale tables); each wave
-// stages its own samples (the 2.5x frame overlap is served by L2, HBM sees every sample once), and has a
-// private FFT buffer that is reused for the octave-spectrum arrays.  FFT: packed-real N-point transform as an
-// N/2-point complex Stockham radix-4 (+ one radix-2 stage when log2(N/2) is odd), in place in LDS (all reads of a
-// stage precede its writes in program order; a wave is lock-step, so no second buffer is needed).
-// Templated on the FFT length (256 / 512 / 1024 / 2048 <-> 8 / 16 / 22.05-32 / 44.1-48 kHz; frame and hop
-// lengths are run-time).
+// Why float64.  The chain is full of DECISIONS: the local-maximum test of the peak enhancement on every bin (also the
+// noise-floor bins, whose float32 FFT error is of the order of the bins themselves), peak picking and ranking of the
+// sub-harmonic summation, the Viterbi path, the lags of the jitter search, the roll-off threshold crossings, and the
+// first-occurrence positions (maxPos / minPos) of all 76 contours.  north_star asks for positions bit-exact and values
+// within 1e-4 of the CPU path; the CPU restatement (oracle/smile_oracle.py) is float64.  Rounds 1-2 ran this kernel in
+// packed float32: 97-99.5 % of the frames took the oracle's decisions and the rest did not.  In float64 the two sides
+// differ by ~1e-15 and a decision flips only on a tie of that size.  The stage is < 1 % of the hot path's time, so
+// the precision is spent here.
 //
-// Spectral flux needs the previous frame's magnitudes: inside a wave's span they are in registers; for its first
-// frame the wave transforms the frame in front of its span once more (window + FFT only: +6 % work), which keeps
-// the waves independent of each other.
+// Mapping.  One wave per run of RUNW consecutive frames of one clip (64-thread workgroups: no workgroup-level
+// synchronisation anywhere).  Per frame: samples -> pre-emphasis / Hamming in registers -> the NFFT-point real FFT as
+// an NFFT/2-point complex Stockham radix-4 (+ one radix-2 stage when log2 is odd) in the wave's LDS buffer, in place
+// (a wave is lock-step: every lane reads its butterflies before any lane writes) -> magnitudes (registers + LDS).
+// Wave-wide sums go 8 at a time through an LDS transpose (8 writes, 8 reads, 3 lane exchanges instead of 8 x 6
+// dependent exchanges).  The tridiagonal system of the natural spline and the cumulative sums of the roll-off points
+// are lane-blocked scans of affine maps / partial sums (exact to rounding, no truncation).  Everything that is a
+// scalar function of a frame's sums (sqrt, pow, log, exp, the moment ratios) is deferred to the end of the run, where
+// lane t finishes frame t: the transcendental code runs once per run instead of once per frame.
+// Spectral flux needs the previous frame's magnitudes: the wave transforms the frame in front of its run once more
+// (window + FFT only), which keeps the waves independent of each other.
 //
-// Semantics are those of oracle/smile_oracle.py (the CPU restatement), parity unpinned.
+// Templated on the FFT length (256 / 512 / 1024 / 2048 <-> 8 / 16 / 22.05-32 / 44.1-48 kHz; frame and hop lengths are
+// run-time).  Semantics are those of oracle/smile_oracle.py (the CPU restatement), parity unpinned.
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -34,63 +39,60 @@
 namespace rsaf {
 namespace smile {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double2 c64;
 
 constexpr int NLLD = RSAF_SMILE_NLLD;
 constexpr int NMEL = 26;
 constexpr int NMFCC = 12;
 constexpr int NCAND = RSAF_SMILE_NCAND;
 constexpr int NHARM = 15;
-constexpr int NLOCAL = 32;               // LLD rows this kernel produces (38 minus the six pitch-chain rows)
-constexpr float PREEMPH = 0.97f;
-constexpr float HTK_SCALE = 32767.0f;
-constexpr float MEL_FLOOR = 1.0f;
+constexpr double PREEMPH = 0.97;
+constexpr double HTK_SCALE = 32767.0;
+constexpr double MEL_FLOOR = 1.0;
+constexpr double I0 = 1e-6;
+constexpr double SHS_MINPITCH = 52.0, SHS_MAXPITCH = 620.0;
+constexpr double LN2 = 0.69314718055994530942;
+
+constexpr int RUNW = 8;                  // frames per wave
+constexpr int NSUM = 24;                 // doubles a frame leaves for the end-of-run pass
+constexpr int RED_D = 8 * 65;            // doubles of the 8-sums-at-a-time reduction scratch
 
 template <int LOG2N>
 struct Geo {
     static constexpr int NFFT = 1 << LOG2N;
     static constexpr int NC = NFFT / 2;              // complex points of the packed-real transform
     static constexpr int NB = NC + 1;                // magnitude bins
-    static constexpr int PPL = NC / 64;              // bins per lane
+    static constexpr int PPL = NC / 64;              // bins per lane (2, 4, 8, 16)
     static constexpr int NBP = NC + 8;               // padded length of the per-bin tables
-    // lanes of carry kept in the lane-blocked tridiagonal solve: a lane block damps a carry by 0.268^PPL, so
-    // 4 lanes reach 0.268^12 ~ 1e-7 of a term that is itself < 0.27 of the local one (PPL = 2: 6 lanes)
-    static constexpr int CARRY = PPL >= 4 ? 4 : 6;
-    static constexpr int HALF = NC + 8 + (NC + 8) / 32 + 1;   // float2 entries of one half of the wave's FFT buffer (swizzled)
-    static constexpr int XF = 4 * HALF;              // floats of the wave's FFT buffer
-    static constexpr int MF = 2 * HALF;              // floats of the wave's magnitude slot
-    static constexpr int WAVES = LOG2N >= 11 ? 4 : 8;
-    static constexpr int PPW = LOG2N <= 9 ? 4 : 2;   // frame pairs per wave
-    static constexpr int RUN = WAVES * PPW * 2;      // frames per workgroup
+    // LDS of one wave, in doubles
+    static constexpr int Z_D = 2 * NC + 8;           // FFT buffer (c64[NC]); later two arrays of NB doubles
+    static constexpr int ARR = NC + 8;               // one per-bin array
+    static constexpr bool RED_IN_Z = Z_D >= RED_D;   // the reduction scratch lives in the FFT buffer when it fits
+    static constexpr int OFF_MAG = Z_D, OFF_MAGP = Z_D + ARR, OFF_S = Z_D + 2 * ARR, OFF_STASH = Z_D + 3 * ARR;
+    static constexpr int OFF_RED = RED_IN_Z ? 0 : OFF_STASH + RUNW * NSUM;
+    static constexpr int WAVE_D = OFF_STASH + RUNW * NSUM + (RED_IN_Z ? 0 : RED_D);
 };
 
 // ---- constant tables (host-computed in double, one blob per (device, sample rate)) -------------------
 template <int LOG2N>
 struct __attribute__((aligned(16))) Tables {
     using G = Geo<LOG2N>;
-    float2 twr[G::NC + G::NC / 2];    // exp(-2 pi i k / NFFT), k < 3 NC / 2: the packed-real unpack uses k < NC, the
-                                      // complex stages exp(-2 pi i m / NC) = twr[2 m], m < 3 NC / 4
-    float ham[G::NFFT];               // Hamming window, zero beyond the frame
-    float lo_wt[G::NBP];              // HTK lower-channel weight per bin (0 where unused)
-    float sharp[G::NBP];              // bark(f) * g(bark) per bin
-    float tb[G::NBP];                 // octave-scale target i: fractional position inside source interval klo[i]
-    float audw[G::NBP];               // auditory weighting of target i
+    c64 tw[G::NC + G::NC / 2];        // exp(-2 pi i k / NFFT), k < 3 NC / 2: the packed-real unpack uses k <= NC, the
+                                      // complex stages exp(-2 pi i m / NC) = tw[2 m], m < 3 NC / 4
+    double ham[G::NFFT];              // Hamming window, zero beyond the frame
+    double lo_wt[G::NBP];             // HTK lower-channel weight per bin (0 where unused)
+    double sharp[G::NBP];             // bark(f) * g(bark) per bin
+    double tb[G::NBP];                // octave-scale target i: fractional position inside source interval klo[i]
+    double audw[G::NBP];              // auditory weighting of target i
+    double sp_g[G::NBP];              // tridiagonal (1, 4, 1) elimination factors, 0 at bin 0
     int klo[G::NBP];
-    float sp_g[G::NBP];               // tridiagonal (1, 4, 1) elimination factors, 0 at bin 0
-    float sp_cf[G::CARRY - 1][64];    // forward / backward carry coefficients of the lane-blocked solve
-    float sp_cb[G::CARRY - 1][64];
-    float dct[NMFCC * NMEL];          // DCT-II rows 1..12 with the lifter folded in
+    double dct[NMFCC * NMEL];         // DCT-II rows 1..12 with the lifter folded in
     int seg_start[32];                // bins with lower channel c are [seg_start[c], seg_start[c+1]), c = 0..26
-    int mel_lane[64];                 // lane's chunk of a band side: start bin | length << 12 | rising << 20 (0 = idle)
-    int mel_band[32];                 // band c-1: first lane | number of lanes << 8
     int shs_shift[16];
-    float shs_w[16];
-    float ham_sum, df, fmin_l2, dl2;
-    float band1_lo, band1_hi, band2_lo, band2_hi;
-    float slope_sf, slope_den, pad0, pad1;
-    int frame, hop, fs, max_seg;
-    int mel_iters, mel_max_n, pad2, pad3;
+    double shs_w[16];
+    double ham_sum, df, fmin_l2, dl2;
+    double slope_sf, slope_den;
+    int frame, hop, fs, pad;
 };
 
 static double mel_d(double f) { return 2595.0 * std::log10(1.0 + f / 700.0); }
@@ -101,16 +103,18 @@ static void build_tables(Tables<LOG2N>& t, int fs, int frame, int hop) {
     std::memset(&t, 0, sizeof(t));
     t.fs = fs; t.frame = frame; t.hop = hop;
     const double df = (double)fs / G::NFFT;
-    t.df = (float)df;
+    t.df = df;
     double hs = 0;
     for (int i = 0; i < frame; ++i) {
         const double w = 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (frame - 1));
-        t.ham[i] = (float)w;
+        t.ham[i] = w;
         hs += w;
     }
-    t.ham_sum = (float)hs;
-    for (int m = 0; m < G::NC + G::NC / 2; ++m)
-        t.twr[m] = make_float2((float)std::cos(2.0 * M_PI * m / G::NFFT), (float)-std::sin(2.0 * M_PI * m / G::NFFT));
+    t.ham_sum = hs;
+    for (int m = 0; m < G::NC + G::NC / 2; ++m) {
+        const long double a = 2.0L * 3.141592653589793238462643383279502884L * m / G::NFFT;
+        t.tw[m] = make_double2((double)cosl(a), (double)-sinl(a));
+    }
     // HTK filterbank between 20 Hz and min(8000 Hz, Nyquist), equally spaced on the mel scale
     const double fhi = std::min(8000.0, fs / 2.0);
     const double lo = mel_d(20.0), hi = mel_d(fhi);
@@ -124,98 +128,54 @@ static void build_tables(Tables<LOG2N>& t, int fs, int frame, int hop) {
         int c = 0;
         while (c < NMEL && cf[c + 1] <= m) ++c;
         lo_chan[b] = c;
-        t.lo_wt[b] = (float)((cf[c + 1] - m) / (cf[c + 1] - cf[c]));
+        t.lo_wt[b] = (cf[c + 1] - m) / (cf[c + 1] - cf[c]);
     }
     int b = 0;
     while (b < G::NB && lo_chan[b] < 0) ++b;
-    int max_seg = 0;
     for (int c = 0; c <= NMEL + 1; ++c) {
         while (b < G::NB && lo_chan[b] >= 0 && lo_chan[b] < c) ++b;
         t.seg_start[c] = b;
-        if (c > 0) max_seg = std::max(max_seg, t.seg_start[c] - t.seg_start[c - 1]);
-    }
-    t.max_seg = max_seg;
-    // lane-balanced schedule of the 52 band sides (falling side of band c = bins with lower channel c weighted lo_wt,
-    // rising side = bins with lower channel c-1 weighted 1 - lo_wt): chunks of at most CH bins, one chunk per lane
-    for (int CH = 1; CH <= G::NB; ++CH) {
-        int need = 0;
-        for (int c = 1; c <= NMEL; ++c)
-            for (int side = 0; side < 2; ++side) {
-                const int seg = side ? c - 1 : c;
-                const int L = t.seg_start[seg + 1] - t.seg_start[seg];
-                need += (L + CH - 1) / CH;
-            }
-        if (need > 64) continue;
-        int lane = 0, max_n = 0;
-        for (int c = 1; c <= NMEL; ++c) {
-            const int first = lane;
-            for (int side = 0; side < 2; ++side) {
-                const int seg = side ? c - 1 : c;
-                for (int b0 = t.seg_start[seg]; b0 < t.seg_start[seg + 1]; b0 += CH) {
-                    const int L = std::min(CH, t.seg_start[seg + 1] - b0);
-                    t.mel_lane[lane++] = b0 | (L << 12) | (side << 20);
-                }
-            }
-            t.mel_band[c - 1] = first | ((lane - first) << 8);
-            max_n = std::max(max_n, lane - first);
-        }
-        t.mel_iters = CH;
-        t.mel_max_n = max_n;
-        break;
     }
     for (int k = 1; k <= NMFCC; ++k) {
         const double lift = 1.0 + 11.0 * std::sin(M_PI * k / 22.0);
         for (int j = 1; j <= NMEL; ++j)
-            t.dct[(k - 1) * NMEL + (j - 1)] = (float)(std::sqrt(2.0 / NMEL) * std::cos(M_PI * k * (j - 0.5) / NMEL) * lift);
+            t.dct[(k - 1) * NMEL + (j - 1)] = std::sqrt(2.0 / NMEL) * std::cos(M_PI * k * (j - 0.5) / NMEL) * lift;
     }
     for (int bb = 0; bb < G::NB; ++bb) {
         const double f = bb * df;
         const double z = 13.0 * std::atan(0.00076 * f) + 3.5 * std::atan((f / 7500.0) * (f / 7500.0));
         const double g = z < 14.0 ? 1.0 : 0.066 * std::exp(0.171 * z);
-        t.sharp[bb] = (float)(z * g);
+        t.sharp[bb] = z * g;
     }
-    t.band1_lo = 250.f; t.band1_hi = 650.f; t.band2_lo = 1000.f; t.band2_hi = 4000.f;
     {   // spectral slope: sum f and sum f^2 over bins 0..NC
-        const double n = G::NC;
-        const double sf = df * n * (n + 1) / 2.0, sff = df * df * n * (n + 1) * (2 * n + 1) / 6.0;
-        t.slope_sf = (float)sf;
-        t.slope_den = (float)(G::NB * sff - sf * sf);
+        double sf = 0.0, sff = 0.0;
+        for (int bb = 0; bb < G::NB; ++bb) { sf += bb * df; sff += (bb * df) * (bb * df); }
+        t.slope_sf = sf;
+        t.slope_den = G::NB * sff - sf * sf;
     }
     // cSpecScale: octave axis from 25 Hz to fs/2 with NB points; natural spline through the equally spaced bins
     const double fmin_l2 = std::log2(25.0), fmax_l2 = std::log2(fs / 2.0);
     const double dl2 = (fmax_l2 - fmin_l2) / (G::NB - 1);
     const double ppo = 1.0 / dl2;
-    t.fmin_l2 = (float)fmin_l2;
-    t.dl2 = (float)dl2;
+    t.fmin_l2 = fmin_l2;
+    t.dl2 = dl2;
     const double atans = ppo * std::log2(65.0 / 50.0) - 1.0;
     for (int i = 0; i < G::NB; ++i) {
         const double pos = std::exp2(fmin_l2 + dl2 * i) / df;
         int k = (int)std::floor(pos);
         if (k > G::NB - 2) k = G::NB - 2;
         t.klo[i] = k;
-        t.tb[i] = (float)(pos - k);
-        t.audw[i] = (float)(0.5 + std::atan(3.0 * (i + 1.0 - atans) / ppo) / M_PI);
+        t.tb[i] = pos - k;
+        t.audw[i] = 0.5 + std::atan(3.0 * (i + 1.0 - atans) / ppo) / M_PI;
     }
     for (int h = 1; h <= NHARM; ++h) {
         t.shs_shift[h - 1] = (int)std::floor(ppo * std::log2((double)h));
-        t.shs_w[h - 1] = (float)std::pow(0.85, h - 1);
+        t.shs_w[h - 1] = std::pow(0.85, h - 1);
     }
     // Thomas factors of tridiag(1, 4, 1) on unknowns at bins 1..NC-1 (m_0 = m_NC = 0):
     //   forward  dp_b = g_b (r_b - dp_{b-1}),  backward  x_b = dp_b - g_b x_{b+1},  g_1 = 1/4, g_b = 1 / (4 - g_{b-1})
-    std::vector<double> g(G::NC + 1, 0.0), P(64, 1.0);
-    for (int bb = 1; bb < G::NC; ++bb) g[bb] = 1.0 / (4.0 - g[bb - 1]);
-    for (int bb = 0; bb < G::NC; ++bb) t.sp_g[bb] = (float)g[bb];
-    for (int L = 0; L < 64; ++L)
-        for (int i = 0; i < G::PPL; ++i) P[L] *= -g[G::PPL * L + i];
-    for (int L = 0; L < 64; ++L) {
-        double cf_ = 1.0, cb_ = 1.0;
-        for (int d = 2; d <= G::CARRY; ++d) {
-            cf_ *= (L - (d - 1) >= 0) ? P[L - (d - 1)] : 0.0;
-            cb_ *= (L + (d - 1) < 64) ? P[L + (d - 1)] : 0.0;
-            t.sp_cf[d - 2][L] = (float)cf_;
-            t.sp_cb[d - 2][L] = (float)cb_;
-        }
-    }
+    double g = 0.0;
+    for (int bb = 1; bb < G::NC; ++bb) { g = 1.0 / (4.0 - g); t.sp_g[bb] = g; }
 }
 
 static std::mutex g_mu;
@@ -265,782 +225,569 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
-// LDS index of entry b of a float2 array read PPL-consecutive-per-lane (32 B lane stride): one pad entry per 32 spreads
-// the 32 lanes of a b64 access group over all 64 banks (plain indexing is a 4-way conflict)
-__device__ __forceinline__ int sw(int b) { return b + (b >> 5); }
-__device__ __forceinline__ v2f vmax2(v2f a, v2f b) { return (v2f){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
-__device__ __forceinline__ v2f wave_sum2(v2f a) { return (v2f){wave_sum(a.x), wave_sum(a.y)}; }
-// 1-ulp hardware forms (the IEEE expansions of /, sqrtf, logf cost ~10 instructions each; the parity bar is 1e-4)
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float flog(float x) { return flog2(x) * 0.6931471805599453f; }
-__device__ __forceinline__ v2f frcp2(v2f a) { return (v2f){frcp(a.x), frcp(a.y)}; }
-__device__ __forceinline__ v2f fsqrt2(v2f a) { return (v2f){fsqrt(a.x), fsqrt(a.y)}; }
-__device__ __forceinline__ v2f flog2_2(v2f a) { return (v2f){flog2(a.x), flog2(a.y)}; }
-__device__ __forceinline__ v2f fexp2_2(v2f a) { return (v2f){fexp2(a.x), fexp2(a.y)}; }
+__device__ __forceinline__ c64 cmul(c64 a, c64 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ c64 cadd(c64 a, c64 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c64 csub(c64 a, c64 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c64 mul_mi(c64 a) { return make_double2(a.y, -a.x); }    // a * (-i)
 
-// Eight wave reductions at once (gfx950 lane swaps): v_permlane32_swap / v_permlane16_swap fold two registers into
-// one whose halves / rows hold different quantities, then three DPP steps finish inside 8-lane groups: 18 vector
-// instructions + 8 v_readlane for eight totals instead of 8 x 7.  v[] comes back wave-uniform.
-template <bool IS_MIN>
-__device__ __forceinline__ void wave_reduce8(float (&v)[8]) {
-    auto op = [](float a, float b) { return IS_MIN ? fminf(a, b) : a + b; };
-    float a[4];
+// a / b by the hardware reciprocal estimate + two Newton steps + one residual correction (error ~1e-16 relative; the
+// IEEE division costs about twice as many instructions and none of its callers here decides anything on the last bit)
+__device__ __forceinline__ double fdiv(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+
+// natural logarithm of a positive normal double: x = m 2^e with m in [sqrt(1/2), sqrt 2), ln m = 2 atanh((m-1)/(m+1)) as an
+// odd series in s (|s| <= 0.1716: twelve terms reach 1e-18), ~30 instructions against ~70 for the library routine
+__device__ __forceinline__ double flog(double x) {
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    const double s = fdiv(m - 1.0, m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    return fma((double)e, LN2, 2.0 * s * p);
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double wave_sum_all(double x) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
-        a[i] = op(__uint_as_float(r[0]), __uint_as_float(r[1]));           // lanes < 32: v[i], lanes >= 32: v[i+4]
-    }
-    float b[2];
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ int wave_min_int(int x) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[2 * i]), __float_as_uint(a[2 * i + 1]), false, false);
-        b[i] = op(__uint_as_float(r[0]), __uint_as_float(r[1]));           // rows: v[2i], v[2i+1], v[2i+4], v[2i+5]
-    }
-    const bool hi8 = (threadIdx.x & 8) != 0;
-    const float keep = hi8 ? b[1] : b[0], give = hi8 ? b[0] : b[1];
-    float z = op(keep, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0x128, 0xF, 0xF, false)));   // row_ror:8
-    z = op(z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z), 0xB1, 0xF, 0xF, false)));
-    z = op(z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z), 0x4E, 0xF, 0xF, false)));
-    z = op(z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(z), 0x141, 0xF, 0xF, false)));             // row_half_mirror
-    // row r, half h holds: (r0: v0 | v2) (r1: v1 | v3) (r2: v4 | v6) (r3: v5 | v7)
-    v[0] = readlane_f32(z, 0);  v[2] = readlane_f32(z, 8);
-    v[1] = readlane_f32(z, 16); v[3] = readlane_f32(z, 24);
-    v[4] = readlane_f32(z, 32); v[6] = readlane_f32(z, 40);
-    v[5] = readlane_f32(z, 48); v[7] = readlane_f32(z, 56);
-}
-__device__ __forceinline__ void wave_sum4x2(v2f& a, v2f& b, v2f& c, v2f& d) {
-    float v[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-    wave_reduce8<false>(v);
-    a = (v2f){v[0], v[1]}; b = (v2f){v[2], v[3]}; c = (v2f){v[4], v[5]}; d = (v2f){v[6], v[7]};
+    for (int o = 32; o >= 1; o >>= 1) x = min(x, __shfl_xor(x, o, 64));
+    return x;
 }
 
-__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {      // zero fill of the shifts is neutral
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true));
-    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-}
-__device__ __forceinline__ float wave_shr1(float v) { return dpp_f32<0x138>(v); }   // lane l <- lane l-1, 0 into lane 0
-__device__ __forceinline__ float wave_shl1(float v) { return dpp_f32<0x130>(v); }   // lane l <- lane l+1, 0 into lane 63
-
-// complex multiply of a packed pair (re, im) by the twiddle (c, s)
-__device__ __forceinline__ void cmul2(v2f& re, v2f& im, float2 w) {
-    const v2f r = re * w.x - im * w.y;
-    const v2f i = re * w.y + im * w.x;
-    re = r; im = i;
-}
-
-struct C2 { v2f re, im; };
-
-__device__ __forceinline__ void radix4(C2& v0, C2& v1, C2& v2, C2& v3) {
-    const C2 a0{v0.re + v2.re, v0.im + v2.im};
-    const C2 a1{v0.re - v2.re, v0.im - v2.im};
-    const C2 a2{v1.re + v3.re, v1.im + v3.im};
-    const C2 t{v1.re - v3.re, v1.im - v3.im};
-    const C2 a3{t.im, -t.re};                       // -i * t
-    v0 = C2{a0.re + a2.re, a0.im + a2.im};
-    v1 = C2{a1.re + a3.re, a1.im + a3.im};
-    v2 = C2{a0.re - a2.re, a0.im - a2.im};
-    v3 = C2{a1.re - a3.re, a1.im - a3.im};
-}
-
-__device__ __forceinline__ C2 ldc(const v4f* X, int i) { const v4f v = X[i]; return C2{(v2f){v.x, v.y}, (v2f){v.z, v.w}}; }
-__device__ __forceinline__ void stc(v4f* X, int i, C2 c) { X[i] = (v4f){c.re.x, c.re.y, c.im.x, c.im.y}; }
-
-// one Stockham radix-4 stage in place: all butterflies of the wave are read, then written
-template <int NC, int NS>
-__device__ __forceinline__ void fft_stage4(v4f* X, const float2* __restrict__ tw, int lane) {
-    constexpr int NBF = NC / 4;
-    constexpr int U = (NBF + 63) / 64;
-    C2 v[U][4];
+// Eight wave-wide sums at once through an LDS transpose: lane writes its 8 partial sums into rows of 65 doubles, lane
+// (q = lane >> 3, p = lane & 7) adds 8 entries of row q, three exchanges inside the 8-lane group finish: every lane of
+// group q then holds total q.  `red` = 520 doubles of wave-private LDS that nothing else is using.
+__device__ __forceinline__ double reduce8(const double (&v)[8], double* red, int lane) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = lane + 64 * u;
-        if (NBF >= 64 || j < NBF) {
+    for (int q = 0; q < 8; ++q) red[q * 65 + lane] = v[q];
+    lds_fence();
+    const int q = lane >> 3, p = lane & 7;
+    double s = 0.0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[u][t] = ldc(X, j + t * NBF);
-            if (NS > 1) {
-                const int m = (j & (NS - 1)) * (NC / (NS * 4));
-                cmul2(v[u][1].re, v[u][1].im, tw[2 * m]);             // tw = exp(-2 pi i k / (2 NC)): every other entry
-                cmul2(v[u][2].re, v[u][2].im, tw[4 * m]);
-                cmul2(v[u][3].re, v[u][3].im, tw[6 * m]);
+    for (int i = 0; i < 8; ++i) s += red[q * 65 + 8 * p + i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    lds_fence();
+    return s;                                          // total (lane >> 3)
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------
+// time-domain part of one frame: raw samples -> zero crossings, pre-emphasis, Hamming -> the packed-real FFT input in Z;
+// returns the lane's partial sums (sum win^2, sum ham win^2, zero crossings)
+template <int LOG2N>
+__device__ __forceinline__ void frame_to_z(const float* __restrict__ x, const Tables<LOG2N>* __restrict__ T, int frame,
+                                           c64* Z, int lane, double& s_w2, double& s_hw2, double& s_zc) {
+    using G = Geo<LOG2N>;
+    s_w2 = 0.0; s_hw2 = 0.0; s_zc = 0.0;
+#pragma unroll
+    for (int j = 0; j < G::PPL; ++j) {
+        const int n = lane + 64 * j, i0 = 2 * n, i1 = i0 + 1;
+        double w0 = 0.0, w1 = 0.0;
+        if (i0 < frame) {
+            const double xm = i0 > 0 ? (double)x[i0 - 1] : 0.0, x0 = (double)x[i0];
+            const double pe = i0 > 0 ? x0 - PREEMPH * xm : x0 * (1.0 - PREEMPH);       // first sample HTK-style
+            const double h = T->ham[i0];
+            w0 = pe * h;
+            s_w2 += w0 * w0;
+            s_hw2 += h * w0 * w0;
+            if (i0 > 0 && x0 * xm < 0.0) s_zc += 1.0;
+            if (i1 < frame) {
+                const double x1 = (double)x[i1];
+                const double h1 = T->ham[i1];
+                w1 = (x1 - PREEMPH * x0) * h1;
+                s_w2 += w1 * w1;
+                s_hw2 += h1 * w1 * w1;
+                if (x1 * x0 < 0.0) s_zc += 1.0;
             }
-            radix4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
-    }
-    lds_fence();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = lane + 64 * u;
-        if (NBF >= 64 || j < NBF) {
-            const int k = j & (NS - 1);
-            const int j0 = ((j - k) << 2) + k;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) stc(X, j0 + t * NS, v[u][t]);
-        }
+        Z[n] = make_double2(w0, w1);
     }
     lds_fence();
 }
 
-template <int NC, int NS>
-__device__ __forceinline__ void fft_stage2(v4f* X, const float2* __restrict__ tw, int lane) {
-    constexpr int NBF = NC / 2;
-    constexpr int U = (NBF + 63) / 64;
-    C2 v[U][2];
+// NC-point complex FFT of Z in place (Stockham autosort: natural order in, natural order out), then the magnitudes of the
+// NFFT-point real transform: mg[j] = |X[lane + 64 j]|, j < PPL, mg[PPL] = |X[NC]| (lane 0; other lanes 0)
+template <int LOG2N>
+__device__ __forceinline__ void fft_mag(c64* Z, const Tables<LOG2N>* __restrict__ T, int lane, double (&mg)[Geo<LOG2N>::PPL + 1]) {
+    using G = Geo<LOG2N>;
+    constexpr int NC = G::NC, Q = NC / 4;
+    constexpr int BPL = Q >= 64 ? Q / 64 : 1;                 // radix-4 butterflies per lane and stage
+    constexpr int LOG2NC = LOG2N - 1;
+    constexpr int R4 = LOG2NC / 2;                            // radix-4 stages; one radix-2 stage follows when LOG2NC is odd
+    int Ns = 1;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = lane + 64 * u;
-        v[u][0] = ldc(X, j);
-        v[u][1] = ldc(X, j + NBF);
-        const int m = (j & (NS - 1)) * (NC / (NS * 2));
-        cmul2(v[u][1].re, v[u][1].im, tw[2 * m]);
-        const C2 a{v[u][0].re + v[u][1].re, v[u][0].im + v[u][1].im};
-        const C2 b{v[u][0].re - v[u][1].re, v[u][0].im - v[u][1].im};
-        v[u][0] = a; v[u][1] = b;
+    for (int st = 0; st < R4; ++st, Ns *= 4) {
+        c64 v[BPL][4];
+#pragma unroll
+        for (int bi = 0; bi < BPL; ++bi) {
+            const int b = lane + 64 * bi;
+            if (b < Q) {
+                const int k = b & (Ns - 1);
+                const int tstep = (2 * NC) / (4 * Ns);          // tw index of exp(-2 pi i k / (4 Ns))
+                v[bi][0] = Z[b];
+                v[bi][1] = Z[b + Q];
+                v[bi][2] = Z[b + 2 * Q];
+                v[bi][3] = Z[b + 3 * Q];
+                if (Ns > 1) {
+                    v[bi][1] = cmul(v[bi][1], T->tw[k * tstep]);
+                    v[bi][2] = cmul(v[bi][2], T->tw[2 * k * tstep]);
+                    v[bi][3] = cmul(v[bi][3], T->tw[3 * k * tstep]);
+                }
+            }
+        }
+        lds_fence();                                           // every read of the stage precedes its writes
+#pragma unroll
+        for (int bi = 0; bi < BPL; ++bi) {
+            const int b = lane + 64 * bi;
+            if (b < Q) {
+                const int k = b & (Ns - 1);
+                const int j0 = ((b - k) << 2) + k;             // (b / Ns) * 4 Ns + k
+                const c64 t0 = cadd(v[bi][0], v[bi][2]), t1 = csub(v[bi][0], v[bi][2]);
+                const c64 t2 = cadd(v[bi][1], v[bi][3]), t3 = mul_mi(csub(v[bi][1], v[bi][3]));
+                Z[j0] = cadd(t0, t2);
+                Z[j0 + Ns] = cadd(t1, t3);
+                Z[j0 + 2 * Ns] = csub(t0, t2);
+                Z[j0 + 3 * Ns] = csub(t1, t3);
+            }
+        }
+        lds_fence();
+    }
+    if (LOG2NC & 1) {                                          // Ns = NC / 2: one radix-2 stage
+        constexpr int H = NC / 2;
+        constexpr int B2 = H >= 64 ? H / 64 : 1;
+        c64 a[B2], bq[B2];
+#pragma unroll
+        for (int bi = 0; bi < B2; ++bi) {
+            const int b = lane + 64 * bi;
+            if (b < H) { a[bi] = Z[b]; bq[bi] = cmul(Z[b + H], T->tw[2 * b]); }     // exp(-2 pi i b / NC)
+        }
+        lds_fence();
+#pragma unroll
+        for (int bi = 0; bi < B2; ++bi) {
+            const int b = lane + 64 * bi;
+            if (b < H) { Z[b] = cadd(a[bi], bq[bi]); Z[b + H] = csub(a[bi], bq[bi]); }
+        }
+        lds_fence();
+    }
+    // real-transform bins: X[k] = E + W^k O, E = (Z[k] + conj Z[NC-k]) / 2, O = -i (Z[k] - conj Z[NC-k]) / 2, W = exp(-2 pi i / NFFT)
+#pragma unroll
+    for (int j = 0; j <= G::PPL; ++j) {
+        const int k = j < G::PPL ? lane + 64 * j : NC;
+        double m = 0.0;
+        if (j < G::PPL || lane == 0) {
+            const c64 A = Z[k & (NC - 1)], Bc = Z[(NC - k) & (NC - 1)];
+            const c64 E = make_double2(0.5 * (A.x + Bc.x), 0.5 * (A.y - Bc.y));
+            const c64 D = make_double2(0.5 * (A.x - Bc.x), 0.5 * (A.y + Bc.y));       // (A - conj B) / 2
+            const c64 O = cmul(T->tw[k], mul_mi(D));
+            const double re = E.x + O.x, im = E.y + O.y;
+            m = sqrt(re * re + im * im);
+        }
+        mg[j] = m;
     }
     lds_fence();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = lane + 64 * u;
-        const int k = j & (NS - 1);
-        const int j0 = ((j - k) << 1) + k;
-        stc(X, j0, v[u][0]);
-        stc(X, j0 + NS, v[u][1]);
-    }
-    lds_fence();
-}
-
-// stages after the first one (which takes its input from registers)
-template <int NC, int NS>
-__device__ __forceinline__ void fft_rest(v4f* X, const float2* __restrict__ tw, int lane) {
-    if constexpr (NS * 4 <= NC) {
-        fft_stage4<NC, NS>(X, tw, lane);
-        fft_rest<NC, NS * 4>(X, tw, lane);
-    } else if constexpr (NS * 2 <= NC) {
-        fft_stage2<NC, NS>(X, tw, lane);
-    }
 }
 
 template <int LOG2N>
-struct Smem {
+__global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__ wav, const int64_t* __restrict__ clip_off,
+                                                       const int64_t* __restrict__ frame_off, int64_t total_frames,
+                                                       double* __restrict__ lld, double* __restrict__ cand,
+                                                       double* __restrict__ octave_dbg,
+                                                       const Tables<LOG2N>* __restrict__ T) {
     using G = Geo<LOG2N>;
-    Tables<LOG2N> tab;
-    float x[G::WAVES][G::XF];             // per-wave FFT buffer, later [a | m], [S | H] (two halves of HALF float2)
-    float mag[G::WAVES][G::MF];           // per-wave magnitudes of the current pair (float2 per bin)
-    float melbuf[G::WAVES][180];          // per-wave: 64 float2 chunk sums, then 26 float2 log mel energies
-    float out[NLOCAL][G::RUN];            // LLD rows of this run
-};
-
-// local row of an LLD index (the six pitch-chain rows 14, 15, 18..21 are written by smile_pitch.hip)
-__host__ __device__ constexpr int local_row(int lld) { return lld < 14 ? lld : (lld < 18 ? lld - 2 : lld - 6); }
-__host__ __device__ constexpr int lld_of_local(int r) { return r < 14 ? r : (r < 16 ? r + 2 : r + 6); }
-
-template <int LOG2N>
-__global__ __launch_bounds__(Geo<LOG2N>::WAVES * 64, LOG2N <= 9 ? 4 : (LOG2N == 10 ? 2 : 1)) void smile_lld_kernel(
-    const float* __restrict__ wav, const int64_t* __restrict__ clip_off, const int64_t* __restrict__ frame_off,
-    int64_t total_frames, float* __restrict__ lld, float* __restrict__ cand, float* __restrict__ octave_dbg,
-    const Tables<LOG2N>* __restrict__ gtab) {
-    using G = Geo<LOG2N>;
-    constexpr int NC = G::NC, NB = G::NB, PPL = G::PPL, HALF = G::HALF, CARRY = G::CARRY;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Smem<LOG2N>& S = *reinterpret_cast<Smem<LOG2N>*>(smem_raw);
-    const Tables<LOG2N>& T = S.tab;
-
+    constexpr int NC = G::NC, NB = G::NB, PPL = G::PPL;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
     const int clip = blockIdx.y;
-    const int64_t s0 = clip_off[clip];
-    const int64_t n_samp = clip_off[clip + 1] - s0;
-    const int frame = gtab->frame, hop = gtab->hop;
-    const int64_t n_fr = n_samp < frame ? 0 : (n_samp - frame) / hop + 1;
-    const int64_t f0 = (int64_t)blockIdx.x * G::RUN;
-    if (f0 >= n_fr) return;                            // uniform per workgroup
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = tid >> 6;
+    const int64_t fo = frame_off[clip];
+    const int n_fr = (int)(frame_off[clip + 1] - fo);
+    const int f0 = blockIdx.x * RUNW;
+    if (f0 >= n_fr) return;
+    const int n_run = min(RUNW, n_fr - f0);
+    const float* xclip = wav + clip_off[clip];
+    const int frame = T->frame, hop = T->hop;
+    const double df = T->df;
 
-    {   // tables -> LDS
-        const float4* g4 = reinterpret_cast<const float4*>(gtab);
-        float4* s4 = reinterpret_cast<float4*>(&S.tab);
-        for (int i = tid; i < (int)(sizeof(Tables<LOG2N>) / 16); i += G::WAVES * 64) s4[i] = g4[i];
+    c64* Z = reinterpret_cast<c64*>(smem);
+    double* ZD = smem;                                   // the FFT buffer as two arrays of NB doubles once the transform is done
+    double* MAG = smem + G::OFF_MAG;
+    double* MAGP = smem + G::OFF_MAGP;
+    double* SS = smem + G::OFF_S;
+    double* STASH = smem + G::OFF_STASH;
+    double* RED = smem + G::OFF_RED;
+
+    double mg[PPL + 1];
+    if (f0 > 0) {                                        // magnitudes of the frame in front of the run (for the flux)
+        double a, b, c;
+        frame_to_z<LOG2N>(xclip + (int64_t)(f0 - 1) * hop, T, frame, Z, lane, a, b, c);
+        fft_mag<LOG2N>(Z, T, lane, mg);
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) MAGP[lane + 64 * j] = mg[j];
+        if (lane == 0) MAGP[NC] = mg[PPL];
+        lds_fence();
     }
-    __syncthreads();
 
-    float* xs = S.x[w];
-    v4f* X = reinterpret_cast<v4f*>(xs);
-    v2f* XA = reinterpret_cast<v2f*>(xs);              // first half: a (spline ordinates), later S (octave spectrum)
-    v2f* XB = XA + HALF;                               // second half: flags / m (spline coefficients), later H (SHS)
-    v2f* M = reinterpret_cast<v2f*>(S.mag[w]);
-    const float* src = wav + s0;
-    const float df = T.df;
-    const float inv_frame = 1.0f / (float)frame;
-
-    const int64_t fw = f0 + (int64_t)w * (2 * G::PPW);  // first frame of this wave
-    bool have_prev = false;
-    v2f prevB[PPL];
-    float prevBx = 0.f;                                 // bin NC (kept on lane 63)
-#pragma unroll
-    for (int i = 0; i < PPL; ++i) prevB[i] = splat(0.f);
-
-    // pass -1 transforms the frame in front of the wave's span (spectral-flux history only: window + FFT + magnitudes,
-    // a quarter of a full pass); the waves stay independent of each other
-    const int p_first = fw > 0 ? -1 : 0;
 #pragma unroll 1
-    for (int p = p_first; p < G::PPW; ++p) {
-        const bool warm = p < 0;
-        const int64_t fA = warm ? fw - 1 : fw + 2 * p;
-        if (fA >= n_fr || fw >= n_fr) break;            // wave-uniform
-        const bool validB = !warm && (fA + 1 < n_fr);
-        const int offB = warm ? 0 : hop;
-        const int fl = (int)(fA - f0);                  // local frame index of A within the run
-
-        // ---- stage the pair's samples (coalesced; overlap between pairs and waves is served by L2) ----
-        {
-            const int span = frame + offB;
-            const int64_t sA = fA * hop;
-            for (int i = lane; i < span; i += 64) {
-                const int64_t si = sA + i;
-                xs[i] = (si < n_samp) ? src[si] : 0.0f;
-            }
-        }
+    for (int tr = 0; tr < n_run; ++tr) {
+        const int fr = f0 + tr;
+        const int64_t fg = fo + fr;
+        double s_w2, s_hw2, s_zc;
+        frame_to_z<LOG2N>(xclip + (int64_t)fr * hop, T, frame, Z, lane, s_w2, s_hw2, s_zc);
+        fft_mag<LOG2N>(Z, T, lane, mg);
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) MAG[lane + 64 * j] = mg[j];
+        if (lane == 0) { MAG[NC] = mg[PPL]; MAG[NC + 1] = 0.0; }
         lds_fence();
 
-        // ---- pre-emphasis, Hamming, frame energies; first radix-4 stage straight from registers ----
-        v2f e_rms = splat(0.f), e_int = splat(0.f), zc = splat(0.f);
+        // ---- cSpectral partial sums over the lane's bins (power spectrum; Androids.conf:258-280) ----
+        double v[8], w[8];
         {
-            constexpr int NBF = NC / 4;
-            constexpr int U = (NBF + 63) / 64;
-            C2 v[U][4];
+            double tot = 0, pf = 0, sm = 0, b1 = 0, b2 = 0, sh = 0, fx = 0, sl = 0, pl = 0, hm = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = lane + 64 * u;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int i0 = 2 * (j + t * NBF), i1 = i0 + 1;
-                    v2f y0 = splat(0.f), y1 = splat(0.f);
-                    if ((NBF >= 64 || j < NBF) && i0 < frame) {
-                        const bool has1 = i1 < frame;
-                        const float h0 = T.ham[i0], h1 = T.ham[i1];      // 0 beyond the frame
-                        const v2f S0 = {xs[i0], xs[i0 + offB]};
-                        const v2f S1 = has1 ? (v2f){xs[i1], xs[i1 + offB]} : splat(0.f);
-                        const v2f SM = i0 > 0 ? (v2f){xs[i0 - 1], xs[i0 - 1 + offB]} : splat(0.f);
-                        const v2f p0 = i0 > 0 ? (S0 - PREEMPH * SM) : (S0 * (1.0f - PREEMPH));
-                        const v2f p1 = S1 - PREEMPH * S0;
-                        y0 = p0 * h0;
-                        y1 = p1 * h1;
-                        e_rms += y0 * y0 + y1 * y1;
-                        e_int += h0 * (y0 * y0) + h1 * (y1 * y1);
-                        const v2f c0 = S0 * SM, c1 = S1 * S0;
-                        zc += (v2f){(i0 > 0 && c0.x < 0.f) ? 1.f : 0.f, (i0 > 0 && c0.y < 0.f) ? 1.f : 0.f};
-                        zc += (v2f){(has1 && c1.x < 0.f) ? 1.f : 0.f, (has1 && c1.y < 0.f) ? 1.f : 0.f};
-                    }
-                    v[u][t] = C2{y0, y1};
-                }
-                radix4(v[u][0], v[u][1], v[u][2], v[u][3]);
+            for (int j = 0; j <= PPL; ++j) {
+                const int k = j < PPL ? lane + 64 * j : NC;
+                if (j == PPL && lane != 0) break;
+                const double m = mg[j], P = m * m, f = (double)k * df;
+                tot += P;
+                pf += P * f;
+                sm += m;
+                if (f >= 250.0 && f <= 650.0) b1 += P;
+                if (f >= 1000.0 && f <= 4000.0) b2 += P;
+                sh += P * T->sharp[k];
+                if (fr > 0) { const double d = m - MAGP[k]; fx += d * d; }
+                const double lp = flog(fmax(P, 1e-30));
+                sl += lp;
+                if (P > 0.0) pl += P * lp;                       // P ln P (P < 1e-30 contributes < 1e-28: below every tolerance)
+                if (k >= 1 && k < NC) hm += fmax(m - 0.5 * (MAG[k - 1] + MAG[k + 1]), 0.0);
             }
-            lds_fence();                                   // every lane has read its samples: the buffer becomes the FFT array
+            v[0] = s_w2; v[1] = s_hw2; v[2] = s_zc; v[3] = tot; v[4] = pf; v[5] = sm; v[6] = b1; v[7] = b2;
+            w[0] = sh; w[1] = fx; w[2] = sl; w[3] = pl; w[4] = hm; w[5] = 0; w[6] = 0; w[7] = 0;
+        }
+        const double r1 = reduce8(v, RED, lane);
+        const double r2 = reduce8(w, RED, lane);
+        double* st = STASH + tr * NSUM;
+        if ((lane & 7) == 0) { st[lane >> 3] = r1; st[8 + (lane >> 3)] = r2; }
+        const double tot = shfl_f64(r1, 24), pfs = shfl_f64(r1, 32);
+        const double safe = tot > 0.0 ? tot : 1.0;
+        const double cen = pfs / safe;
+        {   // central moments about the centroid
+            double m2 = 0, m3 = 0, m4 = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = lane + 64 * u;
-                if (NBF >= 64 || j < NBF) {
+            for (int j = 0; j <= PPL; ++j) {
+                const int k = j < PPL ? lane + 64 * j : NC;
+                if (j == PPL && lane != 0) break;
+                const double P = mg[j] * mg[j], d = (double)k * df - cen, d2 = d * d;
+                m2 += d2 * P; m3 += d2 * d * P; m4 += d2 * d2 * P;
+            }
+            v[0] = m2; v[1] = m3; v[2] = m4; v[3] = 0; v[4] = 0; v[5] = 0; v[6] = 0; v[7] = 0;
+        }
+        const double r3 = reduce8(v, RED, lane);
+        if ((lane & 7) == 0 && lane < 24) st[16 + (lane >> 3)] = r3;
+
+        // ---- roll-off points: first bin whose inclusive cumulative power reaches p * total (lane-blocked prefix sums) ----
+        {
+            double c[PPL];
+            double run = 0.0;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) stc(X, 4 * j + t, v[u][t]);
+            for (int j = 0; j < PPL; ++j) { const double m = MAG[PPL * lane + j]; run += m * m; c[j] = run; }
+            double incl = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+            const double excl = incl - run;
+            const double pr[4] = {0.25, 0.50, 0.75, 0.90};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double th = pr[q] * tot;
+                int first = 0x7fffffff;
+#pragma unroll
+                for (int j = PPL - 1; j >= 0; --j) if (excl + c[j] >= th) first = PPL * lane + j;
+                first = wave_min_int(first);
+                if (first == 0x7fffffff) first = NC;               // only the last bin is left
+                if (lane == 0) st[19 + q] = (double)first * df;
+            }
+        }
+
+        // ---- cMelspec + cMfcc (Androids.conf:101-115): lane 2 c + side = one side of triangular band c ----
+        {
+            double s = 0.0;
+            if (lane < 2 * NMEL) {
+                const int bnd = lane >> 1, side = lane & 1;
+                const int seg = bnd + side;                          // rising side: bins of lower channel bnd, falling: bnd + 1
+                const int b0 = T->seg_start[seg], b1 = T->seg_start[seg + 1];
+                for (int b = b0; b < b1; ++b) {
+                    const double lw = T->lo_wt[b];
+                    s += (side ? lw : 1.0 - lw) * MAG[b];
                 }
+            }
+            s += __shfl_xor(s, 1, 64);
+            const double lm = flog(fmax(s * HTK_SCALE, MEL_FLOOR));
+            if (lane < 2 * NMEL && !(lane & 1)) SS[lane >> 1] = lm;
+            lds_fence();
+            if (lane < NMFCC) {
+                double acc = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < NMEL; ++jj) acc += T->dct[lane * NMEL + jj] * SS[jj];
+                lld[(int64_t)(1 + lane) * total_frames + fg] = acc;
             }
             lds_fence();
         }
-        fft_rest<NC, 4>(X, T.twr, lane);
 
-        // ---- packed-real unpack -> magnitudes (bin k = lane + 64 q), to the wave's magnitude slot ----
+        // ---- the previous-frame magnitudes of the next frame ----
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) {
-            const int k = lane + 64 * q;
-            const C2 zk = ldc(X, k);
-            const C2 zn = ldc(X, (NC - k) & (NC - 1));
-            const v2f ex = 0.5f * (zk.re + zn.re), ey = 0.5f * (zk.im - zn.im);
-            const v2f dx = zk.re - zn.re, dy = zk.im + zn.im;
-            v2f orr = 0.5f * dy, oi = -0.5f * dx;
-            cmul2(orr, oi, T.twr[k]);
-            const v2f xr = ex + orr, xi = ey + oi;
-            const v2f m2 = xr * xr + xi * xi;
-            M[sw(k)] = fsqrt2(m2);
-            if (k == 0) {
-                const v2f ny = zk.re - zk.im;
-                M[sw(NC)] = (v2f){fabsf(ny.x), fabsf(ny.y)};
-            }
-        }
-        lds_fence();
+        for (int j = 0; j < PPL; ++j) MAGP[lane + 64 * j] = mg[j];
+        if (lane == 0) MAGP[NC] = mg[PPL];
 
-        // ---- consecutive layout: lane owns bins PPL*lane .. PPL*lane + PPL-1, lane 63 also bin NC ----
-        const int b0 = PPL * lane;
-        const int sb0 = sw(b0);                            // a lane's PPL entries stay contiguous (PPL divides 32)
-        v2f m[PPL];
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) m[i] = M[sb0 + i];
-        const v2f mleft = lane > 0 ? M[sw(b0 - 1)] : splat(0.f);
-        const v2f mright = M[sw(b0 + PPL)];                    // lane 63: bin NC
-        const bool last = lane == 63;
-        const v2f mx = last ? mright : splat(0.f);
-
-        if (warm) {
-#pragma unroll
-            for (int i = 0; i < PPL; ++i) prevB[i] = m[i];
-            prevBx = mx.x;
-            have_prev = true;
-            continue;
-        }
-
-        // ---- HTK mel bank: one chunk of one band side per lane (host-built balanced schedule), then per-band sums ----
+        // ---- cSpecScale (Androids.conf:142-160): peak enhancement + (1,2,1) smoothing on the linear spectrum ----
+        double* A1 = ZD;                                   // enhanced spectrum   (FFT buffer, first half)
+        double* MM = ZD + NC + 4;                          // spline moments      (FFT buffer, second half)
         {
-            v2f* part = reinterpret_cast<v2f*>(S.melbuf[w]);
-            v2f* lm = part + 64;
-            const int ml = T.mel_lane[lane];
-            const int mb = ml & 0xFFF, mlen = (ml >> 12) & 0xFF;
-            const bool rising = (ml >> 20) & 1;
-            v2f acc = splat(0.f);
-            const int iters = gtab->mel_iters;
-#pragma unroll 2
-            for (int it = 0; it < iters; ++it) {
-                if (it < mlen) {
-                    const float wt = T.lo_wt[mb + it];
-                    acc += (rising ? 1.0f - wt : wt) * M[sw(mb + it)];
+            // local maxima (a[i] > a[i-1] and a[i] >= a[i+1]; the ends count when larger than their one neighbour) as bit
+            // masks of 64 bins; "within 2 bins of a maximum" is then shift arithmetic on the scalar unit
+            unsigned long long mx[PPL + 1];
+#pragma unroll
+            for (int j = 0; j <= PPL; ++j) {
+                const int k = lane + 64 * j;
+                bool is = false;
+                if (k <= NC) {
+                    const double a = MAG[k];
+                    if (k == 0) is = a > MAG[1];
+                    else if (k == NC) is = a > MAG[NC - 1];
+                    else is = a > MAG[k - 1] && a >= MAG[k + 1];
+                }
+                mx[j] = __ballot(is);
+            }
+            int count = 0, first = -1, last = -1;
+#pragma unroll
+            for (int j = 0; j <= PPL; ++j) {
+                count += __popcll(mx[j]);
+                if (mx[j]) {
+                    if (first < 0) first = 64 * j + __ffsll((long long)mx[j]) - 1;
+                    last = 64 * j + 63 - __clzll((long long)mx[j]);
                 }
             }
-            part[lane] = acc;
-            lds_fence();
-            if (lane < NMEL) {
-                const int bd = T.mel_band[lane];
-                const int first = bd & 0xFF, n = bd >> 8;
-                v2f band = splat(0.f);
-                const int mx_n = gtab->mel_max_n;
-                for (int k = 0; k < mx_n; ++k)
-                    if (k < n) band += part[first + k];
-                band = band * HTK_SCALE;
-                lm[lane] = (v2f){flog(fmaxf(band.x, MEL_FLOOR)), flog(fmaxf(band.y, MEL_FLOOR))};
+#pragma unroll
+            for (int j = 0; j <= PPL; ++j) {
+                const int k = lane + 64 * j;
+                if (k > NC) break;
+                unsigned long long near = mx[j] | (mx[j] << 1) | (mx[j] << 2) | (mx[j] >> 1) | (mx[j] >> 2);
+                if (j > 0) near |= (mx[j - 1] >> 63) | (mx[j - 1] >> 62);             // maxima at bins 64 j - 1, 64 j - 2
+                if (j < PPL) near |= (mx[j + 1] << 63) | (mx[j + 1] << 62);           // ... at bins 64 (j + 1), 64 (j + 1) + 1
+                const bool nr = (near >> lane) & 1ull;
+                double a = MAG[k];
+                if (count == 1) { if (!nr) a = 0.0; }
+                else if (count > 1) { if (!nr && k > first && k < last) a = 0.0; }
+                A1[k] = a;
             }
             lds_fence();
-            // DCT-II + lifter: lane 4k + part sums 7 mel channels of cepstral coefficient k + 1
-            const int kk = lane >> 2, prt = lane & 3;
-            v2f dsum = splat(0.f);
-            if (kk < NMFCC) {
+            // smoothing -> A2 (the MAG array: its last reader was the enhancement)
+            double sm[PPL + 1];
 #pragma unroll
-                for (int jj = 0; jj < 7; ++jj) {
-                    const int j = 7 * prt + jj;
-                    if (j < NMEL) dsum += T.dct[kk * NMEL + j] * lm[j];
-                }
+            for (int j = 0; j <= PPL; ++j) {
+                const int k = lane + 64 * j;
+                sm[j] = 0.0;
+                if (k < NC) sm[j] = ((k > 0 ? A1[k - 1] : 0.0) + 2.0 * A1[k] + A1[k + 1]) / 4.0;
+                else if (k == NC) sm[j] = A1[NC];
             }
-            dsum += (v2f){dpp_f32<0xB1>(dsum.x), dpp_f32<0xB1>(dsum.y)};          // quad_perm [1,0,3,2]
-            dsum += (v2f){dpp_f32<0x4E>(dsum.x), dpp_f32<0x4E>(dsum.y)};          // quad_perm [2,3,0,1]
-            if (kk < NMFCC && prt == 0) *reinterpret_cast<v2f*>(&S.out[1 + kk][fl]) = dsum;
+            lds_fence();
+#pragma unroll
+            for (int j = 0; j <= PPL; ++j) { const int k = lane + 64 * j; if (k <= NC) MAG[k] = sm[j]; }
+            lds_fence();
         }
+        double* A2 = MAG;
+        {   // natural cubic spline through the bins: tridiag(1, 4, 1) m = second differences, m_0 = m_NC = 0.
+            // Lane-blocked Thomas algorithm: the forward and the backward recurrence are affine maps x -> A x + B per bin;
+            // a lane composes its PPL bins, a wave scan composes the lanes, the carry then re-runs the lane's bins.
+            double g[PPL], r[PPL], dp[PPL];
+            double Am = 1.0, Bm = 0.0;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int b = PPL * lane + j;
+                g[j] = T->sp_g[b];                                  // 0 at bin 0
+                r[j] = b >= 1 ? (A2[b - 1] - 2.0 * A2[b]) + A2[b + 1] : 0.0;
+                // dp_b = -g dp_{b-1} + g r
+                Bm = fma(-g[j], Bm, g[j] * r[j]);
+                Am = -g[j] * Am;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double Au = __shfl_up(Am, o, 64), Bu = __shfl_up(Bm, o, 64);
+                if (lane >= o) { Bm = fma(Am, Bu, Bm); Am = Am * Au; }
+            }
+            double carry = __shfl_up(Bm, 1, 64);
+            if (lane == 0) carry = 0.0;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) { carry = g[j] * (r[j] - carry); dp[j] = carry; }
+            // backward: x_b = dp_b - g_b x_{b+1}, x_NC = 0
+            Am = 1.0; Bm = 0.0;
+#pragma unroll
+            for (int j = PPL - 1; j >= 0; --j) { Bm = fma(-g[j], Bm, dp[j]); Am = -g[j] * Am; }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double Ad = __shfl_down(Am, o, 64), Bd = __shfl_down(Bm, o, 64);
+                if (lane + o < 64) { Bm = fma(Am, Bd, Bm); Am = Am * Ad; }
+            }
+            carry = __shfl_down(Bm, 1, 64);
+            if (lane == 63) carry = 0.0;
+#pragma unroll
+            for (int j = PPL - 1; j >= 0; --j) { carry = fma(-g[j], carry, dp[j]); MM[PPL * lane + j] = carry; }
+            if (lane == 0) MM[NC] = 0.0;
+            lds_fence();
+        }
+        // spline at the octave-scale targets, negatives reset, auditory weighting -> S
+#pragma unroll
+        for (int j = 0; j <= PPL; ++j) {
+            const int i = lane + 64 * j;
+            if (i > NC) break;
+            const int kl = T->klo[i];
+            const double b = T->tb[i], aa = 1.0 - b;
+            const double y = aa * A2[kl] + b * A2[kl + 1] + (aa * aa * aa - aa) * MM[kl] + (b * b * b - b) * MM[kl + 1];
+            const double s = fmax(y, 0.0) * T->audw[i];
+            SS[i] = s;
+            if (octave_dbg) octave_dbg[fg * NB + i] = s;
+        }
+        lds_fence();
 
-        // ---- cSpectral on the power spectrum ----
-        v2f s_p = splat(0.f), s_fp = splat(0.f), s_b1 = splat(0.f), s_b2 = splat(0.f), s_fl = splat(0.f),
-            s_sh = splat(0.f), s_m = splat(0.f), s_lg = splat(0.f), s_pk = splat(0.f);
-        const bool flux_a = have_prev;
-        const float b1lo = gtab->band1_lo, b1hi = gtab->band1_hi, b2lo = gtab->band2_lo, b2hi = gtab->band2_hi;
+        // ---- cPitchShs (Androids.conf:162-186): sub-harmonic summation, peaks, the 6 best candidates ----
+        double H[PPL + 1];
+        double hsum = 0.0;
 #pragma unroll
-        for (int i = 0; i < PPL; ++i) {
-            const int b = b0 + i;
-            const float fq = b * df;
-            const v2f p = m[i] * m[i];
-            s_p += p;
-            s_fp += p * fq;
-            if (fq >= b1lo && fq <= b1hi) s_b1 += p;
-            if (fq >= b2lo && fq <= b2hi) s_b2 += p;
-            const v2f dm = {flux_a ? m[i].x - prevB[i].y : 0.f, m[i].y - m[i].x};   // B's history is A
-            s_fl += dm * dm;
-            s_sh += p * T.sharp[b];
-            s_m += m[i];
-            s_lg += flog2_2(vmax2(p, splat(1e-30f)));
-            if (b >= 1) {
-                const v2f ml_ = i > 0 ? m[i - 1] : mleft;
-                const v2f mr_ = i < PPL - 1 ? m[i + 1] : mright;
-                s_pk += vmax2(m[i] - 0.5f * (ml_ + mr_), splat(0.f));      // prominence over the neighbours' mean
-            }
-        }
-        const v2f px = mx * mx;                                                // bin NC (lane 63 only, 0 elsewhere)
-        if (last) {
-            const float fq = NC * df;
-            s_fp += px * fq;
-            if (fq >= b1lo && fq <= b1hi) s_b1 += px;
-            if (fq >= b2lo && fq <= b2hi) s_b2 += px;
-            const v2f dm = {flux_a ? mx.x - prevBx : 0.f, mx.y - mx.x};
-            s_fl += dm * dm;
-            s_sh += px * T.sharp[NC];
-            s_m += mx;
-            s_lg += flog2_2(vmax2(px, splat(1e-30f)));
-        }
-        {   // window sums of the pair (a fourth slot of the group is free)
-            v2f dummy = splat(0.f);
-            wave_sum4x2(e_rms, e_int, zc, dummy);
-            if (lane == 0) {
-                auto put0 = [&](int row, v2f val) { *reinterpret_cast<v2f*>(&S.out[local_row(row)][fl]) = val; };
-                const v2f inten = e_int * (1.0e6f / gtab->ham_sum);
-                put0(0, fsqrt2(e_rms * inv_frame));
-                put0(13, zc * inv_frame);
-                put0(16, inten);
-                put0(17, fexp2_2(0.3f * flog2_2(inten)));                   // inten^0.3 (0 -> 0)
-            }
-        }
-        // inclusive scan of the per-lane power (bins 0..NC-1); the total adds bin NC (held by lane 63)
-        const v2f incl = {wave_scan_incl(s_p.x), wave_scan_incl(s_p.y)};
-        const v2f tot = (v2f){readlane_f32(incl.x, 63) + readlane_f32(px.x, 63), readlane_f32(incl.y, 63) + readlane_f32(px.y, 63)};
-        const v2f excl = incl - s_p;
-        wave_sum4x2(s_fp, s_b1, s_b2, s_fl);
-        wave_sum4x2(s_sh, s_m, s_lg, s_pk);
-        const v2f tot_fp = s_fp, band1 = s_b1, band2 = s_b2, flsum = s_fl, sharp = s_sh, msum = s_m, pksum = s_pk;
-        const v2f lgsum = s_lg * 0.6931471805599453f;                          // sum of natural logs
-        const v2f safe = {tot.x > 0.f ? tot.x : 1.0f, tot.y > 0.f ? tot.y : 1.0f};
-        const v2f inv = frcp2(safe);
-        const v2f cen = tot_fp * inv;
-        // roll-off: first bin whose inclusive cumulative power reaches p * total
-        float ro[8];
-        {
-            const float pr[4] = {0.25f, 0.50f, 0.75f, 0.90f};
-            v2f run = excl;
-            v2f cs[PPL];
+        for (int j = 0; j <= PPL; ++j) {
+            const int i = lane + 64 * j;
+            H[j] = 0.0;
+            if (i <= NC) {
+                double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < PPL; ++i) { run += m[i] * m[i]; cs[i] = run; }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const v2f thr = pr[t] * tot;
-                int cA = NC, cB = NC;
-#pragma unroll
-                for (int i = PPL - 1; i >= 0; --i) {
-                    if (cs[i].x >= thr.x) cA = b0 + i;
-                    if (cs[i].y >= thr.y) cB = b0 + i;
+                for (int h = 0; h < NHARM; ++h) {
+                    const int src = i + T->shs_shift[h];
+                    if (src <= NC) acc += T->shs_w[h] * SS[src];
                 }
-                ro[2 * t] = (float)cA;                                          // bin indices are exact in float
-                ro[2 * t + 1] = (float)cB;
-            }
-            wave_reduce8<true>(ro);
-        }
-        // second pass: central moments + entropy
-        v2f s_e = splat(0.f), s_v = splat(0.f), s_s = splat(0.f), s_k = splat(0.f);
-#pragma unroll
-        for (int i = 0; i <= PPL; ++i) {
-            if (i == PPL && !last) break;
-            const float fq = (i < PPL ? b0 + i : NC) * df;
-            const v2f mi_ = i < PPL ? m[i] : mx;
-            const v2f prb = mi_ * mi_ * inv;
-            const v2f d = splat(fq) - cen;
-            const v2f lg = flog2_2(vmax2(prb, splat(1e-37f)));
-            s_e += (v2f){prb.x > 0.f ? prb.x * lg.x : 0.f, prb.y > 0.f ? prb.y * lg.y : 0.f};
-            const v2f d2 = d * d;
-            s_v += d2 * prb;
-            s_s += d2 * d * prb;
-            s_k += d2 * d2 * prb;
-        }
-        wave_sum4x2(s_e, s_v, s_s, s_k);
-        // the three window sums of this pair travel with the sub-harmonic sum below (one more group of four)
-        if (lane == 0) {
-            const v2f var = s_v;
-            const v2f vs = {var.x > 0.f ? var.x : 1.0f, var.y > 0.f ? var.y : 1.0f};
-            const v2f ivs = frcp2(vs);
-            auto put = [&](int row, v2f val) { *reinterpret_cast<v2f*>(&S.out[local_row(row)][fl]) = val; };
-            put(22, band1);
-            put(23, band2);
-            put(24, (v2f){ro[0], ro[1]} * df);
-            put(25, (v2f){ro[2], ro[3]} * df);
-            put(26, (v2f){ro[4], ro[5]} * df);
-            put(27, (v2f){ro[6], ro[7]} * df);
-            put(28, fsqrt2(flsum * (1.0f / NB)));                           // the clip's first frame: history = itself -> 0
-            put(29, cen);
-            put(30, -s_e);
-            put(31, var);
-            put(32, s_s * ivs * fsqrt2(ivs));
-            put(33, s_k * ivs * ivs);
-            put(34, ((float)NB * tot_fp - gtab->slope_sf * tot) * (1.0f / gtab->slope_den));
-            put(35, sharp * inv);
-            put(36, pksum * frcp2((v2f){msum.x > 0.f ? msum.x : 1.0f, msum.y > 0.f ? msum.y : 1.0f}));
-            put(37, fexp2_2(s_lg * (1.0f / NB)) * frcp2(vmax2(tot * (1.0f / NB), splat(1e-30f))));
-        }
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) prevB[i] = m[i];
-        prevBx = mx.y;
-        have_prev = true;
-        (void)lgsum;
-
-        // ---- cSpecScale: peak enhancement + smoothing on the linear spectrum ----
-        // flags word per bin: bit 0 / 1 = "local maximum" in frame A / B; first / last / count from wave ballots (SALU)
-        unsigned* FL = reinterpret_cast<unsigned*>(XB);
-        int gfirstA = 0x7fffffff, gfirstB = 0x7fffffff, glastA = -1, glastB = -1, ncA = 0, ncB = 0;
-#pragma unroll
-        for (int i = 0; i <= PPL; ++i) {
-            const int b = i < PPL ? b0 + i : NC;
-            const v2f me = i < PPL ? m[i] : mx;
-            const v2f ml_ = i == 0 ? mleft : m[i - 1];
-            const v2f mr_ = i < PPL - 1 ? m[i + 1] : (i == PPL - 1 ? mright : splat(0.f));
-            bool fa, fb;
-            if (i == PPL) { fa = last && me.x > ml_.x; fb = last && me.y > ml_.y; }
-            else if (b == 0) { fa = me.x > mr_.x; fb = me.y > mr_.y; }
-            else { fa = me.x > ml_.x && me.x >= mr_.x; fb = me.y > ml_.y && me.y >= mr_.y; }
-            if (i < PPL || last) FL[b] = (fa ? 1u : 0u) | (fb ? 2u : 0u);
-            const unsigned long long ka = __ballot(fa), kb = __ballot(fb);
-            const int stride = i < PPL ? PPL : 0, base = i < PPL ? i : NC;
-            if (ka) {
-                gfirstA = min(gfirstA, stride * (__ffsll((long long)ka) - 1) + base);
-                glastA = max(glastA, stride * (63 - __clzll((long long)ka)) + base);
-                ncA += __popcll(ka);
-            }
-            if (kb) {
-                gfirstB = min(gfirstB, stride * (__ffsll((long long)kb) - 1) + base);
-                glastB = max(glastB, stride * (63 - __clzll((long long)kb)) + base);
-                ncB += __popcll(kb);
+                H[j] = acc;
+                hsum += acc;
             }
         }
         lds_fence();
-        // window of flags for bins b0-3 .. b0+PPL+2
-        unsigned fw_[PPL + 6];
+        double* HH = MAG;                                   // A2 is dead: the summation spectrum takes its place
 #pragma unroll
-        for (int o = 0; o < PPL + 6; ++o) {
-            const int b = b0 - 3 + o;
-            fw_[o] = (b >= 0 && b <= NC) ? FL[b] : 0u;
-        }
-        // enhanced value of bin b0 - 1 + o, o = 0 .. PPL+1 (own bins and one neighbour on each side)
-        v2f en[PPL + 2];
-#pragma unroll
-        for (int o = 0; o < PPL + 2; ++o) {
-            const int b = b0 - 1 + o;
-            const unsigned near = fw_[o] | fw_[o + 1] | fw_[o + 2] | fw_[o + 3] | fw_[o + 4];   // bins b-2 .. b+2
-            const v2f val = o == 0 ? mleft : (o <= PPL ? m[o - 1] : mright);
-            const bool zA = !(near & 1u) && (ncA == 1 || (ncA >= 2 && b > gfirstA && b < glastA));
-            const bool zB = !(near & 2u) && (ncB == 1 || (ncB >= 2 && b > gfirstB && b < glastB));
-            en[o] = (b >= 0 && b <= NC) ? (v2f){zA ? 0.f : val.x, zB ? 0.f : val.y} : splat(0.f);
-        }
-        lds_fence();                                         // flags consumed: the second half is free again
-        // smoothing (1, 2, 1) / 4, zero left of bin 0, bin NC untouched; a -> first half
-        v2f a[PPL];
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) {
-            a[i] = 0.25f * (en[i] + 2.0f * en[i + 1] + en[i + 2]);
-            XA[sb0 + i] = a[i];
-        }
-        if (last) XA[sw(NC)] = en[PPL + 1];                      // bin NC keeps its enhanced value
+        for (int j = 0; j <= PPL; ++j) { const int i = lane + 64 * j; if (i <= NC) HH[i] = H[j]; }
+        const double hmean = wave_sum_all(hsum) / (double)NB;
         lds_fence();
-        // ---- natural cubic spline through the bins: m_{b-1} + 4 m_b + m_{b+1} = a_{b-1} - 2 a_b + a_{b+1} ----
-        {
-            const v2f aleft = lane > 0 ? XA[sw(b0 - 1)] : splat(0.f);
-            const v2f aright = XA[sw(b0 + PPL)];
-            float g[PPL];
-            v2f d[PPL];
-            // forward elimination, local part (carry 0), then the carry of up to CARRY lanes
-            v2f run = splat(0.f);
-            float qf[PPL];
-            float q = 1.0f;
+        // peaks (y2 > y1 and y2 >= y3) with parabolic refinement, inside 52..620 Hz, positive score: compacted into a list
+        double* L_sc = SS;                                  // S is dead: list of (score, f0, index)
+        double* L_f = SS + (NC / 2 + 4);
+        int npk = 0;
 #pragma unroll
-            for (int i = 0; i < PPL; ++i) {
-                g[i] = T.sp_g[b0 + i];
-                const v2f al = i == 0 ? aleft : a[i - 1];
-                const v2f ar = i == PPL - 1 ? aright : a[i + 1];
-                const v2f r = al - 2.0f * a[i] + ar;
-                run = g[i] * (r - run);
-                d[i] = run;
-                q *= -g[i];
-                qf[i] = q;
-            }
-            {
-                v2f e = run, carry = splat(0.f);
-#pragma unroll
-                for (int dd = 1; dd <= CARRY; ++dd) {
-                    e = (v2f){wave_shr1(e.x), wave_shr1(e.y)};
-                    carry += (dd == 1 ? 1.0f : T.sp_cf[dd - 2][lane]) * e;
+        for (int j = 0; j <= PPL; ++j) {
+            const int i = lane + 64 * j;
+            bool ok = false;
+            double sc = 0.0, fq = 0.0;
+            if (i >= 1 && i <= NC - 1) {
+                const double y1 = HH[i - 1], y2 = HH[i], y3 = HH[i + 1];
+                if (y2 > y1 && y2 >= y3) {
+                    const double den = (y1 - 2.0 * y2) + y3;
+                    const double dx = 0.5 * (y1 - y3) / den;
+                    sc = y2 - 0.125 * (y1 - y3) * (y1 - y3) / den;
+                    fq = exp2(T->fmin_l2 + ((double)i + dx) * T->dl2);
+                    ok = fq >= SHS_MINPITCH && fq <= SHS_MAXPITCH && sc > 0.0;
                 }
-#pragma unroll
-                for (int i = 0; i < PPL; ++i) d[i] += qf[i] * carry;
             }
-            // back substitution x_b = dp_b - g_b x_{b+1}
-            v2f x[PPL];
-            float qb[PPL];
-            run = splat(0.f);
-            q = 1.0f;
-#pragma unroll
-            for (int i = PPL - 1; i >= 0; --i) {
-                run = d[i] - g[i] * run;
-                x[i] = run;
-                q *= -g[i];
-                qb[i] = q;
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int p = npk + __popcll(m & ((1ull << lane) - 1ull));
+                L_sc[p] = sc;
+                L_f[p] = fq;
             }
-            {
-                v2f e = run, carry = splat(0.f);
-#pragma unroll
-                for (int dd = 1; dd <= CARRY; ++dd) {
-                    e = (v2f){wave_shl1(e.x), wave_shl1(e.y)};
-                    carry += (dd == 1 ? 1.0f : T.sp_cb[dd - 2][lane]) * e;
-                }
-#pragma unroll
-                for (int i = 0; i < PPL; ++i) x[i] += qb[i] * carry;
-            }
-#pragma unroll
-            for (int i = 0; i < PPL; ++i) XB[sb0 + i] = x[i];
-            if (last) XB[sw(NC)] = splat(0.f);
+            npk += __popcll(m);
         }
         lds_fence();
-        // ---- octave-scale targets i = b0 .. b0+PPL-1 (+ NC on lane 63): spline value, clip, auditory weighting ----
-        v2f sv[PPL + 1];
-#pragma unroll
-        for (int i = 0; i <= PPL; ++i) {
-            sv[i] = splat(0.f);
-            if (i == PPL && !last) break;
-            const int ti = i < PPL ? b0 + i : NC;
-            const int k = T.klo[ti];
-            const float bb = T.tb[ti], aa = 1.0f - bb;
-            const float ca = aa * aa * aa - aa, cb = bb * bb * bb - bb;
-            const v2f y = aa * XA[sw(k)] + bb * XA[sw(k + 1)] + ca * XB[sw(k)] + cb * XB[sw(k + 1)];
-            sv[i] = vmax2(y, splat(0.f)) * T.audw[ti];
-        }
-        lds_fence();                                         // all reads of a / m done: reuse the halves for S / H
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) XA[sb0 + i] = sv[i];
-        if (last) { XA[sw(NC)] = sv[PPL]; XA[sw(NC + 1)] = splat(0.f); }   // entry NC+1 = 0: target of out-of-range shifts
-        if (octave_dbg) {
-            const int64_t fg = frame_off[clip] + fA;
-#pragma unroll
-            for (int i = 0; i <= PPL; ++i) {
-                if (i == PPL && !last) break;
-                const int ti = i < PPL ? b0 + i : NC;
-                octave_dbg[fg * NB + ti] = sv[i].x;
-                if (validB) octave_dbg[(fg + 1) * NB + ti] = sv[i].y;
+        // rank = number of peaks with a higher score (ties: the lower index, i.e. the earlier list entry, first)
+        double* cd = cand + fg * (NCAND * 2);
+        if (lane < NCAND && lane >= npk) { cd[2 * lane] = 0.0; cd[2 * lane + 1] = 0.0; }
+        for (int p0 = 0; p0 < npk; p0 += 64) {
+            const int p = p0 + lane;
+            const double mine = p < npk ? L_sc[p] : 0.0;
+            int rank = 0;
+            for (int q = 0; q < npk; ++q) {
+                const double o = L_sc[q];
+                rank += (o > mine || (o == mine && q < p)) ? 1 : 0;
             }
-        }
-        lds_fence();
-        // ---- cPitchShs: sub-harmonic summation H[i] = sum_h 0.85^(h-1) S[i + shift_h] ----
-        v2f hv[PPL + 1];
-        v2f hsum = splat(0.f);
-#pragma unroll
-        for (int i = 0; i <= PPL; ++i) {
-            hv[i] = splat(0.f);
-            if (i == PPL && !last) break;
-            const int ti = i < PPL ? b0 + i : NC;
-            v2f acc = splat(0.f);
-#pragma unroll
-            for (int h = 0; h < NHARM; ++h) {
-                const int src_i = min(ti + gtab->shs_shift[h], NC + 1);
-                acc += gtab->shs_w[h] * XA[sw(src_i)];
-            }
-            hv[i] = acc;
-            hsum += acc;
-        }
-        const v2f hmean = wave_sum2(hsum) * (1.0f / NB);
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) XB[sb0 + i] = hv[i];
-        if (last) XB[sw(NC)] = hv[PPL];
-        lds_fence();
-        {
-            // local maxima with parabolic refinement, both frames at once; a peak's sort key carries its score in the
-            // high bits and (MASK - index) in the low ones: larger key = higher score, ties / near-ties to the lower index
-            constexpr unsigned MASK = (1u << (LOG2N - 1)) - 1u;
-            constexpr int MAXPK = PPL >= 2 ? PPL / 2 : 1;                    // peaks are never adjacent
-            const v2f hleft = lane > 0 ? XB[sw(b0 - 1)] : splat(0.f);
-            const v2f hright = XB[sw(b0 + PPL)];
-            unsigned kA[MAXPK], kB[MAXPK];
-#pragma unroll
-            for (int k = 0; k < MAXPK; ++k) { kA[k] = 0u; kB[k] = 0u; }
-            const float fmin_l2 = gtab->fmin_l2, dl2 = gtab->dl2;
-#pragma unroll
-            for (int i = 0; i < PPL; ++i) {
-                const int ti = b0 + i;
-                const v2f y1 = i == 0 ? hleft : hv[i - 1];
-                const v2f y2 = hv[i];
-                const v2f y3 = i == PPL - 1 ? hright : hv[i + 1];
-                const v2f den = y1 - 2.0f * y2 + y3;
-                const v2f rden = frcp2(den);
-                const v2f dif = y1 - y3;
-                const v2f sc = y2 - 0.125f * dif * dif * rden;
-                const v2f fq = fexp2_2(splat(fmin_l2) + (splat((float)ti) + 0.5f * dif * rden) * dl2);
-                const bool okA = ti >= 1 && y2.x > y1.x && y2.x >= y3.x && fq.x >= 52.0f && fq.x <= 620.0f && sc.x > 0.f;
-                const bool okB = ti >= 1 && y2.y > y1.y && y2.y >= y3.y && fq.y >= 52.0f && fq.y <= 620.0f && sc.y > 0.f;
-                unsigned ka = okA ? ((__float_as_uint(sc.x) & ~MASK) | (MASK - (unsigned)ti)) : 0u;
-                unsigned kb = okB ? ((__float_as_uint(sc.y) & ~MASK) | (MASK - (unsigned)ti)) : 0u;
-#pragma unroll
-                for (int k = 0; k < MAXPK; ++k) {                             // sorted insertion, largest first
-                    const unsigned ta = max(kA[k], ka), tb = max(kB[k], kb);
-                    ka = min(kA[k], ka); kb = min(kB[k], kb);
-                    kA[k] = ta; kB[k] = tb;
-                }
-            }
-            unsigned wA = 0u, wB = 0u;                                       // lane r keeps the key of slot r
-#pragma unroll 1
-            for (int r = 0; r < NCAND; ++r) {
-                const unsigned ma = wave_max_u32(kA[0]), mb_ = wave_max_u32(kB[0]);
-                if (!(ma | mb_)) break;                                       // wave-uniform
-                if (lane == r) { wA = ma; wB = mb_; }
-                if (kA[0] == ma && ma) {
-#pragma unroll
-                    for (int k = 0; k + 1 < MAXPK; ++k) kA[k] = kA[k + 1];
-                    kA[MAXPK - 1] = 0u;
-                }
-                if (kB[0] == mb_ && mb_) {
-#pragma unroll
-                    for (int k = 0; k + 1 < MAXPK; ++k) kB[k] = kB[k + 1];
-                    kB[MAXPK - 1] = 0u;
-                }
-            }
-            if (lane < NCAND) {
-                const int64_t fg = frame_off[clip] + fA;
-                const float* Hf = reinterpret_cast<const float*>(XB);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (h == 1 && !validB) break;
-                    const unsigned key = h ? wB : wA;
-                    float fqo = 0.f, vo = 0.f;
-                    if (key) {
-                        const int ti = (int)(MASK - (key & MASK));
-                        const float y1 = Hf[2 * sw(ti - 1) + h], y2 = Hf[2 * sw(ti) + h], y3 = Hf[2 * sw(ti + 1) + h];
-                        const float rden = frcp(y1 - 2.0f * y2 + y3);
-                        const float dif = y1 - y3;
-                        const float sc = y2 - 0.125f * dif * dif * rden;
-                        fqo = fexp2(fmin_l2 + ((float)ti + 0.5f * dif * rden) * dl2);
-                        vo = fmaxf(0.f, 1.0f - (h ? hmean.y : hmean.x) * frcp(sc));
-                    }
-                    reinterpret_cast<float2*>(cand)[(fg + h) * NCAND + lane] = make_float2(fqo, vo);
-                }
+            if (p < npk && rank < NCAND) {
+                cd[2 * rank] = L_f[p];
+                cd[2 * rank + 1] = fmax(0.0, 1.0 - hmean / mine);
             }
         }
         lds_fence();
     }
-    __syncthreads();
 
-    // ---- coalesced contour-major store of the run ----
-    const int64_t fbase = frame_off[clip] + f0;
-    const int nvalid = (int)min((int64_t)G::RUN, n_fr - f0);
-    for (int idx = tid; idx < NLOCAL * G::RUN; idx += G::WAVES * 64) {
-        const int r = idx / G::RUN, t = idx % G::RUN;
-        if (t >= nvalid) continue;
-        lld[(int64_t)lld_of_local(r) * total_frames + fbase + t] = S.out[r][t];
+    // ---- end of the run: lane t finishes frame f0 + t from its sums ----
+    if (lane < n_run) {
+        const double* st = STASH + lane * NSUM;
+        const int64_t fg = fo + f0 + lane;
+        const double N = (double)frame, NBd = (double)NB;
+        auto out = [&](int row, double val) { lld[(int64_t)row * total_frames + fg] = val; };
+        const double tot = st[3], safe = tot > 0.0 ? tot : 1.0;
+        out(0, sqrt(st[0] / N));                                             // pcm_RMSenergy (cEnergy on winframe)
+        out(13, st[2] / N);                                                  // pcm_zcr (cMZcr on the raw frame)
+        const double inten = (st[1] / T->ham_sum) / I0;
+        out(16, inten);                                                      // pcm_intensity
+        out(17, pow(inten, 0.3));                                            // pcm_loudness
+        out(22, st[6]);
+        out(23, st[7]);
+        out(24, st[19]); out(25, st[20]); out(26, st[21]); out(27, st[22]);  // roll-off 25 / 50 / 75 / 90 %
+        out(28, sqrt(st[9] / NBd));                                          // flux (0 for the first frame of a clip)
+        out(29, st[4] / safe);                                               // centroid
+        out(30, tot > 0.0 ? log2(tot) - (st[11] / LN2) / tot : 0.0);         // entropy = -sum p log2 p, p = P / total
+        const double var = st[16] / safe, vs = var > 0.0 ? var : 1.0;
+        out(31, var);
+        out(32, (st[17] / safe) / (vs * sqrt(vs)));
+        out(33, (st[18] / safe) / (vs * vs));
+        out(34, (NBd * st[4] - T->slope_sf * tot) / T->slope_den);           // slope of the power spectrum over frequency
+        out(35, st[8] / safe);                                               // psychoacoustic sharpness
+        out(36, st[12] / (st[5] > 0.0 ? st[5] : 1.0));                       // harmonicity proxy
+        // flatness = geometric / arithmetic mean of the power spectrum; a frame of zeros has the limit value 1
+        out(37, tot > 0.0 ? exp(st[10] / NBd) / fmax(tot / NBd, 1e-30) : 1.0);
     }
 }
 
 template <int LOG2N>
 static int launch(const float* wav, const int64_t* clip_off, const int64_t* frame_off, int n_clips,
-                  int64_t max_clip_frames, int64_t total_frames, int fs, int frame, int hop, float* lld, float* cand,
-                  float* octave_dbg, hipStream_t s) {
+                  int64_t max_clip_frames, int64_t total_frames, int fs, int frame, int hop, double* lld, double* cand,
+                  double* octave_dbg, hipStream_t s) {
     using G = Geo<LOG2N>;
     const Tables<LOG2N>* tab = nullptr;
     int rc = get_tables<LOG2N>(fs, frame, hop, &tab);
     if (rc != RSAF_OK) return rc;
-    const int64_t runs = (max_clip_frames + G::RUN - 1) / G::RUN;
+    const int64_t runs = (max_clip_frames + RUNW - 1) / RUNW;
     RSAF_CHECK_ARG(runs <= 0x7fffffffLL, "clip too long");
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    RSAF_CHECK_HIP(hipGetDevice(&dev));
-    RSAF_CHECK_ARG(dev >= 0 && dev < 64, "device index out of range");
-    if (!attr_set[dev]) {
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)smile_lld_kernel<LOG2N>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<LOG2N>)));
-        attr_set[dev] = true;
-    }
-    // algorithmic bytes: every sample read once (4 B) + the LLD rows written (38 * 4 B per frame)
+    constexpr size_t lds = (size_t)G::WAVE_D * sizeof(double);
+    static_assert(lds <= 64 * 1024, "one wave's buffers must fit the default dynamic LDS limit");
+    // algorithmic bytes: every sample read once (4 B) + the LLD rows written (38 * 8 B per frame)
     ProfScope prof("smile_lld", s, 0.0, 0.0);
     dim3 grid((unsigned)runs, (unsigned)n_clips);
-    hipLaunchKernelGGL(smile_lld_kernel<LOG2N>, grid, dim3(G::WAVES * 64), sizeof(Smem<LOG2N>), s, wav, clip_off,
-                       frame_off, total_frames, lld, cand, octave_dbg, tab);
+    hipLaunchKernelGGL(smile_lld_kernel<LOG2N>, grid, dim3(64), lds, s, wav, clip_off, frame_off, total_frames, lld, cand,
+                       octave_dbg, tab);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }
@@ -1075,8 +822,8 @@ int rsaf_init_device(int device) {
 }
 
 int rsaf_smile_lld_batch(const float* wav, const int64_t* clip_off, const int64_t* frame_off,
-                         int n_clips, int64_t max_clip_frames, int64_t total_frames, int sample_rate, float* lld,
-                         float* cand, float* octave_spectrum, rsaf_stream_t stream) {
+                         int n_clips, int64_t max_clip_frames, int64_t total_frames, int sample_rate, double* lld,
+                         double* cand, double* octave_spectrum, rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535, "n_clips must be in [0, 65535] per call");
     RSAF_CHECK_ARG(total_frames >= 0 && max_clip_frames >= 0, "negative frame count");
     int frame = 0, hop = 0, l2 = 0;

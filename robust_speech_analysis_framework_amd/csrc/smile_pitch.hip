@@ -2,10 +2,14 @@
 // cPitchJitter (Androids.conf:190-255 of the reference, reached through src/opensmile_extractor.py:62-87).
 // The per-frame candidates come from smile_lld_kernel (cSpecScale + cPitchShs).
 //
+// Everything here is float64, like the frame kernel: the path costs, the lag decisions and the rows they produce then
+// coincide with the float64 restatement (oracle/smile_oracle.py) except on ties of ~1e-15 (see smile_lld.hip).
+//
 // smile_viterbi_kernel: one wave per clip.  Lane (j, i) = (lane >> 3, lane & 7) owns the transition from state i of
 //   the previous frame to state j of the current one (states 0..5 = candidate slots, 6 = unvoiced); the minimum over
-//   the predecessors is three DPP min steps on a key that carries the predecessor index in the low mantissa bits
-//   (ties and near-ties within 7 ulp go to the lowest index).  Back pointers go to a per-frame byte record; the
+//   the predecessors is three exchange steps on a 64-bit key: the bits of the (non-negative) cost with the predecessor
+//   index in the three lowest mantissa bits (costs within 8 ulp of a double tie towards the lowest index, as an exact
+//   tie does in the oracle).  Back pointers go to a per-frame byte record; the
 //   fixed-lag decisions (bufferLength = 30) are then read off in parallel, one lane per frame, followed by the
 //   energy gate.  Latency bound by construction: one dependent step per frame.
 // smile_jitter_kernel: waveform matching is sequential inside a run of voiced frames and independent between runs:
@@ -23,75 +27,83 @@ namespace smile {
 
 constexpr int NCAND = RSAF_SMILE_NCAND;
 constexpr int NLLD = RSAF_SMILE_NLLD;
-constexpr float W_TVV = 10.0f, W_TVVD = 5.0f, W_TVUV = 10.0f, W_THR = 4.0f, W_TUU = 0.0f, W_LOCAL = 2.0f;
-constexpr float V_CUTOFF = 0.7f;
+constexpr double W_TVV = 10.0, W_TVVD = 5.0, W_TVUV = 10.0, W_THR = 4.0, W_TUU = 0.0, W_LOCAL = 2.0;
+constexpr double V_CUTOFF = 0.7;
 constexpr int BUFLEN = 30;
-constexpr float ENERGY_GATE = 0.001f;
-constexpr float INF = 1e30f;
+constexpr double ENERGY_GATE = 0.001;
+constexpr double INF = 1e30;
 constexpr int JWAVES = 8;
 constexpr int WCAP = 4096;            // floats of the sliding sample window
 constexpr int CCMAX = 1024;           // lags kept for the parabolic refinement (0.5 * fs / 52 + 1 <= 632 up to 65 kHz)
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__global__ __launch_bounds__(64) void smile_viterbi_kernel(const float* __restrict__ cand,
+__global__ __launch_bounds__(64) void smile_viterbi_kernel(const double* __restrict__ cand,
                                                            const int64_t* __restrict__ frame_off, int64_t total_frames,
-                                                           float* __restrict__ lld, unsigned char* __restrict__ back) {
-    __shared__ float dd[64];
+                                                           double* __restrict__ lld, unsigned char* __restrict__ back) {
+    __shared__ double dd[64];
     const int clip = blockIdx.x;
     const int lane = threadIdx.x;
     const int j = lane >> 3, i = lane & 7;
     const int64_t fo = frame_off[clip];
     const int T = (int)(frame_off[clip + 1] - fo);
     if (T <= 0) return;
-    const float2* c2 = reinterpret_cast<const float2*>(cand) + fo * NCAND;
+    const double2* c2 = reinterpret_cast<const double2*>(cand) + fo * NCAND;
     unsigned char* bk = back + fo * 8;
 
-    float pc = INF, ps = 0.f, pl = 0.f;                    // state i of the previous frame: cost, slope, log2 f0
-    float2 nxt = (j < NCAND) ? c2[j] : make_float2(0.f, 0.f);
+    double pc = INF, ps = 0.0, pl = 0.0;                   // state i of the previous frame: cost, slope, log2 f0
+    double2 nxt = (j < NCAND) ? c2[j] : make_double2(0.0, 0.0);
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        const float2 cur = nxt;
+        const double2 cur = nxt;
         if (t + 1 < T && j < NCAND) nxt = c2[(int64_t)(t + 1) * NCAND + j];
         const bool voiced_j = j < NCAND;
-        const bool has = voiced_j ? cur.x > 0.f : (j == NCAND);
-        const float vbest = wave_max_nonneg(voiced_j && has ? cur.y : 0.f);
-        float local;
-        if (voiced_j) local = W_LOCAL * -logf(fmaxf(cur.y, 1e-3f)) + (cur.y < V_CUTOFF ? W_THR : 0.f);
-        else local = W_LOCAL * -logf(fmaxf(1.0f - vbest, 1e-3f)) + (vbest >= V_CUTOFF ? W_THR : 0.f);
-        const float l2f = (voiced_j && has) ? log2f(cur.x) : 0.f;
-        float newcost, slope = 0.f;
+        const bool has = voiced_j ? cur.x > 0.0 : (j == NCAND);
+        double vbest = voiced_j && has ? cur.y : 0.0;     // highest voicing among the frame's candidates
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vbest = fmax(vbest, __shfl_xor(vbest, o, 64));
+        double local;
+        if (voiced_j) local = W_LOCAL * -log(fmax(cur.y, 1e-3)) + (cur.y < V_CUTOFF ? W_THR : 0.0);
+        else local = W_LOCAL * -log(fmax(1.0 - vbest, 1e-3)) + (vbest >= V_CUTOFF ? W_THR : 0.0);
+        const double l2f = (voiced_j && has) ? log2(cur.x) : 0.0;
+        double newcost, slope = 0.0;
         int istar = 0;
         if (t == 0) {
             newcost = has ? local : INF;
         } else {
             const bool ui = i == NCAND, uj = j == NCAND;
-            const float d = (ui || uj) ? 0.f : l2f - pl;
-            const float tr = (ui && uj) ? W_TUU : ((ui || uj) ? W_TVUV : W_TVV * fabsf(d) + W_TVVD * fabsf(d - ps));
-            const float c = (i <= NCAND && pc < INF) ? pc + tr : INF;
-            unsigned key = (__float_as_uint(c) & ~7u) | (unsigned)i;
-            key = min(key, dpp_u32<0xB1>(key));            // quad_perm [1,0,3,2]
-            key = min(key, dpp_u32<0x4E>(key));            // quad_perm [2,3,0,1]
-            key = min(key, dpp_u32<0x141>(key));           // row_half_mirror: the other quad of the 8-lane group
-            istar = (int)(key & 7u);
-            const float cmin = __uint_as_float(key & ~7u);
+            const double d = (ui || uj) ? 0.0 : l2f - pl;
+            const double tr = (ui && uj) ? W_TUU : ((ui || uj) ? W_TVUV : W_TVV * fabs(d) + W_TVVD * fabs(d - ps));
+            const double c = (i <= NCAND && pc < INF) ? pc + tr : INF;
+            unsigned long long key = ((unsigned long long)__double_as_longlong(c) & ~7ull) | (unsigned long long)i;
+            unsigned long long o1 = shfl_xor_u64(key, 1); key = o1 < key ? o1 : key;
+            o1 = shfl_xor_u64(key, 2); key = o1 < key ? o1 : key;
+            o1 = shfl_xor_u64(key, 4); key = o1 < key ? o1 : key;
+            istar = (int)(key & 7ull);
+            const double cmin = __shfl(c, 8 * j + istar, 64);     // the winner's exact cost (the key only ranks)
             newcost = (has && cmin < INF) ? cmin + local : INF;
             dd[lane] = d;
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            slope = (j == NCAND || istar == NCAND) ? 0.f : dd[8 * j + istar];
+            slope = (j == NCAND || istar == NCAND) ? 0.0 : dd[8 * j + istar];
             __builtin_amdgcn_wave_barrier();
         }
         // renormalise by the best state; remember which one it is (ties: lowest state)
-        float mn = INF;
+        double mn = INF;
         int be = 0;
 #pragma unroll
-        for (int s = NCAND; s >= 0; --s) {
-            const float cs = readlane_f32(newcost, 8 * s);
-            if (cs <= mn) { mn = cs; be = s; }
+        for (int st = NCAND; st >= 0; --st) {
+            const double cs = readlane_f64(newcost, 8 * st);
+            if (cs <= mn) { mn = cs; be = st; }
         }
         if (i == 0 && j <= NCAND) bk[(int64_t)t * 8 + j] = (unsigned char)istar;
         if (lane == 56) bk[(int64_t)t * 8 + 7] = (unsigned char)be;
@@ -105,29 +117,29 @@ __global__ __launch_bounds__(64) void smile_viterbi_kernel(const float* __restri
     __threadfence();
     __builtin_amdgcn_wave_barrier();
     // fixed-lag decisions, one lane per frame, then the energy gate (cValbasedSelector on pcm_RMSenergy)
-    const float* rms = lld + fo;
-    float* f0row = lld + (int64_t)14 * total_frames + fo;
-    float* vrow = lld + (int64_t)15 * total_frames + fo;
+    const double* rms = lld + fo;
+    double* f0row = lld + (int64_t)14 * total_frames + fo;
+    double* vrow = lld + (int64_t)15 * total_frames + fo;
     for (int t = lane; t < T; t += 64) {
         const int e = min(t + BUFLEN - 1, T - 1);
         int s = bk[(int64_t)e * 8 + 7];
         for (int u = e; u > t; --u) s = bk[(int64_t)u * 8 + s];
-        float F, V;
+        double F, V;
         if (s == NCAND) {
-            float vb = 0.f;
+            double vb = 0.0;
 #pragma unroll
             for (int k = 0; k < NCAND; ++k) {
-                const float2 c = c2[(int64_t)t * NCAND + k];
-                if (c.x > 0.f) vb = fmaxf(vb, c.y);
+                const double2 c = c2[(int64_t)t * NCAND + k];
+                if (c.x > 0.0) vb = fmax(vb, c.y);
             }
-            F = 0.f; V = vb;
+            F = 0.0; V = vb;
         } else {
-            const float2 c = c2[(int64_t)t * NCAND + s];
+            const double2 c = c2[(int64_t)t * NCAND + s];
             F = c.x; V = c.y;
         }
         const bool keep = rms[t] >= ENERGY_GATE;
-        f0row[t] = keep ? F : 0.f;
-        vrow[t] = keep ? V : 0.f;
+        f0row[t] = keep ? F : 0.0;
+        vrow[t] = keep ? V : 0.0;
     }
 }
 
@@ -150,7 +162,7 @@ __device__ __forceinline__ float wave_min_f32x(float x) {
 __global__ __launch_bounds__(64) void smile_jitter_kernel(const float* __restrict__ wav,
                                                           const int64_t* __restrict__ clip_off,
                                                           const int64_t* __restrict__ frame_off, int64_t total_frames,
-                                                          int fs, int frame, int hop, float* __restrict__ lld) {
+                                                          int fs, int frame, int hop, double* __restrict__ lld) {
     __shared__ float xs[WCAP];
     __shared__ double ccb[CCMAX];
     const int clip = blockIdx.y;
@@ -162,11 +174,11 @@ __global__ __launch_bounds__(64) void smile_jitter_kernel(const float* __restric
     const int T = (int)(frame_off[clip + 1] - fo);
     if (T <= 0) return;
     const float* src = wav + s0;
-    const float* f0row = lld + (int64_t)14 * total_frames + fo;
-    float* o_jl = lld + (int64_t)18 * total_frames + fo;
-    float* o_jd = lld + (int64_t)19 * total_frames + fo;
-    float* o_sh = lld + (int64_t)20 * total_frames + fo;
-    float* o_hn = lld + (int64_t)21 * total_frames + fo;
+    const double* f0row = lld + (int64_t)14 * total_frames + fo;
+    double* o_jl = lld + (int64_t)18 * total_frames + fo;
+    double* o_jd = lld + (int64_t)19 * total_frames + fo;
+    double* o_sh = lld + (int64_t)20 * total_frames + fo;
+    double* o_hn = lld + (int64_t)21 * total_frames + fo;
 
     int run_id = 0;
     bool carry = false;                                    // frame base-1 voiced
@@ -174,8 +186,8 @@ __global__ __launch_bounds__(64) void smile_jitter_kernel(const float* __restric
 #pragma unroll 1
     for (int base = 0; base < T; base += 64) {
         const int tl = base + lane;
-        const bool voiced = tl < T && f0row[tl] > 0.f;
-        if (my == 0 && tl < T && !voiced) { o_jl[tl] = 0.f; o_jd[tl] = 0.f; o_sh[tl] = 0.f; o_hn[tl] = 0.f; }
+        const bool voiced = tl < T && f0row[tl] > 0.0;
+        if (my == 0 && tl < T && !voiced) { o_jl[tl] = 0.0; o_jd[tl] = 0.0; o_sh[tl] = 0.0; o_hn[tl] = 0.0; }
         const unsigned long long vm = __ballot(voiced);
         unsigned long long starts = vm & ~((vm << 1) | (carry ? 1ull : 0ull));
         carry = (vm >> 63) & 1ull;
@@ -189,12 +201,12 @@ __global__ __launch_bounds__(64) void smile_jitter_kernel(const float* __restric
             double pos = (double)(base + b) * hop;
             bool hasT = false, hasD = false, dead = false;
             double prevT = 0, prevD = 0, prevA = 0;
-            float l_jl = 0.f, l_jd = 0.f, l_sh = 0.f, l_hn = 0.f;
+            double l_jl = 0.0, l_jd = 0.0, l_sh = 0.0, l_hn = 0.0;
 #pragma unroll 1
             for (int t = base + b; t < T; ++t) {
-                const float f0f = f0row[t];
-                if (!(f0f > 0.f)) break;
-                const double T0 = (double)fs / (double)f0f;
+                const double f0f = f0row[t];
+                if (!(f0f > 0.0)) break;
+                const double T0 = (double)fs / f0f;
                 const int lo = (int)ceil(0.75 * T0), hi = (int)floor(1.25 * T0);
                 const int W = (int)floor(T0 + 0.5);
                 const double end = (double)(t + 1) * hop;
@@ -272,10 +284,10 @@ __global__ __launch_bounds__(64) void smile_jitter_kernel(const float* __restric
                     const double mT = sT / nT, mA = sA / nT;
                     double c = sC / nT;
                     c = fmin(fmax(c, 1e-3), 1.0 - 1e-6);
-                    l_jl = ndT > 0 ? (float)((sdT / ndT) / mT) : 0.f;
-                    l_jd = ndD > 0 ? (float)((sdD / ndD) / mT) : 0.f;
-                    l_sh = (ndT > 0 && mA > 0.0) ? (float)((sdA / ndT) / mA) : 0.f;
-                    l_hn = (float)log(c / (1.0 - c));
+                    l_jl = ndT > 0 ? (sdT / ndT) / mT : 0.0;
+                    l_jd = ndD > 0 ? (sdD / ndD) / mT : 0.0;
+                    l_sh = (ndT > 0 && mA > 0.0) ? (sdA / ndT) / mA : 0.0;
+                    l_hn = log(c / (1.0 - c));
                 }
                 if (lane == 0) { o_jl[t] = l_jl; o_jd[t] = l_jd; o_sh[t] = l_sh; o_hn[t] = l_hn; }
             }
@@ -293,12 +305,12 @@ extern "C" {
 
 int64_t rsaf_smile_workspace_bytes(int64_t total_frames) {
     if (total_frames < 0) return -1;
-    // candidates (f0, voicing) x 6 per frame + the 8-byte back-pointer record per frame
-    return total_frames * (int64_t)(NCAND * 2 * sizeof(float) + 8) + 256;
+    // candidates (f0, voicing) x 6 per frame (float64) + the 8-byte back-pointer record per frame
+    return total_frames * (int64_t)(NCAND * 2 * sizeof(double) + 8) + 256;
 }
 
 int rsaf_smile_pitch_track(const float* wav, const int64_t* clip_off, const int64_t* frame_off, int n_clips,
-                           int64_t total_frames, int sample_rate, const float* cand, void* back_workspace, float* lld,
+                           int64_t total_frames, int sample_rate, const double* cand, void* back_workspace, double* lld,
                            rsaf_stream_t stream) {
     RSAF_CHECK_ARG(n_clips >= 0 && n_clips <= 65535, "n_clips must be in [0, 65535] per call");
     if (n_clips == 0 || total_frames == 0) return RSAF_OK;

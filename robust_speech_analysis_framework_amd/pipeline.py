@@ -106,7 +106,7 @@ class Pipeline:
         if self.mshds is not None and not self.overlap:
             cols.append(mshds_cols)
         if "smile" in self.stages:
-            cols.append(smile.smile_features(p))
+            cols.append(smile.smile_features(p).to(torch.float32))
         if self.w2v2 is not None:
             offs = np.arange(n_clips, dtype=np.int64) * n_samp
             seq, frame_off = self.w2v2.extract_packed(p.wav, offs, [n_samp] * n_clips)

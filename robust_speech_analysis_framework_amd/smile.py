@@ -110,18 +110,18 @@ def pack_clips(clips, device="cuda", fs=SAMPLE_RATE) -> PackedClips:
 
 
 def smile_lld(p: PackedClips, stream=None, octave_spectrum=False, return_candidates=False):
-    """All 38 LLD contours, float32 [38, total_frames] (contour-major): the frame kernel
+    """All 38 LLD contours, float64 [38, total_frames] (contour-major): the frame kernel
     (``rsaf_smile_lld_batch``) followed by the Viterbi smoother / energy gate / jitter pass (``rsaf_smile_pitch_track``).
     ``octave_spectrum`` also returns the cSpecScale level [total_frames, nfft/2+1]; ``return_candidates`` the
     cPitchShs candidates [total_frames, 6, 2] (f0, voicing)."""
     import torch
     lib = _lib.load()
     dev = p.wav.device
-    lld = torch.empty((NLLD, max(p.total_frames, 1)), dtype=torch.float32, device=dev)
-    cand = torch.zeros((max(p.total_frames, 1), NCAND, 2), dtype=torch.float32, device=dev)
+    lld = torch.empty((NLLD, max(p.total_frames, 1)), dtype=torch.float64, device=dev)
+    cand = torch.zeros((max(p.total_frames, 1), NCAND, 2), dtype=torch.float64, device=dev)
     oct_ = None
     if octave_spectrum:
-        oct_ = torch.zeros((max(p.total_frames, 1), geometry(p.fs)[2] // 2 + 1), dtype=torch.float32, device=dev)
+        oct_ = torch.zeros((max(p.total_frames, 1), geometry(p.fs)[2] // 2 + 1), dtype=torch.float64, device=dev)
     if p.total_frames == 0:
         res = [lld[:, :0]]
     else:
@@ -146,10 +146,10 @@ def smile_lld(p: PackedClips, stream=None, octave_spectrum=False, return_candida
 
 
 def smile_functionals(lld, p: PackedClips, stream=None, window_frames: int = 0):
-    """[n_clips, 912] float32 functionals of the LLD contours (``window_frames`` = 0: whole clip)."""
+    """[n_clips, 912] float64 functionals of the LLD contours (``window_frames`` = 0: whole clip)."""
     import torch
     lib = _lib.load()
-    out = torch.empty((p.n_clips, NFEAT), dtype=torch.float32, device=p.wav.device)
+    out = torch.empty((p.n_clips, NFEAT), dtype=torch.float64, device=p.wav.device)
     if p.n_clips:
         _lib.check(lib.rsaf_smile_functionals(
             _lib.ptr(lld) if lld.numel() else None, _lib.ptr(p.frame_off), p.n_clips,

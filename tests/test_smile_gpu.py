@@ -7,14 +7,13 @@ pytestmark = pytest.mark.gpu
 
 from oracle import smile_oracle as so
 
-# parity metric of SURVEY.md §8d: per LLD row / feature column, max|gpu-cpu| / max|cpu|
+# parity metric of SURVEY.md §8d: per LLD row / feature column, max|gpu-cpu| / max|cpu|.  north_star's bar is 1e-4 for values
+# and exact for indices; the chain is float64 on both sides since round 3, so the values agree far inside it and every
+# decision (peak enhancement, candidate ranking, Viterbi path, jitter lags, roll-off bins, maxPos / minPos) must coincide.
 TOL = 1e-4
+TIGHT = 1e-9                   # what float64-vs-float64 actually delivers (different FFT / summation orders)
 ROLLOFF_ROWS = (24, 25, 26, 27)
 PITCH_ROWS = (14, 15, 18, 19, 20, 21)
-# spectralFlatness = exp(mean(log P)) / mean(P): the log of the weakest bins (pre-emphasised
-# low-frequency bins ~1e-11 in power) is dominated by float32 FFT rounding (~6e-8 * |X|max per
-# bin), so this one row is compared at 1e-3 (openSMILE itself is float32, FLOAT_DMEM).
-ROW_TOL = {37: 1e-3}
 
 
 def _clips(seconds_list, first=0):
@@ -57,29 +56,27 @@ def _run_gpu(clips, fs=16000):
     p = smile.pack_clips(clips, fs=fs)
     lld, octv, cand = smile.smile_lld(p, octave_spectrum=True, return_candidates=True)
     torch.cuda.synchronize()
-    return p, lld.cpu().numpy().astype(np.float64), octv.cpu().numpy().astype(np.float64), cand.cpu().numpy().astype(np.float64)
+    assert lld.dtype == torch.float64 and cand.dtype == torch.float64
+    return p, lld.cpu().numpy(), octv.cpu().numpy(), cand.cpu().numpy()
 
 
-def _check_frame_rows(gpu, ref, P):
-    """The 32 frame-local rows (everything but the pitch chain)."""
+def _check_rows(gpu, ref, P):
+    """All 38 rows, end to end against the float64 oracle: values at TIGHT (<< north_star's 1e-4), roll-off bins and the
+    voiced / unvoiced pattern exact."""
     assert not np.isnan(gpu).any()
+    assert np.array_equal(gpu[14] > 0, ref[14] > 0)                    # the Viterbi path's voicing decisions
     for i in range(so.NLLD):
-        if i in PITCH_ROWS:
-            continue
         scale = np.max(np.abs(ref[i])) + 1e-30
         err = np.abs(gpu[i] - ref[i])
         if i in ROLLOFF_ROWS:
-            # a roll-off is a bin index: fp32 vs fp64 cumulative sums may flip a threshold crossing
-            # by one bin on isolated frames; everything else must be exact
-            assert (err > 1e-3).mean() <= 2e-3, (so.LLD_NAMES[i], (err > 1e-3).mean())
-            assert err.max() <= P.df + 1e-3
+            assert np.array_equal(gpu[i], ref[i]), so.LLD_NAMES[i]     # bin index * df: exact
         else:
-            assert err.max() / scale <= ROW_TOL.get(i, TOL), (so.LLD_NAMES[i], err.max() / scale)
+            assert err.max() / scale <= TIGHT, (so.LLD_NAMES[i], err.max() / scale, int(np.argmax(err)))
 
 
 def _check_pitch_chain(clips, p, g, octv, cand, P, min_voiced=0.05):
-    """Stage by stage, each stage of the oracle fed with the GPU's output of the stage before: then the only
-    differences are float32 vs float64 arithmetic inside ONE stage, and discrete decisions can be compared exactly."""
+    """Diagnostic view of the pitch chain, stage by stage (each oracle stage fed with the GPU's output of the stage
+    before), kept from the float32 era: it says WHERE a disagreement of _check_rows starts."""
     off = 0
     voiced_total = 0
     for c, nf in zip(clips, p.frames):
@@ -87,32 +84,22 @@ def _check_pitch_chain(clips, p, g, octv, cand, P, min_voiced=0.05):
             continue
         sl = slice(off, off + nf)
         _, _, mag = so.magnitudes(c, P)
-        # (a) cSpecScale: float32 FFT noise can flip a local-maximum decision of the peak enhancement on noise-floor
-        # bins (a few frames); elsewhere the octave spectrum agrees to float32 accuracy
-        S_ref = np.stack([so.spec_scale(mag[t], P) for t in range(nf)])
+        S_ref = np.stack([so.spec_scale(mag[t], P) for t in range(nf)])                # (a) cSpecScale
         scale = np.abs(S_ref).max(axis=1) + 1e-30
         err = np.abs(octv[sl] - S_ref).max(axis=1) / scale
-        assert np.median(err) < 2e-6, np.median(err)
-        assert (err > 1e-4).mean() <= 0.05, (err > 1e-4).mean()
-        # (b) cPitchShs on the GPU's own octave spectrum
-        ref_c = np.stack([so.shs_candidates(octv[off + t], P)[:, :2] for t in range(nf)])
+        assert err.max() <= TIGHT, (err.max(), int(np.argmax(err)))
+        ref_c = np.stack([so.shs_candidates(octv[off + t], P)[:, :2] for t in range(nf)])   # (b) cPitchShs
         got_c = cand[sl]
-        same_slots = (got_c[:, :, 0] > 0) == (ref_c[:, :, 0] > 0)
-        fe = np.abs(got_c[:, :, 0] - ref_c[:, :, 0]) / np.maximum(ref_c[:, :, 0], 1.0)
-        ve = np.abs(got_c[:, :, 1] - ref_c[:, :, 1])
-        frame_ok = same_slots.all(axis=1) & (fe.max(axis=1) < 1e-4) & (ve.max(axis=1) < 1e-4)
-        assert frame_ok.mean() >= 0.995, frame_ok.mean()          # score near-ties may swap two slots on isolated frames
-        # (c) Viterbi + energy gate on the GPU's candidates
+        assert np.array_equal(got_c[:, :, 0] > 0, ref_c[:, :, 0] > 0)
+        assert np.abs(got_c - ref_c).max() <= TIGHT * 1000.0                             # f0 up to 620 Hz
         c3 = np.concatenate([got_c, (got_c[:, :, :1] > 0).astype(np.float64)], axis=2)
-        F, V = so.viterbi_smooth(c3)
+        F, V = so.viterbi_smooth(c3)                                                     # (c) Viterbi + energy gate
         F, V = so.energy_gate(F, V, g[0, sl])
-        agree = (np.abs(g[14, sl] - F) <= 1e-6 * np.maximum(F, 1.0)) & (np.abs(g[15, sl] - V) <= 1e-6)
-        assert agree.mean() >= 0.99, agree.mean()                  # float32 path costs: a near-tie can move a decision
-        # (d) jitter / shimmer / logHNR on the GPU's F0final row (float32 values are exact in double: same lags)
-        J = so.jitter_shimmer(c, g[14, sl], P)
+        assert np.array_equal(g[14, sl], F) and np.array_equal(g[15, sl], V)             # same path, same candidates: bit-equal
+        J = so.jitter_shimmer(c, g[14, sl], P)                                           # (d) cPitchJitter
         for r, row in enumerate((18, 19, 20, 21)):
             sc = np.abs(J[r]).max() + 1e-30
-            assert np.abs(g[row, sl] - J[r]).max() / sc <= TOL, (so.LLD_NAMES[row], np.abs(g[row, sl] - J[r]).max() / sc)
+            assert np.abs(g[row, sl] - J[r]).max() / sc <= TIGHT, so.LLD_NAMES[row]
         voiced_total += int((g[14, sl] > 0).sum())
         off += nf
     assert voiced_total >= min_voiced * sum(p.frames)               # the chain was actually exercised
@@ -125,8 +112,8 @@ def test_lld_parity_ragged_batch(rsaf_lib):
     assert p.frames == [so.n_frames(len(c)) for c in clips]       # integer-exact frame counts
     ref = np.concatenate([so.lld(c) for c in clips], axis=1)
     assert g.shape == ref.shape
-    _check_frame_rows(g, ref, P)
     _check_pitch_chain(clips, p, g, octv, cand, P)
+    _check_rows(g, ref, P)
 
 
 def test_lld_parity_30s_clip(rsaf_lib):
@@ -135,14 +122,9 @@ def test_lld_parity_30s_clip(rsaf_lib):
     p, g, octv, cand = _run_gpu(clips)
     assert p.frames == [2998, 2998]
     ref = np.concatenate([so.lld(c) for c in clips], axis=1)
-    _check_frame_rows(g, ref, P)
     _check_pitch_chain(clips, p, g, octv, cand, P)
-    # end to end against the float64 oracle: the rows agree on all but isolated frames
-    sl = slice(2998, 5996)
-    both = (g[14, sl] > 0) == (ref[14, sl] > 0)
-    close = np.abs(g[14, sl] - ref[14, sl]) <= 1e-4 * np.maximum(ref[14, sl], 1.0)
-    assert both.mean() >= 0.98 and (both & close).mean() >= 0.97, (both.mean(), (both & close).mean())
-    assert (ref[14, sl] > 0).mean() > 0.3
+    _check_rows(g, ref, P)                                             # all 38 rows end to end, 30 s voiced clip included
+    assert (ref[14, 2998:] > 0).mean() > 0.3
 
 
 @pytest.mark.parametrize("fs", [8000, 22050, 44100, 48000])
@@ -155,8 +137,8 @@ def test_native_sample_rates(rsaf_lib, fs):
     assert p.frames == [P.n_frames(len(c)) for c in clips]
     ref = np.concatenate([so.lld(c, P) for c in clips], axis=1)
     assert g.shape == ref.shape and octv.shape[1] == P.nbins
-    _check_frame_rows(g, ref, P)
     _check_pitch_chain(clips, p, g, octv, cand, P)
+    _check_rows(g, ref, P)
 
 
 def test_known_answers_through_the_kernels(rsaf_lib):
@@ -199,69 +181,73 @@ def test_functionals_exact_on_identical_input(rsaf_lib, window):
     lld = smile.smile_lld(p)
     f = smile.smile_functionals(lld, p, window_frames=window)
     torch.cuda.synchronize()
-    g = f.cpu().numpy().astype(np.float64)
-    assert np.isfinite(g).all()                                        # 912 / 912 columns, all 38 LLDs built
+    g = f.cpu().numpy()
+    assert f.dtype == torch.float64 and np.isfinite(g).all()          # 912 / 912 columns, all 38 LLDs built
     names = so.feature_names()
     pos = np.array([n.endswith("Pos") for n in names])
-    off = 0
-    refs = []
     x_all = lld.cpu().numpy()
+    off, refs = 0, []
     for nf in p.frames:
-        # the kernel forms sma3/delta in float32 (openSMILE is FLOAT_DMEM); mirror that so the only
-        # difference left is the float64 accumulation order of the statistics themselves
-        x32 = x_all[:, off:off + nf]
-        s32 = _sma32(x32).astype(np.float64)
-        d32 = _delta32(_sma32(x32)).astype(np.float64)
-        if window:
-            s32, d32 = s32[:, :window], d32[:, :window]
-        fs_, fd = so.functionals12(s32), so.functionals12(d32)
-        parts = []
-        for lo, hi in so.LEVELS:
-            parts += [fs_[lo:hi].reshape(-1), fd[lo:hi].reshape(-1)]
-        refs.append(np.concatenate(parts))
+        refs.append(so.functionals(x_all[:, off:off + nf], window))
         off += nf
     ref = np.stack(refs)
     scale = np.max(np.abs(ref), axis=0) + 1e-30
     err = np.abs(g - ref).max(axis=0) / scale
-    assert err[~pos].max() <= TOL, (names[int(np.argmax(np.where(~pos, err, 0)))], err[~pos].max())
+    assert err[~pos].max() <= 1e-8, (names[int(np.argmax(np.where(~pos, err, 0)))], err[~pos].max())
     assert np.array_equal(g[:, pos], ref[:, pos])                      # maxPos / minPos: integer-exact
     if window:
         assert g[:, pos].max() <= window - 1
 
 
-def _sma32(x):
-    p = np.pad(x, ((0, 0), (1, 1)), mode="edge").astype(np.float32)
-    return ((p[:, :-2] + p[:, 1:-1]) + p[:, 2:]) / np.float32(3.0)
-
-
-def _delta32(s):
-    p = np.pad(s, ((0, 0), (2, 2)), mode="edge").astype(np.float32)
-    return ((p[:, 3:-1] - p[:, 1:-3]) + np.float32(2.0) * (p[:, 4:] - p[:, :-4])) / np.float32(10.0)
+def _assert_all_912(g, ref):
+    names = so.feature_names()
+    assert g.shape == ref.shape and np.isfinite(g).all() and np.isfinite(ref).all()
+    pos = np.array([n.endswith("Pos") for n in names])
+    bad = np.argwhere(g[:, pos] != ref[:, pos])
+    assert bad.size == 0, [(int(r), np.array(names)[pos][int(c)], g[:, pos][r, c], ref[:, pos][r, c]) for r, c in bad[:8]]
+    # values: north_star's bar is 1e-4 of the column; float64 on both sides delivers ~1e-10.  Columns whose reference
+    # value is a cancellation residue (a regression slope or skewness that is zero up to rounding) are measured against
+    # the scale of their contour instead of against themselves
+    scale = np.maximum(np.abs(ref), 1e-6 * np.max(np.abs(ref), axis=1, keepdims=True))
+    err = np.abs(g - ref) / scale
+    worst = np.unravel_index(int(np.argmax(err)), err.shape)
+    assert err.max() <= TOL, (names[worst[1]], int(worst[0]), g[worst], ref[worst])
+    col_scale = np.max(np.abs(ref), axis=0) + 1e-30
+    assert (np.abs(g - ref).max(axis=0) / col_scale).max() <= 1e-7
 
 
 def test_end_to_end_features_parity(rsaf_lib):
+    """ALL 912 columns of every clip against the float64 oracle, end to end (no stage-wise feeding): a 30 s voiced clip,
+    a 30 s synthetic-speech clip and a ragged batch; maxPos / minPos columns exact, everything else within 1e-4."""
     import torch
     from robust_speech_analysis_framework_amd import smile
-    clips = _clips([5.0] * 3, first=40) + [voiced_clip(5, 5.0)]
-    p = smile.pack_clips(np.stack(clips))
+    clips = [voiced_clip(5, 30.0)] + _clips([30.0], first=44) + _clips([5.0, 1.003, 2.51, 0.0349, 0.025], first=40) \
+        + [voiced_clip(8, 2.2), voiced_clip(9, 0.61)]
+    p = smile.pack_clips(clips)
     f = smile.smile_features(p)
     torch.cuda.synchronize()
-    g = f.cpu().numpy().astype(np.float64)
-    ref = np.stack([so.extract(c) for c in clips])
-    names = so.feature_names()
-    assert np.isfinite(g).all() and np.isfinite(ref).all()
-    scale = np.max(np.abs(ref), axis=0) + 1e-30
-    err = np.abs(g - ref).max(axis=0) / scale
-    # discrete outputs (positions, roll-off extrema) can move by one step under fp32-vs-fp64 rounding; they are pinned
-    # exactly in test_functionals_exact_on_identical_input.  The six pitch-chain contours are decision sequences
-    # (candidate ranking, Viterbi path): their statistics are compared stage by stage in _check_pitch_chain.
-    pitch = np.array([n.split("_sma")[0] in ("F0final", "voicingFinalUnclipped", "jitterLocal", "jitterDDP", "shimmerLocal", "logHNR")
-                      for n in names])
-    discrete = np.array([n.endswith("Pos") or "RollOff" in n for n in names]) | pitch
-    worst = int(np.argmax(np.where(discrete, 0, err)))
-    assert err[~discrete].max() <= 5e-4, (names[worst], err[worst])
-    smooth = pitch & np.array([n.endswith(("amean", "stddev")) for n in names])
-    assert np.median(err[smooth]) <= 1e-3                               # typical agreement of the pitch statistics
+    g = f.cpu().numpy()
+    ref = np.stack(_oracle_pool(clips))
+    _assert_all_912(g, ref)
+    # the literal [functL1] reading (first 25 ms window) end to end as well
+    f3 = smile.smile_features(p, window_frames=3)
+    torch.cuda.synchronize()
+    _assert_all_912(f3.cpu().numpy(), np.stack(_oracle_pool(clips, 3)))
+
+
+def _oracle_extract(args):
+    from oracle import smile_oracle
+    c, window = args
+    return smile_oracle.extract(c, window_frames=window)
+
+
+def _oracle_pool(clips, window=0):
+    """The Python-loop parts of the oracle (spline, Viterbi, jitter) take ~1 s per audio-second: one process per clip
+    (spawned: the test process has initialised the GPU and must not fork)."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    with cf.ProcessPoolExecutor(max_workers=min(8, len(clips)), mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_oracle_extract, [(c, window) for c in clips]))
 
 
 def test_dropin_dataframe_contract(rsaf_lib, tmp_path):
@@ -284,8 +270,7 @@ def test_dropin_dataframe_contract(rsaf_lib, tmp_path):
     # the 44.1 kHz file went through the 2048-point chain at its own rate
     ref = so.extract(voiced_clip(6, 0.8, fs=44100), fs=44100)
     names = so.feature_names()
-    k = names.index("mfcc_sma[3]_amean")
-    assert abs(vals[1, k] - ref[k]) <= 1e-3 * abs(ref[k])
+    _assert_all_912(vals[1:2], ref[None, :])                           # the whole row of the 44.1 kHz file, positions exact
     first = smile.extract_opensmile_features(df, "x", str(conf), verbose=False, functionals="first-window")
     assert first[[n for n in names if n.endswith("maxPos")]].to_numpy().max() <= 2.0
     # downstream of the drop-in in notebook 01: session aggregation must see finite numbers (SVM pipelines reject NaN)
