@@ -387,6 +387,11 @@ int64_t rsaf_resample_praat_work_bytes(int64_t n_in, double fs_in, double fs_out
  * n float64 samples at out + out_off, through 2^(lg-1) complex numbers at work + work_off (2^lg = first power of two
  * >= n + 2000, 11 <= lg <= lg_max <= 24); upfactor = new rate * old sample period < 1; work_complex = complex numbers
  * in `work`. */
+/* Longest sound (samples) the whole-sound FFT low-pass takes: 2^26 - 2000 (25 min at 44.1 kHz, 69 min at 16 kHz); the
+ * transform runs as two LDS passes of at most 8192 x 4096 complex points.  Longer input: rsaf_resample_praat /
+ * rsaf_praat_lowpass_batch return RSAF_ERR_ARG; the MSHDS drop-in then gives NaN for the formant columns of that clip only
+ * (16 kHz input) or the reference's per-file NaN row (other rates). */
+int64_t rsaf_praat_lowpass_max_samples(void);
 int rsaf_praat_lowpass_batch(const float* in, const void* sigs, int n_sigs, int lg_max, double upfactor, void* work,
                              int64_t work_complex, double* out, rsaf_stream_t stream);
 int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_out, int precision, float* out,

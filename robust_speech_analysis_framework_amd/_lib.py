@@ -85,6 +85,7 @@ SIGNATURES = {
     "rsaf_resample_sinc_hann": (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _L, _P]),
     "rsaf_praat_lowpass_batch": (_I, [_P, _P, _I, _I, C.c_double, _P, _L, _P, _P]),
     "rsaf_resample_praat_work_bytes": (_L, [_L, C.c_double, C.c_double]),
+    "rsaf_praat_lowpass_max_samples": (_L, []),
     "rsaf_resample_praat": (_I, [_P, _L, C.c_double, C.c_double, _I, _P, _L, _P, _L, _P]),
     "rsaf_segment_mean_std": (_I, [_P, _L, _P, _P, _I, _I, _P, _P]),
     "rsaf_gather_rows_f32": (_I, [_P, _L, _P, _L, _I, _P, _L, _P]),

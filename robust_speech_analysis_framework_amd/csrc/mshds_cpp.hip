@@ -592,7 +592,7 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
     RSAF_CHECK_ARG(wav && clip_info && pulses && n_pulses && window1000 && twiddle1024 && seg_table && hdr && resampled &&
                    cepstrogram && cpp_frames && lowpassed && lp_work && out, "NULL pointer");
     RSAF_CHECK_ARG(max_seg >= 1 && cap_res >= 1 && cap_frames >= 1 && cap_frames <= 65535 * 32 && cap_work >= 1024 &&
-                   lg_max >= 11 && lg_max <= 24, "bad capacities");
+                   lg_max >= 11 && lg_max <= resample::LP_LG_MAX, "bad capacities");
     hipStream_t s = (hipStream_t)stream;
     const ClipInfo* ci = (const ClipInfo*)clip_info;
     Seg* segs = (Seg*)seg_table;

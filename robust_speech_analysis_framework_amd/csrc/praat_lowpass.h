@@ -17,7 +17,8 @@ namespace resample {
 // workgroup owns both rows, clears what Praat clears, folds back to Z' and runs the inverse row transforms (decimation
 // in time: bit-reversed in, natural out).  The inverse column pass undoes the first one.  No pass reorders memory.
 typedef double2 c64;
-constexpr int TW_LOG = 12, TW_N = 1 << TW_LOG;        // W_4096^j: butterflies of every LDS transform (length <= 4096)
+constexpr int TW_LOG = 13, TW_N = 1 << TW_LOG;        // W_8192^j: butterflies of every LDS transform (length <= 8192)
+constexpr int LP_LG_MAX = 26;                         // longest transform: 2^26 samples (25 min at 44.1 kHz, 69 min at 16 kHz)
 constexpr int ANTI_TURN_AROUND = 1000;
 
 __device__ __forceinline__ c64 cmul(c64 a, c64 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -30,9 +31,9 @@ __device__ __forceinline__ c64 mul_pi(c64 a) { return make_double2(-a.y, a.x); }
 __device__ __forceinline__ int bitrev(int v, int bits) { return bits ? (int)(__brev((unsigned)v) >> (32 - bits)) : 0; }
 
 struct LpTables {
-    const c64* tw;      // [4096]  e^(-2 pi i j / 4096)
-    const c64* lo;      // [4096]  e^(-2 pi i j / nfft_max)
-    const c64* hi;      // [nfft_max / 4096 or 1]  e^(-2 pi i 4096 j / nfft_max)
+    const c64* tw;      // [TW_N]  e^(-2 pi i j / TW_N)
+    const c64* lo;      // [TW_N]  e^(-2 pi i j / nfft_max)
+    const c64* hi;      // [nfft_max / TW_N or 1]  e^(-2 pi i TW_N j / nfft_max)
     int lg_max;         // the tables belong to nfft_max = 2^lg_max; a shorter transform strides through them
 };
 
@@ -59,11 +60,14 @@ struct LpGeom { int log1, log2, C, logC; };
 __host__ __device__ inline LpGeom lp_geom(int lg) {
     LpGeom g;
     const int logM = lg - 1;                            // lg >= 11
-    g.log2 = (logM + 1) / 2 < 11 ? (logM + 1) / 2 : 11; // about square; rows of at most 2 048 points
+    // about square; rows of at most 2 048 points (two rows = 64 KB of LDS), columns of at most 4 096 (64 KB); the two
+    // longest transforms (2^25, 2^26 samples) take rows of 4 096 and columns of up to 8 192 points: 128 KB of the 160 KB
+    const int row_cap = lg <= 24 ? 11 : 12, col_cap = lg <= 24 ? 4096 : 8192;
+    g.log2 = (logM + 1) / 2 < row_cap ? (logM + 1) / 2 : row_cap;
     g.log1 = logM - g.log2;
     g.C = 8;
     g.logC = 3;
-    while (g.C > 1 && ((int64_t)g.C << g.log1) > 4096) { g.C >>= 1; --g.logC; }
+    while (g.C > 1 && ((int64_t)g.C << g.log1) > col_cap) { g.C >>= 1; --g.logC; }
     return g;
 }
 

@@ -142,6 +142,8 @@ int rsaf_resample_sinc_hann(const float* in, int64_t n_in, const float* taps, co
     return RSAF_OK;
 }
 
+int64_t rsaf_praat_lowpass_max_samples(void) { return ((int64_t)1 << resample::LP_LG_MAX) - 2 * resample::ANTI_TURN_AROUND; }
+
 int64_t rsaf_resample_praat_work_bytes(int64_t n_in, double fs_in, double fs_out) {
     if (n_in <= 0 || !(fs_in > 0.0) || !(fs_out > 0.0)) return 0;
     const double upfactor = fs_out * (1.0 / fs_in);
@@ -159,7 +161,7 @@ int64_t rsaf_resample_praat_work_bytes(int64_t n_in, double fs_in, double fs_out
 static int launch_lowpass(const float* in, double* out, resample::c64* work, const resample::LpSig* sigs, int n_sigs,
                           const resample::LpSig& one, int lg_max, double upfactor, hipStream_t s, int mode = resample::LP_LOWPASS) {
     using namespace resample;
-    RSAF_CHECK_ARG(lg_max >= 11 && lg_max <= 24, "sound longer than 2^24 - 2000 samples: the low-pass transform does not fit its two LDS passes");
+    RSAF_CHECK_ARG(lg_max >= 11 && lg_max <= LP_LG_MAX, "sound longer than 2^26 - 2000 samples: the low-pass transform does not fit its two LDS passes");
     LpTables T;
     const int lg_tab = lg_max + (mode == LP_UPSAMPLE_ODD ? 1 : 0);   // the half-sample turn needs e^(-2 pi i k / (2 nfft))
     {
@@ -222,7 +224,7 @@ int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_o
         int64_t nfft = 1;
         int lg = 0;
         while (nfft < n_in + 2 * resample::ANTI_TURN_AROUND) { nfft *= 2; ++lg; }
-        RSAF_CHECK_ARG(lg <= 24, "sound longer than 2^24 - 2000 samples: the transform does not fit its two LDS passes");
+        RSAF_CHECK_ARG(lg <= resample::LP_LG_MAX, "sound longer than 2^26 - 2000 samples: the transform does not fit its two LDS passes");
         RSAF_CHECK_ARG(work && work_bytes >= rsaf_resample_praat_work_bytes(n_in, fs_in, fs_out), "workspace missing or too small");
         resample::c64* wk = (resample::c64*)work;
         double* even = (double*)(wk + nfft / 2);
@@ -250,7 +252,7 @@ int rsaf_resample_praat(const float* in, int64_t n_in, double fs_in, double fs_o
     int64_t nfft = 1;
     int lg = 0;
     while (nfft < n_in + 2 * resample::ANTI_TURN_AROUND) { nfft *= 2; ++lg; }
-    RSAF_CHECK_ARG(lg <= 24, "sound longer than 2^24 - 2000 samples: the low-pass transform does not fit its two LDS passes");
+    RSAF_CHECK_ARG(lg <= resample::LP_LG_MAX, "sound longer than 2^26 - 2000 samples: the low-pass transform does not fit its two LDS passes");
     RSAF_CHECK_ARG(work && work_bytes >= rsaf_resample_praat_work_bytes(n_in, fs_in, fs_out), "workspace missing or too small");
     resample::c64* wk = (resample::c64*)work;
     double* lp = (double*)(wk + nfft / 2);

@@ -53,7 +53,7 @@ constexpr double I0 = 1e-6;
 constexpr double SHS_MINPITCH = 52.0, SHS_MAXPITCH = 620.0;
 constexpr double LN2 = 0.69314718055994530942;
 
-constexpr int RUNW = 8;                  // frames per wave
+constexpr int RUNW = 16;                 // frames per wave
 constexpr int NSUM = 24;                 // doubles a frame leaves for the end-of-run pass
 constexpr int RED_D = 8 * 65;            // doubles of the 8-sums-at-a-time reduction scratch
 
@@ -67,8 +67,10 @@ struct Geo {
     // LDS of one wave, in doubles
     static constexpr int Z_D = 2 * NC + 8;           // FFT buffer (c64[NC]); later two arrays of NB doubles
     static constexpr int ARR = NC + 8;               // one per-bin array
+    static constexpr int S_D = 2 * NC + 8;           // the octave spectrum + a zero pad longer than the largest harmonic shift (< 0.62 NC)
+    static constexpr int MELCAP = NC / 4;            // cap of the longest side of a triangular mel band, in bins
     static constexpr bool RED_IN_Z = Z_D >= RED_D;   // the reduction scratch lives in the FFT buffer when it fits
-    static constexpr int OFF_MAG = Z_D, OFF_MAGP = Z_D + ARR, OFF_S = Z_D + 2 * ARR, OFF_STASH = Z_D + 3 * ARR;
+    static constexpr int OFF_MAG = Z_D, OFF_MAGP = Z_D + ARR, OFF_S = Z_D + 2 * ARR, OFF_STASH = Z_D + 2 * ARR + S_D;
     static constexpr int OFF_RED = RED_IN_Z ? 0 : OFF_STASH + RUNW * NSUM;
     static constexpr int WAVE_D = OFF_STASH + RUNW * NSUM + (RED_IN_Z ? 0 : RED_D);
 };
@@ -86,8 +88,11 @@ struct __attribute__((aligned(16))) Tables {
     double audw[G::NBP];              // auditory weighting of target i
     double sp_g[G::NBP];              // tridiagonal (1, 4, 1) elimination factors, 0 at bin 0
     int klo[G::NBP];
-    double dct[NMFCC * NMEL];         // DCT-II rows 1..12 with the lifter folded in
+    double dct[NMEL * 16];            // DCT-II rows 1..12 with the lifter folded in, transposed: [band j][coefficient k] (16 per row)
     int seg_start[32];                // bins with lower channel c are [seg_start[c], seg_start[c+1]), c = 0..26
+    double mel_w[G::MELCAP * 64];     // lane 2 c + side = one side of triangular band c: weight of its i-th bin at [i * 64 + lane]
+    int mel_b0[64];                   // ... first bin of that side
+    int mel_len, mel_pad[3];          // bins of the longest side
     int shs_shift[16];
     double shs_w[16];
     double ham_sum, df, fmin_l2, dl2;
@@ -136,10 +141,23 @@ static void build_tables(Tables<LOG2N>& t, int fs, int frame, int hop) {
         while (b < G::NB && lo_chan[b] >= 0 && lo_chan[b] < c) ++b;
         t.seg_start[c] = b;
     }
+    // band c (0-based) = rising side (bins whose lower channel is c, weight 1 - lo_wt) + falling side (lower channel c + 1,
+    // weight lo_wt); lane 2 c + side walks its side, the weights transposed so that a step of all lanes is one coalesced load
+    t.mel_len = 0;
+    for (int L = 0; L < 2 * NMEL; ++L) {
+        const int seg = (L >> 1) + (L & 1);
+        const int b0 = t.seg_start[seg], b1 = t.seg_start[seg + 1];
+        t.mel_b0[L] = b0;
+        t.mel_len = std::max(t.mel_len, b1 - b0);
+        for (int bb = b0; bb < b1 && bb - b0 < G::MELCAP; ++bb)
+            t.mel_w[(bb - b0) * 64 + L] = (L & 1) ? t.lo_wt[bb] : 1.0 - t.lo_wt[bb];
+    }
+    t.mel_len = (t.mel_len + 7) & ~7;                               // the kernel walks the sides 8 bins at a time (zero weights behind a side)
+    if (t.mel_len > G::MELCAP) t.mel_len = -1;                      // get_tables refuses
     for (int k = 1; k <= NMFCC; ++k) {
         const double lift = 1.0 + 11.0 * std::sin(M_PI * k / 22.0);
         for (int j = 1; j <= NMEL; ++j)
-            t.dct[(k - 1) * NMEL + (j - 1)] = std::sqrt(2.0 / NMEL) * std::cos(M_PI * k * (j - 0.5) / NMEL) * lift;
+            t.dct[(j - 1) * 16 + (k - 1)] = std::sqrt(2.0 / NMEL) * std::cos(M_PI * k * (j - 0.5) / NMEL) * lift;
     }
     for (int bb = 0; bb < G::NB; ++bb) {
         const double f = bb * df;
@@ -209,6 +227,8 @@ static int get_tables(int fs, int frame, int hop, const Tables<LOG2N>** out) {
     if (it == g_dev_tables.end()) {
         std::vector<Tables<LOG2N>> h(1);
         build_tables<LOG2N>(h[0], fs, frame, hop);
+        RSAF_CHECK_ARG(h[0].mel_len >= 0, "mel band wider than the kernel's table");
+        RSAF_CHECK_ARG(h[0].shs_shift[NHARM - 1] < Geo<LOG2N>::NC, "harmonic shift longer than the octave spectrum's zero pad");
         void* d = nullptr;
         RSAF_CHECK_HIP(hipMalloc(&d, sizeof(Tables<LOG2N>)));
         RSAF_CHECK_HIP(hipMemcpy(d, h.data(), sizeof(Tables<LOG2N>), hipMemcpyHostToDevice));
@@ -299,7 +319,7 @@ __device__ __forceinline__ double reduce8(const double (&v)[8], double* red, int
 // time-domain part of one frame: raw samples -> zero crossings, pre-emphasis, Hamming -> the packed-real FFT input in Z;
 // returns the lane's partial sums (sum win^2, sum ham win^2, zero crossings)
 template <int LOG2N>
-__device__ __forceinline__ void frame_to_z(const float* __restrict__ x, const Tables<LOG2N>* __restrict__ T, int frame,
+__device__ __forceinline__ void frame_to_z(const float* __restrict__ x, const double (&hm)[2 * Geo<LOG2N>::PPL], int frame,
                                            c64* Z, int lane, double& s_w2, double& s_hw2, double& s_zc) {
     using G = Geo<LOG2N>;
     s_w2 = 0.0; s_hw2 = 0.0; s_zc = 0.0;
@@ -310,14 +330,14 @@ __device__ __forceinline__ void frame_to_z(const float* __restrict__ x, const Ta
         if (i0 < frame) {
             const double xm = i0 > 0 ? (double)x[i0 - 1] : 0.0, x0 = (double)x[i0];
             const double pe = i0 > 0 ? x0 - PREEMPH * xm : x0 * (1.0 - PREEMPH);       // first sample HTK-style
-            const double h = T->ham[i0];
+            const double h = hm[2 * j];
             w0 = pe * h;
             s_w2 += w0 * w0;
             s_hw2 += h * w0 * w0;
             if (i0 > 0 && x0 * xm < 0.0) s_zc += 1.0;
             if (i1 < frame) {
                 const double x1 = (double)x[i1];
-                const double h1 = T->ham[i1];
+                const double h1 = hm[2 * j + 1];
                 w1 = (x1 - PREEMPH * x0) * h1;
                 s_w2 += w1 * w1;
                 s_hw2 += h1 * w1 * w1;
@@ -330,14 +350,42 @@ __device__ __forceinline__ void frame_to_z(const float* __restrict__ x, const Ta
 }
 
 // NC-point complex FFT of Z in place (Stockham autosort: natural order in, natural order out), then the magnitudes of the
-// NFFT-point real transform: mg[j] = |X[lane + 64 j]|, j < PPL, mg[PPL] = |X[NC]| (lane 0; other lanes 0)
+// NFFT-point real transform: mag_out[k] = |X[k]|, k = 0 .. NC (wave-private LDS)
+// The twiddles of a lane do not depend on the frame: for the 256- and 512-point transforms (<= 1 butterfly per lane and
+// stage) they are fetched once per run and stay in registers; the longer transforms read them from the table (L1).
 template <int LOG2N>
-__device__ __forceinline__ void fft_mag(c64* Z, const Tables<LOG2N>* __restrict__ T, int lane, double (&mg)[Geo<LOG2N>::PPL + 1]) {
+struct FftTw {
+    static constexpr int NC = Geo<LOG2N>::NC, Q = NC / 4;
+    static constexpr int BPL = Q >= 64 ? Q / 64 : 1;
+    static constexpr int R4 = (LOG2N - 1) / 2;
+    static constexpr bool HOIST = LOG2N <= 9;
+    c64 w[HOIST ? R4 : 1][3];
+    c64 w2;                                                   // radix-2 stage
+    c64 wu[HOIST ? Geo<LOG2N>::PPL + 1 : 1];                  // unpack
+    __device__ __forceinline__ void load(const Tables<LOG2N>* __restrict__ T, int lane) {
+        if constexpr (HOIST) {
+            int Ns = 1;
+#pragma unroll
+            for (int st = 0; st < R4; ++st, Ns *= 4) {
+                const int k = lane & (Ns - 1), tstep = (2 * NC) / (4 * Ns);
+                w[st][0] = T->tw[k * tstep]; w[st][1] = T->tw[2 * k * tstep]; w[st][2] = T->tw[3 * k * tstep];
+            }
+            w2 = T->tw[2 * (lane & (NC / 2 - 1))];
+#pragma unroll
+            for (int j = 0; j <= Geo<LOG2N>::PPL; ++j) wu[j] = T->tw[j < Geo<LOG2N>::PPL ? lane + 64 * j : NC];
+        }
+    }
+};
+
+template <int LOG2N>
+__device__ __forceinline__ void fft_mag(c64* Z, const Tables<LOG2N>* __restrict__ T, const FftTw<LOG2N>& W, int lane,
+                                        double* __restrict__ mag_out) {
     using G = Geo<LOG2N>;
     constexpr int NC = G::NC, Q = NC / 4;
     constexpr int BPL = Q >= 64 ? Q / 64 : 1;                 // radix-4 butterflies per lane and stage
     constexpr int LOG2NC = LOG2N - 1;
     constexpr int R4 = LOG2NC / 2;                            // radix-4 stages; one radix-2 stage follows when LOG2NC is odd
+    constexpr bool HOIST = FftTw<LOG2N>::HOIST;
     int Ns = 1;
 #pragma unroll
     for (int st = 0; st < R4; ++st, Ns *= 4) {
@@ -353,9 +401,15 @@ __device__ __forceinline__ void fft_mag(c64* Z, const Tables<LOG2N>* __restrict_
                 v[bi][2] = Z[b + 2 * Q];
                 v[bi][3] = Z[b + 3 * Q];
                 if (Ns > 1) {
-                    v[bi][1] = cmul(v[bi][1], T->tw[k * tstep]);
-                    v[bi][2] = cmul(v[bi][2], T->tw[2 * k * tstep]);
-                    v[bi][3] = cmul(v[bi][3], T->tw[3 * k * tstep]);
+                    if constexpr (HOIST) {
+                        v[bi][1] = cmul(v[bi][1], W.w[st][0]);
+                        v[bi][2] = cmul(v[bi][2], W.w[st][1]);
+                        v[bi][3] = cmul(v[bi][3], W.w[st][2]);
+                    } else {
+                        v[bi][1] = cmul(v[bi][1], T->tw[k * tstep]);
+                        v[bi][2] = cmul(v[bi][2], T->tw[2 * k * tstep]);
+                        v[bi][3] = cmul(v[bi][3], T->tw[3 * k * tstep]);
+                    }
                 }
             }
         }
@@ -383,7 +437,7 @@ __device__ __forceinline__ void fft_mag(c64* Z, const Tables<LOG2N>* __restrict_
 #pragma unroll
         for (int bi = 0; bi < B2; ++bi) {
             const int b = lane + 64 * bi;
-            if (b < H) { a[bi] = Z[b]; bq[bi] = cmul(Z[b + H], T->tw[2 * b]); }     // exp(-2 pi i b / NC)
+            if (b < H) { a[bi] = Z[b]; bq[bi] = cmul(Z[b + H], HOIST ? W.w2 : T->tw[2 * b]); }     // exp(-2 pi i b / NC)
         }
         lds_fence();
 #pragma unroll
@@ -397,26 +451,24 @@ __device__ __forceinline__ void fft_mag(c64* Z, const Tables<LOG2N>* __restrict_
 #pragma unroll
     for (int j = 0; j <= G::PPL; ++j) {
         const int k = j < G::PPL ? lane + 64 * j : NC;
-        double m = 0.0;
         if (j < G::PPL || lane == 0) {
             const c64 A = Z[k & (NC - 1)], Bc = Z[(NC - k) & (NC - 1)];
             const c64 E = make_double2(0.5 * (A.x + Bc.x), 0.5 * (A.y - Bc.y));
             const c64 D = make_double2(0.5 * (A.x - Bc.x), 0.5 * (A.y + Bc.y));       // (A - conj B) / 2
-            const c64 O = cmul(T->tw[k], mul_mi(D));
+            const c64 O = cmul(HOIST ? W.wu[HOIST ? j : 0] : T->tw[k], mul_mi(D));
             const double re = E.x + O.x, im = E.y + O.y;
-            m = sqrt(re * re + im * im);
+            mag_out[k] = sqrt(re * re + im * im);
         }
-        mg[j] = m;
     }
     lds_fence();
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__ wav, const int64_t* __restrict__ clip_off,
+__global__ __launch_bounds__(64, LOG2N <= 9 ? 2 : 1) void smile_lld_kernel(const float* __restrict__ wav, const int64_t* __restrict__ clip_off,
                                                        const int64_t* __restrict__ frame_off, int64_t total_frames,
                                                        double* __restrict__ lld, double* __restrict__ cand,
                                                        double* __restrict__ octave_dbg,
-                                                       const Tables<LOG2N>* __restrict__ T) {
+                                                       const Tables<LOG2N>* __restrict__ T, int stop) {
     using G = Geo<LOG2N>;
     constexpr int NC = G::NC, NB = G::NB, PPL = G::PPL;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -439,15 +491,18 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
     double* STASH = smem + G::OFF_STASH;
     double* RED = smem + G::OFF_RED;
 
-    double mg[PPL + 1];
+    // frame-invariant per-lane constants: FFT twiddles, Hamming window
+    FftTw<LOG2N> W;
+    W.load(T, lane);
+    double hm[2 * PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) { hm[2 * j] = T->ham[2 * (lane + 64 * j)]; hm[2 * j + 1] = T->ham[2 * (lane + 64 * j) + 1]; }
+    for (int i = NB + lane; i < G::S_D; i += 64) SS[i] = 0.0;      // the zero pad behind the octave spectrum
+
     if (f0 > 0) {                                        // magnitudes of the frame in front of the run (for the flux)
         double a, b, c;
-        frame_to_z<LOG2N>(xclip + (int64_t)(f0 - 1) * hop, T, frame, Z, lane, a, b, c);
-        fft_mag<LOG2N>(Z, T, lane, mg);
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) MAGP[lane + 64 * j] = mg[j];
-        if (lane == 0) MAGP[NC] = mg[PPL];
-        lds_fence();
+        frame_to_z<LOG2N>(xclip + (int64_t)(f0 - 1) * hop, hm, frame, Z, lane, a, b, c);
+        fft_mag<LOG2N>(Z, T, W, lane, MAGP);
     }
 
 #pragma unroll 1
@@ -455,22 +510,19 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
         const int fr = f0 + tr;
         const int64_t fg = fo + fr;
         double s_w2, s_hw2, s_zc;
-        frame_to_z<LOG2N>(xclip + (int64_t)fr * hop, T, frame, Z, lane, s_w2, s_hw2, s_zc);
-        fft_mag<LOG2N>(Z, T, lane, mg);
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) MAG[lane + 64 * j] = mg[j];
-        if (lane == 0) { MAG[NC] = mg[PPL]; MAG[NC + 1] = 0.0; }
-        lds_fence();
+        frame_to_z<LOG2N>(xclip + (int64_t)fr * hop, hm, frame, Z, lane, s_w2, s_hw2, s_zc);
+        fft_mag<LOG2N>(Z, T, W, lane, MAG);
+        if (stop == 1) continue;                         // profiling aid (env RSAF_SMILE_STOP): leave the frame after phase k
 
         // ---- cSpectral partial sums over the lane's bins (power spectrum; Androids.conf:258-280) ----
         double v[8], w[8];
         {
-            double tot = 0, pf = 0, sm = 0, b1 = 0, b2 = 0, sh = 0, fx = 0, sl = 0, pl = 0, hm = 0;
+            double tot = 0, pf = 0, sm = 0, b1 = 0, b2 = 0, sh = 0, fx = 0, sl = 0, pl = 0, hrm = 0;
 #pragma unroll
             for (int j = 0; j <= PPL; ++j) {
                 const int k = j < PPL ? lane + 64 * j : NC;
                 if (j == PPL && lane != 0) break;
-                const double m = mg[j], P = m * m, f = (double)k * df;
+                const double m = MAG[k], P = m * m, f = (double)k * df;
                 tot += P;
                 pf += P * f;
                 sm += m;
@@ -481,10 +533,10 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
                 const double lp = flog(fmax(P, 1e-30));
                 sl += lp;
                 if (P > 0.0) pl += P * lp;                       // P ln P (P < 1e-30 contributes < 1e-28: below every tolerance)
-                if (k >= 1 && k < NC) hm += fmax(m - 0.5 * (MAG[k - 1] + MAG[k + 1]), 0.0);
+                if (k >= 1 && k < NC) hrm += fmax(m - 0.5 * (MAG[k - 1] + MAG[k + 1]), 0.0);
             }
             v[0] = s_w2; v[1] = s_hw2; v[2] = s_zc; v[3] = tot; v[4] = pf; v[5] = sm; v[6] = b1; v[7] = b2;
-            w[0] = sh; w[1] = fx; w[2] = sl; w[3] = pl; w[4] = hm; w[5] = 0; w[6] = 0; w[7] = 0;
+            w[0] = sh; w[1] = fx; w[2] = sl; w[3] = pl; w[4] = hrm; w[5] = 0; w[6] = 0; w[7] = 0;
         }
         const double r1 = reduce8(v, RED, lane);
         const double r2 = reduce8(w, RED, lane);
@@ -495,17 +547,18 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
         const double cen = pfs / safe;
         {   // central moments about the centroid
             double m2 = 0, m3 = 0, m4 = 0;
-#pragma unroll
+#pragma unroll 1
             for (int j = 0; j <= PPL; ++j) {
                 const int k = j < PPL ? lane + 64 * j : NC;
                 if (j == PPL && lane != 0) break;
-                const double P = mg[j] * mg[j], d = (double)k * df - cen, d2 = d * d;
+                const double mk = MAG[k], P = mk * mk, d = (double)k * df - cen, d2 = d * d;
                 m2 += d2 * P; m3 += d2 * d * P; m4 += d2 * d2 * P;
             }
             v[0] = m2; v[1] = m3; v[2] = m4; v[3] = 0; v[4] = 0; v[5] = 0; v[6] = 0; v[7] = 0;
         }
         const double r3 = reduce8(v, RED, lane);
         if ((lane & 7) == 0 && lane < 24) st[16 + (lane >> 3)] = r3;
+        if (stop == 2) continue;
 
         // ---- roll-off points: first bin whose inclusive cumulative power reaches p * total (lane-blocked prefix sums) ----
         {
@@ -530,16 +583,18 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
             }
         }
 
+        if (stop == 3) continue;
         // ---- cMelspec + cMfcc (Androids.conf:101-115): lane 2 c + side = one side of triangular band c ----
         {
             double s = 0.0;
-            if (lane < 2 * NMEL) {
-                const int bnd = lane >> 1, side = lane & 1;
-                const int seg = bnd + side;                          // rising side: bins of lower channel bnd, falling: bnd + 1
-                const int b0 = T->seg_start[seg], b1 = T->seg_start[seg + 1];
-                for (int b = b0; b < b1; ++b) {
-                    const double lw = T->lo_wt[b];
-                    s += (side ? lw : 1.0 - lw) * MAG[b];
+            {
+                const int b0 = T->mel_b0[lane], nside = T->mel_len;   // lanes >= 52: weights all zero
+                for (int i0 = 0; i0 < nside; i0 += 8) {             // 8 coalesced weight loads in flight
+                    double wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wv[u] = T->mel_w[(i0 + u) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fma(wv[u], MAG[min(b0 + i0 + u, NC)], s);
                 }
             }
             s += __shfl_xor(s, 1, 64);
@@ -549,16 +604,16 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
             if (lane < NMFCC) {
                 double acc = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < NMEL; ++jj) acc += T->dct[lane * NMEL + jj] * SS[jj];
+                for (int jj = 0; jj < NMEL; ++jj) acc += T->dct[jj * 16 + lane] * SS[jj];
                 lld[(int64_t)(1 + lane) * total_frames + fg] = acc;
             }
             lds_fence();
         }
 
-        // ---- the previous-frame magnitudes of the next frame ----
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) MAGP[lane + 64 * j] = mg[j];
-        if (lane == 0) MAGP[NC] = mg[PPL];
+        if (stop == 4) continue;
+        // ---- the previous-frame magnitudes of the next frame (the MAG array is about to be reused) ----
+#pragma unroll 1
+        for (int k = lane; k <= NC; k += 64) MAGP[k] = MAG[k];
 
         // ---- cSpecScale (Androids.conf:142-160): peak enhancement + (1,2,1) smoothing on the linear spectrum ----
         double* A1 = ZD;                                   // enhanced spectrum   (FFT buffer, first half)
@@ -603,19 +658,15 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
             }
             lds_fence();
             // smoothing -> A2 (the MAG array: its last reader was the enhancement)
-            double sm[PPL + 1];
-#pragma unroll
+#pragma unroll 1
             for (int j = 0; j <= PPL; ++j) {
                 const int k = lane + 64 * j;
-                sm[j] = 0.0;
-                if (k < NC) sm[j] = ((k > 0 ? A1[k - 1] : 0.0) + 2.0 * A1[k] + A1[k + 1]) / 4.0;
-                else if (k == NC) sm[j] = A1[NC];
+                if (k < NC) MAG[k] = ((k > 0 ? A1[k - 1] : 0.0) + 2.0 * A1[k] + A1[k + 1]) / 4.0;
+                else if (k == NC) MAG[k] = A1[NC];
             }
             lds_fence();
-#pragma unroll
-            for (int j = 0; j <= PPL; ++j) { const int k = lane + 64 * j; if (k <= NC) MAG[k] = sm[j]; }
-            lds_fence();
         }
+        if (stop == 5) continue;
         double* A2 = MAG;
         {   // natural cubic spline through the bins: tridiag(1, 4, 1) m = second differences, m_0 = m_NC = 0.
             // Lane-blocked Thomas algorithm: the forward and the backward recurrence are affine maps x -> A x + B per bin;
@@ -656,8 +707,9 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
             if (lane == 0) MM[NC] = 0.0;
             lds_fence();
         }
+        if (stop == 6) continue;
         // spline at the octave-scale targets, negatives reset, auditory weighting -> S
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j <= PPL; ++j) {
             const int i = lane + 64 * j;
             if (i > NC) break;
@@ -670,35 +722,29 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
         }
         lds_fence();
 
+        if (stop == 7) continue;
         // ---- cPitchShs (Androids.conf:162-186): sub-harmonic summation, peaks, the 6 best candidates ----
-        double H[PPL + 1];
+        double* HH = MAG;                                   // A2 is dead (spline and evaluation are done): the summation spectrum
         double hsum = 0.0;
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j <= PPL; ++j) {
             const int i = lane + 64 * j;
-            H[j] = 0.0;
             if (i <= NC) {
                 double acc = 0.0;
 #pragma unroll
-                for (int h = 0; h < NHARM; ++h) {
-                    const int src = i + T->shs_shift[h];
-                    if (src <= NC) acc += T->shs_w[h] * SS[src];
-                }
-                H[j] = acc;
+                for (int h = 0; h < NHARM; ++h) acc += T->shs_w[h] * SS[i + T->shs_shift[h]];   // wave-uniform table reads; zeros behind bin NC
+                HH[i] = acc;
                 hsum += acc;
             }
         }
-        lds_fence();
-        double* HH = MAG;                                   // A2 is dead: the summation spectrum takes its place
-#pragma unroll
-        for (int j = 0; j <= PPL; ++j) { const int i = lane + 64 * j; if (i <= NC) HH[i] = H[j]; }
         const double hmean = wave_sum_all(hsum) / (double)NB;
         lds_fence();
+        if (stop == 8) continue;
         // peaks (y2 > y1 and y2 >= y3) with parabolic refinement, inside 52..620 Hz, positive score: compacted into a list
-        double* L_sc = SS;                                  // S is dead: list of (score, f0, index)
-        double* L_f = SS + (NC / 2 + 4);
+        double* L_sc = SS;                                  // S is dead: list of (score, f0); at most NC / 2 peaks, the pad stays zero
+        double* L_f = SS + NC / 2;
         int npk = 0;
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j <= PPL; ++j) {
             const int i = lane + 64 * j;
             bool ok = false;
@@ -722,6 +768,7 @@ __global__ __launch_bounds__(64) void smile_lld_kernel(const float* __restrict__
             npk += __popcll(m);
         }
         lds_fence();
+        if (stop == 9) continue;
         // rank = number of peaks with a higher score (ties: the lower index, i.e. the earlier list entry, first)
         double* cd = cand + fg * (NCAND * 2);
         if (lane < NCAND && lane >= npk) { cd[2 * lane] = 0.0; cd[2 * lane + 1] = 0.0; }
@@ -786,8 +833,9 @@ static int launch(const float* wav, const int64_t* clip_off, const int64_t* fram
     // algorithmic bytes: every sample read once (4 B) + the LLD rows written (38 * 8 B per frame)
     ProfScope prof("smile_lld", s, 0.0, 0.0);
     dim3 grid((unsigned)runs, (unsigned)n_clips);
+    static const int stop = [] { const char* e = getenv("RSAF_SMILE_STOP"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL(smile_lld_kernel<LOG2N>, grid, dim3(64), lds, s, wav, clip_off, frame_off, total_frames, lld, cand,
-                       octave_dbg, tab);
+                       octave_dbg, tab, stop);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

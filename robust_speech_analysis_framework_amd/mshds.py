@@ -178,6 +178,12 @@ class _PitchGeom:
         return win, wr[:self.brent_ixmax + 1].copy()
 
 
+def lowpass_eligible(lengths):
+    """Per clip: does Praat's whole-sound FFT low-pass (the first step of To Formant (burg)) fit the device transform?"""
+    cap = int(_lib.load().rsaf_praat_lowpass_max_samples())
+    return [int(n) <= cap for n in lengths]
+
+
 class MshdsEngine:
     def __init__(self, device="cuda"):
         import torch
@@ -365,6 +371,18 @@ class MshdsEngine:
         n = len(lengths)
         dev = self.device
         dom = dom if dom is not None else SoundDomain(lengths)
+        # To Formant (burg) low-passes the WHOLE sound by one FFT (Sound_resample): a clip beyond the transform's limit
+        # (2^26 - 2000 samples = 69 min at 16 kHz) loses its eight formant columns (NaN), nothing else, and nobody else's
+        ok = lowpass_eligible(lengths)
+        if not all(ok):
+            out = torch.full((n, 8), float("nan"), dtype=torch.float64, device=dev)
+            ids = [i for i in range(n) if ok[i]]
+            if ids:
+                sub = self.formants(wav, [sample_offs[i] for i in ids], [lengths[i] for i in ids],
+                                    gpeak[torch.tensor(ids, dtype=torch.long, device=dev)].contiguous(), floor, ceiling, frame_shift,
+                                    stream, dom.sub(ids))
+                out[torch.tensor(ids, dtype=torch.long, device=dev)] = sub
+            return out
         dxo = 1.0 / RS_RATE
         ratio = RS_RATE / FS
         ri = np.zeros(n, dtype=RESAMPLE_INFO)
@@ -513,7 +531,8 @@ class MshdsEngine:
         # Sound_resample of every extracted part: transforms of the first power of two >= part + 2000 samples, i.e. fewer
         # than part + 2000 complex numbers each
         cap_work = int(max(lengths)) + 2000 * max_seg
-        lg_max = max(11, int(max(lengths) + 2000 - 1).bit_length())
+        # (a voiced interval longer than the transform's limit - 69 min of unbroken voicing - fails that clip alone: NaN)
+        lg_max = min(26, max(11, int(max(lengths) + 2000 - 1).bit_length()))
         segd = int(lib.rsaf_mshds_cpp_seg_doubles())
         ci_all = p["ci"]
         # clips per launch group: bound the cepstrogram workspace (cap_frames x 513 doubles per clip) to ~3 GB

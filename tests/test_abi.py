@@ -41,6 +41,7 @@ def test_abi_version_and_host_only_calls(rsaf_lib):
     assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 8000.0, 16000.0) == 4096 * 8 + 2 * 1000 * 8   # Sound_upsample: even + odd samples
     assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 11025.0, 16000.0) == 0            # rate going up: no low-pass
     assert rsaf_lib.rsaf_resample_praat_work_bytes(1000, 16000.0, 16000.0) == 0
+    assert rsaf_lib.rsaf_praat_lowpass_max_samples() == (1 << 26) - 2000                    # 25 min at 44.1 kHz, 69 min at 16 kHz
     stride = rsaf_lib.rsaf_mshds_resample10k_table_stride(500)
     assert stride % 8 == 0 and stride >= 1001 + 24 + 7
 
@@ -55,3 +56,12 @@ def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("load() must fail loudly without the HIP library")
+
+
+def test_clips_beyond_the_lowpass_limit_lose_only_their_formant_columns(rsaf_lib):
+    """Host logic of the failure path: a clip longer than the FFT low-pass takes is told apart up front, so
+    that only ITS formant columns become NaN and its batch mates are unaffected."""
+    from robust_speech_analysis_framework_amd import mshds
+    cap = (1 << 26) - 2000
+    assert mshds.lowpass_eligible([480000, cap, cap + 1, 16000 * 3600 * 2]) == [True, True, False, False]
+    assert rsaf_lib.rsaf_resample_praat_work_bytes(cap, 44100.0, 16000.0) == (1 << 26) * 8 + cap * 8

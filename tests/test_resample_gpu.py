@@ -45,10 +45,11 @@ def test_praat_resample_matches_restatement(rsaf_lib, fs):
 
 @pytest.mark.parametrize("fs,n,depth", [(44100, 1, 50), (44100, 2, 50), (44100, 7, 50), (48000, 47, 50), (48000, 49, 3), (44100, 2096, 50),
                                         (44100, 2097, 50), (22050, 30721, 50), (48000, 260145, 50), (44100, 1046577, 500),
-                                        (24000, 5000, 1), (20000, 5000, 2)])
+                                        (24000, 5000, 1), (20000, 5000, 2), (32000, (1 << 24) - 1000, 2), (22050, (1 << 25) + 5, 1)])
 def test_praat_resample_sizes_and_depths(rsaf_lib, fs, n, depth):
     """Every shape of the four-step transform (nfft 2^11 ... 2^21: 2 ... 512 rows), the clipped interpolation depths at the
-    edges (nearest / linear / cubic), odd and even first-cleared positions."""
+    edges (nearest / linear / cubic), odd and even first-cleared positions; the two longest transforms (2^25 and 2^26
+    samples: rows of 4 096, columns of 4 096 / 8 192 points in 128 KB of LDS) with 8.7 and 12.7 minutes of sound."""
     from robust_speech_analysis_framework_amd.resample import resample_praat
     rng = np.random.Generator(np.random.PCG64(n))
     x = (0.3 * rng.standard_normal(n)).astype(np.float32)             # white: energy at every cleared and kept bin
@@ -200,3 +201,15 @@ def test_praat_resampled_sound_keeps_its_time_axis(rsaf_lib):
     y = y.cpu().numpy()
     assert np.abs(y[0::2][100:-100] - x[100:-100]).max() <= 1e-5                           # 440 Hz lies far below the ramp
     assert abs((phase_at_zero(y, x1) - ph) / (2 * np.pi * f0) - 0.25 / 8000.0) <= 1e-8       # Praat's labelling, kept
+
+
+def test_praat_resample_refuses_sounds_beyond_the_transform(rsaf_lib):
+    """2^26 - 2000 samples is the longest sound the low-pass takes; one more sample is an argument error (no launch)."""
+    import torch
+    from robust_speech_analysis_framework_amd import _lib
+    lib = _lib.load()
+    n = int(lib.rsaf_praat_lowpass_max_samples()) + 1
+    assert lib.rsaf_resample_praat_work_bytes(n, 44100.0, 16000.0) > 0
+    x = torch.zeros(16, device="cuda")                                  # never touched: the size check comes first
+    rc = lib.rsaf_resample_praat(_lib.ptr(x), n, 44100.0, 16000.0, 50, _lib.ptr(x), 1, _lib.ptr(x), 1 << 40, _lib.stream_ptr(None))
+    assert rc != 0 and b"2^26" in lib.rsaf_last_error()
