@@ -1127,13 +1127,18 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
 }
 
 // ---- Viterbi path finder: one wave per clip (lane = candidate of the current frame) -------------------
-struct PathIn { double nc, fq, st, inten; };
-struct PathNode { double delta, logf; int vl, valid; };
+constexpr int PATH_CH = 32;          // frames whose own costs are computed at once (lane-parallel) ahead of the dependent steps
+constexpr int PATH_RING = 4 * PATH_CH;   // frames of the LDS ring: the chunk being written lies >= 2 chunks behind the frames being read
 
 __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ fr, const ClipInfo* __restrict__ ci,
                                                   double dt, double silence_thr, double voicing_thr, double octave_cost,
                                                   double octave_jump_cost, double vuv_cost, double ceiling,
                                                   unsigned char* __restrict__ psi, int* __restrict__ end_state) {
+    // ring of PATH_RING frames: a frame's own costs at [(f mod PATH_RING) * MAXC + candidate]
+    __shared__ double s_delta[PATH_RING * MAXC], s_logf[PATH_RING * MAXC];
+    __shared__ unsigned char s_flag[PATH_RING * MAXC];       // bit 0: voiceless, bit 1: valid
+    __shared__ double s_cur[2][MAXC];                        // path costs of the previous frame (double-buffered by frame parity)
+    __shared__ __attribute__((aligned(16))) unsigned char s_psi[PATH_CH * MAXC];   // back pointers of the current chunk
     const ClipInfo c = ci[blockIdx.x];
     const int lane = threadIdx.x;
     const int nF = c.n_frames;
@@ -1142,56 +1147,99 @@ __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ f
     unsigned char* P = psi + c.frame_off * MAXC;
     const double corr = 0.01 / dt;
     const double ojc = octave_jump_cost * corr, vuc = vuv_cost * corr;
-    const int cl = lane < MAXC ? lane : MAXC - 1;
-    // The only loop-carried chain is `cur`; the frame's own costs (two log2 per lane) are computed one frame
-    // ahead and its loads are issued two frames ahead so that neither sits on the chain.
-    auto load = [&](int f) {
-        f = f < nF ? f : nF - 1;
-        return PathIn{F[f].ncand, F[f].freq[cl], F[f].strength[cl], F[f].intensity};
-    };
-    auto derive = [&](const PathIn& in) {
-        PathNode nd;
-        nd.valid = lane < (int)in.nc;
-        nd.vl = !(in.fq > 0.0 && in.fq < ceiling);
-        double unv = silence_thr <= 0.0 ? 0.0 : 2.0 - in.inten / (silence_thr / (1.0 + voicing_thr));
-        unv = voicing_thr + fmax(0.0, unv);
-        nd.delta = nd.valid ? (nd.vl ? unv : in.st - octave_cost * log2(ceiling / in.fq)) : -1e300;
-        nd.logf = nd.vl ? 0.0 : log2(in.fq);
-        return nd;
-    };
-    PathNode nd = derive(load(0));
-    PathIn in1 = load(1);
-    double cur = nd.delta, prev_logf = nd.logf;
-    int prev_vl = nd.vl, prev_valid = nd.valid;
-    if (lane < MAXC) P[lane] = 0;
+    // The loop-carried chain is the vector of path costs alone.  (1) A frame's own costs (two log2 per candidate) do not
+    // depend on the path: they are computed for PATH_CH frames at a time with every lane busy, one chunk ahead, into an LDS
+    // ring; the global loads of the chunk after that are in flight while the dependent steps run.  (2) A step is the
+    // 16 x 16 table of transitions: lane (j, q) = (lane >> 2, lane & 3) evaluates predecessors q, q + 4, q + 8, q + 12 of
+    // candidate j (four independent evaluations), the quad combines them in two exchange steps (first maximum: ties go
+    // to the lower predecessor, as Praat's strict > in ascending order does), lane (j, 0) publishes the new cost through
+    // LDS.  One LDS round trip per frame instead of up to 15 dependent v_readlane rounds.
     auto clampn = [](double nc) { const int v = (int)nc; return v < 0 ? 0 : (v > MAXC ? MAXC : v); };
-    int prev_n = __builtin_amdgcn_readfirstlane(clampn(F[0].ncand));
-    for (int f = 1; f < nF; ++f) {
-        const PathIn in2 = load(f + 1);
-        const int cur_n = __builtin_amdgcn_readfirstlane(clampn(in1.nc));
-        nd = derive(in1);
-        in1 = in2;
-        double best = -INFINITY;
-        int place = 0;
-        // only the previous frame's candidates can be predecessors (their count is wave-uniform)
-        for (int c1 = 0; c1 < prev_n; ++c1) {
-            const double pc = readlane_f64(cur, c1);
-            const double pl = readlane_f64(prev_logf, c1);
-            const int pv = __builtin_amdgcn_readlane(prev_vl, c1);
-            const int pval = __builtin_amdgcn_readlane(prev_valid, c1);
-            const double tc = (pv && nd.vl) ? 0.0 : ((pv || nd.vl) ? vuc : ojc * fabs(pl - nd.logf));
-            const double v = pval ? pc - tc + nd.delta : -INFINITY;
-            if (v > best) { best = v; place = c1; }
+    constexpr int PPLN = PATH_CH * MAXC / 64;                  // (frame, candidate) pairs per lane
+    constexpr int RING = PATH_RING;
+    double lfq[PPLN], lst[PPLN], lnc[PPLN], lin[PPLN];
+    auto fetch = [&](int f0) {                                // frames [f0, f0 + PATH_CH) -> registers
+#pragma unroll
+        for (int u = 0; u < PPLN; ++u) {
+            const int pr = lane + 64 * u, fi = f0 + (pr >> 4), cd = pr & (MAXC - 1);
+            const int f = fi < nF ? fi : nF - 1;
+            lfq[u] = F[f].freq[cd]; lst[u] = F[f].strength[cd]; lnc[u] = F[f].ncand; lin[u] = F[f].intensity;
         }
-        if (!nd.valid) best = -1e300;
-        if (lane < MAXC) P[(int64_t)f * MAXC + lane] = (unsigned char)place;
-        cur = best;
-        prev_logf = nd.logf; prev_vl = nd.vl; prev_valid = nd.valid;
-        prev_n = cur_n;
+    };
+    auto derive_to = [&](int f0) {                            // registers -> ring slots of frames [f0, f0 + PATH_CH)
+        const int base = (f0 % RING) * MAXC;
+#pragma unroll
+        for (int u = 0; u < PPLN; ++u) {
+            const int pr = lane + 64 * u, cd = pr & (MAXC - 1);
+            const bool valid = cd < clampn(lnc[u]);
+            const bool vl = !(lfq[u] > 0.0 && lfq[u] < ceiling);
+            double unv = silence_thr <= 0.0 ? 0.0 : 2.0 - lin[u] / (silence_thr / (1.0 + voicing_thr));
+            unv = voicing_thr + fmax(0.0, unv);
+            s_delta[base + pr] = valid ? (vl ? unv : lst[u] - octave_cost * log2(ceiling / lfq[u])) : -1e300;
+            s_logf[base + pr] = vl ? 0.0 : log2(lfq[u]);
+            s_flag[base + pr] = (unsigned char)((vl ? 1 : 0) | (valid ? 2 : 0));
+        }
+    };
+    // one wave per workgroup: wavefront-scope fences order the LDS traffic without draining the global stores (a
+    // workgroup-scope release waits for vmcnt(0): with a global store per step that was most of the step)
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int j = lane >> 2, q = lane & 3;
+    fetch(0);
+    derive_to(0);
+    fetch(PATH_CH);
+    lds_sync();
+    if (q == 0) { s_cur[0][j] = s_delta[j]; s_psi[j] = 0; }   // frame 0: the path cost is the frame's own cost
+    double cur = s_delta[j];
+    for (int f0 = 0; f0 < nF; f0 += PATH_CH) {
+        if (f0 + PATH_CH < nF) {                               // the next chunk's costs, then the loads of the one after it
+            derive_to(f0 + PATH_CH);
+            fetch(f0 + 2 * PATH_CH);
+        }
+        lds_sync();
+        const int fend = f0 + PATH_CH < nF ? f0 + PATH_CH : nF;
+#pragma unroll 1
+        for (int f = f0 > 0 ? f0 : 1; f < fend; ++f) {
+            const int me = (f % RING) * MAXC + j, pb = ((f - 1) % RING) * MAXC;
+            const double delta = s_delta[me], logf = s_logf[me];
+            const int fl = s_flag[me], vl = fl & 1, valid = (fl >> 1) & 1;
+            const double* pcur = s_cur[(f - 1) & 1];
+            double best = -INFINITY;
+            int place = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c1 = q + 4 * u;
+                const double pc = pcur[c1], pl = s_logf[pb + c1];
+                const int pf = s_flag[pb + c1], pv = pf & 1, pval = (pf >> 1) & 1;
+                const double tc = (pv && vl) ? 0.0 : ((pv || vl) ? vuc : ojc * fabs(pl - logf));
+                const double v = pval ? pc - tc + delta : -INFINITY;
+                if (v > best) { best = v; place = c1; }
+            }
+            {                                                  // the quad's maximum (two DPP quad permutes: VALU latency, no
+                double ov = dpp_f64<0xB1>(best);               // LDS crossbar); ties: the lower predecessor
+                int op = __builtin_amdgcn_update_dpp(0, place, 0xB1, 0xf, 0xf, false);
+                if (ov > best || (ov == best && op < place)) { best = ov; place = op; }
+                ov = dpp_f64<0x4E>(best);
+                op = __builtin_amdgcn_update_dpp(0, place, 0x4E, 0xf, 0xf, false);
+                if (ov > best || (ov == best && op < place)) { best = ov; place = op; }
+            }
+            if (best == -INFINITY) place = 0;                  // no valid predecessor: Praat leaves place at its initial 0
+            if (!valid) best = -1e300;
+            cur = best;
+            if (q == 0) { s_cur[f & 1][j] = best; s_psi[(f - f0) * MAXC + j] = (unsigned char)place; }
+            lds_sync();
+        }
+        // the chunk's back pointers leave as 16-byte rows
+        if (lane < fend - f0)
+            reinterpret_cast<uint4*>(P + (int64_t)f0 * MAXC)[lane] = reinterpret_cast<const uint4*>(s_psi)[lane];
+        lds_sync();
     }
     // best end state: first maximum
-    double bv = lane < MAXC ? cur : -INFINITY;
-    int bi = lane;
+    double bv = q == 0 ? cur : -INFINITY;
+    int bi = j;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const double ov = __shfl_xor(bv, o, 64);
@@ -1202,8 +1250,12 @@ __global__ __launch_bounds__(64) void path_kernel(const FrameOut* __restrict__ f
 }
 
 // backtrack in its own launch: the kernel boundary makes the psi stores of path_kernel visible.
-// The back-pointer walk is a dependent chain of byte loads, so the table is staged in LDS chunk by chunk
-// (from the last frame backwards), one thread walks the chunk, then all threads gather the selected values.
+// The back-pointer walk is a dependent chain of byte loads (state of frame f-1 = psi[f][state of frame f]).  The table
+// is staged in LDS chunk by chunk (from the last frame backwards); inside a chunk the chain is cut into 256 segments:
+// (1) every thread walks its segment for all 16 possible entry states at once (16 independent chains: the segment's
+// map entry -> exit), (2) one thread threads the true state through the 256 maps, (3) every thread walks its segment
+// again from its true entry state and records the states, (4) all threads gather the selected values.
+// 2 x 12 + 256 dependent LDS reads per 3 072 frames instead of 3 072.
 constexpr int BT_CHUNK = 3072;
 __global__ __launch_bounds__(256) void backtrack_kernel(const FrameOut* __restrict__ fr, const ClipInfo* __restrict__ ci,
                                                         const unsigned char* __restrict__ psi,
@@ -1211,6 +1263,8 @@ __global__ __launch_bounds__(256) void backtrack_kernel(const FrameOut* __restri
                                                         double* __restrict__ sel_strength) {
     __shared__ __attribute__((aligned(16))) unsigned char s_psi[BT_CHUNK * MAXC];
     __shared__ unsigned char s_state[BT_CHUNK];
+    __shared__ unsigned char s_map[256 * MAXC];
+    __shared__ unsigned char s_entry[256];
     __shared__ int s_carry;
     const ClipInfo c = ci[blockIdx.x];
     if (c.n_frames <= 0) return;
@@ -1224,13 +1278,34 @@ __global__ __launch_bounds__(256) void backtrack_kernel(const FrameOut* __restri
         uint4* dst = reinterpret_cast<uint4*>(s_psi);
         for (int i = tid; i < cnt; i += 256) dst[i] = src[i];
         __syncthreads();
-        if (tid == 0) {
-            int s = s_carry;                                    // state of frame hi-1
-            for (int f = cnt - 1; f >= 0; --f) {
-                s_state[f] = (unsigned char)s;
-                if (lo + f > 0) s = s_psi[f * MAXC + s];        // state of frame lo+f-1
+        const int SL = (cnt + 255) / 256, nseg = (cnt + SL - 1) / SL;
+        const int fb = tid * SL, ft = min(fb + SL, cnt) - 1;   // this thread's frames [fb, ft] of the chunk (top = ft)
+        if (tid < nseg) {
+            unsigned char x[MAXC];
+#pragma unroll
+            for (int e = 0; e < MAXC; ++e) x[e] = (unsigned char)e;
+            for (int f = ft; f >= fb; --f) {
+                if (lo + f > 0) {
+#pragma unroll
+                    for (int e = 0; e < MAXC; ++e) x[e] = s_psi[f * MAXC + x[e]];
+                }
             }
-            s_carry = s;
+#pragma unroll
+            for (int e = 0; e < MAXC; ++e) s_map[tid * MAXC + e] = x[e];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int st = s_carry;                                   // state of frame hi-1
+            for (int t = nseg - 1; t >= 0; --t) { s_entry[t] = (unsigned char)st; st = s_map[t * MAXC + st]; }
+            s_carry = st;                                       // state of frame lo-1
+        }
+        __syncthreads();
+        if (tid < nseg) {
+            int st = s_entry[tid];
+            for (int f = ft; f >= fb; --f) {
+                s_state[f] = (unsigned char)st;
+                if (lo + f > 0) st = s_psi[f * MAXC + st];
+            }
         }
         __syncthreads();
         for (int i = tid; i < cnt; i += 256) {
@@ -2629,11 +2704,18 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         const double ac_flops = 2.0 * 5.0 * Mfft * log2(Mfft) + 30.0 * Mfft;
         // CC: one complex FFT of ncc points, one of ncc / 2, the spectrum pass (~40 flops per point) and the prefix sums
         const double cc_flops = 5.0 * ncc * log2((double)ncc) + 2.5 * ncc * log2(0.5 * ncc) + 40.0 * 0.5 * ncc + 4.0 * seg_len;
-        ProfScope prof(P.is_cc ? "mshds_pitch_cc_frames" : "mshds_pitch_ac_frames", s,
-                       (P.is_cc ? cc_flops : ac_flops) * (double)max_frames * (double)n_clips, 0.0);
+        // LDS bytes a frame moves through the FFT kernel (every pass reads and writes its N complex doubles: log4 stages of
+        // each transform, the staging pass and the spectrum pass): the kernel's own roofline is the LDS, not the FLOPs
+        const double ac_lds = 16.0 * Mfft * (2.0 * ceil(log2(Mfft) / 2.0) + 3.0) * 2.0;
+        const double cc_lds = 16.0 * ncc * (ceil(log2((double)ncc) / 2.0) + 2.0) * 2.0 + 16.0 * 0.5 * ncc * (ceil(log2(0.5 * ncc) / 2.0) + 1.0) * 2.0;
         for (int c0 = 0; c0 < n_clips; c0 += group) {
             const int nc = std::min(group, n_clips - c0);
             const ClipInfo* cig = (const ClipInfo*)clip_info + c0;
+            {
+            // family "mshds_pitch_{ac,cc}_fft": the correlation kernel alone (FLOPs = its FFTs, bytes = its LDS traffic)
+            ProfScope prof(P.is_cc ? "mshds_pitch_cc_fft" : "mshds_pitch_ac_fft", s,
+                           (P.is_cc ? cc_flops : ac_flops) * (double)max_frames * (double)nc,
+                           (P.is_cc ? cc_lds : ac_lds) * (double)max_frames * (double)nc);
             if (P.is_cc) {
 #define RSAF_CC_CASE(LG)                                                                                              \
     case LG:                                                                                                          \
@@ -2663,6 +2745,9 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
 #undef RSAF_AC_CASE
             }
             RSAF_CHECK_HIP(hipGetLastError());
+            }
+            // family "mshds_pitch_cand": maxima, candidate lists, Brent refinement (latency / issue bound, no FLOP model)
+            ProfScope prof(cheb ? "mshds_pitch_cand_cheb" : "mshds_pitch_cand_direct", s, 0.0, 0.0);
             hipLaunchKernelGGL(pitch_cand_kernel, dim3(max_frames, nc), dim3(CT), lds_cand, s, cig, gpeak + c0, P,
                                (const double*)workspace, rstride, max_frames, (FrameOut*)frame_out,
                                dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb);

@@ -33,6 +33,7 @@ constexpr int BUFLEN = 30;
 constexpr double ENERGY_GATE = 0.001;
 constexpr double INF = 1e30;
 constexpr int JWAVES = 8;
+constexpr int VCH = 64;               // frames whose local costs are computed at once ahead of the Viterbi steps
 constexpr int WCAP = 4096;            // floats of the sliding sample window
 constexpr int CCMAX = 1024;           // lags kept for the parabolic refinement (0.5 * fs / 52 + 1 <= 632 up to 65 kHz)
 
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(64) void smile_viterbi_kernel(const double* __restr
                                                            const int64_t* __restrict__ frame_off, int64_t total_frames,
                                                            double* __restrict__ lld, unsigned char* __restrict__ back) {
     __shared__ double dd[64];
+    __shared__ double s_local[2][VCH * 8], s_l2f[2][VCH * 8];
+    __shared__ unsigned char s_has[2][VCH * 8];
     const int clip = blockIdx.x;
     const int lane = threadIdx.x;
     const int j = lane >> 3, i = lane & 7;
@@ -60,59 +63,100 @@ __global__ __launch_bounds__(64) void smile_viterbi_kernel(const double* __restr
     const double2* c2 = reinterpret_cast<const double2*>(cand) + fo * NCAND;
     unsigned char* bk = back + fo * 8;
 
+    // A frame's local costs (two logarithms per state) do not depend on the path: they are computed for VCH frames at a
+    // time with every lane busy (8 (frame, state) pairs per lane), one chunk ahead of the dependent steps, into LDS; the
+    // candidate loads of the chunk after that are in flight meanwhile.
+    constexpr int PP = VCH * 8 / 64;
+    double2 cv[PP];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int pr = lane + 64 * u, t = t0 + (pr >> 3), st = pr & 7;
+            cv[u] = (st < NCAND && t < T) ? c2[(int64_t)t * NCAND + st] : make_double2(0.0, 0.0);
+        }
+    };
+    auto derive_to = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int pr = lane + 64 * u, st = pr & 7;
+            const bool voiced = st < NCAND;
+            const bool has = voiced ? cv[u].x > 0.0 : (st == NCAND);
+            double vbest = voiced && has ? cv[u].y : 0.0;     // highest voicing among the frame's candidates (8-lane group)
+            vbest = fmax(vbest, __shfl_xor(vbest, 1, 64));
+            vbest = fmax(vbest, __shfl_xor(vbest, 2, 64));
+            vbest = fmax(vbest, __shfl_xor(vbest, 4, 64));
+            double local;
+            if (voiced) local = W_LOCAL * -log(fmax(cv[u].y, 1e-3)) + (cv[u].y < V_CUTOFF ? W_THR : 0.0);
+            else local = W_LOCAL * -log(fmax(1.0 - vbest, 1e-3)) + (vbest >= V_CUTOFF ? W_THR : 0.0);
+            s_local[buf][pr] = local;
+            s_l2f[buf][pr] = (voiced && has) ? log2(cv[u].x) : 0.0;
+            s_has[buf][pr] = has ? 1 : 0;
+        }
+    };
+    fetch(0);
+    derive_to(0);
+    fetch(VCH);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
     double pc = INF, ps = 0.0, pl = 0.0;                   // state i of the previous frame: cost, slope, log2 f0
-    double2 nxt = (j < NCAND) ? c2[j] : make_double2(0.0, 0.0);
+    const int jj = j < 7 ? j : 7;
 #pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-        const double2 cur = nxt;
-        if (t + 1 < T && j < NCAND) nxt = c2[(int64_t)(t + 1) * NCAND + j];
-        const bool voiced_j = j < NCAND;
-        const bool has = voiced_j ? cur.x > 0.0 : (j == NCAND);
-        double vbest = voiced_j && has ? cur.y : 0.0;     // highest voicing among the frame's candidates
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) vbest = fmax(vbest, __shfl_xor(vbest, o, 64));
-        double local;
-        if (voiced_j) local = W_LOCAL * -log(fmax(cur.y, 1e-3)) + (cur.y < V_CUTOFF ? W_THR : 0.0);
-        else local = W_LOCAL * -log(fmax(1.0 - vbest, 1e-3)) + (vbest >= V_CUTOFF ? W_THR : 0.0);
-        const double l2f = (voiced_j && has) ? log2(cur.x) : 0.0;
-        double newcost, slope = 0.0;
-        int istar = 0;
-        if (t == 0) {
-            newcost = has ? local : INF;
-        } else {
-            const bool ui = i == NCAND, uj = j == NCAND;
-            const double d = (ui || uj) ? 0.0 : l2f - pl;
-            const double tr = (ui && uj) ? W_TUU : ((ui || uj) ? W_TVUV : W_TVV * fabs(d) + W_TVVD * fabs(d - ps));
-            const double c = (i <= NCAND && pc < INF) ? pc + tr : INF;
-            unsigned long long key = ((unsigned long long)__double_as_longlong(c) & ~7ull) | (unsigned long long)i;
-            unsigned long long o1 = shfl_xor_u64(key, 1); key = o1 < key ? o1 : key;
-            o1 = shfl_xor_u64(key, 2); key = o1 < key ? o1 : key;
-            o1 = shfl_xor_u64(key, 4); key = o1 < key ? o1 : key;
-            istar = (int)(key & 7ull);
-            const double cmin = __shfl(c, 8 * j + istar, 64);     // the winner's exact cost (the key only ranks)
-            newcost = (has && cmin < INF) ? cmin + local : INF;
-            dd[lane] = d;
+    for (int t0 = 0; t0 < T; t0 += VCH) {
+        const int buf = (t0 / VCH) & 1;
+        if (t0 + VCH < T) {
+            derive_to(buf ^ 1);
+            fetch(t0 + 2 * VCH);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            slope = (j == NCAND || istar == NCAND) ? 0.0 : dd[8 * j + istar];
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        // renormalise by the best state; remember which one it is (ties: lowest state)
-        double mn = INF;
-        int be = 0;
+        const int tend = t0 + VCH < T ? t0 + VCH : T;
+#pragma unroll 1
+        for (int t = t0; t < tend; ++t) {
+            const int li = (t - t0) * 8 + jj;
+            const double local = s_local[buf][li], l2f = s_l2f[buf][li];
+            const bool has = j <= NCAND && s_has[buf][li];
+            double newcost, slope = 0.0;
+            int istar = 0;
+            if (t == 0) {
+                newcost = has ? local : INF;
+            } else {
+                const bool ui = i == NCAND, uj = j == NCAND;
+                const double d = (ui || uj) ? 0.0 : l2f - pl;
+                const double tr = (ui && uj) ? W_TUU : ((ui || uj) ? W_TVUV : W_TVV * fabs(d) + W_TVVD * fabs(d - ps));
+                const double c = (i <= NCAND && pc < INF) ? pc + tr : INF;
+                unsigned long long key = ((unsigned long long)__double_as_longlong(c) & ~7ull) | (unsigned long long)i;
+                unsigned long long o1 = shfl_xor_u64(key, 1); key = o1 < key ? o1 : key;
+                o1 = shfl_xor_u64(key, 2); key = o1 < key ? o1 : key;
+                o1 = shfl_xor_u64(key, 4); key = o1 < key ? o1 : key;
+                istar = (int)(key & 7ull);
+                const double cmin = __shfl(c, 8 * j + istar, 64);     // the winner's exact cost (the key only ranks)
+                newcost = (has && cmin < INF) ? cmin + local : INF;
+                dd[lane] = d;
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                slope = (j == NCAND || istar == NCAND) ? 0.0 : dd[8 * j + istar];
+                __builtin_amdgcn_wave_barrier();
+            }
+            // renormalise by the best state; remember which one it is (ties: lowest state)
+            double mn = INF;
+            int be = 0;
 #pragma unroll
-        for (int st = NCAND; st >= 0; --st) {
-            const double cs = readlane_f64(newcost, 8 * st);
-            if (cs <= mn) { mn = cs; be = st; }
+            for (int st = NCAND; st >= 0; --st) {
+                const double cs = readlane_f64(newcost, 8 * st);
+                if (cs <= mn) { mn = cs; be = st; }
+            }
+            if (i == 0 && j <= NCAND) bk[(int64_t)t * 8 + j] = (unsigned char)istar;
+            if (lane == 56) bk[(int64_t)t * 8 + 7] = (unsigned char)be;
+            newcost = newcost < INF ? newcost - mn : INF;
+            // state s's values to every lane whose predecessor index is s
+            const int srcl = 8 * i;
+            pc = __shfl(newcost, srcl, 64);
+            ps = __shfl(slope, srcl, 64);
+            pl = __shfl(l2f, srcl, 64);
         }
-        if (i == 0 && j <= NCAND) bk[(int64_t)t * 8 + j] = (unsigned char)istar;
-        if (lane == 56) bk[(int64_t)t * 8 + 7] = (unsigned char)be;
-        newcost = newcost < INF ? newcost - mn : INF;
-        // state s's values to every lane whose predecessor index is s
-        const int srcl = 8 * i;
-        pc = __shfl(newcost, srcl, 64);
-        ps = __shfl(slope, srcl, 64);
-        pl = __shfl(l2f, srcl, 64);
     }
     __threadfence();
     __builtin_amdgcn_wave_barrier();

@@ -631,7 +631,11 @@ static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* p
     const int threads = c.C <= 256 ? c.C : 256;
     const int cpt = c.C / threads;
     dim3 grid((unsigned)slabs, (unsigned)n);
-    ProfScope prof(APPLY ? "w2v2_conv0_apply" : "w2v2_conv0_stats", s, 2.0 * 10 * c.C * (double)T0 * n, 0.0);
+    // HBM-bound: the apply pass writes C channels x T0 frames per window as three bf16 planes (6 B per element: 49 MB per
+    // 5 s window at C = 512) and reads the window once; the statistics pass only reads the window (both recompute the
+    // 10-tap convolution: Cin = 1, 0.16 GFLOP per window)
+    ProfScope prof(APPLY ? "w2v2_conv0_apply" : "w2v2_conv0_stats", s, 0.0,
+                   APPLY ? (double)n * ((double)c.C * T0 * 6.0 + 4.0 * (5.0 * T0 + 5.0)) : (double)n * 4.0 * (5.0 * T0 + 5.0));
 #define RSAF_C0(CPT)                                                                                       \
     hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, outp, plane, len, T0, \
                        c.C, slab, slabs)

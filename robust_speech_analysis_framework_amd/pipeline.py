@@ -15,8 +15,14 @@ from . import _lib, smile
 BUILT_STAGES = ["mshds", "smile", "w2v2", "cnnlstm"]     # bench config C4 ("cnnlstm_only") runs the classifier without a Pipeline
 
 # algorithmic traffic per audio-second of the HBM-bound kernels:
-#   16 000 float32 samples read + 38 float32 LLDs x 100 frames/s written
-SMILE_LLD_BYTES_PER_AUDIO_S = 16000 * 4 + 38 * 4 * 100
+#   16 000 float32 samples read + 38 float64 LLDs x 100 frames/s written (32 by the frame kernel; the chain is float64)
+SMILE_LLD_BYTES_PER_AUDIO_S = 16000 * 4 + 38 * 8 * 100
+LDS_PEAK_GBS = 256 * 128 * 2.4        # 256 CUs x 128 B per clock x 2.4 GHz = 78.6 TB/s aggregate LDS bandwidth (MI355X_MICROARCH.md)
+LATENCY_FAMILIES = {                  # one dependent step per frame: the figure that matters is the time per step
+    "mshds_pitch_path": "Viterbi over <= 15 candidates, one wave per clip",
+    "smile_viterbi": "Viterbi over 7 states, one wave per clip",
+    "lstm_recurrent": "persistent bi-LSTM recurrence",
+}
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 
@@ -139,17 +145,40 @@ class Pipeline:
         return f"{' -> '.join(parts)} on {clips} x {seconds:g} s synthetic 16 kHz mono clips per GPU"
 
 
-def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_tflops, f64_peak_tflops):
+def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_tflops, f64_peak_tflops, wall_ms=None,
+              frames_per_launch=None):
     """roofline objects of the profiled kernel families that have an algorithmic work model, largest event time first
     (the first one is the line's ``roofline``).  achieved = algorithmic FLOPs (or bytes) per launch / average launch
-    time from HIP events on the launch stream."""
+    time from HIP events on the launch stream.  ``share_of_step_wall`` = the family's event time / the timed region's
+    wall time; the MSHDS analyses run on two HIP streams beside each other, so the shares of concurrent families add up
+    to more than 1 (their event times overlap).  ``frames_per_launch``: {family: dependent steps per launch} for the
+    latency-bound families, which get ``us_per_step``."""
     out = []
     for name, rec in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
         if rec["launches"] <= 0 or rec["ms"] <= 0:
             continue
         avg_ms = rec["ms"] / rec["launches"]
         base = {"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": rec["launches"], "traffic": None,
-                "share_of_event_time": round(rec["ms"] / max(sum(r["ms"] for r in prof.values()), 1e-30), 4)}
+                "share_of_step_wall": round(rec["ms"] / wall_ms, 4) if wall_ms else None}
+        if name in LATENCY_FAMILIES and name != "lstm_recurrent":
+            r = {**base, "bound": "latency", "what": LATENCY_FAMILIES[name]}
+            if frames_per_launch and frames_per_launch.get(name):
+                r["steps_per_launch"] = int(frames_per_launch[name])
+                r["us_per_step"] = round(1e3 * avg_ms / frames_per_launch[name], 3)
+            out.append(r)
+            continue
+        if name in ("mshds_pitch_ac_fft", "mshds_pitch_cc_fft"):
+            # the FFT correlation kernels live in LDS: every Stockham pass reads and writes the frame's N complex doubles.
+            # Their roofline is the LDS bandwidth (the fp64 FLOP rate is kept beside it).
+            per_launch = rec["bytes"] / rec["launches"]
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            out.append({**base, "bound": "lds", "achieved": round(ach, 1), "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s",
+                        "frac": round(ach / LDS_PEAK_GBS, 4), "algorithmic_lds_bytes_per_launch": per_launch,
+                        "fp64_tflops": round(rec["flops"] / (rec["ms"] * 1e-3) / 1e12, 3),
+                        "fp64_frac_of_vector_peak": round(rec["flops"] / (rec["ms"] * 1e-3) / 1e12 / f64_peak_tflops, 4),
+                        "note": "LDS bytes = 16 B x points x 2 (read + write) per pass, passes = radix-4 stages of both transforms + "
+                                "staging + spectrum pass; PMC view (LDS busy, bank conflicts): profiles/r02/pmc_pitch_fft_kernels.json"})
+            continue
         if rec["flops"] > 0:
             fp64 = name.startswith("mshds_")
             split6 = name in ("w2v2_gemm", "w2v2_posconv_gemm")      # both on gemm_bf16x6 (base geometry)
@@ -159,15 +188,7 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
             # pipe, priced with the FLOPs the pipe actually executes; the algorithmic (fp32-equivalent) rate is kept beside it
             ach = 6.0 * alg if split6 else alg
             r = {**base, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                 "arithmetic": (("f64 vector ALU: FFT autocorrelation (two complex FFTs + the spectrum pass per frame) and the "
-                                 "candidate kernel's Chebyshev coefficients (fp64 MFMA); the frames scope also spans the "
-                                 "latency-bound maxima / Brent phases, whose work is not in the FLOP count"
-                                 if name == "mshds_pitch_ac_frames" else
-                                 ("f64 vector ALU: cross-correlation by one complex FFT of N >= window + lags points and one of N / 2 "
-                                  "per frame; the frames scope also spans the candidate kernel (Chebyshev coefficients on the fp64 "
-                                  "matrix pipe, depth-clipped direct sinc sums, Brent), whose work is not in the FLOP count"
-                                  if name == "mshds_pitch_cc_frames" else
-                                  "f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)")) if fp64 else
+                 "arithmetic": ("f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)" if fp64 else
                                 ("fp32-accurate result from 6 bf16 MFMA products of three-way operand splits, fp32 accumulation"
                                  if split6 else "f32 MFMA")),
                  "algorithmic_flops_per_launch": rec["flops"] / rec["launches"]}
@@ -182,8 +203,9 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
             ach = per_launch / (avg_ms * 1e-3) / 1e9
             out.append({**base, "bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s",
                         "frac": round(ach / hbm_peak_gbs, 5), "algorithmic_bytes_per_launch": per_launch,
-                        "note": "SURVEY.md 8d assigns HBM (79 200 B per audio-second); measured: VALU-issue / LDS-latency bound "
-                                "(profiles/r02/pmc_smile_lld.json), see DESIGN.md"})
+                        "note": "SURVEY.md 8d assigns HBM (64 000 B read + 30 400 B of float64 LLD rows written per audio-second); the "
+                                "kernel is float64 since round 3 (every decision of the chain coincides with the oracle) and is "
+                                "bound by fp64 issue + LDS round trips at 2 waves / SIMD: profiles/r03/smile_phase.txt, DESIGN.md"})
         elif rec["bytes"] > 0:
             per_launch = rec["bytes"] / rec["launches"]
             ach = per_launch / (avg_ms * 1e-3) / 1e9

@@ -49,7 +49,7 @@ for name, kw in cfgs.items():
         eng.pitch(flat, offs, lens, gpeak, **kw)
         torch.cuda.synchronize()
         pr = _lib.prof_end()
-        ms = sum(v["ms"] for k, v in pr.items() if k.endswith("_frames"))
+        ms = sum(v["ms"] for k, v in pr.items() if k.startswith("mshds_pitch_") and k != "mshds_pitch_path")
         res[f"{name}/stop{stop}"] = round(ms, 3)
         print(name, "stop", stop, "frame kernel ms", round(ms, 3), "path ms", round(pr.get("mshds_pitch_path", {}).get("ms", 0), 3), flush=True)
 os.environ.pop("RSAF_PITCH_STOP", None)
