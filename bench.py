@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true",
                     help="run the MSHDS stage on a second HIP stream beside Wav2Vec2 (per-kernel event times then include "
                          "time-sharing, so the roofline object is only clean without it)")
+    ap.add_argument("--no-per-config", action="store_true",
+                    help="skip the short BASELINE config C2 / C3 / C4 measurements that the e2e line carries in `per_config`")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work and NOT a measurement: every rank fabricates its shard's rows on the CPU (gloo), the ranks "
                          "run the sharding plan, the all-gather, the barriers and the MAX-over-ranks timing of the real run; "
@@ -275,7 +277,7 @@ def parity_vs_oracle(pipe, ref, stages, dev, model=None):
             g, r = row[col:col + 912], np.asarray(ref["smile"])
             cmp("opensmile_768_functionals_of_the_32_frame_local_LLDs_30s", g[~pitch], r[~pitch], "none (own restatement of openSMILE)")
             cmp("opensmile_144_functionals_of_the_pitch_chain_LLDs_30s", g[pitch], r[pitch],
-                "none (own restatement; decision sequences: compared stage by stage in tests/)")
+                "none (own restatement; float64 on both sides since round 3: tests/ assert all 912 columns end to end, positions exact)")
         col += 912
     if "cnnlstm" in stages and "logits" in ref:
         cmp("wav2vec2_to_cnnlstm_logits_30s", row[col:col + 2], ref["logits"][0], "reference module (CNN-LSTM) / transformers (Wav2Vec2 arithmetic)")
@@ -297,7 +299,7 @@ def attach_traffic(roof, args, n_local):
     attached only when that profile was taken with this run's shape and kernel sources."""
     if not roof:
         return
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_bench_traffic.json")
         if not os.path.exists(path):
             continue
@@ -440,6 +442,32 @@ def main():
                      "h2d_bytes": int(pcm.numel() * 2), "d2h_bytes": int(rows.numel() * 4), "ranks": 1,
                      "what": "rank 0's shard: pinned int16 PCM -> H2D -> rsaf_pcm_to_mono_f32 -> hot path -> D2H rows (best of 2)"}
 
+    # BASELINE configs C2 / C3 / C4 on their own, same process, after the timed region (N = 1, e2e only): the same code
+    # paths as `--config C2|C3|C4`, 1 warm-up + 2 timed steps each, so that the per-config table is driver-visible
+    per_config = None
+    if rank == 0 and world == 1 and args.config == "e2e" and not args.stages and not args.no_per_config and n_local:
+        per_config = {}
+
+        def timed(fn, audio_s):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t1) / 2
+            return {"value": round(audio_s / el, 2), "unit": "audio-s/s", "ms_per_step": round(1e3 * el, 3), "steps": 2, "warmup": 1}
+        per_config["C2"] = {**timed(lambda: pipe.run(wav, only=("mshds", "smile")), n_local * args.seconds),
+                            "workload": f"MSHDS 25/25 + openSMILE-style 38 LLD / 912 functionals on {n_local} x {args.seconds:g} s clips"}
+        per_config["C3"] = {**timed(lambda: pipe.run(wav, only=("w2v2",)), n_local * args.seconds),
+                            "workload": f"Wav2Vec2-base frame embeddings on {n_local} x {args.seconds:g} s clips"}
+        x4 = torch.randn(256, 1500, 768, generator=torch.Generator().manual_seed(1234)).to(dev)
+        per_config["C4"] = {**timed(lambda: pipe.model(x4), 256 * 30.0),
+                            "workload": "CNN-LSTM-attn forward on randn(256, 1500, 768) seed 1234 (7 680 audio-s per batch)"}
+        del x4
+        per_config["note"] = "measured after the timed region in the same process (resident inputs, no CPU baseline); the headline value is the e2e line"
+        log("per-config lines: " + ", ".join(f"{k} {v['value']}" for k, v in per_config.items() if k != "note"))
+
     if rank == 0:
         value = audio_s_per_step * args.steps / dt
         frames = {"mshds_pitch_path": 6000.0 * args.seconds / 30.0, "smile_viterbi": 2998.0 * args.seconds / 30.0}
@@ -469,7 +497,7 @@ def main():
                        "distinct_clips": len(set(members)), "clip_seconds": args.seconds, "stages": list(stages),
                        "sharding": f"clips/{world} ranks, all_gather of result rows",
                        "w2v2_windows_per_call": args.w2v2_chunks_per_call},
-            "roofline": roof, "other_rooflines": roofs[1:],
+            "roofline": roof, "other_rooflines": roofs[1:], "per_config": per_config,
             "inclusive_of_pcie_and_decode": inclusive,
             "checks": {"finite": True, "duplicate_clips_bit_identical": dup_ok,
                        "rccl_all_gather_executed": bool(world > 1 or force_collective),

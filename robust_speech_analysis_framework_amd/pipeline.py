@@ -86,9 +86,21 @@ class Pipeline:
             self._packed_key = key
         return self._packed
 
-    def run(self, wav):
-        """wav: float32 [clips, samples] on the device -> rows float32 [clips, width]."""
+    def run(self, wav, only=None):
+        """wav: float32 [clips, samples] on the device -> rows float32 [clips, width].  ``only``: run this subset of the
+        pipeline's stages (bench.py's per-config lines reuse one pipeline: C2 = mshds + smile, C3 = w2v2)."""
         import torch
+        if only is not None:
+            keep = (self.stages, self.mshds, self.w2v2, self.model, self.overlap)
+            self.stages = [s for s in self.stages if s in only]
+            self.mshds = self.mshds if "mshds" in only else None
+            self.w2v2 = self.w2v2 if "w2v2" in only else None
+            self.model = self.model if "cnnlstm" in only else None
+            self.overlap = False
+            try:
+                return self.run(wav)
+            finally:
+                self.stages, self.mshds, self.w2v2, self.model, self.overlap = keep
         cols = []
         p = self._pack(wav)
         n_clips, n_samp = int(wav.shape[0]), int(wav.shape[1])

@@ -170,6 +170,33 @@ _EXPECT = {
 }
 
 
+# Options of the pitch chain and of cSpectral that the kernels hard-code (Androids.conf:142-280).  A section that is present must
+# carry exactly these values where it sets the option at all (an absent option = the value here, which is also what the kernels
+# do); a config that changes one of them is refused instead of being silently analysed with the built-in value.
+_EXPECT_IF_PRESENT = {
+    "scale": {"scale": "octave", "sourcescale": "lin", "interpmethod": "spline", "minf": 25.0, "maxf": -1.0, "npointstarget": 0.0,
+              "specsmooth": 1.0, "specenhance": 1.0, "auditoryweighting": 1.0},
+    "shs": {"maxpitch": 620.0, "minpitch": 52.0, "ncandidates": 6.0, "scores": 1.0, "voicing": 1.0, "f0c1": 0.0, "voicingc1": 0.0,
+            "f0raw": 1.0, "voicingclip": 1.0, "voicingcutoff": 0.7, "octavecorrection": 0.0, "nharmonics": 15.0,
+            "compressionfactor": 0.85, "greedypeakalgo": 1.0},
+    "pitchSmooth": {"bufferlength": 30.0, "f0final": 1.0, "f0finalenv": 0.0, "voicingfinalclipped": 0.0, "voicingfinalunclipped": 1.0,
+                    "f0raw": 0.0, "voicingc1": 0.0, "voicingclip": 0.0, "wtvv": 10.0, "wtvvd": 5.0, "wtvuv": 10.0, "wthr": 4.0,
+                    "wtuu": 0.0, "wlocal": 2.0, "wrange": 1.0},
+    "volmerge": {"idx": 0.0, "threshold": 0.001, "removeidx": 1.0, "zerovec": 1.0, "outputval": 0.0},
+    "pitchJitter": {"f0field": "F0final", "searchrangerel": 0.25, "jitterlocal": 1.0, "jitterddp": 1.0, "jitterlocalenv": 0.0,
+                    "jitterddpenv": 0.0, "shimmerlocal": 1.0, "shimmerlocalenv": 0.0, "onlyvoiced": 0.0, "loghnr": 1.0,
+                    "usebrokenjitterthresh": 0.0},
+    "spectral": {"bands[0]": "250-650", "bands[1]": "1000-4000", "rolloff[0]": 0.25, "rolloff[1]": 0.5, "rolloff[2]": 0.75,
+                 "rolloff[3]": 0.9, "flux": 1.0, "centroid": 1.0, "maxpos": 0.0, "minpos": 0.0, "entropy": 1.0, "variance": 1.0,
+                 "skewness": 1.0, "kurtosis": 1.0, "slope": 1.0, "sharpness": 1.0, "tonality": 0.0, "harmonicity": 1.0,
+                 "flatness": 1.0},
+    "energy": {"rms": 1.0, "log": 0.0},
+    "lld": {"smawin": 3.0}, "lld2": {"smawin": 3.0}, "lld3": {"smawin": 3.0},
+    "mzcr": {"zcr": 1.0, "amax": 0.0, "mcr": 0.0, "maxmin": 0.0, "dc": 0.0},
+    "Int": {"intensity": 1.0, "loudness": 1.0},
+}
+
+
 def parse_smile_conf(path: str):
     """Parse an openSMILE INI-style config into {instance: {key: value}} (lower-cased keys)."""
     sections, cur = {}, None
@@ -184,7 +211,7 @@ def parse_smile_conf(path: str):
                 continue
             if cur is not None and "=" in line:
                 k, v = line.split("=", 1)
-                cur[k.strip().lower()] = v.strip()
+                cur[k.strip().lower()] = re.split(r"\s+(?:;|//)", v.strip())[0].strip()     # drop a trailing comment
     return sections
 
 
@@ -217,8 +244,28 @@ def validate_smile_conf(path: str):
     fe = sec.get("functL1", {}).get("functionalsenabled", "")
     if [s.strip() for s in fe.split(";")] != ["Extremes", "Regression", "Moments"]:
         raise ValueError("functionalsEnabled must be Extremes;Regression;Moments")
+    for inst, opts in _EXPECT_IF_PRESENT.items():
+        got = sec.get(inst)
+        if got is None:
+            continue
+        for key, want in opts.items():
+            if key not in got:
+                continue
+            val = got[key]
+            if isinstance(want, str):
+                ok = val.strip().lower() == want.lower()
+            else:
+                try:
+                    ok = abs(float(val) - want) <= 1e-9
+                except ValueError:
+                    ok = False
+            if not ok:
+                raise ValueError(f"[{inst}] {key}={val} unsupported (the kernels implement {want})")
     functionals_window(sec)                     # framing must be one the kernels can produce
     return sec
+
+
+_FRAMING_ANNOUNCED = False
 
 
 def extract_opensmile_features(input_df, opensmile_exe_path, config_file_path,
@@ -252,6 +299,13 @@ def extract_opensmile_features(input_df, opensmile_exe_path, config_file_path,
         return pd.DataFrame()
     _lib.load()
     _lib.require_gpu()
+    global _FRAMING_ANNOUNCED
+    if verbose and not _FRAMING_ANNOUNCED:
+        # once per process: which reading of [functL1] (Androids.conf:349-356) the numbers follow
+        print("[rsaf] openSMILE functionals: " + ("statistics of the FIRST 25 ms window (frameSize=0.025, frameStep=0 read literally)"
+                                                   if window else "statistics over the COMPLETE input (the config's own comment; "
+                                                   "pass functionals='first-window' for the literal reading of frameSize=0.025 / frameStep=0)"))
+        _FRAMING_ANNOUNCED = True
     names = feature_names()
     rows = {}
     paths = list(input_df[audio_file_column])
