@@ -31,7 +31,7 @@ extern "C" {
 #define RSAF_ERR_HIP 2      /* a HIP runtime call failed */
 #define RSAF_ERR_WORKSPACE 3 /* workspace too small */
 
-#define RSAF_ABI_VERSION 5   /* 4: clip_info rows carry the sound's x1 / xmax (48 bytes); rsaf_resample_praat restates Sound_upsample for a rate ratio of 2.  5: the openSMILE-style chain is float64 end to end (lld / cand / functionals buffers are double) */
+#define RSAF_ABI_VERSION 6   /* 6: params_host[18] of rsaf_mshds_pitch (per-depth Chebyshev tables behind sinc_cheb).  4: clip_info rows carry the sound's x1 / xmax (48 bytes); rsaf_resample_praat restates Sound_upsample for a rate ratio of 2.  5: the openSMILE-style chain is float64 end to end (lld / cand / functionals buffers are double) */
 
 typedef void* rsaf_stream_t;
 
@@ -265,14 +265,17 @@ int rsaf_mshds_clip_peak(const float* wav, const void* clip_info, int n_clips, d
 int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, int max_frames,
                          const double* window, int half_window, double time_step, int subtract_mean,
                          double* db_out, double* stats_out, rsaf_stream_t stream);
-/* params_host[17] = {dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, octave_jump_cost,
+/* params_host[18] = {dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, octave_jump_cost,
  *   voiced_unvoiced_cost, nsamp_window, nsamp_period, min_lag, max_lag, brent_ixmax, max_candidates,
- *   refine_depth, is_cc, dt_window}.  sel_freq / sel_strength: the path finder's choice per frame.
+ *   refine_depth, is_cc, dt_window, cheb_has_clipped_depths}.  sel_freq / sel_strength: the path finder's choice per frame.
  * stats_out[clip][8] = {n(f != 0), mean, population sd, mean after |z| <= 2, n voiced, mean Hz,
  *   sd in semitones (n-1), n after filter}.
  * sinc_cheb (may be NULL): [2 * refine_depth][16] Chebyshev coefficients on frac in [0, 1] of the sinc-interpolation
  *   weights of tap offsets -(depth-1) .. depth (mshds.sinc_cheb_table); with it the Brent refinement evaluates a
- *   16-term polynomial per step instead of the 2*depth-term sum whenever no candidate's depth is clipped.
+ *   16-term polynomial per step instead of the 2*depth-term sum whenever no candidate's depth is clipped.  With
+ *   params_host[17] = 1 the table is followed by the tables of the clipped depths e = 1 .. refine_depth - 1
+ *   ([2 e][16] each, depth e at offset 2 * refine_depth * 16 + 16 e (e - 1) doubles): candidates whose depth the array
+ *   ends clip to e >= 3 (cross-correlation passes) then take the polynomial form too (ABI 6).
  * workspace: the per-frame correlation rows between the correlation kernel (fp64 FFT auto- / cross-correlation, one
  *   workgroup per 16 frames) and the candidate kernel (one wave per frame); at least rsaf_mshds_pitch_workspace_bytes_per_clip bytes, the
  *   clips are processed in groups of floor(workspace_bytes / that). */

@@ -56,6 +56,8 @@ struct PitchParams {
     int nfft;               // AC: FFT length, the smallest power of two >= 1.5 nsamp_window (Praat's nsampFFT)
     double voicing_thr2;    // >= 0: also emit the candidate lists for this (lower) voicing threshold into out2
     int debug_stop;         // profiling aid (env RSAF_PITCH_STOP): leave the frame kernel after phase k; 0 = run all
+    int cheb_all_full;      // no candidate of this analysis can have its interpolation depth clipped by the array ends
+    int cheb_clipped;       // the Chebyshev table is followed by the tables of the clipped depths 1 .. refine_depth - 1
 };
 
 // Sampled_xToLowIndex / xToNearestIndex / xToHighIndex of the sound (0-based), x1 = time of its first sample
@@ -996,7 +998,33 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     // Lanes per candidate follow the candidate count (uniform per frame): few candidates (the usual AC case)
     // get a whole wave each, a full list gets 16 lanes each, so one or two rounds cover every frame.
     auto refine_list = [&](int nc, const int* place_lag, double* cf, double* cs) {
-        if (cheb != nullptr) {
+        // Depth of the sinc interpolation on a cell whose left sample is b (0-based): Praat clips it to the samples that
+        // exist on either side, min(depth, b + 1, n - b - 1), for BOTH halves of the kernel.  A frame whose cells all
+        // have the full depth takes the shared table on the matrix pipe; a clipped cell (cc passes: lags within `depth` of
+        // the end of the array) has its own table per depth (host-built, depths 3 .. depth - 1; 618 KB at depth 70) and
+        // its 16 coefficients cost 2 d_c x 16 multiply-adds on the vector ALU - against ~15 Brent evaluations of the
+        // 2 d_c-term sum with a reciprocal and a cosine per term in the direct form.  Depths below 3 (nearest / linear /
+        // cubic in NUM_interpolate_sinc) and analyses without per-depth tables (depth 700: 140 tables of 41 KB would not
+        // stay in L2) keep the direct form.
+        bool use_cheb = cheb != nullptr;
+        int n_clip_cols = 0;
+        if (use_cheb && !P.cheb_all_full) {
+            int dmin = P.refine_depth;
+            for (int k = 1; k < nc; ++k) {                           // uniform: every lane scans the (<= 15) candidates
+                const int b0 = place_lag[k] + RC - 1;
+#pragma unroll
+                for (int cell = 0; cell < 2; ++cell) {
+                    const int b = b0 + cell;
+                    int dc = P.refine_depth;
+                    dc = dc < b + 1 ? dc : b + 1;
+                    dc = dc < RN - b - 1 ? dc : RN - b - 1;
+                    if (dc < P.refine_depth) ++n_clip_cols;
+                    dmin = dc < dmin ? dc : dmin;
+                }
+            }
+            if (n_clip_cols > 0 && (!P.cheb_clipped || dmin < 3)) use_cheb = false;
+        }
+        if (use_cheb) {
             // Chebyshev coefficients of both cells of every candidate on the fp64 matrix pipe:
             //   P[j][(k, cell)] = sum_o cheb[o][j] * r[b_k + cell + o]      (16 coefficients x up to 30 columns x 2 d taps)
             // as v_mfma_f64_16x16x4: A[m = j][kk] = cheb[o + kk][j] (a lane's table load is the A operand as it is),
@@ -1015,10 +1043,12 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
                     bmax = bb > bmax ? bb : bmax;
                 }
                 int rbase[2];
+                bool colfull[2];                                      // clipped cells are rebuilt below: their B operand is zero here
 #pragma unroll
                 for (int T = 0; T < 2; ++T) {
                     const int n = 16 * T + nn, k = 1 + (n >> 1);
                     rbase[T] = place_lag[k < nc ? k : 1] + RC - 1 + (n & 1);   // 0-based left sample of the cell
+                    colfull[T] = n_clip_cols == 0 || (rbase[T] + 1 >= d && RN - rbase[T] - 1 >= d);
                 }
                 // r is zero outside [nz_lo, nz_hi]: taps that reach no candidate's non-zero range are skipped
                 int o_lo = nz_lo - (bmax + 1), o_hi = nz_hi - bmin;
@@ -1035,15 +1065,15 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int oo = o + 4 * u + kq;
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw[u], r[rbase[0] + oo], acc0, 0, 0, 0);
-                        if (tiles > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw[u], r[rbase[1] + oo], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw[u], colfull[0] ? r[rbase[0] + oo] : 0.0, acc0, 0, 0, 0);
+                        if (tiles > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw[u], colfull[1] ? r[rbase[1] + oo] : 0.0, acc1, 0, 0, 0);
                     }
                 }
                 for (; o <= o_hi; o += 4) {
                     const int oo = o + kq, oc = oo <= o_hi ? oo : o_hi;          // taps past o_hi contribute zero
                     const double cw = oo <= o_hi ? ctab[(int64_t)oc * NCH] : 0.0;
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw, r[rbase[0] + oc], acc0, 0, 0, 0);
-                    if (tiles > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw, r[rbase[1] + oc], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw, colfull[0] ? r[rbase[0] + oc] : 0.0, acc0, 0, 0, 0);
+                    if (tiles > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cw, colfull[1] ? r[rbase[1] + oc] : 0.0, acc1, 0, 0, 0);
                 }
                 // D layout: lane (kq, nn), register v -> row j = kq + 4 v, column nn
 #pragma unroll
@@ -1052,6 +1082,35 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
                     if (T < tiles && k < nc) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) s_P[(k * 2 + (n & 1)) * NCH + kq + 4 * v] = T == 0 ? acc0[v] : acc1[v];
+                    }
+                }
+                if (n_clip_cols > 0) {
+                    // clipped cells: coefficient j = sum over the 2 d_c taps of the depth's own table; lane = (tap phase, j)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const double* clip_tabs = cheb + (int64_t)2 * d * NCH;        // tables of depths 1 .. d - 1, depth e at 16 e (e - 1)
+                    const int jj = lane & 15, ph = lane >> 4;
+                    for (int col = 0; col < ncol; ++col) {
+                        const int k = 1 + (col >> 1), b = place_lag[k] + RC - 1 + (col & 1);
+                        int dc = d;
+                        dc = dc < b + 1 ? dc : b + 1;
+                        dc = dc < RN - b - 1 ? dc : RN - b - 1;
+                        if (dc >= d) continue;                           // uniform
+                        const double* tab = clip_tabs + (int64_t)NCH * dc * (dc - 1) + jj;
+                        double acc = 0.0;
+                        int o = -(dc - 1) + ph;
+                        for (; o + 12 <= dc; o += 16) {                   // four table loads in flight
+                            double tw4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) tw4[u] = tab[(int64_t)(o + 4 * u + dc - 1) * NCH];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) acc = fma(tw4[u], r[b + o + 4 * u], acc);
+                        }
+                        for (; o <= dc; o += 4) acc = fma(tab[(int64_t)(o + dc - 1) * NCH], r[b + o], acc);
+                        acc += __shfl_xor(acc, 16, 64);
+                        acc += __shfl_xor(acc, 32, 64);
+                        if (ph == 0) s_P[(k * 2 + (col & 1)) * NCH + jj] = acc;
                     }
                 }
             }
@@ -2631,6 +2690,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     P.nsamp_window = (int)h[8]; P.nsamp_period = (int)h[9]; P.min_lag = (int)h[10]; P.max_lag = (int)h[11];
     P.brent_ixmax = (int)h[12]; P.max_cand = (int)h[13]; P.refine_depth = (int)h[14]; P.is_cc = (int)h[15];
     P.dt_window = h[16];
+    P.cheb_clipped = (int)h[17];
     P.voicing_thr2 = dual ? voicing_thr2 : -1.0;
     { const char* e = getenv("RSAF_PITCH_STOP"); P.debug_stop = e ? atoi(e) : 0; }
     P.refine_margin = 0.0;   // lazy refinement is off: it changed a few frames' selection (parity first)
@@ -2694,7 +2754,10 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         int lag_hi = P.max_lag - 1;
         if (lag_hi > P.brent_ixmax - 1) lag_hi = P.brent_ixmax - 1;
         const bool unclipped = P.brent_ixmax + lag_lo - 1 >= P.refine_depth && lag_hi + 2 + P.refine_depth <= P.brent_ixmax;
-        if (!unclipped || getenv("RSAF_PITCH_NO_CHEB")) cheb = nullptr;
+        P.cheb_all_full = unclipped ? 1 : 0;
+        if (cheb == nullptr) P.cheb_clipped = 0;
+        // clipped analyses keep the Chebyshev form only with the per-depth tables behind the shared one
+        if ((!unclipped && !P.cheb_clipped) || getenv("RSAF_PITCH_NO_CHEB")) cheb = nullptr;
     }
     if (max_frames > 0) {
         // algorithmic flops of the correlation kernels, counted for equal-length clips (an upper bound for ragged batches);
@@ -2778,14 +2841,14 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
 
 // bytes of correlation rows per clip (max_frames rows of max_lag + 2 doubles); the analysis runs the clips in groups of
 // floor(workspace_bytes / this), so any multiple >= 1 works and n_clips multiples avoid the grouping
-int64_t rsaf_mshds_pitch_workspace_bytes_per_clip(int max_frames, const double* params_host /* 17 doubles */) {
+int64_t rsaf_mshds_pitch_workspace_bytes_per_clip(int max_frames, const double* params_host /* 18 doubles */) {
     if (!params_host || max_frames < 0) return -1;
     const int Lr = (int)params_host[15] ? (int)params_host[11] : (int)params_host[12];
     return (int64_t)max_frames * (Lr + 2) * (int64_t)sizeof(double);
 }
 
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
-                     const double* window, const double* window_r, const double* params_host /* 17 doubles */,
+                     const double* window, const double* window_r, const double* params_host /* 18 doubles */,
                      void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
                      const double* sinc_cheb, void* workspace, int64_t workspace_bytes, rsaf_stream_t stream) {
     return pitch_impl(wav, clip_info, n_clips, max_frames, gpeak, window, window_r, params_host, frame_out, psi, end_state,
@@ -2794,7 +2857,7 @@ int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int m
 }
 
 int rsaf_mshds_pitch_dual(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
-                          const double* window, const double* window_r, const double* params_host /* 17 doubles */,
+                          const double* window, const double* window_r, const double* params_host /* 18 doubles */,
                           void* frame_out, unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength,
                           double* stats_out, double voicing_threshold2, void* frame_out2, unsigned char* psi2, int* end_state2,
                           double* sel_freq2, double* sel_strength2, double* stats_out2, const double* sinc_cheb,

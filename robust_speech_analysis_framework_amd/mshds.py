@@ -141,6 +141,18 @@ def sinc_cheb_table(depth: int, ncoef: int = 16):
     return np.ascontiguousarray(c.T)
 
 
+CHEB_CLIP_MAX_DEPTH = 128
+
+
+def sinc_cheb_tables(depth: int, with_clipped: bool):
+    """The table ``rsaf_mshds_pitch`` takes as ``sinc_cheb``: the full-depth Chebyshev table, and behind it (``with_clipped``)
+    the tables of the clipped depths e = 1 .. depth - 1, depth e at offset 2 depth 16 + 16 e (e - 1) doubles."""
+    parts = [sinc_cheb_table(depth).reshape(-1)]
+    if with_clipped:
+        parts += [sinc_cheb_table(e).reshape(-1) for e in range(1, depth)]
+    return np.concatenate(parts)
+
+
 class _PitchGeom:
     """Window geometry of Sound: To Pitch (ac/cc) for one parameter set (Boersma 1993)."""
 
@@ -225,10 +237,13 @@ class MshdsEngine:
         sel_f = torch.zeros(tf, dtype=torch.float64, device=dev)
         sel_s = torch.zeros(tf, dtype=torch.float64, device=dev)
         stats = torch.empty((max(n, 1), 8), dtype=torch.float64, device=dev)
-        params = (C.c_double * 17)(g.dt, g.floor, g.ceiling, voicing_threshold, octave_cost, silence_threshold,
+        # cross-correlation passes can have candidates whose interpolation depth the array ends clip: the per-depth tables
+        # ride behind the shared one when they are small (depth 70: 618 KB; depth 700 would be 63 MB: direct evaluation)
+        clipped_tables = bool(is_cc) and int(refine_depth) <= CHEB_CLIP_MAX_DEPTH
+        params = (C.c_double * 18)(g.dt, g.floor, g.ceiling, voicing_threshold, octave_cost, silence_threshold,
                                    octave_jump_cost, voiced_unvoiced_cost, g.nsamp_window, g.nsamp_period, g.min_lag,
                                    g.max_lag, g.brent_ixmax, max_candidates, refine_depth, 1 if is_cc else 0,
-                                   g.dt_window)
+                                   g.dt_window, 1 if clipped_tables else 0)
         second = None
         if voicing_threshold2 is not None:
             second = {"geom": g, "ci": ci, "ci_dev": ci_d, "total_frames": total, "max_frames": mx,
@@ -240,7 +255,8 @@ class MshdsEngine:
                       "stats": torch.empty((max(n, 1), 8), dtype=torch.float64, device=dev)}
         wp = _lib.ptr(win) if win is not None else None
         wrp = _lib.ptr(wr) if wr is not None else None
-        (cheb,) = self._table(("sinc_cheb", int(refine_depth)), lambda: (sinc_cheb_table(int(refine_depth)).reshape(-1),))
+        (cheb,) = self._table(("sinc_cheb", int(refine_depth), clipped_tables),
+                              lambda: (sinc_cheb_tables(int(refine_depth), clipped_tables),))
         chp = _lib.ptr(cheb)
         # correlation rows between the two pitch kernels: all clips at once if that stays below ~4 GB, else in groups
         per_clip = int(lib.rsaf_mshds_pitch_workspace_bytes_per_clip(mx, params)) if n else 0
