@@ -2104,32 +2104,79 @@ __device__ double pitch_value_at(const double* __restrict__ f, int n, double t1,
     return fn + phase * (ff - fn);
 }
 
-// Sound_findMaximumCorrelation with the shifts spread over the lanes; returns corr, *tout, *peak (uniform)
-constexpr int PULSE_LDS = 1536;
+// Sound_findMaximumCorrelation with the shifts spread over the lanes; returns corr, *tout, *peak (uniform).
+// The samples come from a wave-private LDS window that SLIDES with the walk: the fixed window and the union of the
+// shifted windows of one pulse span ~2.5 periods, the window holds PULSE_LDS samples, so it is refilled from global
+// memory once per ~10-20 pulses (in the walking direction) instead of twice per pulse; every lane then reads the fixed
+// window as a broadcast and its own shifted window with unit stride.  `win0` = sample index of the window's first
+// entry (INT64_MIN: empty), kept by the caller across pulses; dir = -1 / +1: the walk goes left / right.
+constexpr int PULSE_LDS = 3072;
+constexpr int PULSE_FW = 128;         // pitch frames of the walker's sliding window
 __device__ double max_correlation_wave(const float* __restrict__ x, int n, double x1, double t1, double window, double tmin2,
-                                       double tmax2, int lane, double* tout, double* peak, float* ps1, float* ps2) {
+                                       double tmax2, int lane, double* tout, double* peak, float* pwin, int64_t* win0, int dir) {
     const double half = 0.5 * window;
     const int64_t ileft1 = nearest_index(t1 - half, x1);
     const int64_t iright1 = nearest_index(t1 + half, x1);
     const int64_t l2min = low_index(tmin2 - half, x1);
     const int64_t l2max = high_index(tmax2 - half, x1);
     double best = -1.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r1b = 0.0, r3b = 0.0, ir = 0.0, pk = 0.0;
-    // stage the fixed window and the union of the shifted windows in LDS (float): every lane then reads
-    // the fixed window as a broadcast and its own shifted window with unit stride
     const int wlen = (int)(iright1 - ileft1 + 1);
     const int slen = (int)(l2max - l2min) + wlen;
-    const bool staged = wlen > 0 && wlen <= PULSE_LDS && slen > 0 && slen <= PULSE_LDS;
-    if (staged) {
-        for (int i = lane; i < wlen; i += 64) { const int64_t j = ileft1 + i; ps1[i] = (j >= 0 && j < n) ? x[j] : 0.0f; }
-        for (int i = lane; i < slen; i += 64) { const int64_t j = l2min + i; ps2[i] = (j >= 0 && j < n) ? x[j] : 0.0f; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const int64_t ulo = ileft1 < l2min ? ileft1 : l2min;                      // union of both ranges
+    const int64_t uhi = (ileft1 + wlen > l2min + slen ? ileft1 + wlen : l2min + slen);
+    const bool staged = wlen > 0 && slen > 0 && uhi - ulo <= PULSE_LDS;
+    if (staged && (*win0 == INT64_MIN || ulo < *win0 || uhi > *win0 + PULSE_LDS)) {
+        // refill: the needed span at the trailing end of the window, the rest ahead in the walking direction
+        const int64_t w0 = dir < 0 ? uhi - PULSE_LDS : ulo;
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int i = lane; i < PULSE_LDS; i += 64) { const int64_t j = w0 + i; pwin[i] = (j >= 0 && j < n) ? x[j] : 0.0f; }
+        *win0 = w0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const float* ps1 = pwin + (staged ? (int)(ileft1 - *win0) : 0);
+    const float* ps2 = pwin + (staged ? (int)(l2min - *win0) : 0);
+    // Interior case (every sample of both windows lies inside the sound: all pulses but the ones at the very ends of a
+    // clip): no pair is skipped, so the sum of squares of the fixed window is one number, the one of the shifted window
+    // slides (norm2(s + 1) = norm2(s) - a[s]^2 + a[s + wlen]^2: one scan over the 64 shifts of a batch), and the local
+    // peak is only needed for the one step that detects the maximum.  The loop over the window then carries the cross
+    // product alone: 2 LDS reads, 2 conversions and 1 FMA per sample instead of 3 FMAs, a maximum and an absolute value more.
+    const bool interior = staged && ulo >= 0 && uhi <= n;
+    double n1_all = 0.0;
+    if (interior) {
+        for (int i = lane; i < wlen; i += 64) { const double a = ps1[i]; n1_all = fma(a, a, n1_all); }
+        n1_all = group_sum<64>(n1_all);
     }
     for (int64_t b = l2min; b <= l2max; b += 64) {
         const int64_t ileft2 = b + lane;
         double norm1 = 0.0, norm2 = 0.0, prod = 0.0, lp = 0.0;
-        if (ileft2 <= l2max) {
+        if (interior) {
+            const int ob = (int)(b - l2min);                       // window offset of the batch's first shift
+            double n20 = 0.0;                                      // sum of squares of shift ob
+            for (int i = lane; i < wlen; i += 64) { const double a = ps2[ob + i]; n20 = fma(a, a, n20); }
+            n20 = group_sum<64>(n20);
+            const bool in = ileft2 <= l2max;
+            const int o2 = ob + lane;
+            // d_t = a[t + wlen]^2 - a[t]^2 for shift t -> t + 1 (reads stay inside the union: the last lane that matters is cnt - 1)
+            double dsc = 0.0;
+            if (in && ileft2 < l2max) { const double lo_ = ps2[o2], hi_ = ps2[o2 + wlen]; dsc = hi_ * hi_ - lo_ * lo_; }
+            double incl = dsc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+            norm1 = n1_all;
+            norm2 = n20 + (incl - dsc);                            // exclusive prefix of the differences
+            if (in) {
+                double p0 = 0.0, p1 = 0.0;
+                int i = 0;
+                for (; i + 1 < wlen; i += 2) {
+                    p0 = fma((double)ps1[i], (double)ps2[o2 + i], p0);
+                    p1 = fma((double)ps1[i + 1], (double)ps2[o2 + i + 1], p1);
+                }
+                if (i < wlen) p0 = fma((double)ps1[i], (double)ps2[o2 + i], p0);
+                prod = p0 + p1;
+            }
+        } else if (ileft2 <= l2max) {
             if (staged) {
                 const int o2 = (int)(ileft2 - l2min);
                 // Praat skips pairs outside the sound: the pairs inside are one index range, worked out once per lag
@@ -2164,7 +2211,15 @@ __device__ double max_correlation_wave(const float* __restrict__ x, int n, doubl
         if (m > best) {
             const int kw = __ffsll((long long)__ballot(ok && s2 == m)) - 1;
             best = m;
-            r1b = readlane_f64(s1, kw); r3b = readlane_f64(rr, kw); pk = readlane_f64(lp, kw);
+            r1b = readlane_f64(s1, kw); r3b = readlane_f64(rr, kw);
+            if (interior) {                                        // local peak of the detecting step's shifted window
+                const int ok_ = (int)(b - l2min) + kw;
+                double mx = 0.0;
+                for (int i = lane; i < wlen; i += 64) mx = fmax(mx, fabs((double)ps2[ok_ + i]));
+                pk = wave_max_dpp(mx);
+            } else {
+                pk = readlane_f64(lp, kw);
+            }
             ir = (double)(b + kw - 1);
         }
         const double last = readlane_f64(rr, cnt - 1);
@@ -2289,12 +2344,13 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
                                                          const double* __restrict__ abs_peak, const Stretch* __restrict__ st,
                                                          int max_st, const int* __restrict__ n_st, double2* __restrict__ left,
                                                          double* __restrict__ right, int cap_slots, int2* __restrict__ counts) {
-    __shared__ float s_ps[4][2][PULSE_LDS];
+    __shared__ float s_ps[4][PULSE_LDS];
+    __shared__ double s_fw[4][PULSE_FW];                       // sliding window of the pitch track (the walk reads it once per pulse)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int clip = blockIdx.y, k = blockIdx.x * 4 + wv;
     if (k >= n_st[clip]) return;
-    float* ps1 = s_ps[wv][0];
-    float* ps2 = s_ps[wv][1];
+    float* pwin = s_ps[wv];
+    int64_t win0 = INT64_MIN;
     const ClipInfo c = pci[clip];
     const float* x = wav + c.sample_off;
     const int n = c.n_samples, nF = c.n_frames;
@@ -2303,6 +2359,35 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
     double2* L = left + (int64_t)clip * cap_slots + S.off;
     double* R = right + (int64_t)clip * cap_slots + S.off;
     const int cap = S.pad;
+    double* fw = s_fw[wv];
+    int fw0 = -(1 << 30);                                     // frame index of fw[0]; far away = empty
+    // Pitch "Get value at time" (pitch_value_at) on the LDS window: the two frames around t, refilled when the walk leaves it
+    auto f0_at = [&](double t, int dir) -> double {
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        if (nF <= 0) return qn;
+        const double ireal = (t - c.t1) / pdt;
+        const int64_t ileft = (int64_t)floor(ireal);
+        double phase = ireal - (double)ileft;
+        int64_t inear, ifar;
+        if (phase < 0.5) { inear = ileft; ifar = ileft + 1; } else { inear = ileft + 1; ifar = ileft; phase = 1.0 - phase; }
+        if (inear < 0 || inear >= nF) return qn;
+        const int64_t lo = ileft, hi = ileft + 1;              // both frames (either may lie outside the track: read as 0)
+        if (lo < fw0 || hi >= fw0 + PULSE_FW) {
+            const int64_t w0 = dir < 0 ? hi - (PULSE_FW - 1) : lo;
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < PULSE_FW; i += 64) { const int64_t j = w0 + i; fw[i] = (j >= 0 && j < nF) ? f[j] : 0.0; }
+            fw0 = (int)w0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const double fn = fw[inear - fw0];
+        if (!(fn > 0.0 && fn < ceiling)) return qn;
+        if (ifar < 0 || ifar >= nF) return fn;
+        const double ff = fw[ifar - fw0];
+        if (!(ff > 0.0 && ff < ceiling)) return fn;
+        return fn + phase * (ff - fn);
+    };
     const double duration = c.xmax;                          // Pitch_getVoicedIntervalAfter works on the Pitch's domain = the sound's
     const double gp = abs_peak[clip];
     int nl = 0, nr = 0;
@@ -2319,10 +2404,10 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
         nl = 1;
         const double tsave = tmax;
         for (int g2 = 0; g2 < 200000; ++g2) {                      // to the left
-            const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
+            const double f0 = f0_at(tmax, -1);
             if (!(f0 == f0)) break;
             double peak, tout;
-            const double corr = max_correlation_wave(x, n, c.x1, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, lane, &tout, &peak, ps1, ps2);
+            const double corr = max_correlation_wave(x, n, c.x1, tmax, 1.0 / f0, tmax - 1.25 / f0, tmax - 0.8 / f0, lane, &tout, &peak, pwin, &win0, -1);
             tmax = tout;
             if (corr == -1.0) tmax -= 1.0 / f0;
             if (tmax < tleft) {
@@ -2333,10 +2418,10 @@ __global__ __launch_bounds__(256) void pulse_walk_kernel(const float* __restrict
         }
         tmax = tsave;
         for (int g2 = 0; g2 < 200000; ++g2) {                      // to the right
-            const double f0 = pitch_value_at(f, nF, c.t1, pdt, ceiling, tmax);
+            const double f0 = f0_at(tmax, +1);
             if (!(f0 == f0)) break;
             double peak, tout;
-            const double corr = max_correlation_wave(x, n, c.x1, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, lane, &tout, &peak, ps1, ps2);
+            const double corr = max_correlation_wave(x, n, c.x1, tmax, 1.0 / f0, tmax + 0.8 / f0, tmax + 1.25 / f0, lane, &tout, &peak, pwin, &win0, +1);
             tmax = tout;
             if (corr == -1.0) tmax += 1.0 / f0;
             if (tmax > tright) {
