@@ -1925,6 +1925,8 @@ __global__ __launch_bounds__(256) void resample_edge_kernel(const double* __rest
 }
 
 // ---- Formant (burg): one wave per frame -----------------------------------------------------------------------
+// (wave sums / maxima on DPP + v_readlane, root broadcasts on v_readlane: the ds_bpermute forms - ~50 LDS-crossbar round
+// trips per Aberth iteration, 24 per Burg order - were most of the 34 000 cycles a frame took)
 // Gaussian-windowed 50 ms frame of the pre-emphasised 10 kHz signal -> Burg LPC (order 10) -> roots by
 // Aberth-Ehrlich iteration (all ten simultaneously, lanes 0..9) + Newton polish -> reflect into the unit
 // circle -> (frequency, bandwidth) of the roots in the upper half plane, ascending, at most 5.
@@ -1965,8 +1967,8 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
         b1[j + 1] = xv;
         p += xv * xv;
     }
-    mxi = wave_max_f64(mxi);
-    p = wave_sum_f64(p);
+    mxi = wave_max_dpp(mxi);
+    p = group_sum<64>(p);
     if (len < FB_ORDER + 2 || mxi == 0.0 || p <= 0.0) {
         if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
         return;
@@ -1986,8 +1988,8 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
     for (int i = 1; i <= FB_ORDER; ++i) {
         double num = 0.0, den = 0.0;
         for (int j = 1 + lane; j <= len - i; j += 64) { const double u = b1[j], v = b2[j]; num += u * v; den += u * u + v * v; }
-        num = wave_sum_f64(num);
-        den = wave_sum_f64(den);
+        num = group_sum<64>(num);
+        den = group_sum<64>(den);
         if (den <= 0.0) { bad = true; break; }
         a[i] = 2.0 * num / den;
         for (int j = 1; j < i; ++j) a[j] = aa[j] - a[i] * aa[i - j];
@@ -2039,7 +2041,7 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int j = 0; j < FB_ORDER; ++j) {
-            const double or_ = __shfl(zr, j, 64), oi = __shfl(zi, j, 64);
+            const double or_ = readlane_f64(zr, j), oi = readlane_f64(zi, j);   // v_readlane: no LDS crossbar round trip
             const double ex = zr - or_, ey = zi - oi;
             const double ee = ex * ex + ey * ey;
             if (j != li && ee > 0.0) { sr += ex / ee; si -= ey / ee; }
@@ -2051,7 +2053,7 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
         if (qq > 0.0) { er = (wr_ * qr + wi_ * qi) / qq; ei = (wi_ * qr - wr_ * qi) / qq; }
         zr -= er; zi -= ei;
         const double step = (lane < FB_ORDER) ? fabs(er) + fabs(ei) : 0.0;
-        if (wave_max_f64(step) < 1e-14) break;
+        if (wave_max_dpp(step) < 1e-11) break;              // the three Newton steps below square this down to rounding (1e-14 here ran most frames to the iteration cap: the steps hover at a few ulp)
     }
     for (int it = 0; it < 3; ++it) {                              // Newton polish on the original polynomial
         double pr = cf[0], pi_ = 0.0, dr = 0.0, di = 0.0;
@@ -2077,7 +2079,7 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
     int rank = 0;
 #pragma unroll
     for (int j = 0; j < FB_ORDER; ++j) {
-        const double of = __shfl(fq, j, 64);
+        const double of = readlane_f64(fq, j);
         rank += (of < fq) || (of == fq && j < lane);
     }
     if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
@@ -2290,18 +2292,36 @@ __device__ __forceinline__ bool voiced_at(const double* f, int nF, double ceilin
     return i >= 0 && i < nF && f[i] > 0.0 && f[i] < ceiling;
 }
 
-__global__ __launch_bounds__(64) void pulse_stretches_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ pci,
-                                                             const double* __restrict__ sel_freq, double pdt, double ceiling,
-                                                             Stretch* __restrict__ st, int max_st, int* __restrict__ n_st,
-                                                             double* __restrict__ abs_peak) {
+// 256 threads: all four waves scan the samples for the absolute peak (a single wave took 7 500 dependent-ish rounds over a
+// 30 s clip: most of this kernel's 3.2 ms), wave 0 then lists the stretches.
+__global__ __launch_bounds__(256) void pulse_stretches_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ pci,
+                                                              const double* __restrict__ sel_freq, double pdt, double ceiling,
+                                                              Stretch* __restrict__ st, int max_st, int* __restrict__ n_st,
+                                                              double* __restrict__ abs_peak) {
+    __shared__ float s_pk[4];
     const ClipInfo c = pci[blockIdx.x];
-    const int lane = threadIdx.x, nF = c.n_frames;
+    const int lane = threadIdx.x & 63, nF = c.n_frames;
     {   // Vector_getAbsoluteExtremum of the whole sound (no mean subtraction, unlike the pitch analysis)
         const float* x = wav + c.sample_off;
-        double gp = 0.0;
-        for (int i = lane; i < c.n_samples; i += 64) gp = fmax(gp, fabs((double)x[i]));
-        gp = wave_max_f64(gp);
-        if (lane == 0) abs_peak[blockIdx.x] = gp;
+        float gp = 0.0f;                                      // |x| of float samples: exact in float
+        const int n4 = c.n_samples >> 2;
+        const bool al = ((c.sample_off & 3) == 0);            // 16-byte loads when the clip starts on a 16-byte boundary
+        if (al) {
+            const float4* x4 = reinterpret_cast<const float4*>(x);
+            for (int i = threadIdx.x; i < n4; i += 256) {
+                const float4 v = x4[i];
+                gp = fmaxf(fmaxf(gp, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+            for (int i = 4 * n4 + threadIdx.x; i < c.n_samples; i += 256) gp = fmaxf(gp, fabsf(x[i]));
+        } else {
+            for (int i = threadIdx.x; i < c.n_samples; i += 256) gp = fmaxf(gp, fabsf(x[i]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) gp = fmaxf(gp, __shfl_xor(gp, o, 64));
+        if (lane == 0) s_pk[threadIdx.x >> 6] = gp;
+        __syncthreads();
+        if (threadIdx.x == 0) abs_peak[blockIdx.x] = (double)fmaxf(fmaxf(s_pk[0], s_pk[1]), fmaxf(s_pk[2], s_pk[3]));
+        if (threadIdx.x >= 64) return;
     }
     const double* f = sel_freq + c.frame_off;
     Stretch* S = st + (int64_t)blockIdx.x * max_st;
@@ -3069,7 +3089,7 @@ int rsaf_mshds_pulses(const float* wav, const void* pitch_clip_info, int n_clips
     int* n_st = (int*)w;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("mshds_pulses", s, 0.0, 0.0);
-    hipLaunchKernelGGL(pulse_stretches_kernel, dim3(n_clips), dim3(64), 0, s, wav, (const ClipInfo*)pitch_clip_info, sel_freq,
+    hipLaunchKernelGGL(pulse_stretches_kernel, dim3(n_clips), dim3(256), 0, s, wav, (const ClipInfo*)pitch_clip_info, sel_freq,
                        pitch_dt, pitch_ceiling, st, max_st, n_st, abs_peak);
     RSAF_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(pulse_walk_kernel, dim3((max_st + 3) / 4, n_clips), dim3(256), 0, s, wav, (const ClipInfo*)pitch_clip_info,
