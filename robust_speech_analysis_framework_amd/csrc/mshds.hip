@@ -1933,95 +1933,111 @@ __global__ __launch_bounds__(256) void resample_edge_kernel(const double* __rest
 constexpr int FB_ORDER = 10;
 struct FormantFrame { double f[5]; double b[5]; };
 
+// A wave takes FB_GROUP consecutive frames: the Burg recursion runs frame by frame with all 64 lanes on the frame's
+// samples; the root finding - ten lanes per polynomial - then runs for the FB_GROUP polynomials at once (lane = 10 g + root),
+// so that the most expensive phase (~650 instructions per Aberth iteration, 10-15 iterations) is paid once per 6 frames
+// instead of once per frame with 54 idle lanes.
+constexpr int FB_GROUP = 6;
 __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__ y10, const ResampleInfo* __restrict__ ri,
                                                       const ClipInfo* __restrict__ ci, const double* __restrict__ win,
                                                       int nsw, double dt, double dxo, double preemph,
                                                       FormantFrame* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ double s_cf[4][FB_GROUP][FB_ORDER + 1];
+    __shared__ double2 s_z[4][64];
+    __shared__ double s_fq[4][64];
+    __shared__ int s_okf[4][FB_GROUP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ClipInfo c = ci[blockIdx.y];
-    const int f = blockIdx.x * 4 + wv;
-    if (f >= c.n_frames) return;
+    const int fbase = (blockIdx.x * 4 + wv) * FB_GROUP;
+    if (fbase >= c.n_frames) return;
     const ResampleInfo r = ri[blockIdx.y];
     double* b1 = reinterpret_cast<double*>(smem_raw) + (size_t)wv * 2 * (nsw + 2);
     double* b2 = b1 + (nsw + 2);
     const double* y = y10 + r.out_off;
     const int n = r.n_out;
     const double x1o = r.x1o;
-    const double t = c.t1 + f * dt;
-    const int left = (int)floor((t - x1o) / dxo);
-    const int half = nsw / 2;
-    int start = left + 1 - half, end = left + half;
-    start = start < 0 ? 0 : start;
-    end = end > n - 1 ? n - 1 : end;
-    const int len = end - start + 1;
-    FormantFrame* o = out + c.frame_off + f;
     const double qn = __longlong_as_double(0x7ff8000000000000LL);
-    // pre-emphasised, windowed frame into b1[1..len] (Burg's 1-based arrays); also the max intensity
-    double mxi = 0.0, p = 0.0;
-    for (int j = lane; j < len; j += 64) {
-        const int i = start + j;
-        const double v = (i > 0) ? y[i] - preemph * y[i - 1] : y[i];
-        mxi = fmax(mxi, v * v);
-        const double xv = v * win[j];
-        b1[j + 1] = xv;
-        p += xv * xv;
-    }
-    mxi = wave_max_dpp(mxi);
-    p = group_sum<64>(p);
-    if (len < FB_ORDER + 2 || mxi == 0.0 || p <= 0.0) {
-        if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
-        return;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // NUMburg.  x = b1 copy: b2[j] = x[j+1] for j = 1..len-1, b1[j] = x[j] for j = 1..len-1
-    for (int j = 1 + lane; j <= len - 1; j += 64) b2[j] = b1[j + 1];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    double a[FB_ORDER + 1], aa[FB_ORDER + 1];
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int ng = min(FB_GROUP, c.n_frames - fbase);
+#pragma unroll 1
+    for (int g = 0; g < ng; ++g) {
+        const int f = fbase + g;
+        const double t = c.t1 + f * dt;
+        const int left = (int)floor((t - x1o) / dxo);
+        const int half = nsw / 2;
+        int start = left + 1 - half, end = left + half;
+        start = start < 0 ? 0 : start;
+        end = end > n - 1 ? n - 1 : end;
+        const int len = end - start + 1;
+        // pre-emphasised, windowed frame into b1[1..len] (Burg's 1-based arrays); also the max intensity
+        double mxi = 0.0, p = 0.0;
+        for (int j = lane; j < len; j += 64) {
+            const int i = start + j;
+            const double v = (i > 0) ? y[i] - preemph * y[i - 1] : y[i];
+            mxi = fmax(mxi, v * v);
+            const double xv = v * win[j];
+            b1[j + 1] = xv;
+            p += xv * xv;
+        }
+        mxi = wave_max_dpp(mxi);
+        p = group_sum<64>(p);
+        bool ok = !(len < FB_ORDER + 2 || mxi == 0.0 || p <= 0.0);
+        wsync();
+        double a[FB_ORDER + 1], aa[FB_ORDER + 1];
 #pragma unroll
-    for (int i = 0; i <= FB_ORDER; ++i) { a[i] = 0.0; aa[i] = 0.0; }
-    bool bad = false;
-    for (int i = 1; i <= FB_ORDER; ++i) {
-        double num = 0.0, den = 0.0;
-        for (int j = 1 + lane; j <= len - i; j += 64) { const double u = b1[j], v = b2[j]; num += u * v; den += u * u + v * v; }
-        num = group_sum<64>(num);
-        den = group_sum<64>(den);
-        if (den <= 0.0) { bad = true; break; }
-        a[i] = 2.0 * num / den;
-        for (int j = 1; j < i; ++j) a[j] = aa[j] - a[i] * aa[i - j];
-        if (i < FB_ORDER) {
-            for (int j = 1; j <= i; ++j) aa[j] = a[j];
-            const double k = aa[i];
-            // b1[j] -= k*b2[j]; b2[j] = b2[j+1] - k*b1[j+1] (old b1) for j = 1..len-i-1
-            for (int j0 = 1; j0 <= len - i - 1; j0 += 64) {
-                const int j = j0 + lane;
-                double nb1 = 0.0, nb2 = 0.0;
-                const bool on = j <= len - i - 1;
-                if (on) { nb1 = b1[j] - k * b2[j]; nb2 = b2[j + 1] - k * b1[j + 1]; }
-                __builtin_amdgcn_wave_barrier();
-                if (on) { b1[j] = nb1; b2[j] = nb2; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int i = 0; i <= FB_ORDER; ++i) { a[i] = 0.0; aa[i] = 0.0; }
+        if (ok) {
+            // NUMburg.  x = b1 copy: b2[j] = x[j+1] for j = 1..len-1, b1[j] = x[j] for j = 1..len-1
+            for (int j = 1 + lane; j <= len - 1; j += 64) b2[j] = b1[j + 1];
+            wsync();
+            for (int i = 1; i <= FB_ORDER; ++i) {
+                double num = 0.0, den = 0.0;
+                for (int j = 1 + lane; j <= len - i; j += 64) { const double u = b1[j], v = b2[j]; num += u * v; den += u * u + v * v; }
+                num = group_sum<64>(num);
+                den = group_sum<64>(den);
+                if (den <= 0.0) { ok = false; break; }
+                a[i] = 2.0 * num / den;
+                for (int j = 1; j < i; ++j) a[j] = aa[j] - a[i] * aa[i - j];
+                if (i < FB_ORDER) {
+                    for (int j = 1; j <= i; ++j) aa[j] = a[j];
+                    const double k = aa[i];
+                    // b1[j] -= k*b2[j]; b2[j] = b2[j+1] - k*b1[j+1] (old b1) for j = 1..len-i-1
+                    for (int j0 = 1; j0 <= len - i - 1; j0 += 64) {
+                        const int j = j0 + lane;
+                        double nb1 = 0.0, nb2 = 0.0;
+                        const bool on = j <= len - i - 1;
+                        if (on) { nb1 = b1[j] - k * b2[j]; nb2 = b2[j + 1] - k * b1[j + 1]; }
+                        __builtin_amdgcn_wave_barrier();
+                        if (on) { b1[j] = nb1; b2[j] = nb2; }
+                        wsync();
+                    }
+                }
             }
         }
-    }
-    if (bad) {
-        if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
-        return;
-    }
-    // polynomial z^10 - a1 z^9 - ... - a10 ; c[k] = coefficient of z^(10-k)
-    double cf[FB_ORDER + 1];
-    cf[0] = 1.0;
+        // polynomial z^10 - a1 z^9 - ... - a10 ; cf[k] = coefficient of z^(10-k)
+        if (lane == 0) {
+            s_okf[wv][g] = ok ? 1 : 0;
+            s_cf[wv][g][0] = 1.0;
 #pragma unroll
-    for (int k = 1; k <= FB_ORDER; ++k) cf[k] = -a[k];
-    // Aberth-Ehrlich: lane i < 10 owns root i; start on a circle of radius 0.9
+            for (int k = 1; k <= FB_ORDER; ++k) s_cf[wv][g][k] = -a[k];
+        }
+        wsync();
+    }
+    // ---- roots of the ng polynomials at once: lane = 10 g + root ----
+    const int g = lane / FB_ORDER, li = lane - g * FB_ORDER;
+    const bool mine = g < ng;
+    const int gg = mine ? g : 0;
+    const bool okf = mine && s_okf[wv][gg] != 0;
+    double cf[FB_ORDER + 1];
+#pragma unroll
+    for (int k = 0; k <= FB_ORDER; ++k) cf[k] = s_cf[wv][gg][k];
+    // Aberth-Ehrlich: start on a circle of radius 0.9
     double zr = 0.0, zi = 0.0;
-    const int li = lane < FB_ORDER ? lane : 0;
     { double sn, cs; sincos(2.0 * PI * (li + 0.35) / FB_ORDER, &sn, &cs); zr = 0.9 * cs; zi = 0.9 * sn; }
     for (int it = 0; it < 80; ++it) {
         // p(z), p'(z) by Horner
@@ -2036,24 +2052,27 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
         // w = p/p'
         const double dd = dr * dr + di * di;
         double wr_ = 0.0, wi_ = 0.0;
-        if (dd > 0.0) { wr_ = (pr * dr + pi_ * di) / dd; wi_ = (pi_ * dr - pr * di) / dd; }
-        // s = sum_{j != i} 1/(z_i - z_j)
+        if (dd > 0.0) { const double rd = fast_rcp(dd); wr_ = (pr * dr + pi_ * di) * rd; wi_ = (pi_ * dr - pr * di) * rd; }
+        // s = sum_{j != i} 1/(z_i - z_j) over the roots of the same polynomial
+        s_z[wv][lane] = make_double2(zr, zi);
+        wsync();
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int j = 0; j < FB_ORDER; ++j) {
-            const double or_ = readlane_f64(zr, j), oi = readlane_f64(zi, j);   // v_readlane: no LDS crossbar round trip
-            const double ex = zr - or_, ey = zi - oi;
+            const double2 oz = s_z[wv][gg * FB_ORDER + j];
+            const double ex = zr - oz.x, ey = zi - oz.y;
             const double ee = ex * ex + ey * ey;
-            if (j != li && ee > 0.0) { sr += ex / ee; si -= ey / ee; }
+            if (j != li && ee > 0.0) { const double re = fast_rcp(ee); sr += ex * re; si -= ey * re; }
         }
+        wsync();
         // delta = w / (1 - w*s)
         const double qr = 1.0 - (wr_ * sr - wi_ * si), qi = -(wr_ * si + wi_ * sr);
         const double qq = qr * qr + qi * qi;
         double er = wr_, ei = wi_;
-        if (qq > 0.0) { er = (wr_ * qr + wi_ * qi) / qq; ei = (wi_ * qr - wr_ * qi) / qq; }
+        if (qq > 0.0) { const double rq = fast_rcp(qq); er = (wr_ * qr + wi_ * qi) * rq; ei = (wi_ * qr - wr_ * qi) * rq; }
         zr -= er; zi -= ei;
-        const double step = (lane < FB_ORDER) ? fabs(er) + fabs(ei) : 0.0;
-        if (wave_max_dpp(step) < 1e-11) break;              // the three Newton steps below square this down to rounding (1e-14 here ran most frames to the iteration cap: the steps hover at a few ulp)
+        const double step = okf ? fabs(er) + fabs(ei) : 0.0;
+        if (wave_max_dpp(step) < 1e-11) break;               // the three Newton steps below square this down to rounding
     }
     for (int it = 0; it < 3; ++it) {                              // Newton polish on the original polynomial
         double pr = cf[0], pi_ = 0.0, dr = 0.0, di = 0.0;
@@ -2073,19 +2092,28 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
     if (mag2 > 1.0) { zr /= mag2; zi /= mag2; mag2 = zr * zr + zi * zi; }   // z -> 1/conj(z)
     double fq = fabs(atan2(zi, zr)) * nyq / PI;
     const double bw = -log(mag2) * nyq / PI;
-    const bool keep = lane < FB_ORDER && zi >= 0.0 && fq >= 50.0 && fq <= nyq - 50.0;
+    const bool keep = okf && zi >= 0.0 && fq >= 50.0 && fq <= nyq - 50.0;
     if (!keep) fq = 1e300;
-    // rank among kept roots (stable by lane), write the first five
+    // rank among the kept roots of the same frame (stable by root index), write the first five
+    s_fq[wv][lane] = fq;
+    wsync();
     int rank = 0;
 #pragma unroll
     for (int j = 0; j < FB_ORDER; ++j) {
-        const double of = readlane_f64(fq, j);
-        rank += (of < fq) || (of == fq && j < lane);
+        const double of = s_fq[wv][gg * FB_ORDER + j];
+        rank += (of < fq) || (of == fq && j < li);
     }
-    if (lane < 5) { o->f[lane] = qn; o->b[lane] = qn; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (keep && rank < 5) { o->f[rank] = fq; o->b[rank] = bw; }
+    // the five lowest of each frame through LDS, so that one lane writes each output slot
+    s_z[wv][lane] = make_double2(qn, qn);
+    wsync();
+    if (keep && rank < 5) s_z[wv][gg * FB_ORDER + rank] = make_double2(fq, bw);
+    wsync();
+    if (mine && li < 5) {
+        FormantFrame* o = out + c.frame_off + fbase + gg;
+        const double2 v = s_z[wv][gg * FB_ORDER + li];
+        o->f[li] = v.x;
+        o->b[li] = v.y;
+    }
 }
 
 // ---- glottal pulses: Sound & Pitch: To PointProcess (cc), one wave per clip ----------------------------------
@@ -3046,7 +3074,7 @@ int rsaf_mshds_formants(const double* y10, const void* resample_info, const void
     if (lds > 48 * 1024)
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)formant_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof("mshds_formant_frames", s, 0.0, 0.0);
-    hipLaunchKernelGGL(formant_kernel, dim3((max_frames + 3) / 4, n_clips), dim3(256), lds, s, y10,
+    hipLaunchKernelGGL(formant_kernel, dim3((max_frames + 4 * FB_GROUP - 1) / (4 * FB_GROUP), n_clips), dim3(256), lds, s, y10,
                        (const ResampleInfo*)resample_info, (const ClipInfo*)clip_info, window, nsamp_window, time_step,
                        dx_out, preemph_factor, (FormantFrame*)frames_out);
     RSAF_CHECK_HIP(hipGetLastError());
