@@ -23,6 +23,7 @@
 
 #include "praat_interp.h"
 #include "rsaf_common.h"
+#include "wave_fft.h"
 
 // Frame times sit exactly on half-sample positions, where Praat's nearest/low index rounding is
 // decided by the last bit: evaluate t1 + f*dt etc. as separately rounded IEEE operations (no FMA
@@ -830,6 +831,332 @@ __global__ __launch_bounds__(256) void pitch_cc_kernel(const float* __restrict__
         rb[l] = (l <= loc_max_lag && den > 0.0) ? v / sqrt(den) : 0.0;
     }
     __syncthreads();                                        // the next frame overwrites the buffers
+    }
+}
+
+// ---- the two correlation kernels with ONE WAVE per frame (csrc/wave_fft.h) --------------------------------------
+// Transform lengths of 512, 1024 and 2048 complex points (every analysis of the MSHDS feature scripts at 16 kHz except the
+// 512-point cross-correlation of the 100 Hz harmonicity pass, whose second transform would have 256 points) run here:
+// the frame lives in the registers of one wavefront from the sample loads to the normalised correlation row.  The local
+// mean, the window, the local peak and sum x^2 are taken on the registers the transform starts from (wave reductions by
+// DPP, no LDS round trip, no workgroup barrier anywhere), the spectrum step evaluates every conjugate pair once, and only
+// the lags the candidate kernel reads are normalised and stored.  A wave takes WF_FRAMES consecutive frames so that its
+// five base twiddles are fetched once.
+constexpr int WF_FRAMES = 8;
+
+__device__ __forceinline__ wfft::cplx ld_tw(const double2_t* __restrict__ tw, int i) {
+    const double2_t w = tw[i];
+    return wfft::cplx{w.x, w.y};
+}
+// 1 / sqrt(d) for d > 0: hardware estimate + two Newton steps
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside the rows of 16, the row totals through v_readlane
+__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
+    v += dpp_f64<0x111>(v);
+    v += dpp_f64<0x112>(v);
+    v += dpp_f64<0x114>(v);
+    v += dpp_f64<0x118>(v);
+    const double t0 = readlane_f64(v, 15), t1 = readlane_f64(v, 31), t2 = readlane_f64(v, 47);
+    const int row = lane >> 4;
+    return v + (row == 0 ? 0.0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : (t0 + t1) + t2)));
+}
+
+template <int R>
+__global__ __launch_bounds__(64, R == 32 ? 2 : (R == 16 ? 3 : 4)) void pitch_ac_wave_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                           const double* __restrict__ gpeak, const double* __restrict__ win,
+                                                           const double* __restrict__ wr, const PitchParams P,
+                                                           const double2_t* __restrict__ tw, double* __restrict__ rbuf,
+                                                           int rstride, int max_frames) {
+    using namespace wfft;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    const ClipInfo c = ci[blockIdx.y];
+    const int f0 = blockIdx.x * WF_FRAMES;
+    if (f0 >= c.n_frames) return;
+    const int lane_ = threadIdx.x;
+    constexpr int S = 64 * R, N = 2 * S, L2 = 64 / R;        // tw = W_N^k, k < S
+    const int nw = P.nsamp_window, L = P.brent_ixmax;
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples;
+    const double gp = gpeak[blockIdx.y];
+    LdsMem mem{lds};
+    const int f1 = f0 + WF_FRAMES < c.n_frames ? f0 + WF_FRAMES : c.n_frames;
+    int pa = P.half_window - P.half_period, pb = P.half_window + P.half_period;
+    pa = pa < 0 ? 0 : pa;
+    pb = pb > nw ? nw : pb;
+#pragma unroll 1
+    for (int f = f0; f < f1; ++f) {
+        // Everything below that depends only on the lane (addresses, range predicates, the powers of the base twiddles) is
+        // loop-invariant, and hoisted out of the frame loop it costs more registers than the frame itself: the lane index and
+        // the base twiddles pass through an empty asm so that they count as redefined per frame.
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        // base twiddles (three 16-byte loads per frame, L1): W_S^lane = W_N^(2 lane), W_64^(lane % L2), W_N^lane
+        cplx w_s = ld_tw(tw, 2 * lane), w_b = ld_tw(tw, (lane % L2) * (N / 64));
+        double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
+        const double t = c.t1 + f * P.dt;
+        const int left = (int)low_index(t, c.x1), right = left + 1;
+        // The raw samples first, as the S complex points z[k] = x[2 k] + i x[2 k + 1], k = lane + 64 m: every load of the frame is
+        // in flight at once.  (A separate pass for the local mean in front of them made the frame wait for memory twice.)
+        const int start = right - P.half_window;
+        const bool inside = start >= 0 && start + nw <= n;        // the window lies inside the sound
+        // (Loads are unconditional, on clamped indices, and what lies outside the window is zeroed afterwards: a load inside a
+        // branch is waited for inside that branch, and the frame would cross the memory latency once per register.)
+        cplx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int j = 128 * m + 2 * lane;
+            int i0 = start + j, i1 = i0 + 1;
+            i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);
+            i1 = i1 < 0 ? 0 : (i1 > n - 1 ? n - 1 : i1);
+            v[m] = cplx{(double)x[i0], (double)x[i1]};
+        }
+        // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat): from the registers when the
+        // window holds that range (always, for windows of two periods and more away from the ends of the sound)
+        double local_mean;
+        {
+            int s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
+            s0 = s0 < 0 ? 0 : (s0 > n - 1 ? n - 1 : s0);
+            s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
+            double sm = 0.0;
+            if (inside && s0 >= start && s1 < start + nw) {
+                const int a0 = s0 - start, a1 = s1 - start;
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                    const int jb = 128 * m, j = jb + 2 * lane;
+                    if (jb + 127 >= a0 && jb <= a1) {
+                        if (j >= a0 && j <= a1) sm += v[m].x;
+                        if (j + 1 >= a0 && j + 1 <= a1) sm += v[m].y;
+                    }
+                }
+            } else {
+                for (int i = s0 + lane; i <= s1; i += 256) {      // four loads in flight
+                    const float q0 = x[i], q1 = i + 64 <= s1 ? x[i + 64] : 0.f, q2 = i + 128 <= s1 ? x[i + 128] : 0.f,
+                                q3 = i + 192 <= s1 ? x[i + 192] : 0.f;
+                    sm += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+                }
+            }
+            local_mean = group_sum<64>(sm) / (2.0 * P.nsamp_period);
+        }
+        // the windowed frame; the local peak over half a longest period around the window centre
+        constexpr int WCH = R == 32 ? 8 : 4;
+        double pk = 0.0;
+#pragma unroll
+        for (int mc = 0; mc < R; mc += WCH) {                     // WCH registers' window loads in flight
+            double2_t w2[WCH];
+#pragma unroll
+            for (int u = 0; u < WCH; ++u) {
+                const int j = 128 * (mc + u) + 2 * lane;
+                w2[u] = *reinterpret_cast<const double2_t*>(win + (j < nw ? j : nw - 2));      // nw is even
+            }
+#pragma unroll
+            for (int u = 0; u < WCH; ++u) {
+                const int m = mc + u, jb = 128 * m, j = jb + 2 * lane;
+                const bool on = j < nw;
+                const double e0 = on ? (v[m].x - local_mean) * w2[u].x : 0.0, e1 = on ? (v[m].y - local_mean) * w2[u].y : 0.0;
+                if (jb + 127 >= pa && jb < pb) {                  // uniform
+                    if (j >= pa && j < pb) pk = fmax(pk, fabs(e0));
+                    if (j + 1 >= pa && j + 1 < pb) pk = fmax(pk, fabs(e1));
+                }
+                v[m] = cplx{e0, e1};
+            }
+            asm volatile("" ::: "memory");
+        }
+        const double local_peak = wave_max_dpp(pk);
+        const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
+        if (P.debug_stop == 1) continue;
+        // transform, |X|^2 repacked (conjugated), transform: r[2 k] = Re, r[2 k + 1] = -Im of element k
+        wave_fft<R>(v, lds, lane, w_s, w_b);
+        {
+            ac_spec_store<R>(v, mem, lane);
+            wave_sync();
+            const cplx y_half = ac_spec_pairs<R>(v, mem, lane, ld_tw(tw, lane));
+            wave_sync();
+            ac_spec_load<R>(v, mem, lane, y_half);
+            wave_sync();
+        }
+        // (the powers of the base twiddles are recomputed: kept from the first transform they would cost 120 registers)
+        asm volatile("" : "+v"(lane));
+        w_s = ld_tw(tw, 2 * lane);
+        w_b = ld_tw(tw, (lane % L2) * (N / 64));
+        wave_fft<R>(v, lds, lane, w_s, w_b);
+        if (P.debug_stop == 2) continue;
+        const double r0 = readlane_f64(v[0].x, 0);
+        if (lane == 0) { rb[0] = 1.0; rb[L + 1] = intensity; }
+        double wa[8], wb[8];                                      // L <= 1023: lags 2 (lane + 64 m), m < 8; loads first
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int l0 = 2 * (lane + 64 * m);
+            wa[m] = wr[l0 < L ? l0 : L];
+            wb[m] = wr[l0 + 1 < L ? l0 + 1 : L];
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int l0 = 2 * (lane + 64 * m);
+            if (128 * m > L) break;                               // uniform
+            if (l0 >= 1 && l0 <= L) rb[l0] = r0 > 0.0 ? v[m].x * fast_rcp(r0 * wa[m]) : 0.0;
+            if (l0 + 1 <= L) rb[l0 + 1] = r0 > 0.0 ? -v[m].y * fast_rcp(r0 * wb[m]) : 0.0;
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(64, R == 32 ? 2 : 3) void pitch_cc_wave_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                           const double* __restrict__ gpeak, const PitchParams P,
+                                                           const double2_t* __restrict__ tw, double* __restrict__ rbuf,
+                                                           int rstride, int max_frames) {
+    using namespace wfft;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    double* s_sy = lds + Plan<R>::LDS_DOUBLES;                 // [L + 1] sumy2(l)
+    const ClipInfo c = ci[blockIdx.y];
+    const int f0 = blockIdx.x * WF_FRAMES;
+    if (f0 >= c.n_frames) return;
+    const int lane_ = threadIdx.x;
+    constexpr int S = 64 * R, H = R / 2, L2 = 64 / R, L2H = 64 / H;   // tw = W_S^k, k < S / 2; transforms of S, then S / 2 points
+    const int nw = P.nsamp_window, L = P.max_lag;
+    const int seg_len = nw + L + 1;
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples;
+    const double gp = gpeak[blockIdx.y];
+    LdsMem mem{lds};
+    const int f1 = f0 + WF_FRAMES < c.n_frames ? f0 + WF_FRAMES : c.n_frames;
+    int pa = P.half_window - P.half_period, pb = P.half_window + P.half_period;
+    pa = pa < 0 ? 0 : pa;
+    pb = pb > nw ? nw : pb;
+#pragma unroll 1
+    for (int f = f0; f < f1; ++f) {
+        int lane = lane_;                                          // redefined per frame: see pitch_ac_wave_kernel
+        asm volatile("" : "+v"(lane));
+        double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;   // r[0..L], then the intensity
+        const double t = c.t1 + f * P.dt;
+        const int left = (int)low_index(t, c.x1), right = left + 1;
+        // Praat: startTime = t - 0.5 * (1 / minimumPitch + dt_window), dt_window = periods / minimumPitch
+        const double start_time = t - 0.5 * (1.0 / P.min_pitch + P.dt_window);
+        int64_t start64 = low_index(start_time, c.x1);
+        if (start64 < 0) start64 = 0;
+        const int start = (int)start64;
+        int span = L + nw;
+        if (span > n - start) span = n - start;
+        const int loc_max_lag = span - nw;
+        const int avail = n - start < seg_len ? n - start : seg_len;      // samples of the segment inside the sound
+        // every load of the frame first: the raw segment b[j], j = lane + 64 m, and the samples nw behind the first L of them
+        // (for the running sum below)
+        // (unconditional loads on clamped indices, zeroed afterwards: see pitch_ac_wave_kernel)
+        cplx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            int gi = start + lane + 64 * m;
+            gi = gi > n - 1 ? n - 1 : gi;
+            v[m] = cplx{0.0, (double)x[gi]};
+        }
+        float tail[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {                             // L <= 1023
+            int gi = start + lane + 64 * q + nw;
+            gi = gi > n - 1 ? n - 1 : gi;
+            tail[q] = x[gi];
+        }
+        // local mean over one longest period to each side (divisor 2*nsamp_period as in Praat), from the registers when the
+        // segment holds that range
+        double local_mean;
+        {
+            int s0 = right - P.nsamp_period, s1 = left + P.nsamp_period;
+            s0 = s0 < 0 ? 0 : (s0 > n - 1 ? n - 1 : s0);
+            s1 = s1 < 0 ? 0 : (s1 > n - 1 ? n - 1 : s1);
+            double sm = 0.0;
+            if (s0 >= start && s1 < start + avail) {
+                const int a0 = s0 - start, a1 = s1 - start;
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                    const int jb = 64 * m, j = jb + lane;
+                    if (jb + 63 >= a0 && jb <= a1 && j >= a0 && j <= a1) sm += v[m].y;
+                }
+            } else {
+                for (int i = s0 + lane; i <= s1; i += 256) {      // four loads in flight
+                    const float q0 = x[i], q1 = i + 64 <= s1 ? x[i + 64] : 0.f, q2 = i + 128 <= s1 ? x[i + 128] : 0.f,
+                                q3 = i + 192 <= s1 ? x[i + 192] : 0.f;
+                    sm += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+                }
+            }
+            local_mean = group_sum<64>(sm) / (2.0 * P.nsamp_period);
+        }
+        // z = a + i b: b = the segment minus the mean, a = its first nw samples; the local peak and sumx2 = sum a^2 on the way
+        double pk = 0.0, sx = 0.0;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int jb = 64 * m, j = jb + lane;
+            double e = 0.0, a = 0.0;
+            if (j < avail) e = v[m].y - local_mean;
+            if (j < nw) a = e;
+            if (jb + 63 >= pa && jb < pb && j >= pa && j < pb) pk = fmax(pk, fabs(e));
+            sx = fma(a, a, sx);
+            v[m] = cplx{a, e};
+        }
+        const double local_peak = wave_max_dpp(pk);
+        const double intensity = gp > 0.0 ? (local_peak > gp ? 1.0 : local_peak / gp) : 0.0;
+        const double sumx2 = group_sum<64>(sx);
+        // sumy2(l) = sum_{j=l}^{l+nw-1} b_j^2 = sumx2 + sum_{i<l} (b_{i+nw}^2 - b_i^2): a running sum over the L lags, 64 at a time
+        {
+            double carry = 0.0;
+            if (lane == 0) s_sy[0] = sumx2;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (64 * q >= L) break;                            // uniform
+                const int i = lane + 64 * q;
+                double d = 0.0;
+                if (i < L) {
+                    const double u = i + nw < avail ? (double)tail[q] - local_mean : 0.0, w0 = v[q].y;
+                    d = u * u - w0 * w0;
+                }
+                const double sc = wave_scan_incl(d, lane);
+                if (i < L) s_sy[i + 1] = sumx2 + (carry + sc);
+                carry += readlane_f64(sc, 63);
+            }
+        }
+        if (P.debug_stop == 1) continue;
+        const cplx w_s1 = ld_tw(tw, lane);                        // W_S^lane; W_64^(lane % L2) = W_S^(R (lane % L2))
+        wave_fft<R>(v, lds, lane, w_s1, ld_tw(tw, (lane % L2) * R));
+        // C = conj(A) B repacked into the S / 2 points of the transform back (wave_fft.h)
+        cplx y[H];
+        cc_spec_store<R>(v, mem, lane);
+        wave_sync();
+        const cplx y_half = cc_spec_pairs<R>(v, y, mem, lane, w_s1);
+        wave_sync();
+        cc_spec_load<R>(y, mem, lane, y_half);
+        wave_sync();
+        wave_fft<H>(y, lds, lane, ld_tw(tw, 2 * lane), ld_tw(tw, (lane % L2H) * R));   // W_(S/2)^lane, W_64^(lane % (2 L2))
+        if (P.debug_stop == 2) continue;
+        // r[2 k] = Re, r[2 k + 1] = -Im of element k, times S; normalised by sqrt(sumx2 sumy2(l))
+        if (lane == 0) { rb[0] = 1.0; rb[L + 1] = intensity; }
+        const double inv_n = 1.0 / (double)S;
+        constexpr int MO = H < 8 ? H : 8;                         // L <= 1023: lags 2 (lane + 64 m), m < 8
+        double ya[MO], yb[MO];
+#pragma unroll
+        for (int m = 0; m < MO; ++m) {
+            const int l0 = 2 * (lane + 64 * m);
+            ya[m] = s_sy[l0 < L ? l0 : L];
+            yb[m] = s_sy[l0 + 1 < L ? l0 + 1 : L];
+        }
+#pragma unroll
+        for (int m = 0; m < MO; ++m) {
+            const int l0 = 2 * (lane + 64 * m);
+            if (128 * m > L) break;                               // uniform
+            if (l0 >= 1 && l0 <= L) {
+                const double den = sumx2 * ya[m];
+                rb[l0] = (l0 <= loc_max_lag && den > 0.0) ? (y[m].x * inv_n) * fast_rsqrt(den) : 0.0;
+            }
+            if (l0 + 1 <= L) {
+                const double den = sumx2 * yb[m];
+                rb[l0 + 1] = (l0 + 1 <= loc_max_lag && den > 0.0) ? (-y[m].y * inv_n) * fast_rsqrt(den) : 0.0;
+            }
+        }
+        wave_sync();                                              // the next frame rewrites s_sy
     }
 }
 
@@ -2861,7 +3188,15 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     while ((2 << log2m) < P.nfft) ++log2m;                           // nfft = 2 M = 2^(log2m + 1)
     int log2n = 0;
     while ((1 << log2n) < ncc) ++log2n;
-    if (lds_corr > 48 * 1024) {
+    // transform lengths of 512 .. 2048 complex points run one wave per frame (RSAF_PITCH_FFT=wg: the workgroup kernels)
+    int wave_r = 0;
+    {
+        const char* e = getenv("RSAF_PITCH_FFT");
+        const bool want = !(e && e[0] == 'w' && e[1] == 'g');
+        if (want && !P.is_cc && log2m >= 9 && log2m <= 11) wave_r = 1 << (log2m - 6);
+        if (want && P.is_cc && log2n >= 10 && log2n <= 11) wave_r = 1 << (log2n - 6);
+    }
+    if (!wave_r && lds_corr > 48 * 1024) {
         const void* fn = (const void*)pitch_ac_kernel<11>;            // 4 096 points: 64 KB (the only AC instance above 48 KB)
         if (P.is_cc) fn = log2n == 11 ? (const void*)pitch_cc_kernel<11> : (const void*)pitch_cc_kernel<12>;   // 64 / 128 KB
         RSAF_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_corr));
@@ -2912,7 +3247,28 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
             ProfScope prof(P.is_cc ? "mshds_pitch_cc_fft" : "mshds_pitch_ac_fft", s,
                            (P.is_cc ? cc_flops : ac_flops) * (double)max_frames * (double)nc,
                            (P.is_cc ? cc_lds : ac_lds) * (double)max_frames * (double)nc);
-            if (P.is_cc) {
+            if (wave_r) {
+                // one wave per frame (wave_fft.h): S = 64 R complex points
+                const dim3 grid((max_frames + WF_FRAMES - 1) / WF_FRAMES, nc);
+                const double2_t* twz = reinterpret_cast<const double2_t*>(P.is_cc ? twiddles2 : twiddles);
+                if (P.is_cc) {
+                    const size_t lds_w = (size_t)((wave_r == 16 ? wfft::Plan<16>::LDS_DOUBLES : wfft::Plan<32>::LDS_DOUBLES) + ((Lr + 3) & ~1)) * sizeof(double);
+                    if (wave_r == 16)
+                        hipLaunchKernelGGL(pitch_cc_wave_kernel<16>, grid, dim3(64), lds_w, s, wav, cig, gpeak + c0, P, twz,
+                                           (double*)workspace, rstride, max_frames);
+                    else
+                        hipLaunchKernelGGL(pitch_cc_wave_kernel<32>, grid, dim3(64), lds_w, s, wav, cig, gpeak + c0, P, twz,
+                                           (double*)workspace, rstride, max_frames);
+                } else {
+#define RSAF_ACW_CASE(RR)                                                                                             \
+    case RR:                                                                                                          \
+        hipLaunchKernelGGL(pitch_ac_wave_kernel<RR>, grid, dim3(64), (size_t)wfft::Plan<RR>::LDS_DOUBLES * sizeof(double), s, wav, \
+                           cig, gpeak + c0, window, window_r, P, twz, (double*)workspace, rstride, max_frames);        \
+        break;
+                    switch (wave_r) { RSAF_ACW_CASE(8) RSAF_ACW_CASE(16) RSAF_ACW_CASE(32) default: break; }
+#undef RSAF_ACW_CASE
+                }
+            } else if (P.is_cc) {
 #define RSAF_CC_CASE(LG)                                                                                              \
     case LG:                                                                                                          \
         hipLaunchKernelGGL(pitch_cc_kernel<LG>, dim3((max_frames + CC_FRAMES_PER_WG - 1) / CC_FRAMES_PER_WG, nc),      \

@@ -112,10 +112,15 @@ def _clip_info(sample_offs, lengths, grid, dom=None):
 
 
 def _dev(arr, device):
+    """Host array -> device tensor (structured arrays as bytes), queued on the current stream from a pinned staging buffer.
+    A plain ``.to(device)`` of pageable memory is a synchronous copy: the host then waits for everything queued before it,
+    about fifty times per batch, and every wait leaves the GPU idle until the next launch arrives."""
     import torch
     a = np.ascontiguousarray(arr)
-    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device) if a.dtype.fields is not None else \
-        torch.from_numpy(a).to(device)
+    t = torch.from_numpy(a.view(np.uint8).reshape(-1)) if a.dtype.fields is not None else torch.from_numpy(a)
+    if torch.device(device).type != "cuda" or t.numel() == 0:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 def sinc_cheb_table(depth: int, ncoef: int = 16):
@@ -395,9 +400,9 @@ class MshdsEngine:
             ids = [i for i in range(n) if ok[i]]
             if ids:
                 sub = self.formants(wav, [sample_offs[i] for i in ids], [lengths[i] for i in ids],
-                                    gpeak[torch.tensor(ids, dtype=torch.long, device=dev)].contiguous(), floor, ceiling, frame_shift,
+                                    gpeak[_dev(np.asarray(ids, dtype=np.int64), dev)].contiguous(), floor, ceiling, frame_shift,
                                     stream, dom.sub(ids))
-                out[torch.tensor(ids, dtype=torch.long, device=dev)] = sub
+                out[_dev(np.asarray(ids, dtype=np.int64), dev)] = sub
             return out
         dxo = 1.0 / RS_RATE
         ratio = RS_RATE / FS
@@ -430,8 +435,8 @@ class MshdsEngine:
         wstride = int(lib.rsaf_mshds_resample10k_table_stride(RS_DEPTH))   # rows zero-padded for the kernel's tap blocks
         tab = np.zeros((len(tabs), 5, wstride))
         tab[:, :, :2 * RS_DEPTH + 1] = np.stack(tabs)
-        tab_d = torch.from_numpy(tab.reshape(-1)).to(dev)
-        base_d = torch.from_numpy(np.asarray(bases, dtype=np.int32).reshape(-1)).to(dev)
+        tab_d = _dev(tab.reshape(-1), dev)
+        base_d = _dev(np.asarray(bases, dtype=np.int32).reshape(-1), dev)
         # Sound_resample(10000, 500): whole-sound FFT low-pass (16 kHz -> 10 kHz goes down), then sinc interpolation
         lp = torch.empty(int(wav.numel()), dtype=torch.float64, device=dev)
         work = torch.empty(2 * work_off, dtype=torch.float64, device=dev)
@@ -653,7 +658,7 @@ class MshdsEngine:
             so = [sample_offs[i] for i in ids]
             ln = [lengths[i] for i in ids]
             dm = dom.sub(ids)
-            idx = torch.tensor(ids, dtype=torch.long, device=self.device)
+            idx = _dev(np.asarray(ids, dtype=np.int64), self.device)
             gp = gpeak[idx].contiguous()
             floor, ceiling = float(rng[0]), float(rng[1])
 

@@ -105,8 +105,10 @@ def pack_clips(clips, device="cuda", fs=SAMPLE_RATE) -> PackedClips:
     co[1:] = np.cumsum(lengths)
     fo = np.zeros(len(lengths) + 1, dtype=np.int64)
     fo[1:] = np.cumsum(frames)
-    return PackedClips(wav, torch.from_numpy(co).to(device), torch.from_numpy(fo).to(device),
-                       lengths, frames, fs)
+    def small(a):                                          # offsets: pinned staging, queued copy (no host wait)
+        t = torch.from_numpy(a)
+        return t.pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" else t.to(device)
+    return PackedClips(wav, small(co), small(fo), lengths, frames, fs)
 
 
 def smile_lld(p: PackedClips, stream=None, octave_spectrum=False, return_candidates=False):
