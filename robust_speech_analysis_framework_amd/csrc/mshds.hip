@@ -835,9 +835,8 @@ __global__ __launch_bounds__(256) void pitch_cc_kernel(const float* __restrict__
 }
 
 // ---- the two correlation kernels with ONE WAVE per frame (csrc/wave_fft.h) --------------------------------------
-// Transform lengths of 512, 1024 and 2048 complex points (every analysis of the MSHDS feature scripts at 16 kHz except the
-// 512-point cross-correlation of the 100 Hz harmonicity pass, whose second transform would have 256 points) run here:
-// the frame lives in the registers of one wavefront from the sample loads to the normalised correlation row.  The local
+// Transform lengths up to 2048 complex points (every analysis of the MSHDS feature scripts at 16 kHz; shorter transforms
+// are zero-padded up to 512 / 1024 points, which returns the same linear correlation) run here: the frame lives in the registers of one wavefront from the sample loads to the normalised correlation row.  The local
 // mean, the window, the local peak and sum x^2 are taken on the registers the transform starts from (wave reductions by
 // DPP, no LDS round trip, no workgroup barrier anywhere), the spectrum step evaluates every conjugate pair once, and only
 // the lags the candidate kernel reads are normalised and stored.  A wave takes WF_FRAMES consecutive frames so that its
@@ -3193,9 +3192,14 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     {
         const char* e = getenv("RSAF_PITCH_FFT");
         const bool want = !(e && e[0] == 'w' && e[1] == 'g');
-        if (want && !P.is_cc && log2m >= 9 && log2m <= 11) wave_r = 1 << (log2m - 6);
-        if (want && P.is_cc && log2n >= 10 && log2n <= 11) wave_r = 1 << (log2n - 6);
+        // A shorter transform is zero-padded up to the smallest wave size: the correlation is linear as long as the lags stay
+        // below (transform length - window), so a longer transform returns the same values (autocorrelation: 512 complex =
+        // 1024 real points; cross-correlation: 1024 points, whose transform back has the 512 the wave kernel needs).
+        if (want && !P.is_cc && log2m <= 11) wave_r = log2m <= 9 ? 8 : 1 << (log2m - 6);
+        if (want && P.is_cc && log2n <= 11) wave_r = log2n <= 10 ? 16 : 32;
     }
+    if (wave_r && !P.is_cc) P.nfft = 128 * wave_r;                  // 2 S real points
+    if (wave_r && P.is_cc) ncc = 64 * wave_r;
     if (!wave_r && lds_corr > 48 * 1024) {
         const void* fn = (const void*)pitch_ac_kernel<11>;            // 4 096 points: 64 KB (the only AC instance above 48 KB)
         if (P.is_cc) fn = log2n == 11 ? (const void*)pitch_cc_kernel<11> : (const void*)pitch_cc_kernel<12>;   // 64 / 128 KB
@@ -3237,8 +3241,11 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         const double cc_flops = 5.0 * ncc * log2((double)ncc) + 2.5 * ncc * log2(0.5 * ncc) + 40.0 * 0.5 * ncc + 4.0 * seg_len;
         // LDS bytes a frame moves through the FFT kernel (every pass reads and writes its N complex doubles: log4 stages of
         // each transform, the staging pass and the spectrum pass): the kernel's own roofline is the LDS, not the FLOPs
-        const double ac_lds = 16.0 * Mfft * (2.0 * ceil(log2(Mfft) / 2.0) + 3.0) * 2.0;
-        const double cc_lds = 16.0 * ncc * (ceil(log2((double)ncc) / 2.0) + 2.0) * 2.0 + 16.0 * 0.5 * ncc * (ceil(log2(0.5 * ncc) / 2.0) + 1.0) * 2.0;
+        // (one wave per frame, wave_fft.h: two exchanges per transform, each writing and reading the S complex doubles, and the
+        // paired spectrum step: 160 S bytes per autocorrelation frame, 120 S + the running sums per cross-correlation frame)
+        const double ac_lds = wave_r ? 160.0 * Mfft : 16.0 * Mfft * (2.0 * ceil(log2(Mfft) / 2.0) + 3.0) * 2.0;
+        const double cc_lds = wave_r ? 120.0 * ncc + 16.0 * Lr
+                                     : 16.0 * ncc * (ceil(log2((double)ncc) / 2.0) + 2.0) * 2.0 + 16.0 * 0.5 * ncc * (ceil(log2(0.5 * ncc) / 2.0) + 1.0) * 2.0;
         for (int c0 = 0; c0 < n_clips; c0 += group) {
             const int nc = std::min(group, n_clips - c0);
             const ClipInfo* cig = (const ClipInfo*)clip_info + c0;

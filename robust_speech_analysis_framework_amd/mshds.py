@@ -111,14 +111,15 @@ def _clip_info(sample_offs, lengths, grid, dom=None):
     return ci, off, int(ci["n_frames"].max()) if len(ci) else 0
 
 
-def _dev(arr, device):
-    """Host array -> device tensor (structured arrays as bytes), queued on the current stream from a pinned staging buffer.
+def _dev(arr, device, blocking=False):
+    """Host array -> device tensor (structured arrays as bytes), queued on the current stream from a pinned staging buffer
+    (``blocking``: complete on return - for tables that are cached and later read from other streams).
     A plain ``.to(device)`` of pageable memory is a synchronous copy: the host then waits for everything queued before it,
     about fifty times per batch, and every wait leaves the GPU idle until the next launch arrives."""
     import torch
     a = np.ascontiguousarray(arr)
     t = torch.from_numpy(a.view(np.uint8).reshape(-1)) if a.dtype.fields is not None else torch.from_numpy(a)
-    if torch.device(device).type != "cuda" or t.numel() == 0:
+    if blocking or torch.device(device).type != "cuda" or t.numel() == 0:
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
 
@@ -210,13 +211,13 @@ class MshdsEngine:
         self._tables = {}
         self.fo_doubles = _lib.load().rsaf_mshds_frameout_doubles()
         import os
-        self.n_streams = int(os.environ.get("RSAF_MSHDS_STREAMS", "2"))     # 1: every analysis on the caller's stream
+        self.n_streams = int(os.environ.get("RSAF_MSHDS_STREAMS", "3"))     # 1: every analysis on the caller's stream
         self._aux = None
 
     # ---- cached device tables ----
     def _table(self, key, builder):
         if key not in self._tables:
-            self._tables[key] = tuple(None if a is None else _dev(np.asarray(a, dtype=np.float64), self.device)
+            self._tables[key] = tuple(None if a is None else _dev(np.asarray(a, dtype=np.float64), self.device, blocking=True)
                                       for a in builder())
         return self._tables[key]
 

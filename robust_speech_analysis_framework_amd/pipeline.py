@@ -180,16 +180,18 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
             out.append(r)
             continue
         if name in ("mshds_pitch_ac_fft", "mshds_pitch_cc_fft"):
-            # the FFT correlation kernels live in LDS: every Stockham pass reads and writes the frame's N complex doubles.
-            # Their roofline is the LDS bandwidth (the fp64 FLOP rate is kept beside it).
+            # One wave per frame (csrc/wave_fft.h): the transforms run in registers and make two trips through LDS each, so
+            # the kernel's ceiling is the fp64 vector rate; the LDS traffic it still has is kept beside it.
             per_launch = rec["bytes"] / rec["launches"]
-            ach = per_launch / (avg_ms * 1e-3) / 1e9
-            out.append({**base, "bound": "lds", "achieved": round(ach, 1), "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s",
-                        "frac": round(ach / LDS_PEAK_GBS, 4), "algorithmic_lds_bytes_per_launch": per_launch,
-                        "fp64_tflops": round(rec["flops"] / (rec["ms"] * 1e-3) / 1e12, 3),
-                        "fp64_frac_of_vector_peak": round(rec["flops"] / (rec["ms"] * 1e-3) / 1e12 / f64_peak_tflops, 4),
-                        "note": "LDS bytes = 16 B x points x 2 (read + write) per pass, passes = radix-4 stages of both transforms + "
-                                "staging + spectrum pass; PMC view (LDS busy, bank conflicts): profiles/r02/pmc_pitch_fft_kernels.json"})
+            lds = per_launch / (avg_ms * 1e-3) / 1e9
+            tf = rec["flops"] / (rec["ms"] * 1e-3) / 1e12
+            out.append({**base, "bound": "fp64_vector", "achieved": round(tf, 3), "peak": f64_peak_tflops, "unit": "TFLOP/s",
+                        "frac": round(tf / f64_peak_tflops, 4), "algorithmic_flops_per_launch": rec["flops"] / rec["launches"],
+                        "lds_gbs": round(lds, 1), "lds_frac_of_peak": round(lds / LDS_PEAK_GBS, 4),
+                        "algorithmic_lds_bytes_per_launch": per_launch,
+                        "note": "FLOPs = 5 S log2 S per complex transform + ~30 per point of the spectrum step (real operations, an "
+                                "FMA counts two); LDS bytes = the two exchanges of each transform (16 B x S written and read) + the "
+                                "paired spectrum step; phase timing: profiles/r03/pitch_phase_r03.txt"})
             continue
         if rec["flops"] > 0:
             fp64 = name.startswith("mshds_")
