@@ -18,6 +18,7 @@
 #include "praat_interp.h"
 #include "praat_lowpass.h"
 #include "rsaf_common.h"
+#include "wave_fft.h"
 
 #pragma clang fp contract(off)
 
@@ -259,6 +260,11 @@ __device__ void fft_inplace(double2* a, int n, int log2n, const double2* __restr
     }
 }
 
+__device__ __forceinline__ wfft::cplx ld_c(const double2* __restrict__ tw, int i) {
+    const double2 w = tw[i];
+    return wfft::cplx{w.x, w.y};
+}
+
 __device__ __forceinline__ int bitrev(int i, int log2n) { return log2n ? (int)(__brev((unsigned)i) >> (32 - log2n)) : 0; }
 
 // Real-input FFT of n = 2m points from an m-point complex FFT of z[j] = x[2j] + i x[2j+1] (already transformed in `a`):
@@ -271,17 +277,22 @@ __device__ __forceinline__ double2 real_fft_bin(const double2* a, int m, int k, 
     return make_double2(er + w.x * orr - w.y * oi, ei + w.x * oi + w.y * orr);
 }
 
+// Frames of intervals shorter than the 0.1 s window (transform lengths below 1024): the one-wave kernel below lists them,
+// a fixed grid of workgroups walks the list.
 __global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
                                                        const double* __restrict__ res, int cap_res, int cap_frames,
                                                        const double* __restrict__ win1000, const double2* __restrict__ tw,
-                                                       double preemph, double* __restrict__ ceps) {
+                                                       double preemph, double* __restrict__ ceps, const int* __restrict__ list,
+                                                       const int* __restrict__ list_count) {
     __shared__ double2 a[NFFT_MAX / 2];
     __shared__ double xs[NFFT_MAX + 1];                 // windowed frame, then the ln-power half spectrum
     __shared__ double s_red[4];
-    const int clip = blockIdx.y, f = blockIdx.x;
-    const int nseg = hdr[4 * clip];
-    if (nseg <= 0 || f >= hdr[4 * clip + 2]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int count = *list_count;
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    __syncthreads();                                    // the previous frame's readers of a / xs / s_red are done
+    const int clip = list[2 * item], f = list[2 * item + 1];
+    const int nseg = hdr[4 * clip];
     const Seg* S = segs + (int64_t)clip * max_seg;
     const Seg s = S[find_seg<4>(S, nseg, f)];
     const int fl = f - (int)s.frame_off;
@@ -352,6 +363,139 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ s
     for (int k = tid; k <= m; k += 256) {
         const double cv = real_fft_bin(a, m, k, tw, twstep).x * sdx;
         o[k] = cv * cv;
+    }
+    }
+}
+
+// One wavefront per frame for the usual case (0.1 s window = 1000 samples at 10 kHz, transform length 1024): both real
+// transforms are 512-point complex transforms in registers (wave_fft.h, 8 points per lane), the conjugate pairs (k, 512 - k)
+// of the real-input split are evaluated once each by the lane that holds k < 256, the ln-power half spectrum goes through
+// LDS once to become the even sequence of the second transform.  No workgroup barrier; CEP_FRAMES frames per wave.
+constexpr int CEP_FRAMES = 4;
+constexpr int CEP_LDS_DOUBLES = wfft::Plan<8>::LDS_DOUBLES + 516;
+
+__global__ __launch_bounds__(64, 4) void cepstrum_wave_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                              const double* __restrict__ res, int cap_res, int cap_frames,
+                                                              const double* __restrict__ win1000, const double2* __restrict__ tw,
+                                                              double preemph, double* __restrict__ ceps, int* __restrict__ list,
+                                                              int* __restrict__ list_count, int list_cap) {
+    using namespace wfft;
+    __shared__ double lds[CEP_LDS_DOUBLES];
+    double* lp = lds + Plan<8>::LDS_DOUBLES;            // ln-power half spectrum, bins 0 .. 512
+    constexpr int R = 8, S = 512, H = 4;
+    const int clip = blockIdx.y;
+    const int nseg = hdr[4 * clip];
+    if (nseg <= 0) return;
+    const int nframes = hdr[4 * clip + 2];
+    const int f0 = blockIdx.x * CEP_FRAMES;
+    if (f0 >= nframes) return;
+    const Seg* SG = segs + (int64_t)clip * max_seg;
+    const int lane_ = threadIdx.x;
+    LdsMem mem{lds};
+    const int f1 = f0 + CEP_FRAMES < nframes ? f0 + CEP_FRAMES : nframes;
+#pragma unroll 1
+    for (int f = f0; f < f1; ++f) {
+        int lane = lane_;                               // redefined per frame (keeps lane-only expressions out of the loop preheader)
+        asm volatile("" : "+v"(lane));
+        const Seg s = SG[find_seg<4>(SG, nseg, f)];
+        if ((int)s.nfft != 1024) {                      // a short interval: the workgroup kernel takes the frame
+            if (lane == 0) {
+                const int at = atomicAdd(list_count, 1);
+                if (at < list_cap) { list[2 * at] = clip; list[2 * at + 1] = f; }
+            }
+            continue;
+        }
+        const int fl = f - (int)s.frame_off;
+        const int nx = (int)s.nx, m_out = (int)s.m_out;
+        const double* y = res + (int64_t)clip * cap_res + (int64_t)s.res_off;
+        const double t = s.t1 + (double)fl * DT;
+        const int idx0 = (int)floor((t - 0.5 * s.window - s.x1o) / DXO + 0.5);   // Sampled_xToNearestIndex, 0-based
+        // gather with the pre-emphasis y[j] - a y[j-1] (the first sample of the sound is kept): element k = lane + 64 m of
+        // the packed frame holds samples 2 k and 2 k + 1.  Loads are unconditional on clamped indices.
+        cplx v[R];
+        double sum = 0.0;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int i0 = 2 * (lane + 64 * m), j0 = idx0 + i0;
+            const int ja = j0 - 1 < 0 ? 0 : (j0 - 1 > m_out - 1 ? m_out - 1 : j0 - 1);
+            const int jb = j0 < 0 ? 0 : (j0 > m_out - 1 ? m_out - 1 : j0);
+            const int jc = j0 + 1 < 0 ? 0 : (j0 + 1 > m_out - 1 ? m_out - 1 : j0 + 1);
+            const double ya = y[ja], yb = y[jb], yc = y[jc];
+            double e0 = 0.0, e1 = 0.0;
+            if (i0 < nx && j0 >= 0 && j0 < m_out) e0 = j0 >= 1 ? yb - preemph * ya : yb;
+            if (i0 + 1 < nx && j0 + 1 >= 0 && j0 + 1 < m_out) e1 = j0 + 1 >= 1 ? yc - preemph * yb : yc;
+            v[m] = cplx{e0, e1};
+            sum += e0 + e1;
+        }
+        const double mean = wave_sum_f64(sum) / (double)nx;
+        const double imid = 0.5 * (nx + 1), edge = exp(-12.0);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int i0 = 2 * (lane + 64 * m);
+            double w0, w1;
+            if (nx == 1000) {                           // uniform
+                w0 = win1000[i0 < 999 ? i0 : 999];
+                w1 = win1000[i0 + 1 < 999 ? i0 + 1 : 999];
+            } else {
+                const double d0 = (double)(i0 + 1) - imid, d1 = (double)(i0 + 2) - imid, q = (double)((nx + 1) * (nx + 1));
+                w0 = (exp(-48.0 * (d0 * d0) / q) - edge) / (1.0 - edge);
+                w1 = (exp(-48.0 * (d1 * d1) / q) - edge) / (1.0 - edge);
+            }
+            v[m] = cplx{i0 < nx ? (v[m].x - mean) * w0 : 0.0, i0 + 1 < nx ? (v[m].y - mean) * w1 : 0.0};
+        }
+        // first transform; X[k] = E + W^k O, X[512 - k] = conj(E - W^k O) from the pair (Z[k], Z[512 - k]); ln power
+        wave_fft<R>(v, lds, lane, ld_c(tw, 2 * lane), ld_c(tw, (lane % 8) * 16));
+        ac_spec_store<R>(v, mem, lane);
+        wave_sync();
+        const cplx wl = ld_c(tw, lane);
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const int k = lane + 64 * m;
+            const int pp = k ? S / 2 - k : 0;
+            cplx zc{mem.ld(pp), mem.ld(S / 2 + pp)};
+            if (m == 0) zc = cplx{lane == 0 ? v[0].x : zc.x, lane == 0 ? v[0].y : zc.y};
+            const cplx zk = v[m], w = mul_w64(wl, m * 4);                       // W_1024^(64 m) = W_64^(4 m)
+            const double er = 0.5 * (zk.x + zc.x), ei = 0.5 * (zk.y - zc.y), orr = 0.5 * (zk.y + zc.y), oi = -0.5 * (zk.x - zc.x);
+            const double tr = w.x * orr - w.y * oi, ti = w.x * oi + w.y * orr;
+            const double ar = (er + tr) * DXO, ai = (ei + ti) * DXO, br = (er - tr) * DXO, bi = (ti - ei) * DXO;
+            lp[k] = log(ar * ar + ai * ai + 1e-300);
+            lp[S - k] = log(br * br + bi * bi + 1e-300);                        // k = 0: bin 512 = Re Z[0] - Im Z[0]
+        }
+        if (lane == 0) {                                                       // bin 256 pairs with itself: X = conj(Z[256])
+            const double ar = v[H].x * DXO, ai = v[H].y * DXO;
+            lp[S / 2] = log(ar * ar + ai * ai + 1e-300);
+        }
+        wave_sync();
+        // the real even sequence e[n] = lp[min(n, 1024 - n)], packed as e[2 j] + i e[2 j + 1]
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int j = lane + 64 * m;
+            v[m] = m < H ? cplx{lp[2 * j], lp[2 * j + 1]} : cplx{lp[1024 - 2 * j], lp[1023 - 2 * j]};
+        }
+        wave_sync();
+        wave_fft<R>(v, lds, lane, ld_c(tw, 2 * lane), ld_c(tw, (lane % 8) * 16));
+        ac_spec_store<R>(v, mem, lane);
+        wave_sync();
+        const double sdx = 1.0 / (DXO * 1024.0);
+        double* o = ceps + ((int64_t)clip * cap_frames + f) * NQ_MAX;
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const int k = lane + 64 * m;
+            const int pp = k ? S / 2 - k : 0;
+            cplx zc{mem.ld(pp), mem.ld(S / 2 + pp)};
+            if (m == 0) zc = cplx{lane == 0 ? v[0].x : zc.x, lane == 0 ? v[0].y : zc.y};
+            const cplx zk = v[m], w = mul_w64(wl, m * 4);
+            const double er = 0.5 * (zk.x + zc.x), orr = 0.5 * (zk.y + zc.y), oi = -0.5 * (zk.x - zc.x);
+            const double tr = w.x * orr - w.y * oi;
+            const double ca = (er + tr) * sdx, cb = (er - tr) * sdx;
+            o[k] = ca * ca;
+            o[S - k] = cb * cb;
+        }
+        if (lane == 0) {
+            const double cm = v[H].x * sdx;
+            o[S / 2] = cm * cm;
+        }
+        wave_sync();                                    // the next frame rewrites the exchange buffer
     }
 }
 
@@ -645,8 +789,20 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
     }
     {
         ProfScope prof("mshds_cpp_cepstrum", s, 0.0, 0.0);
-        hipLaunchKernelGGL(cepstrum_kernel, dim3(cap_frames, n_clips), dim3(256), 0, s, segs, max_seg, hdr, resampled, cap_res,
-                           cap_frames, window1000, (const double2*)twiddle1024, exp(-2.0 * PI * 50.0 * DXO), cepstrogram);
+        // frames with the full 1024-point transform: one wave each; the others are listed in cpp_frames (free until the next
+        // kernel writes it; the counter is its last slot) and taken by the workgroup kernel
+        const int64_t slots = (int64_t)n_clips * cap_frames;
+        int* list = reinterpret_cast<int*>(cpp_frames);
+        int* list_count = list + 2 * (slots - 1);
+        const int list_cap = (int)std::min<int64_t>(slots - 1, 0x7fffffff);
+        RSAF_CHECK_HIP(hipMemsetAsync(list_count, 0, sizeof(int), s));
+        const double pre = exp(-2.0 * PI * 50.0 * DXO);
+        hipLaunchKernelGGL(cepstrum_wave_kernel, dim3((cap_frames + CEP_FRAMES - 1) / CEP_FRAMES, n_clips), dim3(64), 0, s, segs,
+                           max_seg, hdr, resampled, cap_res, cap_frames, window1000, (const double2*)twiddle1024, pre, cepstrogram,
+                           list, list_count, list_cap);
+        RSAF_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(cepstrum_kernel, dim3(2048), dim3(256), 0, s, segs, max_seg, hdr, resampled, cap_res, cap_frames,
+                           window1000, (const double2*)twiddle1024, pre, cepstrogram, list, list_count);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     {
