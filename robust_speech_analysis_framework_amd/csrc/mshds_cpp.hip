@@ -580,15 +580,18 @@ __device__ double quantile_half(const double* a, int n) {     // Praat NUMquanti
 __global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
                                                         const double* __restrict__ ceps, int cap_frames, int n_time,
                                                         int n_quef, double pitch_floor, double pitch_ceiling,
-                                                        double* __restrict__ cpp_out) {
+                                                        double* __restrict__ cpp_out, const int* __restrict__ list,
+                                                        const int* __restrict__ list_count) {
     __shared__ double zt[NQ_MAX + 3], db[NQ_MAX + 3], srt[NFFT_MAX];
     __shared__ double s_val[4];
     __shared__ int s_ord[4];
     __shared__ double s_xq[4];
-    const int clip = blockIdx.y, f = blockIdx.x;
-    const int nseg = hdr[4 * clip];
-    if (nseg <= 0 || f >= hdr[4 * clip + 2]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int count = *list_count;
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    __syncthreads();                                    // the previous frame's readers of the shared arrays are done
+    const int clip = list[2 * item], f = list[2 * item + 1];
+    const int nseg = hdr[4 * clip];
     const Seg* S = segs + (int64_t)clip * max_seg;
     const Seg s = S[find_seg<4>(S, nseg, f)];
     const int fl = f - (int)s.frame_off, nf = (int)s.nf, nfft = (int)s.nfft, nq = nfft / 2 + 1;
@@ -688,6 +691,220 @@ __global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ 
             out = best - (slope * qpeak + icpt);
         }
         cpp_out[(int64_t)clip * cap_frames + f] = out;
+    }
+    }
+}
+
+// One wavefront per frame for the frames of full-window intervals (513 quefrency bins: lane l holds bins 8 l .. 8 l + 7,
+// lane 63 also bin 512).  The two medians of Theil's line are order statistics, not sorts: wave_select_pair finds the
+// elements of rank t and t + 1 of the 64 E values the lanes hold by partitioning around pivots taken from the data
+// (compare + ballot + scalar popcount per element and round, about a dozen rounds), with no exchange of data between lanes
+// and no arithmetic on the values, so the medians are the ones a full sort gives.  Same operation order as the
+// workgroup kernel everywhere else (fp contraction is off in this file): the two kernels return identical bits.
+template <int E>
+__device__ __forceinline__ void wave_select_pair(const double (&x)[E], int t, double& a, double& b) {
+    double lo = -INFINITY, hi = INFINITY;               // the element of rank t lies in the open interval (lo, hi)
+    int count_le = 0;
+    a = 0.0;
+    for (int round = 0; round <= 64 * E; ++round) {
+        double p = 0.0;
+        bool found = false;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (!found) {
+                const unsigned long long mk = __ballot(x[e] > lo && x[e] < hi);
+                if (mk) {
+                    const int src = __ffsll((long long)mk) - 1;
+                    p = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[e]), src),
+                                         __builtin_amdgcn_readlane(__double2loint(x[e]), src));
+                    found = true;
+                }
+            }
+        }
+        if (!found) break;                              // cannot happen: rank t always has an element in the interval
+        int lt = 0, le = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            lt += __popcll(__ballot(x[e] < p));
+            le += __popcll(__ballot(x[e] <= p));
+        }
+        if (lt <= t && t < le) { a = p; count_le = le; break; }
+        if (t < lt) hi = p; else lo = p;
+    }
+    if (count_le > t + 1) { b = a; return; }
+    double mn = INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) mn = (x[e] > a && x[e] < mn) ? x[e] : mn;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(mn, o, 64);
+        mn = ov < mn ? ov : mn;
+    }
+    b = mn;
+}
+
+constexpr int CPPF_FRAMES = 4;
+
+__global__ __launch_bounds__(64, 4) void cpp_frame_wave_kernel(const Seg* __restrict__ segs, int max_seg, const int* __restrict__ hdr,
+                                                               const double* __restrict__ ceps, int cap_frames, int n_time,
+                                                               int n_quef, double pitch_floor, double pitch_ceiling,
+                                                               double* __restrict__ cpp_out, int* __restrict__ list,
+                                                               int* __restrict__ list_count, int list_cap) {
+    __shared__ double sq[NQ_MAX + 7];                    // smoothed power per bin, then dB per bin
+    constexpr int NQ = NQ_MAX;                           // 513
+    const int clip = blockIdx.y;
+    const int nseg = hdr[4 * clip];
+    if (nseg <= 0) return;
+    const int nframes = hdr[4 * clip + 2];
+    const int f0 = blockIdx.x * CPPF_FRAMES;
+    if (f0 >= nframes) return;
+    const Seg* SG = segs + (int64_t)clip * max_seg;
+    const int lane_ = threadIdx.x;
+    const int f1 = f0 + CPPF_FRAMES < nframes ? f0 + CPPF_FRAMES : nframes;
+    const double qlo = 1.0 / pitch_ceiling, qhi = 1.0 / pitch_floor;
+#pragma unroll 1
+    for (int f = f0; f < f1; ++f) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        const Seg s = SG[find_seg<4>(SG, nseg, f)];
+        if ((int)s.nfft != 1024) {                      // a short interval: the workgroup kernel takes the frame
+            if (lane == 0) {
+                const int at = atomicAdd(list_count, 1);
+                if (at < list_cap) { list[2 * at] = clip; list[2 * at + 1] = f; }
+            }
+            continue;
+        }
+        const int fl = f - (int)s.frame_off, nf = (int)s.nf;
+        const double* Z = ceps + ((int64_t)clip * cap_frames + (int64_t)s.frame_off) * NQ_MAX;   // frames of this interval
+        // moving average over time (VECsmoothByMovingAverage: [i - w/2, i + w/2], one less on the right for even w)
+        int lo = fl, hi = fl;
+        if (n_time > 1) {
+            lo = fl - n_time / 2;
+            hi = fl + n_time / 2 - ((n_time & 1) == 0 ? 1 : 0);
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > nf - 1 ? nf - 1 : hi;
+        }
+        const int q0 = 8 * lane;
+        double zt[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) zt[e] = 0.0;
+        for (int j = lo; j <= hi; ++j) {
+            const double* row = Z + (int64_t)j * NQ_MAX;
+            double r[9];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = row[q0 + e];
+            r[8] = row[NQ - 1];                          // bin 512 (lane 63's ninth)
+#pragma unroll
+            for (int e = 0; e < 9; ++e) zt[e] += r[e];
+        }
+        if (n_time > 1) {
+            const double cnt = (double)(hi - lo + 1);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) zt[e] = zt[e] / cnt;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sq[q0 + e] = zt[e];
+        if (lane == 63) sq[NQ - 1] = zt[8];
+        wfft::wave_sync();
+        // moving average over quefrency, then dB
+        double db[9];
+        if (n_quef == 10) {                              // [q - 5, q + 4]: 18 consecutive values cover the lane's nine bins
+            double w[18];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const int jj = q0 - 5 + i;
+                const double v = sq[jj < 0 ? 0 : (jj > NQ - 1 ? NQ - 1 : jj)];
+                w[i] = (jj >= 0 && jj <= NQ - 1) ? v : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const int q = q0 + e;
+                int a = q - 5, b = q + 4;
+                a = a < 0 ? 0 : a;
+                b = b > NQ - 1 ? NQ - 1 : b;
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) v += w[e + i];   // entries outside [0, 512] are 0.0: the sum is the one over [a, b]
+                v /= (double)(b - a + 1);
+                db[e] = 10.0 * log10(v + 1e-30);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const int q = q0 + e < NQ ? q0 + e : NQ - 1;
+                double v = sq[q];
+                if (n_quef > 1) {
+                    int a = q - n_quef / 2, b = q + n_quef / 2 - ((n_quef & 1) == 0 ? 1 : 0);
+                    a = a < 0 ? 0 : a;
+                    b = b > NQ - 1 ? NQ - 1 : b;
+                    v = 0.0;
+                    for (int j = a; j <= b; ++j) v += sq[j];
+                    v /= (double)(b - a + 1);
+                }
+                db[e] = 10.0 * log10(v + 1e-30);
+            }
+        }
+        wfft::wave_sync();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sq[q0 + e] = db[e];
+        if (lane == 63) sq[NQ - 1] = db[8];
+        wfft::wave_sync();
+        // Theil's incomplete method over all 513 points: slope = median of the 256 half-distance slopes ...
+        double sl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * lane + e;
+            sl[e] = (sq[257 + i] - sq[i]) / ((double)(257 + i) * DQ - (double)i * DQ);
+        }
+        double m0, m1;
+        wave_select_pair<4>(sl, 127, m0, m1);                                   // NUMquantile(0.5) of 256: place 128.5
+        const double slope = m1 == m0 ? m0 : m0 + 0.5 * (m1 - m0);
+        // ... intercept = median of the 513 residual offsets: the ranks 255 and 256 of the first 512 bracket it
+        double rs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rs[e] = db[e] - slope * ((double)(q0 + e) * DQ);
+        double lo_v, hi_v;
+        wave_select_pair<8>(rs, 255, lo_v, hi_v);
+        const double e512 = sq[NQ - 1] - slope * ((double)(NQ - 1) * DQ);
+        const double icpt = e512 <= lo_v ? lo_v : (e512 >= hi_v ? hi_v : e512);
+        // Vector_getMaximumAndX (parabolic) over [1/ceiling, 1/floor]: end points first, then the local maxima in
+        // ascending order, a later candidate wins only if strictly greater -> (value, order) reduction
+        int imin = (int)ceil(qlo / DQ), imax = (int)floor(qhi / DQ);
+        imax = imax > NQ - 1 ? NQ - 1 : imax;
+        double best = -INFINITY, bx = 0.0;
+        int bord = 0x7fffffff;
+        if (imax >= imin) {
+            if (lane == 0) { best = sq[imin]; bx = (double)imin; bord = 0; }
+            if (lane == 1 && sq[imax] > sq[imin]) { best = sq[imax]; bx = (double)imax; bord = 1; }
+            const int a = imin < 1 ? 1 : imin, b = imax > NQ - 2 ? NQ - 2 : imax;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = q0 + e;
+                const int il = i >= 1 ? i - 1 : 0, ir = i + 1 <= NQ - 1 ? i + 1 : NQ - 1;
+                const double dl = sq[il], dc = db[e], dr = sq[ir];
+                if (i >= a && i <= b && dc > dl && dc >= dr) {
+                    const double dy = 0.5 * (dr - dl), d2y = 2.0 * dc - dl - dr;
+                    const double v = dc + 0.5 * dy * dy / d2y;
+                    if (v > best) { best = v; bx = (double)i + dy / d2y; bord = 2 + i; }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ov = __shfl_xor(best, o, 64), ox = __shfl_xor(bx, o, 64);
+            const int oo = __shfl_xor(bord, o, 64);
+            if (ov > best || (ov == best && oo < bord)) { best = ov; bx = ox; bord = oo; }
+        }
+        if (lane == 0) {
+            double out = __longlong_as_double(0x7ff8000000000000LL);
+            if (imax >= imin) {
+                double qpeak = bx * DQ;
+                qpeak = qpeak < qlo ? qlo : (qpeak > qhi ? qhi : qpeak);
+                out = best - (slope * qpeak + icpt);
+            }
+            cpp_out[(int64_t)clip * cap_frames + f] = out;
+        }
+        wfft::wave_sync();                              // the next frame rewrites sq
     }
 }
 
@@ -789,12 +1006,12 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
     }
     {
         ProfScope prof("mshds_cpp_cepstrum", s, 0.0, 0.0);
-        // frames with the full 1024-point transform: one wave each; the others are listed in cpp_frames (free until the next
-        // kernel writes it; the counter is its last slot) and taken by the workgroup kernel
-        const int64_t slots = (int64_t)n_clips * cap_frames;
-        int* list = reinterpret_cast<int*>(cpp_frames);
-        int* list_count = list + 2 * (slots - 1);
-        const int list_cap = (int)std::min<int64_t>(slots - 1, 0x7fffffff);
+        // frames with the full 1024-point transform: one wave each; the others are listed in lp_work (free once the intervals
+        // are resampled; the counter is its last slot) and taken by the workgroup kernel
+        const int64_t lp_doubles = (int64_t)n_clips * cap_work * 2;
+        int* list = reinterpret_cast<int*>(lp_work);
+        int* list_count = list + 2 * (lp_doubles - 1);
+        const int list_cap = (int)std::min<int64_t>(lp_doubles - 1, 0x7fffffff);
         RSAF_CHECK_HIP(hipMemsetAsync(list_count, 0, sizeof(int), s));
         const double pre = exp(-2.0 * PI * 50.0 * DXO);
         hipLaunchKernelGGL(cepstrum_wave_kernel, dim3((cap_frames + CEP_FRAMES - 1) / CEP_FRAMES, n_clips), dim3(64), 0, s, segs,
@@ -807,8 +1024,17 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
     }
     {
         ProfScope prof("mshds_cpp_frames", s, 0.0, 0.0);
-        hipLaunchKernelGGL(cpp_frame_kernel, dim3(cap_frames, n_clips), dim3(256), 0, s, segs, max_seg, hdr, cepstrogram,
-                           cap_frames, (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0, cpp_frames);
+        const int64_t lp_doubles = (int64_t)n_clips * cap_work * 2;
+        int* list = reinterpret_cast<int*>(lp_work);
+        int* list_count = list + 2 * (lp_doubles - 1);
+        const int list_cap = (int)std::min<int64_t>(lp_doubles - 1, 0x7fffffff);
+        RSAF_CHECK_HIP(hipMemsetAsync(list_count, 0, sizeof(int), s));
+        hipLaunchKernelGGL(cpp_frame_wave_kernel, dim3((cap_frames + CPPF_FRAMES - 1) / CPPF_FRAMES, n_clips), dim3(64), 0, s, segs,
+                           max_seg, hdr, cepstrogram, cap_frames, (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0,
+                           cpp_frames, list, list_count, list_cap);
+        RSAF_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(cpp_frame_kernel, dim3(2048), dim3(256), 0, s, segs, max_seg, hdr, cepstrogram, cap_frames,
+                           (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0, cpp_frames, list, list_count);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(n_clips), dim3(256), 0, s, segs, max_seg, hdr, cpp_frames, cap_frames, 4.0, out);
