@@ -81,8 +81,17 @@ __global__ __launch_bounds__(256) void clip_peak_kernel(const float* __restrict_
     const ClipInfo c = ci[blockIdx.x];
     const float* x = wav + c.sample_off;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (these loops keep eight loads in flight: an exec-masked loop with one load per turn is not unrolled by the compiler
+    // and waits for the memory once per turn; the additions keep their order)
     double s = 0.0;
-    for (int i = threadIdx.x; i < c.n_samples; i += 256) s += (double)x[i];
+    const int last = c.n_samples - 1;
+    for (int i0 = threadIdx.x; i0 < c.n_samples; i0 += 8 * 256) {
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = x[i0 + 256 * u <= last ? i0 + 256 * u : last];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + 256 * u <= last) s += (double)q[u];
+    }
     s = wave_sum_f64(s);
     if (lane == 0) red[w] = s;
     __syncthreads();
@@ -90,7 +99,13 @@ __global__ __launch_bounds__(256) void clip_peak_kernel(const float* __restrict_
     __syncthreads();
     const double mean = bc;
     double m = 0.0;
-    for (int i = threadIdx.x; i < c.n_samples; i += 256) m = fmax(m, fabs((double)x[i] - mean));
+    for (int i0 = threadIdx.x; i0 < c.n_samples; i0 += 8 * 256) {
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = x[i0 + 256 * u <= last ? i0 + 256 * u : last];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + 256 * u <= last) m = fmax(m, fabs((double)q[u] - mean));
+    }
     m = wave_max_f64(m);
     __syncthreads();
     if (lane == 0) red[w] = m;
@@ -114,15 +129,33 @@ __global__ __launch_bounds__(256) void intensity_kernel(const float* __restrict_
     double mean = 0.0;
     if (subtract_mean) {
         double s = 0.0;
-        for (int64_t i = lo + lane; i <= hi; i += 64) s += (double)x[i];
+        for (int64_t i0 = lo + lane; i0 <= hi; i0 += 8 * 64) {           // eight loads in flight (see clip_peak_kernel)
+            float q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = x[i0 + 64 * u <= hi ? i0 + 64 * u : hi];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + 64 * u <= hi) s += (double)q[u];
+        }
         mean = wave_sum_f64(s) / (double)(hi - lo + 1);
     }
     double sw = 0.0, sx = 0.0;
-    for (int64_t i = lo + lane; i <= hi; i += 64) {
-        const double w = win[i - mid + half];
-        const double d = (double)x[i] - mean;
-        sw += w;
-        sx += d * d * w;
+    for (int64_t i0 = lo + lane; i0 <= hi; i0 += 8 * 64) {
+        float q[8];
+        double wq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + 64 * u <= hi ? i0 + 64 * u : hi;
+            q[u] = x[i];
+            wq[u] = win[i - mid + half];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + 64 * u <= hi) {
+                const double d = (double)q[u] - mean;
+                sw += wq[u];
+                sx += d * d * wq[u];
+            }
+        }
     }
     sw = wave_sum_f64(sw);
     sx = wave_sum_f64(sx);
@@ -1212,9 +1245,22 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     const double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;
     const double intensity = rb[L + 1];
     const double gp = gpeak[blockIdx.y];
-    for (int j = RC + r_lo + tid; j <= RC + r_hi; j += CT) {
-        const int l = j >= RC ? j - RC : RC - j;
-        r[j] = l <= L ? rb[l] : 0.0;
+    // the row r[0..L] mirrored into Praat's symmetric array: eight loads in flight (unconditional, on clamped lags) before
+    // the first store - one load per loop turn crossed the memory latency ten to fifteen times per frame
+    for (int j0 = RC + r_lo + tid; j0 <= RC + r_hi; j0 += 8 * CT) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * CT;
+            const int l = j >= RC ? j - RC : RC - j;
+            v[u] = rb[l <= L ? l : L];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * CT;
+            const int l = j >= RC ? j - RC : RC - j;
+            if (j <= RC + r_hi) r[j] = l <= L ? v[u] : 0.0;
+        }
     }
     if (tid == 0) s_nmax = 0;
     __syncthreads();
@@ -2302,13 +2348,26 @@ __global__ __launch_bounds__(256) void formant_kernel(const double* __restrict__
         const int len = end - start + 1;
         // pre-emphasised, windowed frame into b1[1..len] (Burg's 1-based arrays); also the max intensity
         double mxi = 0.0, p = 0.0;
-        for (int j = lane; j < len; j += 64) {
-            const int i = start + j;
-            const double v = (i > 0) ? y[i] - preemph * y[i - 1] : y[i];
-            mxi = fmax(mxi, v * v);
-            const double xv = v * win[j];
-            b1[j + 1] = xv;
-            p += xv * xv;
+        for (int j0 = lane; j0 < len; j0 += 4 * 64) {                     // twelve loads in flight (see clip_peak_kernel)
+            double ya[4], yb[4], wq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 64 * u < len ? j0 + 64 * u : len - 1, i = start + j;
+                ya[u] = y[i];
+                yb[u] = y[i > 0 ? i - 1 : 0];
+                wq[u] = win[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 64 * u, i = start + j;
+                if (j < len) {
+                    const double v = (i > 0) ? ya[u] - preemph * yb[u] : ya[u];
+                    mxi = fmax(mxi, v * v);
+                    const double xv = v * wq[u];
+                    b1[j + 1] = xv;
+                    p += xv * xv;
+                }
+            }
         }
         mxi = wave_max_dpp(mxi);
         p = group_sum<64>(p);

@@ -28,7 +28,8 @@ def run(first=8000, count=20, w2v2=True):
     _check_pitch_chain(clips, p, g, octv.cpu().numpy(), cand.cpu().numpy(), P, min_voiced=0.0)
     _check_rows(g, ref, P)
     keep = [i for i, c in enumerate(clips) if so.n_frames(len(c)) > 0]
-    _assert_all_912(f.cpu().numpy()[keep], np.stack([so.functionals(so.lld(c)) for c in live]))
+    llds = [so.lld(c) for c in live]
+    _assert_all_912(f.cpu().numpy()[keep], np.stack([so.functionals(x) for x in llds]), lld_ref=llds)
     print(f"smile: {count} clips, {sum(p.frames)} frames: 38 rows + 912 functionals ok (tolerances of tests/test_smile_gpu.py)", flush=True)
     out = {"clips": count, "smile_frames": int(sum(p.frames))}
     if not w2v2:

@@ -199,12 +199,38 @@ def test_functionals_exact_on_identical_input(rsaf_lib, window):
         assert g[:, pos].max() <= window - 1
 
 
-def _assert_all_912(g, ref):
+def _column_contours():
+    """(LLD row, is_delta) of each of the 912 columns, in cCsvSink order (smile_oracle.functionals)."""
+    rows, deltas = [], []
+    for lo, hi in so.LEVELS:
+        for de in (False, True):
+            for i in range(lo, hi):
+                rows += [i] * so.NFUNC
+                deltas += [de] * so.NFUNC
+    return rows, deltas
+
+
+def _assert_all_912(g, ref, lld_ref=None):
+    """``lld_ref`` (the oracle's [38, frames] LLD per row of ``ref``): a maxPos / minPos that differs is accepted when the
+    ORACLE's own contour ties at the two positions to 1e-9 of its largest value.  That is structural for clips of three
+    frames - the smoothed contour of x0, x1, x2 with edge replication is linear, so its delta regression is (d, 1.2 d, d)
+    and the first and the last frame tie in exact arithmetic: the position is decided by the last bit on either side."""
     names = so.feature_names()
     assert g.shape == ref.shape and np.isfinite(g).all() and np.isfinite(ref).all()
     pos = np.array([n.endswith("Pos") for n in names])
-    bad = np.argwhere(g[:, pos] != ref[:, pos])
-    assert bad.size == 0, [(int(r), np.array(names)[pos][int(c)], g[:, pos][r, c], ref[:, pos][r, c]) for r, c in bad[:8]]
+    rows, deltas = _column_contours()
+    bad = []
+    for r, c in np.argwhere(g != ref):
+        if not pos[c]:
+            continue
+        tie = False
+        if lld_ref is not None:
+            contour = so.sma3(lld_ref[r][rows[c]])
+            contour = so.delta2(contour) if deltas[c] else contour
+            tie = abs(contour[int(g[r, c])] - contour[int(ref[r, c])]) <= 1e-9 * np.max(np.abs(contour))
+        if not tie:
+            bad.append((int(r), names[c], g[r, c], ref[r, c]))
+    assert not bad, bad[:8]
     # values: north_star's bar is 1e-4 of the column; float64 on both sides delivers ~1e-10.  Columns whose reference
     # value is a cancellation residue (a regression slope or skewness that is zero up to rounding) are measured against
     # the scale of their contour instead of against themselves
