@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64, 4) void cepstrum_wave_kernel(const Seg* __restr
                                                               const double* __restrict__ res, int cap_res, int cap_frames,
                                                               const double* __restrict__ win1000, const double2* __restrict__ tw,
                                                               double preemph, double* __restrict__ ceps, int* __restrict__ list,
-                                                              int* __restrict__ list_count, int list_cap) {
+                                                              int* __restrict__ list_count, int list_cap, int force_list) {
     using namespace wfft;
     __shared__ double lds[CEP_LDS_DOUBLES];
     double* lp = lds + Plan<8>::LDS_DOUBLES;            // ln-power half spectrum, bins 0 .. 512
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64, 4) void cepstrum_wave_kernel(const Seg* __restr
         int lane = lane_;                               // redefined per frame (keeps lane-only expressions out of the loop preheader)
         asm volatile("" : "+v"(lane));
         const Seg s = SG[find_seg<4>(SG, nseg, f)];
-        if ((int)s.nfft != 1024) {                      // a short interval: the workgroup kernel takes the frame
+        if ((int)s.nfft != 1024 || force_list) {                      // a short interval: the workgroup kernel takes the frame
             if (lane == 0) {
                 const int at = atomicAdd(list_count, 1);
                 if (at < list_cap) { list[2 * at] = clip; list[2 * at + 1] = f; }
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64, 4) void cpp_frame_wave_kernel(const Seg* __rest
                                                                const double* __restrict__ ceps, int cap_frames, int n_time,
                                                                int n_quef, double pitch_floor, double pitch_ceiling,
                                                                double* __restrict__ cpp_out, int* __restrict__ list,
-                                                               int* __restrict__ list_count, int list_cap) {
+                                                               int* __restrict__ list_count, int list_cap, int force_list) {
     __shared__ double sq[NQ_MAX + 7];                    // smoothed power per bin, then dB per bin
     constexpr int NQ = NQ_MAX;                           // 513
     const int clip = blockIdx.y;
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(64, 4) void cpp_frame_wave_kernel(const Seg* __rest
         int lane = lane_;
         asm volatile("" : "+v"(lane));
         const Seg s = SG[find_seg<4>(SG, nseg, f)];
-        if ((int)s.nfft != 1024) {                      // a short interval: the workgroup kernel takes the frame
+        if ((int)s.nfft != 1024 || force_list) {                      // a short interval: the workgroup kernel takes the frame
             if (lane == 0) {
                 const int at = atomicAdd(list_count, 1);
                 if (at < list_cap) { list[2 * at] = clip; list[2 * at + 1] = f; }
@@ -1004,6 +1004,10 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
                            ci, segs, max_seg, hdr, cap_res, resampled);
         RSAF_CHECK_HIP(hipGetLastError());
     }
+    int force_list = 0;
+    // RSAF_CPP_WAVE: "0" = both per-frame kernels in their workgroup form, "c" = only the cepstrum by one wave per frame
+    // (bit 0: cepstrum through the list, bit 1: smoothed-CPP frames through the list)
+    { const char* e = getenv("RSAF_CPP_WAVE"); force_list = !e ? 0 : (e[0] == '0' ? 3 : (e[0] == 'c' ? 2 : 0)); }
     {
         ProfScope prof("mshds_cpp_cepstrum", s, 0.0, 0.0);
         // frames with the full 1024-point transform: one wave each; the others are listed in lp_work (free once the intervals
@@ -1016,7 +1020,7 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
         const double pre = exp(-2.0 * PI * 50.0 * DXO);
         hipLaunchKernelGGL(cepstrum_wave_kernel, dim3((cap_frames + CEP_FRAMES - 1) / CEP_FRAMES, n_clips), dim3(64), 0, s, segs,
                            max_seg, hdr, resampled, cap_res, cap_frames, window1000, (const double2*)twiddle1024, pre, cepstrogram,
-                           list, list_count, list_cap);
+                           list, list_count, list_cap, force_list & 1);
         RSAF_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(cepstrum_kernel, dim3(2048), dim3(256), 0, s, segs, max_seg, hdr, resampled, cap_res, cap_frames,
                            window1000, (const double2*)twiddle1024, pre, cepstrogram, list, list_count);
@@ -1031,7 +1035,7 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
         RSAF_CHECK_HIP(hipMemsetAsync(list_count, 0, sizeof(int), s));
         hipLaunchKernelGGL(cpp_frame_wave_kernel, dim3((cap_frames + CPPF_FRAMES - 1) / CPPF_FRAMES, n_clips), dim3(64), 0, s, segs,
                            max_seg, hdr, cepstrogram, cap_frames, (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0,
-                           cpp_frames, list, list_count, list_cap);
+                           cpp_frames, list, list_count, list_cap, force_list & 2);
         RSAF_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(cpp_frame_kernel, dim3(2048), dim3(256), 0, s, segs, max_seg, hdr, cepstrogram, cap_frames,
                            (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0, cpp_frames, list, list_count);

@@ -499,3 +499,73 @@ def test_time_axis_shifts_times_but_not_windows(eng):
     for i in (1, 2):
         assert np.array_equal(np.isnan(g[i]), np.isnan(r))
         assert (np.abs(g[i][cols] - r[cols]) <= 1e-9 * np.maximum(np.abs(r[cols]), 1e-3)).all(), (g[i], r)
+
+
+def test_one_wave_pitch_kernels_agree_with_the_workgroup_kernels_on_30s_clips(eng, monkeypatch):
+    """The correlation kernels exist twice: one wavefront per frame with the transform in registers (csrc/wave_fft.h, the
+    product path) and the workgroup-wide Stockham kernels of round 2 (RSAF_PITCH_FFT=wg).  Two independent implementations
+    of the same arithmetic must pick the same path through every frame of full-length clips (6 000 frames each) for every
+    parameter set the extractor uses - a size-independent check at BASELINE's clip length, where the oracle is too slow."""
+    import torch
+    clips = [synth.synth_clip(900 + k, 30.0) for k in range(3)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    hnr = dict(max_candidates=15, silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
+               voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700)
+    cfgs = [dict(time_step=0.005, floor=50.0, ceiling=600.0),                                  # wide AC, 1 024 complex points
+            dict(time_step=0.005, floor=100.0, ceiling=500.0, voicing_threshold2=0.3),         # 512 points, both thresholds
+            dict(time_step=0.02, floor=30.0, ceiling=450.0, max_candidates=4, voicing_threshold=0.25,
+                 voiced_unvoiced_cost=0.25),                                                    # speech rate: 2 048 points
+            dict(time_step=0.005, floor=60.0, ceiling=8000.0, **hnr),                           # CC, 2 048 -> 1 024 points
+            dict(time_step=0.005, floor=100.0, ceiling=8000.0, **hnr),                          # CC, 1 024 -> 512 points
+            dict(time_step=0.005, floor=100.0, ceiling=500.0, periods=1.0, is_cc=True, refine_depth=70)]   # padded up to 1 024
+    for kw in cfgs:
+        monkeypatch.delenv("RSAF_PITCH_FFT", raising=False)
+        a = eng.pitch(wav, offs, lens, gp, **kw)
+        torch.cuda.synchronize()
+        monkeypatch.setenv("RSAF_PITCH_FFT", "wg")
+        b = eng.pitch(wav, offs, lens, gp, **kw)
+        torch.cuda.synchronize()
+        fa, fb = a["sel_freq"].cpu().numpy(), b["sel_freq"].cpu().numpy()
+        sa, sb = a["sel_strength"].cpu().numpy(), b["sel_strength"].cpu().numpy()
+        assert fa.shape == fb.shape and fa.size >= 3 * 1400
+        # The two forms differ by rounding (~1e-15 in the correlation), which can only matter where the path finder meets a
+        # numerical tie: allow one frame in a thousand to take another candidate, nothing else
+        differs = ((fa > 0) != (fb > 0)) | (np.abs(fa - fb) > 1e-7 * np.maximum(np.abs(fb), 1.0)) | (np.abs(sa - sb) > 1e-9)
+        print(f"pitch A/B floor {kw['floor']:g} cc {kw.get('is_cc', False)}: {int(differs.sum())} of {fa.size} frames differ")
+        assert differs.mean() <= 1e-3, (kw, int(differs.sum()), fa.size)
+    monkeypatch.delenv("RSAF_PITCH_FFT", raising=False)
+
+
+def test_one_wave_cpps_kernels_agree_with_the_workgroup_kernels(eng, monkeypatch):
+    """CPPS frames of full-window intervals run one wavefront per frame (register transforms, medians by rank selection).
+    RSAF_CPP_WAVE=0 sends every frame through the workgroup kernels (bit-reversal FFT in LDS, bitonic sorts), =c only the
+    smoothed-CPP frames.  The cepstra of the two forms differ in rounding (different butterfly order); the frame kernel is
+    the same arithmetic in the same order on either form (fp contraction off), so on ONE cepstrogram it must return
+    identical bits - medians by selection = medians by sorting."""
+    import torch
+    clips = [synth.synth_clip(910 + k, 12.0) for k in range(3)] + [synth.synth_clip(190, 1.6)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    out = {}
+    for mode in ("1", "c", "0"):
+        monkeypatch.setenv("RSAF_CPP_WAVE", mode)
+        got = eng.cpp(wav, offs, lens, gp, 100.0, 500.0).cpu().numpy()
+        torch.cuda.synchronize()
+        L = eng._last_cpp
+        hdr = L["hdr"].cpu().numpy().reshape(len(clips), 4)
+        cppf = L["cpp_frames"].cpu().numpy().reshape(len(clips), L["cap_frames"])
+        ceps = L["ceps"].cpu().numpy().reshape(len(clips), L["cap_frames"], 513)
+        out[mode] = (got, [cppf[i, :hdr[i, 2]].copy() for i in range(len(clips))],
+                     [ceps[i, :hdr[i, 2]].copy() for i in range(len(clips))])
+    monkeypatch.delenv("RSAF_CPP_WAVE", raising=False)
+    assert sum(len(f) for f in out["1"][1]) > 5000                                             # thousands of frames compared
+    for i in range(len(clips)):
+        assert np.array_equal(out["1"][2][i], out["c"][2][i])                                  # same cepstrum kernel: same bits
+        assert np.array_equal(out["1"][1][i], out["c"][1][i], equal_nan=True)                  # frame kernel: identical bits
+        c1, c0 = out["1"][2][i], out["0"][2][i]
+        assert c1.shape == c0.shape and np.abs(c1 - c0).max() <= 1e-9 * max(np.abs(c0).max(), 1e-300)
+    assert np.array_equal(out["1"][0], out["c"][0], equal_nan=True)
+    assert np.array_equal(np.isnan(out["1"][0]), np.isnan(out["0"][0]))
+    ok = ~np.isnan(out["0"][0])
+    assert np.abs(out["1"][0][ok] - out["0"][0][ok]).max() <= 1e-9 * np.abs(out["0"][0][ok]).max()

@@ -230,6 +230,9 @@ def _assert_all_912(g, ref, lld_ref=None):
             tie = abs(contour[int(g[r, c])] - contour[int(ref[r, c])]) <= 1e-9 * np.max(np.abs(contour))
         if not tie:
             bad.append((int(r), names[c], g[r, c], ref[r, c]))
+        else:
+            g = g.copy()
+            g[r, c] = ref[r, c]                       # accepted tie: out of the value comparison below
     assert not bad, bad[:8]
     # values: north_star's bar is 1e-4 of the column; float64 on both sides delivers ~1e-10.  Columns whose reference
     # value is a cancellation residue (a regression slope or skewness that is zero up to rounding) are measured against
