@@ -1950,6 +1950,119 @@ __global__ __launch_bounds__(512) void spec_moments_kernel(const float* __restri
 }
 
 // mean of each moment over gated frames whose value is not NaN (reference :366-374)
+// The same analysis, one wavefront per frame, for the usual transform length of 1 024 (25 ms Gaussian window at 16 kHz):
+// the real transform is one 512-point complex transform in registers (wave_fft.h), the power of bins k and 512 - k comes
+// from the conjugate pair the lane holding k < 256 evaluates, and the four moments are sums over the registers.
+constexpr int SPM_FRAMES = 4;
+__global__ __launch_bounds__(64, 4) void spec_moments_wave_kernel(const float* __restrict__ wav, const ClipInfo* __restrict__ ci,
+                                                                  const ClipInfo* __restrict__ pitch_ci, const double* __restrict__ sel_freq,
+                                                                  double pitch_dt, double ceiling, const double* __restrict__ win,
+                                                                  const double2* __restrict__ tw, int nsamp, int half, int nbins,
+                                                                  double tstep, double fstep, double* __restrict__ mom) {
+    using namespace wfft;
+    __shared__ double lds[Plan<8>::LDS_DOUBLES];
+    constexpr int R = 8, S = 512, H = 4;
+    const ClipInfo c = ci[blockIdx.y];
+    const int f0 = blockIdx.x * SPM_FRAMES;
+    if (f0 >= c.n_frames) return;
+    const ClipInfo pc = pitch_ci[blockIdx.y];
+    const int lane_ = threadIdx.x;
+    const float* x = wav + c.sample_off;
+    const int n = c.n_samples;
+    LdsMem mem{lds};
+    const int f1 = f0 + SPM_FRAMES < c.n_frames ? f0 + SPM_FRAMES : c.n_frames;
+#pragma unroll 1
+    for (int f = f0; f < f1; ++f) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        double* o = mom + (c.frame_off + f) * 5;
+        const double t = c.t1 + f * tstep;
+        // gate: Pitch "Get value at time" defined iff the nearest pitch frame is voiced
+        {
+            const double ireal = (t - pc.t1) / pitch_dt;
+            const double il = floor(ireal);
+            const int64_t near = (ireal - il < 0.5) ? (int64_t)il : (int64_t)il + 1;
+            bool ok = near >= 0 && near < pc.n_frames;
+            if (ok) {
+                const double pf = sel_freq[pc.frame_off + near];
+                ok = pf > 0.0 && pf < ceiling;
+            }
+            if (!ok) {                                            // uniform
+                if (lane == 0) o[0] = 0.0;
+                continue;
+            }
+        }
+        const int start = (int)(low_index(t, c.x1) + 1 - half);
+        cplx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int j = 2 * (lane + 64 * m);                    // samples 2 k, 2 k + 1 of the frame (loads on clamped indices)
+            int i0 = start + j, i1 = i0 + 1;
+            i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);
+            i1 = i1 < 0 ? 0 : (i1 > n - 1 ? n - 1 : i1);
+            const int w0 = j < nsamp ? j : nsamp - 1, w1 = j + 1 < nsamp ? j + 1 : nsamp - 1;
+            const double a0 = (double)x[i0] * win[w0], a1 = (double)x[i1] * win[w1];
+            v[m] = cplx{j < nsamp ? a0 : 0.0, j + 1 < nsamp ? a1 : 0.0};
+        }
+        const double2_t wl2 = reinterpret_cast<const double2_t*>(tw)[lane];
+        const cplx wl{wl2.x, wl2.y};
+        {
+            const double2_t a = reinterpret_cast<const double2_t*>(tw)[2 * lane], b = reinterpret_cast<const double2_t*>(tw)[(lane % 8) * 16];
+            wave_fft<R>(v, lds, lane, cplx{a.x, a.y}, cplx{b.x, b.y});
+        }
+        ac_spec_store<R>(v, mem, lane);
+        wave_sync();
+        // power of bins k (pa) and 512 - k (pb) for the lane's k = lane + 64 m < 256; lane 0 also holds bin 256 (p256)
+        double pa[H], pb[H];
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const int k = lane + 64 * m;
+            const int pp = k ? S / 2 - k : 0;
+            cplx zc{mem.ld(pp), mem.ld(S / 2 + pp)};
+            if (m == 0) zc = cplx{lane == 0 ? v[0].x : zc.x, lane == 0 ? v[0].y : zc.y};
+            const cplx zk = v[m], w = mul_w64(wl, m * 4);                       // W_1024^(64 m) = W_64^(4 m)
+            const double er = 0.5 * (zk.x + zc.x), ei = 0.5 * (zk.y - zc.y), orr = 0.5 * (zk.y + zc.y), oi = -0.5 * (zk.x - zc.x);
+            const double tr = w.x * orr - w.y * oi, ti = w.x * oi + w.y * orr;
+            const double ar = er + tr, ai = ei + ti, br = er - tr, bi = ti - ei;
+            pa[m] = ar * ar + ai * ai;
+            pb[m] = br * br + bi * bi;
+        }
+        const double p256 = v[H].x * v[H].x + v[H].y * v[H].y;
+        wave_sync();
+        // bins: k (pa[m]), 512 - k (pb[m]; k = 0: bin 512), 256 (lane 0)
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const int k = lane + 64 * m, kb = S - k;
+            if (k < nbins) { s0 += pa[m]; s1 += pa[m] * (k * fstep); }
+            if (kb < nbins) { s0 += pb[m]; s1 += pb[m] * (kb * fstep); }
+        }
+        if (lane == 0 && S / 2 < nbins) { s0 += p256; s1 += p256 * ((S / 2) * fstep); }
+        const double tot = group_sum<64>(s0);
+        const double cog = group_sum<64>(s1) / tot;
+        double m2 = 0.0, m3 = 0.0, m4 = 0.0;
+        auto acc = [&](double p, int k) {
+            const double d = k * fstep - cog, d2 = d * d;
+            m2 += p * d2; m3 += p * d2 * d; m4 += p * d2 * d2;
+        };
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const int k = lane + 64 * m, kb = S - k;
+            if (k < nbins) acc(pa[m], k);
+            if (kb < nbins) acc(pb[m], kb);
+        }
+        if (lane == 0 && S / 2 < nbins) acc(p256, S / 2);
+        const double u2 = group_sum<64>(m2) / tot, u3 = group_sum<64>(m3) / tot, u4 = group_sum<64>(m4) / tot;
+        if (lane == 0) {
+            o[0] = 1.0;
+            o[1] = cog;
+            o[2] = sqrt(u2);
+            o[3] = u3 / (u2 * sqrt(u2));
+            o[4] = u4 / (u2 * u2) - 3.0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void moments_stats_kernel(const double* __restrict__ mom, const ClipInfo* __restrict__ ci,
                                                            double* __restrict__ out) {
     const ClipInfo c = ci[blockIdx.x];
@@ -3603,6 +3716,13 @@ int rsaf_mshds_spectral_moments(const float* wav, const void* clip_info, const v
     if (max_frames > 0) {
         ProfScope prof("mshds_spec_moments", s, 0.0, 0.0);
         const int threads = nfft >= 2048 ? 512 : 256;      // nfft / 4 butterflies per pass of the half-length FFT
+        const char* e = getenv("RSAF_SPM_WAVE");
+        if (nfft == 1024 && nsamp_window >= 2 && !(e && e[0] == '0'))
+            hipLaunchKernelGGL(spec_moments_wave_kernel, dim3((max_frames + SPM_FRAMES - 1) / SPM_FRAMES, n_clips), dim3(64), 0, s,
+                               wav, (const ClipInfo*)clip_info, (const ClipInfo*)pitch_clip_info, sel_freq, pitch_dt, ceiling,
+                               window, (const double2*)twiddle, nsamp_window, nsamp_window / 2, nbins, time_step, freq_step,
+                               moments);
+        else
         hipLaunchKernelGGL(spec_moments_kernel, dim3(max_frames, n_clips), dim3(threads), lds, s, wav,
                            (const ClipInfo*)clip_info, (const ClipInfo*)pitch_clip_info, sel_freq, pitch_dt, ceiling,
                            window, (const double2*)twiddle, nsamp_window, nsamp_window / 2, nfft, nbins, time_step,

@@ -554,10 +554,17 @@ def test_one_wave_cpps_kernels_agree_with_the_workgroup_kernels(eng, monkeypatch
         torch.cuda.synchronize()
         L = eng._last_cpp
         hdr = L["hdr"].cpu().numpy().reshape(len(clips), 4)
+        segs = L["segs"].cpu().numpy().reshape(len(clips), L["max_seg"], L["seg_doubles"])
         cppf = L["cpp_frames"].cpu().numpy().reshape(len(clips), L["cap_frames"])
         ceps = L["ceps"].cpu().numpy().reshape(len(clips), L["cap_frames"], 513)
-        out[mode] = (got, [cppf[i, :hdr[i, 2]].copy() for i in range(len(clips))],
-                     [ceps[i, :hdr[i, 2]].copy() for i in range(len(clips))])
+        rows = []
+        for i in range(len(clips)):
+            c = ceps[i, :hdr[i, 2]].copy()
+            for k in range(hdr[i, 0]):                            # a short interval's frames hold nfft / 2 + 1 bins: the rest of
+                f0, nf, nfft = int(segs[i, k, 4]), int(segs[i, k, 5]), int(segs[i, k, 11])   # the row is never written
+                c[f0:f0 + nf, nfft // 2 + 1:] = 0.0
+            rows.append(c)
+        out[mode] = (got, [cppf[i, :hdr[i, 2]].copy() for i in range(len(clips))], rows)
     monkeypatch.delenv("RSAF_CPP_WAVE", raising=False)
     assert sum(len(f) for f in out["1"][1]) > 5000                                             # thousands of frames compared
     for i in range(len(clips)):
@@ -569,3 +576,26 @@ def test_one_wave_cpps_kernels_agree_with_the_workgroup_kernels(eng, monkeypatch
     assert np.array_equal(np.isnan(out["1"][0]), np.isnan(out["0"][0]))
     ok = ~np.isnan(out["0"][0])
     assert np.abs(out["1"][0][ok] - out["0"][0][ok]).max() <= 1e-9 * np.abs(out["0"][0][ok]).max()
+
+
+def test_one_wave_spectral_moments_agree_with_the_workgroup_kernel(eng, monkeypatch):
+    """Spectral moments per frame by one wavefront (register transform, csrc/wave_fft.h) against the 256-thread radix-2
+    kernel (RSAF_SPM_WAVE=0) on 30 s clips: the gate pattern identical, every moment of every frame within 1e-9."""
+    import torch
+    clips = [synth.synth_clip(920 + k, 30.0) for k in range(2)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    p = eng.pitch(wav, offs, lens, gp, time_step=0.005, floor=100.0, ceiling=500.0)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RSAF_SPM_WAVE", mode)
+        sm = eng.spectral_moments(wav, offs, lens, p, 0.025, 0.005)
+        torch.cuda.synchronize()
+        res[mode] = (sm["moments"].cpu().numpy().reshape(-1, 5).copy(), sm["stats"].cpu().numpy().copy())
+    monkeypatch.delenv("RSAF_SPM_WAVE", raising=False)
+    m1, m0 = res["1"][0], res["0"][0]
+    assert m1.shape == m0.shape and m1.shape[0] > 10000
+    assert np.array_equal(m1[:, 0], m0[:, 0]) and m1[:, 0].sum() > 1000                       # gate: same frames analysed
+    on = m0[:, 0] == 1.0
+    assert np.abs(m1[on, 1:] - m0[on, 1:]).max() <= 1e-9 * np.abs(m0[on, 1:]).max()
+    assert np.abs(res["1"][1] - res["0"][1]).max() <= 1e-9 * np.abs(res["0"][1]).max()
