@@ -464,7 +464,7 @@ __device__ __forceinline__ void fft_mag(c64* Z, const Tables<LOG2N>* __restrict_
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(64, LOG2N <= 9 ? 2 : 1) void smile_lld_kernel(const float* __restrict__ wav, const int64_t* __restrict__ clip_off,
+__global__ __launch_bounds__(64, LOG2N <= 9 ? 3 : 2) void smile_lld_kernel(const float* __restrict__ wav, const int64_t* __restrict__ clip_off,
                                                        const int64_t* __restrict__ frame_off, int64_t total_frames,
                                                        double* __restrict__ lld, double* __restrict__ cand,
                                                        double* __restrict__ octave_dbg,
@@ -472,7 +472,8 @@ __global__ __launch_bounds__(64, LOG2N <= 9 ? 2 : 1) void smile_lld_kernel(const
     using G = Geo<LOG2N>;
     constexpr int NC = G::NC, NB = G::NB, PPL = G::PPL;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x;
+    const int lane_ = threadIdx.x;
+    const int lane = lane_;
     const int clip = blockIdx.y;
     const int64_t fo = frame_off[clip];
     const int n_fr = (int)(frame_off[clip + 1] - fo);
@@ -491,7 +492,9 @@ __global__ __launch_bounds__(64, LOG2N <= 9 ? 2 : 1) void smile_lld_kernel(const
     double* STASH = smem + G::OFF_STASH;
     double* RED = smem + G::OFF_RED;
 
-    // frame-invariant per-lane constants: FFT twiddles, Hamming window
+    // frame-invariant per-lane constants kept in registers for the run: the FFT twiddles.  (The Hamming window values are
+    // re-read per frame and the lane index is redefined per frame through an empty asm: with every lane-only expression
+    // hoisted out of the run loop the 512-point instance needed 247 registers - two waves per SIMD - against 166 now.)
     FftTw<LOG2N> W;
     W.load(T, lane);
     double hm[2 * PPL];
@@ -507,9 +510,14 @@ __global__ __launch_bounds__(64, LOG2N <= 9 ? 2 : 1) void smile_lld_kernel(const
 
 #pragma unroll 1
     for (int tr = 0; tr < n_run; ++tr) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
         const int fr = f0 + tr;
         const int64_t fg = fo + fr;
         double s_w2, s_hw2, s_zc;
+        double hm[2 * PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { hm[2 * j] = T->ham[2 * (lane + 64 * j)]; hm[2 * j + 1] = T->ham[2 * (lane + 64 * j) + 1]; }
         frame_to_z<LOG2N>(xclip + (int64_t)fr * hop, hm, frame, Z, lane, s_w2, s_hw2, s_zc);
         fft_mag<LOG2N>(Z, T, W, lane, MAG);
         if (stop == 1) continue;                         // profiling aid (env RSAF_SMILE_STOP): leave the frame after phase k
