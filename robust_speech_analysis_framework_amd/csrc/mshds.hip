@@ -1380,20 +1380,25 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
         // stay in L2) keep the direct form.
         bool use_cheb = cheb != nullptr;
         int n_clip_cols = 0;
+        // lane k holds candidate k (k < 16: one DPP row): the scans over the candidates below are one LDS read per lane and
+        // row reductions, not loops of dependent LDS reads
+        const bool cand_lane = lane >= 1 && lane < nc;
+        const int my_b0 = (cand_lane ? place_lag[lane] : 0) + RC - 1;
+        auto row_min = [](int v) {
+            v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+            v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+            v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+            v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+            return __builtin_amdgcn_readlane(v, 0);
+        };
         if (use_cheb && !P.cheb_all_full) {
-            int dmin = P.refine_depth;
-            for (int k = 1; k < nc; ++k) {                           // uniform: every lane scans the (<= 15) candidates
-                const int b0 = place_lag[k] + RC - 1;
-#pragma unroll
-                for (int cell = 0; cell < 2; ++cell) {
-                    const int b = b0 + cell;
-                    int dc = P.refine_depth;
-                    dc = dc < b + 1 ? dc : b + 1;
-                    dc = dc < RN - b - 1 ? dc : RN - b - 1;
-                    if (dc < P.refine_depth) ++n_clip_cols;
-                    dmin = dc < dmin ? dc : dmin;
-                }
-            }
+            int dc0 = P.refine_depth, dc1 = P.refine_depth;
+            dc0 = dc0 < my_b0 + 1 ? dc0 : my_b0 + 1;
+            dc0 = dc0 < RN - my_b0 - 1 ? dc0 : RN - my_b0 - 1;
+            dc1 = dc1 < my_b0 + 2 ? dc1 : my_b0 + 2;
+            dc1 = dc1 < RN - my_b0 - 2 ? dc1 : RN - my_b0 - 2;
+            n_clip_cols = __popcll(__ballot(cand_lane && dc0 < P.refine_depth)) + __popcll(__ballot(cand_lane && dc1 < P.refine_depth));
+            const int dmin = row_min(cand_lane ? min(dc0, dc1) : P.refine_depth);
             if (n_clip_cols > 0 && (!P.cheb_clipped || dmin < 3)) use_cheb = false;
         }
         if (use_cheb) {
@@ -1408,12 +1413,7 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
             const int kq = lane >> 4, nn = lane & 15;
             const int ncol = 2 * (nc - 1), tiles = (ncol + 15) >> 4;
             if (nc > 1) {
-                int bmin = 0x7fffffff, bmax = -0x7fffffff;
-                for (int k = 1; k < nc; ++k) {                       // uniform: every lane scans the (<= 15) candidates
-                    const int bb = place_lag[k] + RC - 1;
-                    bmin = bb < bmin ? bb : bmin;
-                    bmax = bb > bmax ? bb : bmax;
-                }
+                const int bmin = row_min(cand_lane ? my_b0 : 0x7fffffff), bmax = -row_min(cand_lane ? -my_b0 : 0x7fffffff);
                 int rbase[2];
                 bool colfull[2];                                      // clipped cells are rebuilt below: their B operand is zero here
 #pragma unroll
@@ -1520,10 +1520,14 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
         refine_list(nc_a, pl_a, cf_a, cs_a);
         if (tid == 0) s_cnt[3] = 0;
         __syncthreads();
-        if (tid >= 1 && tid < nc_b) {
+        {
+            const int pa_reg = tid < MAXC ? pl_a[tid] : 0;             // lane z holds the lag of candidate z of the refined list
+            const int mine = (tid >= 1 && tid < nc_b) ? pl_b[tid] : -1;
             int hit = 0;
-            for (int z = 1; z < nc_a; ++z) if (pl_a[z] == pl_b[tid]) hit = z;
-            if (hit) { cf_b[tid] = cf_a[hit]; cs_b[tid] = cs_a[hit]; } else atomicAdd(&s_cnt[3], 1);
+            for (int z = 1; z < nc_a; ++z) if (__builtin_amdgcn_readlane(pa_reg, z) == mine) hit = z;   // v_readlane: no LDS round trip per z
+            if (tid >= 1 && tid < nc_b) {
+                if (hit) { cf_b[tid] = cf_a[hit]; cs_b[tid] = cs_a[hit]; } else atomicAdd(&s_cnt[3], 1);
+            }
         }
         __syncthreads();
         if (s_cnt[3] > 0) {
