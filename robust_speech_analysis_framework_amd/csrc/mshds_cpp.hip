@@ -225,20 +225,94 @@ __global__ __launch_bounds__(1024) void seg_lowpass_lds_kernel(const float* __re
     }
 }
 
+// 16 kHz -> 10 kHz is a step of 1.6 input samples per output: the fractional position repeats every 5 outputs (8 input samples),
+// so an interval has five sets of 2 * DEPTH weights.  A workgroup whose 256 outputs lie in one interval builds the five sets
+// once (500 weights, two per thread) and stages its 508-sample input window in LDS; an output with the full depth on both
+// sides is then 100 multiply-adds.  Outputs near the ends of an interval (clipped depth), workgroups that straddle two
+// intervals and phases whose fraction lies within 1e-6 of an integer take Praat's formula term by term as before
+// (`RSAF_CPP_POLYPHASE=0`: everything does).  Against the term-by-term form the sums differ by rounding only (the weights
+// are those of the phase's first output: positions 8 samples apart differ by ~1e-11 in the fraction).
+constexpr int RS_TAPS = 2 * DEPTH;                    // 100
+constexpr int RS_WIN = 512;                            // input window of a workgroup: 255 * 1.6 + 100 samples
 __global__ __launch_bounds__(256) void resample_kernel(const double* __restrict__ lowpassed, int64_t lp_origin,
                                                        const ClipInfo* __restrict__ ci, const Seg* __restrict__ segs, int max_seg,
-                                                       const int* __restrict__ hdr, int cap_res, double* __restrict__ res) {
+                                                       const int* __restrict__ hdr, int cap_res, double* __restrict__ res,
+                                                       int polyphase) {
+    __shared__ double s_w[RS_TAPS * 5];
+    __shared__ double s_in[RS_WIN];
+    __shared__ int s_si0;
     const int clip = blockIdx.y;
     const int nseg = hdr[4 * clip], total = hdr[4 * clip + 3];
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= total || nseg <= 0) return;
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * 256;
+    if (g0 >= total || nseg <= 0) return;               // workgroup-uniform
+    const int g = g0 + tid;
+    const bool live = g < total;
     const Seg* S = segs + (int64_t)clip * max_seg;
-    const Seg s = S[find_seg<3>(S, nseg, g)];
+    const int si = find_seg<3>(S, nseg, live ? g : total - 1);
+    const Seg s = S[si];
     const ClipInfo c = ci[clip];
     const double* y = lowpassed + (c.sample_off - lp_origin) + (int64_t)s.ix1;   // the extracted part, low-passed
-    const int i = g - (int)s.res_off;
+    const int64_t n = (int64_t)s.m_in;
+    const int i = (live ? g : total - 1) - (int)s.res_off;
     const double pos = (s.x1o + (double)i * DXO - s.x1_seg) / DXS;       // real 0-based index into the extracted part
-    res[(int64_t)clip * cap_res + g] = praat_interpolate_sinc(y, (int64_t)s.m_in, pos + 1.0, DEPTH);
+    const double x = pos + 1.0;                                          // Praat's 1-based index
+    double* out = res + (int64_t)clip * cap_res + g;
+    if (tid == 0) s_si0 = si;
+    __syncthreads();
+    const bool one_seg = __syncthreads_and(si == s_si0) != 0;            // (threads past the clip's last output repeat it)
+    if (!polyphase || !one_seg) {
+        if (live) *out = praat_interpolate_sinc(y, n, x, DEPTH);
+        return;
+    }
+    constexpr double PI_ = 3.14159265358979323846;
+    const int64_t midleft = (int64_t)floor(x);
+    const double frac = x - (double)midleft;
+    const int i0 = g0 - (int)s.res_off;                                  // output index of thread 0 within the interval
+    // fraction of the first output of the workgroup that has phase r = (i0 + q) mod 5, q < 5 (the same expression thread q evaluates)
+    auto phase_frac = [&](int q) {
+        const double xr = (s.x1o + (double)(i0 + q) * DXO - s.x1_seg) / DXS + 1.0;
+        return xr - floor(xr);
+    };
+    for (int e = tid; e < RS_TAPS * 5; e += 256) {
+        const int t = e / 5, r = e - 5 * t;                               // weight of tap t for phase r
+        const double fr = phase_frac((r - i0 % 5 + 5) % 5);
+        double wt = 0.0;
+        if (fr > 1e-6 && fr < 1.0 - 1e-6) {
+            // left half: tap t < DEPTH is k = DEPTH - 1 - t samples left of midleft; right half: k = t - DEPTH right of midright
+            const bool left = t < DEPTH;
+            const int k = left ? DEPTH - 1 - t : t - DEPTH;
+            const double a0 = PI_ * (left ? fr : 1.0 - fr), span = (left ? fr : 1.0 - fr) + (double)DEPTH;
+            const double a = a0 + PI_ * (double)k;
+            double hs = 0.5 * sin(a0);
+            if (k & 1) hs = -hs;
+            wt = hs / a * (1.0 + cos(a / span));
+        }
+        s_w[e] = wt;
+    }
+    const double fr_mine = phase_frac(tid % 5);                          // the first output of this thread's phase
+    const bool phase_ok = fr_mine > 1e-6 && fr_mine < 1.0 - 1e-6 && fabs(fr_mine - frac) < 1e-9;
+    // input window of the workgroup: 0-based samples base ... base + RS_WIN - 1, base = midleft(thread 0) - DEPTH
+    const double x0 = (s.x1o + (double)i0 * DXO - s.x1_seg) / DXS + 1.0;
+    const int64_t base = (int64_t)floor(x0) - DEPTH;
+    for (int e = tid; e < RS_WIN; e += 256) {
+        const int64_t j = base + e;
+        s_in[e] = (j >= 0 && j < n) ? y[j] : 0.0;
+    }
+    __syncthreads();
+    if (!live) return;
+    const int64_t midright = midleft + 1;
+    const bool full = x <= (double)n && x >= 1.0 && midright - 1 >= DEPTH && n - midleft >= DEPTH;
+    const int off = (int)(midleft - DEPTH - base);                       // window element of tap 0 (sample midleft - DEPTH + 1, 1-based)
+    if (!full || !phase_ok || off < 0 || off + RS_TAPS > RS_WIN) {
+        *out = praat_interpolate_sinc(y, n, x, DEPTH);
+        return;
+    }
+    const int r = (i0 + tid) % 5;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int t = 0; t < RS_TAPS; ++t) acc += s_w[5 * t + r] * s_in[off + t];
+    *out = acc;
 }
 
 // ---- 3. power cepstrum of every frame ----------------------------------------------------------------------
@@ -1000,8 +1074,9 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
             hipLaunchKernelGGL(seg_lowpass_kernel<1>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);
             hipLaunchKernelGGL(seg_lowpass_kernel<2>, grid, dim3(256), lds, s, wav, ci, segs, max_seg, hdr, wk, cap_work, lowpassed, lp_origin, lg_lo, lg_hi, T);
         }
+        const char* pe = getenv("RSAF_CPP_POLYPHASE");
         hipLaunchKernelGGL(resample_kernel, dim3((cap_res + 255) / 256, n_clips), dim3(256), 0, s, (const double*)lowpassed, lp_origin,
-                           ci, segs, max_seg, hdr, cap_res, resampled);
+                           ci, segs, max_seg, hdr, cap_res, resampled, (pe && pe[0] == '0') ? 0 : 1);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     int force_list = 0;

@@ -599,3 +599,29 @@ def test_one_wave_spectral_moments_agree_with_the_workgroup_kernel(eng, monkeypa
     on = m0[:, 0] == 1.0
     assert np.abs(m1[on, 1:] - m0[on, 1:]).max() <= 1e-9 * np.abs(m0[on, 1:]).max()
     assert np.abs(res["1"][1] - res["0"][1]).max() <= 1e-9 * np.abs(res["0"][1]).max()
+
+
+def test_cpps_polyphase_resampling_agrees_with_the_term_by_term_form(eng, monkeypatch):
+    """The 16 -> 10 kHz interpolation of the voiced intervals takes five weight sets per interval (the fractional position
+    repeats every 5 outputs); RSAF_CPP_POLYPHASE=0 evaluates Praat's formula term by term for every output.  Every
+    resampled sample of 12 s clips within 1e-9 of the interval's largest sample, CPPS within 1e-9."""
+    import torch
+    clips = [synth.synth_clip(930 + k, 12.0) for k in range(3)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RSAF_CPP_POLYPHASE", mode)
+        got = eng.cpp(wav, offs, lens, gp, 100.0, 500.0).cpu().numpy()
+        torch.cuda.synchronize()
+        L = eng._last_cpp
+        hdr = L["hdr"].cpu().numpy().reshape(len(clips), 4)
+        res = L["res"].cpu().numpy().reshape(len(clips), L["cap_res"])
+        out[mode] = (got, [res[i, :hdr[i, 3]].copy() for i in range(len(clips))])
+    monkeypatch.delenv("RSAF_CPP_POLYPHASE", raising=False)
+    assert sum(len(r) for r in out["1"][1]) > 100000
+    for a, b in zip(out["1"][1], out["0"][1]):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
+    ok = ~np.isnan(out["0"][0])
+    assert np.array_equal(np.isnan(out["1"][0]), ~ok)
+    assert np.abs(out["1"][0][ok] - out["0"][0][ok]).max() <= 1e-9 * np.abs(out["0"][0][ok]).max()
