@@ -143,6 +143,32 @@ int rsaf_gemm_bf16x6_panels(const uint16_t* A_planes, int64_t a_plane_stride, co
                             rsaf_stream_t stream);
 
 
+/* ---- fp32-accurate GEMM on the fp16 matrix pipe: two-way operand splits, three products --------------------------
+ * The same contraction and call sites as above (nn.Linear / nn.Conv1d inside Wav2Vec2Model,
+ * src/foundation_model_extractor.py:115), from three v_mfma_f32_32x32x16_f16 products per term (csrc/gemm_f16x3.hip):
+ * every operand row is multiplied by a power of two `scale[r]` that puts its largest magnitude into [2^14, 2^15) and
+ * split into two fp16 planes, x * scale = hi + lo (11 + 11 significand bits); a b = (a_h b_h + a_h b_l + a_l b_h) /
+ * (s_a s_b), fp32 accumulation.  Error against float64: at or below that of an fp32 FMA chain.
+ *   rsaf_f16x2_row_scales: scale[r] from the exact maximum of row r of src[rows][K] (row stride ld); norm2 (may be NULL)
+ *     receives the rows' Euclidean norms (the Cauchy-Schwarz bound a producer needs for a GEMM OUTPUT's scale).
+ *   rsaf_split_f16x2: src * scale[r * scale_stride] -> planes (fp16 bit patterns, plane_stride elements apart), row-major
+ *     [rows][K] or (panels != 0) k16 panels: element (r, k) at (k / 16) * (rows * 16) + r * 16 + k % 16.
+ *   rsaf_gemm_f16x3: C (fp32, row stride ldc) and / or C_planes (the next GEMM's A, scaled by c_scale[m * c_scale_stride],
+ *     which must keep |x| * c_scale below 65504), either may be NULL; a_scale[m * a_scale_stride], b_scale[n]: the scales
+ *     the planes were built with; amax_out (may be NULL): atomicMax of the bit pattern of max |x| over everything
+ *     written (zero it first).  Supported: {act 0, C} {act 0, C, R} {act 0, C_planes} {act 0, C, C_planes} {act 1 or 2, C}
+ *     {act 1, C_planes}.  K % 16 == 0, N % 16 == 0.                                                                */
+int rsaf_f16x2_row_scales(const float* src, int64_t rows, int K, int64_t ld, float* scale, float* norm2,
+                          rsaf_stream_t stream);
+int rsaf_split_f16x2(const float* src, int64_t rows, int K, int64_t ld, const float* scale, int scale_stride,
+                     uint16_t* planes, int64_t plane_stride, int panels, rsaf_stream_t stream);
+int rsaf_gemm_f16x3(const uint16_t* A_planes, int64_t a_plane_stride, const float* a_scale, int a_scale_stride,
+                    const uint16_t* B_planes, int64_t b_plane_stride, const float* b_scale, float* C,
+                    uint16_t* C_planes, int64_t c_plane_stride, const float* c_scale, int c_scale_stride,
+                    uint32_t* amax_out, const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
+                    int64_t ldc, int64_t ldr, int act, float alpha, int a_panels, int b_panels, int c_panels,
+                    rsaf_stream_t stream);
+
 /* ---- CNN-LSTM-with-attention classifier forward ----------------------------------------------------
  * Replaces CNNLSTM.forward (src/models.py:161-193) in eval mode: x[B,T,input_dim] float32 ->
  * logits[B,num_classes].  Zero-padded frames are processed like any other frame (the reference's

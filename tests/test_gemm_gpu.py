@@ -255,3 +255,106 @@ def test_bf16x6_panel_layout_is_bit_identical_to_row_major(rsaf_lib, M, N, K):
     _, P0 = run(False, False, False, 1, False, True)
     _, P1 = run(True, True, True, 1, False, True)
     assert torch.equal(to_row_major(P1, M, N), P0.view(3, M, N))
+
+
+# ---- fp32-accurate GEMM on the fp16 matrix pipe (three products of two-way fp16 splits, power-of-two row scales) --------
+def _h3_scales(X, loose=1.0):
+    """Per-row power-of-two scales from rsaf_f16x2_row_scales (+ row norms); loose > 1 shrinks them as a loose bound would."""
+    import torch
+    from robust_speech_analysis_framework_amd import _lib
+    lib = _lib.load()
+    rows, k = X.shape
+    s = torch.empty(rows, device="cuda")
+    nrm = torch.empty(rows, device="cuda")
+    _lib.check(lib.rsaf_f16x2_row_scales(_lib.ptr(X), rows, k, k, _lib.ptr(s), _lib.ptr(nrm), None), "row scales")
+    return s / loose, nrm
+
+
+def _h3_split(X, s, panels):
+    import torch
+    from robust_speech_analysis_framework_amd import _lib
+    lib = _lib.load()
+    rows, k = X.shape
+    P = torch.zeros((2, rows * k), dtype=torch.int16, device="cuda")
+    _lib.check(lib.rsaf_split_f16x2(_lib.ptr(X), rows, k, k, _lib.ptr(s), 1, _lib.ptr(P), rows * k, int(panels), None), "split f16x2")
+    return P
+
+
+def _h3_to_f64(P, s, rows, k, panels):
+    """planes -> the float64 values they stand for (hi + lo) / scale, as [rows][k]"""
+    import torch
+    v = P.view(torch.float16).double()
+    v = v[0] + v[1]
+    v = v.view(k // 16, rows, 16).permute(1, 0, 2).reshape(rows, k) if panels else v.view(rows, k)
+    return v / s.double()[:, None]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 208, 64), (256, 256, 16), (1000, 144, 512), (513, 768, 3072), (257, 2304, 768), (700, 48, 6144)])
+@pytest.mark.parametrize("loose", [1.0, 4096.0])
+def test_f16x3_gemm_is_fp32_accurate(rsaf_lib, M, N, K, loose):
+    """Every output mode of rsaf_gemm_f16x3 against float64: the error is that of an fp32 FMA chain (same bar as, and
+    compared with, rsaf_gemm_f32 on the same operands), with exact row scales and with scales 4 096 x smaller (what a loose
+    Cauchy-Schwarz bound on a GEMM output gives: the low plane is then largely subnormal); edges (M, N not multiples of
+    the tile), both operand layouts and the plane output (scaled by its own c_scale) included."""
+    import torch
+    from robust_speech_analysis_framework_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=g)
+    A[:, :3] *= 40.0                                                    # outlier channels, as transformer activations have
+    A = A.cuda()
+    W = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
+    bias = torch.randn((N,), generator=g).cuda()
+    R = torch.randn((M, N), generator=g).cuda()
+    sa, anorm = _h3_scales(A, loose)
+    sw, wnorm = _h3_scales(W)
+    lin = A.double() @ W.double().T + bias.double()
+    ref_plain, ref_res, ref_gelu = lin, lin + R.double(), torch.nn.functional.gelu(lin)
+    ref_silu = lin * torch.sigmoid(lin)
+    e32 = (ops.linear(A, W, bias=bias).double() - ref_plain).abs().max().item() / ref_plain.abs().max().item()
+    bar = max(3 * e32, 2e-6)
+    # the scale of a plane OUTPUT comes from a bound on the row: |x_mn| <= |a_m| |w_n| + |b_n|
+    bound = anorm * wnorm.max() + bias.abs().max()
+    cs = torch.exp2(14 - torch.floor(torch.log2(bound)))
+    results = {}
+    for panels in (False, True):
+        ap, wp = _h3_split(A, sa, panels), _h3_split(W, sw, panels)
+        torch.cuda.synchronize()
+        back = _h3_to_f64(wp, sw, N, K, panels)
+        assert ((back - W.double()).abs() <= W.double().abs() * 2.0 ** -21 + W.abs().max().item() * 2.0 ** -38).all()
+
+        def run(act, want_f32, want_planes, resid, c_panels=False):
+            C = torch.full((M, N), float("nan"), device="cuda") if want_f32 else None
+            P = torch.zeros((2, M * N), dtype=torch.int16, device="cuda") if want_planes else None
+            amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+            _lib.check(lib.rsaf_gemm_f16x3(_lib.ptr(ap), M * K, _lib.ptr(sa), 1, _lib.ptr(wp), N * K, _lib.ptr(sw),
+                                           _lib.ptr(C) if want_f32 else None, _lib.ptr(P) if want_planes else None, M * N,
+                                           _lib.ptr(cs) if want_planes else None, 1, _lib.ptr(amax), _lib.ptr(bias),
+                                           _lib.ptr(R) if resid else None, M, N, K, K, K, N, N, act, 1.0, int(panels), int(panels),
+                                           int(c_panels), None), "gemm3")
+            torch.cuda.synchronize()
+            return C, P, amax.view(torch.float32).item()
+
+        C, _, amax = run(0, True, False, False)
+        assert (C.double() - ref_plain).abs().max().item() / ref_plain.abs().max().item() < bar
+        assert amax == C.abs().max().item()                                 # the reported maximum is the maximum written
+        results[panels] = C
+        C, _, _ = run(0, True, False, True)
+        assert (C.double() - ref_res).abs().max().item() / ref_res.abs().max().item() < bar
+        C, _, _ = run(1, True, False, False)
+        assert (C.double() - ref_gelu).abs().max().item() / ref_gelu.abs().max().item() < bar
+        C, _, _ = run(2, True, False, False)
+        assert (C.double() - ref_silu).abs().max().item() / ref_silu.abs().max().item() < bar
+        _, P, amax = run(1, False, True, False, c_panels=panels)
+        got = _h3_to_f64(P, cs, M, N, panels)
+        assert torch.isfinite(got).all()                                    # the bound held: no fp16 overflow
+        assert (got - ref_gelu).abs().max().item() / ref_gelu.abs().max().item() < bar
+        assert abs(amax - got.abs().max().item()) <= 1e-6 * amax
+        C, P, _ = run(0, True, True, False, c_panels=panels)
+        assert (_h3_to_f64(P, cs, M, N, panels) - C.double()).abs().max().item() <= 2.0 ** -21 * C.abs().max().item()
+    assert torch.equal(results[False], results[True])                   # the panel layout is a permutation: same bits
+    with pytest.raises(_lib.RsafError):
+        lib_rc = lib.rsaf_gemm_f16x3(_lib.ptr(ap), M * K, _lib.ptr(sa), 1, _lib.ptr(wp), N * K, _lib.ptr(sw), None, None, 0, None, 0,
+                                     None, None, None, M, N, K, K, K, N, N, 0, 1.0, 1, 1, 0, None)
+        _lib.check(lib_rc, "no output")
