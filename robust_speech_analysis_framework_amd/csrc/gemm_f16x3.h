@@ -43,6 +43,7 @@ struct GemmH3Params {
     int nz2;
     int64_t sA2, sB2, sC2, sBias2;
     int b_panel_rows;
+    int dbg;                 // measurement knobs (RSAF_G3_DBG): bit 0 = skip the epilogue (timing only, wrong results)
 };
 
 int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag);

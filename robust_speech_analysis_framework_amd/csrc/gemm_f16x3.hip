@@ -55,7 +55,10 @@ struct H3Cfg {
     static constexpr int A_PLANE = BM * BK, B_PLANE = BN * BK;          // fp16 elements per plane per stage
     static constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
     static constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;          // 1 KiB DMA wave-instructions per plane
-    static constexpr int LDS_BYTES = (NST * STAGE * 2) > (WM * WN * 32 * 36 * 4) ? (NST * STAGE * 2) : (WM * WN * 32 * 36 * 4);
+    static constexpr int PATCH_BYTES = WM * WN * 32 * 36 * 4;           // wave-private transposition patches of the epilogue
+    static constexpr int TAB_BYTES = 2 * (BM + BN) * 4;                 // the tile's row / column scales and biases (epilogue)
+    static constexpr int LDS_BYTES = NST * STAGE * 2 + PATCH_BYTES + TAB_BYTES;     // the patches do NOT alias the stages: the next tile's
+                                                                        // first k-tiles land while the epilogue runs
 };
 
 // DMA source address = wave-uniform base (kept in an SGPR pair) + 32-bit per-lane byte offset: the instruction's
@@ -81,33 +84,41 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     constexpr int A_PLANE = CFG::A_PLANE, B_PLANE = CFG::B_PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
-    const int64_t z = blockIdx.y;
-    const int64_t z1 = p.nz2 > 1 ? z / p.nz2 : z, z2 = p.nz2 > 1 ? z % p.nz2 : 0;   // (window, group) of a grouped convolution
-    const int Mz = p.m_per_z ? p.m_per_z[z1] : p.M;                              // rows of this batch (ragged windows)
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int nwg = tiles_n * tiles_m;
-    const int orig = blockIdx.x;
-    // XCD-aware bijective remap of the 1-D grid, then GROUP_M row-tiles x all column-tiles walked column by column
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int GROUP_M = p.group_m;
-    const int per_group = GROUP_M * tiles_n;
-    const int grp = wg / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-    const int in_grp = wg - grp * per_group;
-    const int m0 = (first_m + in_grp % gsz) * BM;
-    const int n0 = (in_grp / gsz) * BN;
-    if (m0 >= Mz) return;                                                        // (workgroup-uniform: no barrier is skipped)
+    const int64_t total_tiles = (int64_t)nwg * p.nz;
     const int wm0 = (wave / CFG::WN) * (32 * TM), wn0 = (wave % CFG::WN) * (32 * TN);
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // Persistent workgroups: workgroup b walks tiles b, b + gridDim.x, ...  Tile t -> batch z = t / nwg and, inside the batch,
+    // the XCD-aware bijective remap of the index, then GROUP_M row-tiles x all column-tiles walked column by column.
+    struct Tile { int m0, n0, Mz; int64_t z, z1, z2; };
+    auto tile_at = [&](int64_t t) {
+        Tile T;
+        T.z = t / nwg;
+        const int orig = (int)(t - T.z * nwg);
+        T.z1 = p.nz2 > 1 ? T.z / p.nz2 : T.z;
+        T.z2 = p.nz2 > 1 ? T.z % p.nz2 : 0;                              // (window, group) of a grouped convolution
+        T.Mz = p.m_per_z ? p.m_per_z[T.z1] : p.M;                        // rows of this batch (ragged windows)
+        const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        const int GROUP_M = p.group_m;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = wg / per_group;
+        const int first_m = grp * GROUP_M;
+        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        const int in_grp = wg - grp * per_group;
+        T.m0 = (first_m + in_grp % gsz) * BM;
+        T.n0 = (in_grp / gsz) * BN;
+        return T;
+    };
+    // the first tile at or after t (stride gridDim.x) that has rows: tiles past a short batch's rows are skipped
+    auto next_valid = [&](int64_t t, Tile& T) {
+        for (; t < total_tiles; t += gridDim.x) {
+            T = tile_at(t);
+            if (T.m0 < T.Mz) return t;
+        }
+        return (int64_t)-1;
+    };
 
     // DMA: one wave-instruction moves 32 rows of one plane (1 KiB).  Instruction j of an operand covers rows 32 j ..;
     // the A_INSTR + B_INSTR instructions of a plane pair are dealt round-robin to the waves.
@@ -125,26 +136,31 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         live[i] = j < NI;
         const bool isA = j < CFG::A_INSTR;
         const int jj = isA ? j : j - CFG::A_INSTR;
-        const int row = 32 * jj + (lane >> 1);
-        const int dch = (lane & 1) ^ ((row >> 3) & 1);
-        if (isA) {
-            const int rr = (m0 + row < Mz) ? row : Mz - 1 - m0;           // rows past M re-read the last row
-            const int64_t rs = p.a_panel ? 16 : p.lda;                    // row stride; k-tile stride below (elements)
-            sbase[i] = p.A + z1 * p.sA + z2 * p.sA2 + (int64_t)m0 * rs;
-            voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
-            pstride[i] = p.a_plane;
-            kstride[i] = p.a_panel ? (int64_t)p.M * 16 : 16;
-            ldsoff[i] = jj * 512;
-        } else {
-            const int rr = (n0 + row < p.N) ? row : p.N - 1 - n0;
-            const int64_t rs = p.b_panel ? 16 : p.ldb;
-            sbase[i] = p.B + z2 * p.sB2 + (int64_t)n0 * rs;
-            voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
-            pstride[i] = p.b_plane;
-            kstride[i] = p.b_panel ? (int64_t)(p.b_panel_rows > 0 ? p.b_panel_rows : p.N) * 16 : 16;
-            ldsoff[i] = NPL * A_PLANE + jj * 512;
-        }
+        pstride[i] = isA ? p.a_plane : p.b_plane;
+        kstride[i] = isA ? (p.a_panel ? (int64_t)p.M * 16 : 16) : (p.b_panel ? (int64_t)(p.b_panel_rows > 0 ? p.b_panel_rows : p.N) * 16 : 16);
+        ldsoff[i] = isA ? jj * 512 : NPL * A_PLANE + jj * 512;
     }
+    auto set_tile = [&](const Tile& T) {                                  // DMA sources of a tile
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int j = wave + NW * i;
+            const bool isA = j < CFG::A_INSTR;
+            const int jj = isA ? j : j - CFG::A_INSTR;
+            const int row = 32 * jj + (lane >> 1);
+            const int dch = (lane & 1) ^ ((row >> 3) & 1);
+            if (isA) {
+                const int rr = (T.m0 + row < T.Mz) ? row : T.Mz - 1 - T.m0;   // rows past M re-read the last row
+                const int64_t rs = p.a_panel ? 16 : p.lda;                // row stride (elements)
+                sbase[i] = p.A + T.z1 * p.sA + T.z2 * p.sA2 + (int64_t)T.m0 * rs;
+                voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
+            } else {
+                const int rr = (T.n0 + row < p.N) ? row : p.N - 1 - T.n0;
+                const int64_t rs = p.b_panel ? 16 : p.ldb;
+                sbase[i] = p.B + T.z2 * p.sB2 + (int64_t)T.n0 * rs;
+                voff[i] = 2u * ((unsigned)rr * (unsigned)rs + 8u * dch);
+            }
+        }
+    };
     const int nk = p.K / BK;
 
 #define H3_DMA(KT, ST)                                                                                          \
@@ -159,24 +175,58 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         }                                                                                                       \
     } while (0)
 
+    static_assert(NST == 3 && TM % 2 == 0, "the staggered loop needs three stages and an even number of m-tiles");
+    const int grpB = wave >= NW / 2 ? 1 : 0;
+    constexpr int NDMA = NPL * IPW;                          // DMA instructions of this wave per k-tile
+    constexpr int HM = TM / 2;
+    constexpr int PATCH_LD = 36;                             // floats per patch row (16-byte aligned rows, 2-way write conflicts)
+    float* patch = reinterpret_cast<float*>(smem3 + NST * STAGE) + wave * (32 * PATCH_LD);
+
+    // The epilogue's per-row and per-column operands (scales of A and of the plane output; scales of B and bias) reach it
+    // through LDS: thread t fetches row t's (t < BM) or column t - BM's pair when the tile STARTS, keeps it in two registers
+    // through the main loop and files it behind the last k-tile.  (As global loads inside the epilogue they sat behind the
+    // stores in the wave's in-order memory counter, or cost 30+ registers when all fetched up front.)
+    static_assert(CFG::THREADS >= BM + BN, "one thread per row and per column of the tile");
+    float* tab0 = reinterpret_cast<float*>(smem3 + NST * STAGE) + NW * (32 * PATCH_LD);   // [BM] a_scale | [BN] b_scale
+    float* tab1 = tab0 + (BM + BN);                                                        // [BM] c_scale | [BN] bias
+    float e0 = 1.0f, e1 = 0.0f;
+    auto load_epi = [&](const Tile& T) {
+        if (tid < BM) {
+            const int row = T.m0 + tid < T.Mz ? T.m0 + tid : T.Mz - 1;                      // clamped: rows past M are never stored
+            e0 = p.a_scale[T.z1 * p.a_scale_zs + (int64_t)row * p.a_scale_ms];
+            e1 = OUT_PLANES ? p.c_scale[T.z1 * p.c_scale_zs + (int64_t)row * p.c_scale_ms] : 1.0f;
+        } else if (tid < BM + BN) {
+            const int col = T.n0 + tid - BM;
+            e0 = col < p.N ? p.b_scale[T.z2 * p.sBias2 + col] : 1.0f;
+            e1 = (p.bias && col < p.N) ? p.bias[T.z2 * p.sBias2 + col] : 0.0f;
+        }
+    };
+    Tile cur;
+    int64_t t_cur = next_valid(blockIdx.x, cur);
+    if (t_cur < 0) return;                                   // (workgroup-uniform)
+    load_epi(cur);
+    set_tile(cur);
+    H3_DMA(0, 0);
+    if (nk > 1) H3_DMA(1, 1);
+
+    while (true) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
     // Main loop: ONE instruction stream, two barriers per k-tile, the two waves of every SIMD half a k-tile apart
     // (waves NW/2 .. NW-1 pass one extra barrier in front of the loop and the others one behind it: barriers match by
     // count).  A wave issues its DMA instructions at the head of its first half, behind the B-fragment reads of the new
     // k-tile; group A (slot 2 kt) fetches k-tile kt + 1 into the stage of k-tile kt - 2 and waits for it in front of its
     // next top barrier; group B (slot 2 kt + 1) fetches k-tile kt + 2 into the stage of k-tile kt - 1 and waits for it
     // in front of the middle barrier of its k-tile kt + 1 (counted: its next DMA instructions stay in flight).
-    static_assert(NST == 3 && TM % 2 == 0, "the staggered loop needs three stages and an even number of m-tiles");
-    H3_DMA(0, 0);
-    if (nk > 1) H3_DMA(1, 1);
-    const int grpB = wave >= NW / 2 ? 1 : 0;
-    constexpr int NDMA = NPL * IPW;                          // DMA instructions of this wave per k-tile
-    constexpr int HM = TM / 2;
-    if (nk > 1) {                                            // k-tile 0 has landed (k-tile 1 may stay in flight)
-        if (IPW == 1 || !live[IPW - 1]) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL * (IPW - 1) > 0 ? NPL * (IPW - 1) : NPL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL * IPW) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // Everything this wave has in flight - its share of k-tiles 0 and 1 and, from the second tile on, the previous
+    // epilogue's stores (loads and stores share the counter and do not retire in order with each other) - has landed:
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (grpB) __builtin_amdgcn_s_barrier();
     int st = 0;                                              // stage of k-tile kt
     for (int kt = 0; kt < nk; ++kt) {
@@ -248,121 +298,164 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         st = st == NST - 1 ? 0 : st + 1;
     }
     if (!grpB) __builtin_amdgcn_s_barrier();
-#undef H3_DMA
 
     // ---- epilogue ----
     // MFMA layout: lane l31 = column, register e -> row (e & 3) + 8 (e >> 2) + 4 h of a 32 x 32 tile.  Each tile is
-    // transposed through a wave-private LDS patch into rows: lane -> row lane >> 1, 16 consecutive columns, then
-    // scales / bias / residual / activation in that layout and 16-byte stores.
-    __syncthreads();                                     // every wave is done reading the last k-tile
-    constexpr int PATCH_LD = 36;                         // floats per patch row (16-byte aligned rows, 2-way write conflicts)
-    float* patch = reinterpret_cast<float*>(smem3) + wave * (32 * PATCH_LD);
-    const int prow = lane >> 1, pcol = 16 * (lane & 1);
-    float row_amax[TM];
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt) row_amax[mt] = 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        const int tn = n0 + wn0 + nt * 32;
-        const int gc = tn + pcol;                        // first of this lane's 16 columns
-        const bool c_ok = gc < p.N;                      // N % 16 == 0: the 16 columns are valid together
-        float bias16[16], bsi16[16];
+    // transposed through a wave-private LDS patch so that one store instruction writes FULL LINES: lane -> 4 consecutive
+    // columns 4 (lane & 7), rows 8 q + (lane >> 3) for q = 0..3, i.e. instruction q covers 8 rows x 128 bytes.  (First
+    // version: lane -> one row, 16 columns, four 16-byte stores: every instruction scattered 64 pieces of 16 bytes over 32
+    // lines, and the L1 -> L2 write path took them one piece at a time: 10-12 us of stores per 256 x 256 tile, a sixth of a
+    // K = 768 tile, measured by knocking the stores out.)
+    // The counter of a wave's vector-memory operations retires IN ORDER, loads and stores alike: the residual of the next
+    // sub-tile is fetched in front of the current one's stores, and the next tile's first DMA instructions go out in
+    // front of the first store.
+    const Tile done = cur;
+    const bool epi = !(p.dbg & 1);
+    // fp32 output: 4 columns per lane (8 lanes = one 128-byte line of a row, 8 rows per instruction).  Planes only: 8 columns
+    // per lane (16 bytes per plane: 2 lanes = one 32-byte panel row, 16 rows per instruction = 512 contiguous bytes per panel).
+    constexpr int CW = (OUT_PLANES && !OUT_F32) ? 8 : 4, LPR = 32 / CW, RPI = 64 / LPR, NQ = 32 / RPI;
+    const int lr = lane / LPR, c4 = CW * (lane % LPR);
+    float4 r4[4];                                        // residual of the sub-tile in hand (fp32 output only: CW = 4)
+    auto load_r = [&](int mt, int nt) {
+        const int tn = done.n0 + wn0 + nt * 32, tm = done.m0 + wm0 + mt * 32;
+        const float* Rt = p.R + done.z * p.sR + (int64_t)tm * p.ldr + tn + c4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b4 = (p.bias && c_ok) ? *reinterpret_cast<const float4*>(p.bias + z2 * p.sBias2 + gc + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bias16[4 * q] = b4.x; bias16[4 * q + 1] = b4.y; bias16[4 * q + 2] = b4.z; bias16[4 * q + 3] = b4.w;
-            const float4 s4 = c_ok ? *reinterpret_cast<const float4*>(p.b_scale + z2 * p.sBias2 + gc + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
-            bsi16[4 * q] = pow2_inverse(s4.x); bsi16[4 * q + 1] = pow2_inverse(s4.y);
-            bsi16[4 * q + 2] = pow2_inverse(s4.z); bsi16[4 * q + 3] = pow2_inverse(s4.w);
+            const bool ok = (tn + c4) < p.N && (tm + 8 * q + lr) < done.Mz;
+            r4[q] = ok ? *reinterpret_cast<const float4*>(Rt + (8 * q + lr) * (int)p.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (tid < BM + BN) { tab0[tid] = e0; tab1[tid] = e1; }
+    if (epi && HAS_R) load_r(0, 0);
+
+    // ---- next tile: its first two k-tiles travel while this tile's epilogue runs ----
+    __syncthreads();                                     // every wave is done reading the stages; the tables are filed
+    t_cur = next_valid(t_cur + gridDim.x, cur);
+    if (t_cur >= 0) {
+        set_tile(cur);
+        load_epi(cur);
+        H3_DMA(0, 0);
+        if (nk > 1) H3_DMA(1, 1);
+    }
+
+    if (epi) {
+    const int m0 = done.m0, n0 = done.n0, Mz = done.Mz;
+    const int64_t z = done.z, z1 = done.z1, z2 = done.z2;
+    static_assert(!HAS_R || CW == 4, "the residual comes with the fp32 output");
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int tm = m0 + wm0 + mt * 32;
+        float asi[NQ], csc[NQ], row_amax[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            asi[q] = p.alpha * pow2_inverse(tab0[wm0 + mt * 32 + RPI * q + lr]);
+            csc[q] = tab1[wm0 + mt * 32 + RPI * q + lr];
+            row_amax[q] = 0.0f;
         }
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int tm = m0 + wm0 + mt * 32;
-            const bool r_ok = (tm + prow) < Mz;
-            const bool ok = c_ok && r_ok;
-            const int64_t grow = (int64_t)(r_ok ? tm + prow : Mz - 1);                // clamped row for the scale look-ups
-            const float asi = p.alpha * pow2_inverse(p.a_scale[z1 * p.a_scale_zs + grow * p.a_scale_ms]);
-            float4 r4[4];
-            if (HAS_R) {
-                const float* Rt = p.R + z * p.sR + (int64_t)tm * p.ldr + tn;
+        for (int nt = 0; nt < TN; ++nt) {
+            const int tn = n0 + wn0 + nt * 32;
+            const int gc = tn + c4;
+            const bool c_ok = gc < p.N;                  // N % 16 == 0 and c4 % CW == 0: the lane's columns are valid together
+            float bsi[CW], bias4[CW];                    // 1 / s_b (a power of two) and the bias of this lane's columns
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    r4[q] = ok ? *reinterpret_cast<const float4*>(Rt + prow * (int)p.ldr + pcol + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j4 = 0; j4 < CW / 4; ++j4) {
+                const float4 bs4 = *reinterpret_cast<const float4*>(tab0 + BM + wn0 + nt * 32 + c4 + 4 * j4);
+                const float4 bi4 = *reinterpret_cast<const float4*>(tab1 + BM + wn0 + nt * 32 + c4 + 4 * j4);
+                bsi[4 * j4] = pow2_inverse(bs4.x); bsi[4 * j4 + 1] = pow2_inverse(bs4.y);
+                bsi[4 * j4 + 2] = pow2_inverse(bs4.z); bsi[4 * j4 + 3] = pow2_inverse(bs4.w);
+                bias4[4 * j4] = bi4.x; bias4[4 * j4 + 1] = bi4.y; bias4[4 * j4 + 2] = bi4.z; bias4[4 * j4 + 3] = bi4.w;
             }
+            constexpr int LAST = TM * TN - 1;
+            const int sub = mt * TN + nt;
+            if (!(p.dbg & 4))
 #pragma unroll
             for (int e = 0; e < 16; ++e) patch[(4 * h + (e & 3) + 8 * (e >> 2)) * PATCH_LD + l31] = acc[mt][nt][e];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float v[16];
+            float v[NQ][CW];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 t4 = *reinterpret_cast<const float4*>(patch + prow * PATCH_LD + pcol + 4 * q);
-                v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
-            }
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j4 = 0; j4 < CW / 4; ++j4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(patch + (RPI * q + lr) * PATCH_LD + c4 + 4 * j4);
+                    v[q][4 * j4] = t4.x; v[q][4 * j4 + 1] = t4.y; v[q][4 * j4 + 2] = t4.z; v[q][4 * j4 + 3] = t4.w;
+                }
             __builtin_amdgcn_wave_barrier();             // the patch may be overwritten by the next tile
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float x = v[q] * (asi * bsi16[q]) + bias16[q];           // asi * bsi: a product of powers of two (and alpha)
-                if (HAS_R) x += (q & 3) == 0 ? r4[q >> 2].x : ((q & 3) == 1 ? r4[q >> 2].y : ((q & 3) == 2 ? r4[q >> 2].z : r4[q >> 2].w));
-                if (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-                if (ACT == ACT_SILU) x = x / (1.0f + expf(-x));
-                v[q] = x;
-            }
-            if (p.amax_out && ok && gc >= p.amax_col_min) {
-                float mx = 0.0f;
+            for (int q = 0; q < NQ; ++q) {
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (HAS_R) { rv[0] = r4[q % 4].x; rv[1] = r4[q % 4].y; rv[2] = r4[q % 4].z; rv[3] = r4[q % 4].w; }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) mx = fmaxf(mx, fabsf(v[q]));
-                row_amax[mt] = fmaxf(row_amax[mt], mx);
-            }
-            if (ok) {
-                if (OUT_F32) {
-                    float* Ct = p.C + z1 * p.sC + z2 * p.sC2 + (int64_t)tm * p.ldc + tn + prow * (int)p.ldc + pcol;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(Ct + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                for (int j = 0; j < CW; ++j) {
+                    float y = v[q][j] * (asi[q] * bsi[j]) + bias4[j];       // asi * bsi: a product of powers of two (and alpha)
+                    if (HAS_R) y += rv[j % 4];
+                    if (ACT == ACT_GELU) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+                    if (ACT == ACT_SILU) y = y / (1.0f + expf(-y));
+                    v[q][j] = y;
+                    if (ACT != ACT_NONE && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four erf / exp chains at a time: registers
                 }
-                if (OUT_PLANES) {
-                    const float cs = p.c_scale[z1 * p.c_scale_zs + grow * p.c_scale_ms];
-                    unsigned short hh[16], ll[16];
+            }
+            if (HAS_R && sub < LAST) load_r((sub + 1) / TN, (sub + 1) % TN);   // the next residual, in front of this sub-tile's stores
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) split2(v[q] * cs, hh[q], ll[q]);
-                    // row-major [M][ldcp], or the k16 panels of the next GEMM's A: panel (tn + pcol) / 16, row tm + prow
-                    unsigned short* Pt = p.cp_panel ? p.Cp + (int64_t)((tn + pcol) >> 4) * ((int64_t)p.M * 16) + (int64_t)(tm + prow) * 16
-                                                    : p.Cp + z * p.sCp + (int64_t)tm * p.ldcp + tn + prow * (int)p.ldcp + pcol;
-                    auto pk = [](const unsigned short* s_, int o) {
-                        return make_uint4(s_[o] | ((unsigned)s_[o + 1] << 16), s_[o + 2] | ((unsigned)s_[o + 3] << 16),
-                                          s_[o + 4] | ((unsigned)s_[o + 5] << 16), s_[o + 6] | ((unsigned)s_[o + 7] << 16));
-                    };
-                    *reinterpret_cast<uint4*>(Pt) = pk(hh, 0);
-                    *reinterpret_cast<uint4*>(Pt + 8) = pk(hh, 8);
-                    *reinterpret_cast<uint4*>(Pt + p.c_plane) = pk(ll, 0);
-                    *reinterpret_cast<uint4*>(Pt + p.c_plane + 8) = pk(ll, 8);
+            for (int q = 0; q < NQ; ++q) {
+                const int row = tm + RPI * q + lr;
+                const bool ok = c_ok && row < Mz;
+                if (p.amax_out && ok && gc >= p.amax_col_min) {
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) row_amax[q] = fmaxf(row_amax[q], fabsf(v[q][j]));
+                }
+                if (ok && !(p.dbg & 2)) {
+                    if (OUT_F32) *reinterpret_cast<float4*>(p.C + z1 * p.sC + z2 * p.sC2 + (int64_t)row * p.ldc + gc) =
+                        make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+                    if (OUT_PLANES) {
+                        const float cs = csc[q];
+                        unsigned short hh[CW], ll[CW];
+#pragma unroll
+                        for (int j = 0; j < CW; ++j) split2(v[q][j] * cs, hh[j], ll[j]);
+                        // row-major [M][ldcp], or the k16 panels of the next GEMM's A (panel gc / 16, row, k = gc % 16)
+                        unsigned short* Pt = p.cp_panel ? p.Cp + (int64_t)(gc >> 4) * ((int64_t)p.M * 16) + (int64_t)row * 16 + (gc & 15)
+                                                        : p.Cp + z * p.sCp + (int64_t)row * p.ldcp + gc;
+                        if (CW == 8) {
+                            *reinterpret_cast<uint4*>(Pt) = make_uint4(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16),
+                                                                      hh[4 % CW] | ((unsigned)hh[5 % CW] << 16), hh[6 % CW] | ((unsigned)hh[7 % CW] << 16));
+                            *reinterpret_cast<uint4*>(Pt + p.c_plane) = make_uint4(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16),
+                                                                                  ll[4 % CW] | ((unsigned)ll[5 % CW] << 16), ll[6 % CW] | ((unsigned)ll[7 % CW] << 16));
+                        } else {
+                            *reinterpret_cast<uint2*>(Pt) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+                            *reinterpret_cast<uint2*>(Pt + p.c_plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+                        }
+                    }
+                }
+            }
+        }
+        if (p.amax_out) {
+            // the largest |x| this wave wrote, per slot: rows are ordered by slot, so the rows of a store instruction hold
+            // one slot, seldom two: one masked wave reduction + one atomic per distinct slot
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int row = tm + RPI * q + lr;
+                const bool r_ok = row < Mz;
+                const int slot = !r_ok ? -1 : (int)(z1 * p.amax_zs) + (p.amax_row_slot ? p.amax_row_slot[row] : (p.amax_div > 0 ? row / p.amax_div : 0));
+                unsigned long long todo = __ballot(r_ok);
+                while (todo) {
+                    const int first = __ffsll((long long)todo) - 1;
+                    const int s0 = __shfl(slot, first, 64);
+                    const bool mine = r_ok && slot == s0;
+                    float mx = mine ? row_amax[q] : 0.0f;
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    if (lane == first && mx > 0.0f) atomicMax(p.amax_out + s0, __float_as_uint(mx));
+                    todo &= ~__ballot(mine);
                 }
             }
         }
     }
-    if (p.amax_out) {
-        // the largest |x| this wave wrote, per slot: rows are ordered by slot, so a 32-row tile holds one or two of them
-        // (more only for windows shorter than 32 frames): one masked wave reduction + one atomic per distinct slot
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int row = m0 + wm0 + mt * 32 + prow;
-            const bool r_ok = row < Mz;
-            const int slot = !r_ok ? -1 : (int)(z1 * p.amax_zs) + (p.amax_row_slot ? p.amax_row_slot[row] : (p.amax_div > 0 ? row / p.amax_div : 0));
-            unsigned long long todo = __ballot(r_ok);
-            while (todo) {
-                const int first = __ffsll((long long)todo) - 1;
-                const int s0 = __shfl(slot, first, 64);
-                const bool mine = r_ok && slot == s0;
-                float mx = mine ? row_amax[mt] : 0.0f;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                if (lane == first && mx > 0.0f) atomicMax(p.amax_out + s0, __float_as_uint(mx));
-                todo &= ~__ballot(mine);
-            }
-        }
     }
+    if (t_cur < 0) break;
+    }
+#undef H3_DMA
 }
 
 // ---- operand preparation ------------------------------------------------------------------------------------------
@@ -496,9 +589,9 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     do {                                                                                                                \
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16x3_kernel<CFG, ACT, F32, PL, HR>,                        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES));                 \
-        const int64_t tiles = (int64_t)((p.N + CFG::BN - 1) / CFG::BN) * ((p.M + CFG::BM - 1) / CFG::BM);               \
+        const int64_t tiles = (int64_t)((p.N + CFG::BN - 1) / CFG::BN) * ((p.M + CFG::BM - 1) / CFG::BM) * p.nz;        \
         RSAF_CHECK_ARG(tiles <= 0x7fffffffLL, "too many tiles");                                                        \
-        hipLaunchKernelGGL((gemm_f16x3_kernel<CFG, ACT, F32, PL, HR>), dim3((unsigned)tiles, (unsigned)p.nz),           \
+        hipLaunchKernelGGL((gemm_f16x3_kernel<CFG, ACT, F32, PL, HR>), dim3((unsigned)std::min<int64_t>(tiles, persistent_wgs)), \
                            dim3(CFG::THREADS), CFG::LDS_BYTES, stream, pp);                                              \
     } while (0)
 #define H3_LAUNCH(ACT, F32, PL, HR)                                                                                     \
@@ -508,6 +601,21 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     } while (0)
     GemmH3Params pp = p;
     if (pp.group_m <= 0) pp.group_m = 2;
+    {
+        static const int dbg = [] { const char* e = getenv("RSAF_G3_DBG"); return e ? atoi(e) : 0; }();
+        static const int gm = [] { const char* e = getenv("RSAF_G3_GROUP_M"); return e ? atoi(e) : 0; }();
+        pp.dbg = dbg;
+        if (gm > 0) pp.group_m = gm;
+    }
+    // persistent workgroups, one per CU (RSAF_GEMM_WGS overrides the count: a measurement knob)
+    int persistent_wgs = 256;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            persistent_wgs = cus;
+        static const int forced = [] { const char* e = getenv("RSAF_GEMM_WGS"); return e ? atoi(e) : 0; }();
+        if (forced > 0) persistent_wgs = forced;
+    }
     const bool f32o = p.C != nullptr, plo = p.Cp != nullptr, hr = p.R != nullptr;
     // the combinations the Wav2Vec2 / CNN stages use (anything else is an argument error, not a silent fallback)
     if (p.act == ACT_NONE && f32o && !plo && !hr) H3_LAUNCH(ACT_NONE, true, false, false);
