@@ -7,7 +7,8 @@
 // :575-608 post-LN encoder layers).  Chunking (80 000-sample windows every 64 000, per-chunk
 // normalisation, duplicated overlap) stays on the host side exactly as the reference does it.
 //
-// Every dense contraction is an exact-fp32 MFMA GEMM (gemm_f32.hip):
+// Every dense contraction runs on the fp32-accurate fp16-split GEMM (gemm_f16x3.hip: operands as two fp16 planes with
+// power-of-two scales, three MFMA products per term):
 //   conv1..6  : channels-last activations make a k-tap/stride-2 conv a GEMM with lda = 2*C, K = k*C
 //   pos-conv  : activations regrouped to [chunk][group][T+K-1 (zero padded)][C/G], one batched GEMM
 //   attention : S = QK^T/sqrt(d) and O = PV as (chunk, head)-batched GEMMs on the packed qkv buffer
@@ -18,7 +19,7 @@
 #include <vector>
 
 #include "gemm_f32.h"
-#include "gemm_bf16x6.h"
+#include "gemm_f16x3.h"
 
 namespace rsaf {
 namespace w2v2 {
@@ -86,18 +87,29 @@ static void chunk_lengths(int len, int T[7]) {
     }
 }
 
-// The dense GEMMs run on rsaf's fp32-accurate bf16x6 kernel (gemm_bf16x6.hip): their operands live as three bf16
-// planes.  Offsets are in floats; a planes buffer of N elements takes 3 N uint16 = 1.5 N floats.
+// The dense GEMMs run on rsaf's fp32-accurate f16x3 kernel (gemm_f16x3.hip): their operands live as two fp16 planes,
+// scaled per row (encoder activations, weights) or per window (feature-encoder activations) by a power of two.
+// Offsets are in floats; a planes buffer of N elements takes 2 N uint16 = N floats.
 struct Workspace {
     int64_t xn, part, ab, P, Q, c6, lnfp, x, xp, y, att, attp, xg, qkv, S, ffnp, wp, total;
     int64_t wp_conv[6], wp_fp, wp_pos;
     std::vector<int64_t> wp_qkv, wp_o, wp_1, wp_2;
+    // scales of the weight rows, and per weight matrix two words {max row norm, max |w|} (bit patterns, atomicMax)
+    int64_t ws_conv[6], ws_fp, ws_pos, wstat;            // wstat: [6 + 2 + 4 L][2] (+ [L][2] for the ffn1 biases)
+    std::vector<int64_t> ws_qkv, ws_o, ws_1, ws_2;
+    // scales of the activations: per window of the current conv group (conv_scale[7][G], conv_amax[7][G]), per window of
+    // the call (pos_scale, fp_amax, v_amax) and per frame (ln scale, ffn scale, attention scale)
+    int64_t conv_scale, conv_amax, pos_scale, fp_amax, v_amax, s_lnfp, s_x, s_ffn, s_att;
     int slabs, Tp, G;
 };
 constexpr int STAT_SLAB = 512;
 constexpr int CONV_GROUP = 512;      // windows per pass of the feature encoder (its ping-pong buffers are the big ones)
 
-static inline int64_t planes_floats(int64_t n) { return pad4((3 * n + 1) / 2); }
+static inline int64_t planes_floats(int64_t n) { return pad4(n); }
+
+// index of a weight matrix in the wstat table
+static inline int wstat_conv(int i) { return i; }                       // i = 0..5 (conv1..6)
+constexpr int WSTAT_FP = 6, WSTAT_POS = 7, WSTAT_LAYER0 = 8;             // layer l: qkv, o, ffn1, ffn2, ffn1 bias
 
 static Workspace make_ws(const Cfg& c, int n, int len) {
     int T[7];
@@ -111,7 +123,7 @@ static Workspace make_ws(const Cfg& c, int n, int len) {
     w.slabs = (T[0] + STAT_SLAB - 1) / STAT_SLAB;
     w.Tp = (int)pad4(Tt);
     w.xn = take((int64_t)G * len);
-    w.part = take((int64_t)G * w.slabs * 2 * c.C);
+    w.part = take((int64_t)G * w.slabs * 3 * c.C);
     w.ab = take((int64_t)G * 2 * c.C);
     w.P = take(planes_floats((int64_t)G * T[0] * c.C));
     w.Q = take(planes_floats((int64_t)G * T[1] * c.C));
@@ -122,20 +134,29 @@ static Workspace make_ws(const Cfg& c, int n, int len) {
     w.y = take((int64_t)n * Tt * c.Hd);
     w.att = take((int64_t)n * Tt * c.Hd);
     w.attp = take(planes_floats((int64_t)n * Tt * c.Hd));
-    w.xg = take(planes_floats((int64_t)n * (Tt + c.PK - 1) * c.Hd));     // fp32 or three bf16 planes (1.5 x)
+    w.xg = take((int64_t)n * (Tt + c.PK - 1) * c.Hd);                     // fp32 or two fp16 planes (same size)
     w.qkv = take((int64_t)n * Tt * 3 * c.Hd);
     w.S = take((int64_t)n * c.NH * Tt * w.Tp);
     w.ffnp = take(planes_floats((int64_t)n * Tt * c.I));
-    // weight planes (split once per forward call)
-    for (int i = 0; i < 6; ++i) w.wp_conv[i] = take(planes_floats((int64_t)c.C * KERN[i + 1] * c.C));
-    w.wp_fp = take(planes_floats((int64_t)c.Hd * c.C));
-    w.wp_pos = take(planes_floats((int64_t)c.Hd * c.PK * (c.Hd / c.PG)));
-    for (int l = 0; l < c.L; ++l) {
-        w.wp_qkv.push_back(take(planes_floats((int64_t)3 * c.Hd * c.Hd)));
-        w.wp_o.push_back(take(planes_floats((int64_t)c.Hd * c.Hd)));
-        w.wp_1.push_back(take(planes_floats((int64_t)c.I * c.Hd)));
-        w.wp_2.push_back(take(planes_floats((int64_t)c.Hd * c.I)));
+    // weight planes and row scales (built once per forward call)
+    for (int i = 0; i < 6; ++i) {
+        w.wp_conv[i] = take(planes_floats((int64_t)c.C * KERN[i + 1] * c.C));
+        w.ws_conv[i] = take(c.C);
     }
+    w.wp_fp = take(planes_floats((int64_t)c.Hd * c.C)); w.ws_fp = take(c.Hd);
+    w.wp_pos = take(planes_floats((int64_t)c.Hd * c.PK * (c.Hd / c.PG))); w.ws_pos = take(c.Hd);
+    for (int l = 0; l < c.L; ++l) {
+        w.wp_qkv.push_back(take(planes_floats((int64_t)3 * c.Hd * c.Hd))); w.ws_qkv.push_back(take(3 * c.Hd));
+        w.wp_o.push_back(take(planes_floats((int64_t)c.Hd * c.Hd))); w.ws_o.push_back(take(c.Hd));
+        w.wp_1.push_back(take(planes_floats((int64_t)c.I * c.Hd))); w.ws_1.push_back(take(c.I));
+        w.wp_2.push_back(take(planes_floats((int64_t)c.Hd * c.I))); w.ws_2.push_back(take(c.Hd));
+    }
+    w.wstat = take((int64_t)(WSTAT_LAYER0 + 5 * c.L) * 2);
+    w.conv_scale = take((int64_t)7 * G);
+    w.conv_amax = take((int64_t)7 * G);
+    w.pos_scale = take(n); w.fp_amax = take(n); w.v_amax = take(n);
+    const int64_t rows = (int64_t)n * Tt;
+    w.s_lnfp = take(rows); w.s_x = take(rows); w.s_ffn = take(rows); w.s_att = take(rows);
     w.total = o;
     return w;
 }
@@ -170,36 +191,42 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
 }
 
 // ---- conv0 (1 -> C, k = 10, s = 5) + GroupNorm(C groups) + GELU, two passes ----------------------
-__device__ __forceinline__ unsigned short bf16_bits_w(float x) {
-    const __bf16 h = (__bf16)x;
-    return __builtin_bit_cast(unsigned short, h);
+__device__ __forceinline__ unsigned short f16_bits_w(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+// xs = hi + lo (+ 2^-22 |xs|): the two fp16 planes of a value that already carries its power-of-two scale (gemm_f16x3.hip)
+__device__ __forceinline__ void split2_w(float xs, unsigned short& h, unsigned short& l) {
+    const _Float16 hh = (_Float16)xs;
+    h = f16_bits_w(hh);
+    l = f16_bits_w((_Float16)(xs - (float)hh));
 }
-__device__ __forceinline__ float bf16_to_f32_w(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
-// thread <-> channel(s); the 10 samples of a frame are wave-uniform (scalar loads)
+// thread <-> channel(s); the 10 samples of a frame are wave-uniform (scalar loads).  Statistics pass: per slab and channel
+// the sum, the sum of squares and the largest |y| (the bound behind the window's plane scale).  Apply pass: the output
+// goes out as the two fp16 planes of GELU(a y + b) * scale[window] (A operand of conv1).
 template <int CPT, bool APPLY>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn, const float* __restrict__ w0,
                                                     float* __restrict__ part, const float* __restrict__ ab,
+                                                    const float* __restrict__ scale,
                                                     unsigned short* __restrict__ outp, int64_t plane, int len,
                                                     int T0, int C, int slab, int slabs) {
     const int chunk = blockIdx.y, sl = blockIdx.x;
     const int t0 = sl * slab, t1 = min(T0, t0 + slab);
     const float* __restrict__ x = xn + (int64_t)chunk * len;
-    float wr[CPT][10], a[CPT], b[CPT], s[CPT], q[CPT];
+    float wr[CPT][10], a[CPT], b[CPT], s[CPT], q[CPT], mx[CPT];
     int ch[CPT];
+    const float sc = APPLY ? scale[chunk] : 1.0f;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         ch[k] = CPT * threadIdx.x + k;                      // adjacent channels: the planes go out as packed pairs
 #pragma unroll
         for (int j = 0; j < 10; ++j) wr[k][j] = w0[ch[k] * 10 + j];
-        s[k] = 0.f; q[k] = 0.f;
+        s[k] = 0.f; q[k] = 0.f; mx[k] = 0.f;
         if (APPLY) { a[k] = ab[((int64_t)chunk * 2 + 0) * C + ch[k]]; b[k] = ab[((int64_t)chunk * 2 + 1) * C + ch[k]]; }
     }
     for (int t = t0; t < t1; ++t) {
         float xv[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) xv[j] = x[5 * t + j];
-        unsigned short hh[CPT], mm[CPT], ll[CPT];
+        unsigned short hh[CPT], ll[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             float y = 0.f;
@@ -208,13 +235,9 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
             if (APPLY) {
                 const float v = fmaf(y, a[k], b[k]);
                 const float gl = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                // the next layer's GEMM takes its A operand as three bf16 planes (gemm_bf16x6.hip)
-                hh[k] = bf16_bits_w(gl);
-                const float r1 = gl - bf16_to_f32_w(hh[k]);
-                mm[k] = bf16_bits_w(r1);
-                ll[k] = bf16_bits_w(r1 - bf16_to_f32_w(mm[k]));
+                split2_w(gl * sc, hh[k], ll[k]);
             } else {
-                s[k] += y; q[k] += y * y;
+                s[k] += y; q[k] += y * y; mx[k] = fmaxf(mx[k], fabsf(y));
             }
         }
         if (APPLY) {
@@ -223,54 +246,64 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
 #pragma unroll
                 for (int k = 0; k < CPT; k += 2) {
                     *reinterpret_cast<unsigned*>(outp + o + k) = hh[k] | ((unsigned)hh[k + 1] << 16);
-                    *reinterpret_cast<unsigned*>(outp + plane + o + k) = mm[k] | ((unsigned)mm[k + 1] << 16);
-                    *reinterpret_cast<unsigned*>(outp + 2 * plane + o + k) = ll[k] | ((unsigned)ll[k + 1] << 16);
+                    *reinterpret_cast<unsigned*>(outp + plane + o + k) = ll[k] | ((unsigned)ll[k + 1] << 16);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < CPT; ++k) { outp[o + k] = hh[k]; outp[plane + o + k] = mm[k]; outp[2 * plane + o + k] = ll[k]; }
+                for (int k = 0; k < CPT; ++k) { outp[o + k] = hh[k]; outp[plane + o + k] = ll[k]; }
             }
         }
     }
     if (!APPLY) {
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            part[(((int64_t)chunk * slabs + sl) * 2 + 0) * C + ch[k]] = s[k];
-            part[(((int64_t)chunk * slabs + sl) * 2 + 1) * C + ch[k]] = q[k];
+            part[(((int64_t)chunk * slabs + sl) * 3 + 0) * C + ch[k]] = s[k];
+            part[(((int64_t)chunk * slabs + sl) * 3 + 1) * C + ch[k]] = q[k];
+            part[(((int64_t)chunk * slabs + sl) * 3 + 2) * C + ch[k]] = mx[k];
         }
     }
 }
 
+// GroupNorm coefficients per (window, channel) and the window's bound: |GELU(a y + b)| <= |a| max|y| + |b|
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ g,
                                                           const float* __restrict__ be, float* __restrict__ ab,
-                                                          int n, int C, int slabs, int T0) {
+                                                          unsigned* __restrict__ amax, int n, int C, int slabs, int T0) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)n * C) return;
     const int chunk = (int)(i / C), c = (int)(i % C);
     double s = 0.0, q = 0.0;
+    float mx = 0.f;
     for (int sl = 0; sl < slabs; ++sl) {
-        s += (double)part[(((int64_t)chunk * slabs + sl) * 2 + 0) * C + c];
-        q += (double)part[(((int64_t)chunk * slabs + sl) * 2 + 1) * C + c];
+        s += (double)part[(((int64_t)chunk * slabs + sl) * 3 + 0) * C + c];
+        q += (double)part[(((int64_t)chunk * slabs + sl) * 3 + 1) * C + c];
+        mx = fmaxf(mx, part[(((int64_t)chunk * slabs + sl) * 3 + 2) * C + c]);
     }
     const double mean = s / T0;
     double var = q / T0 - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + 1e-5);
     const double a = (double)g[c] * rstd;
-    ab[((int64_t)chunk * 2 + 0) * C + c] = (float)a;
-    ab[((int64_t)chunk * 2 + 1) * C + c] = (float)((double)be[c] - mean * a);
+    const float af = (float)a, bf = (float)((double)be[c] - mean * a);
+    ab[((int64_t)chunk * 2 + 0) * C + c] = af;
+    ab[((int64_t)chunk * 2 + 1) * C + c] = bf;
+    atomicMax(amax + chunk, __float_as_uint((fabsf(af) * mx + fabsf(bf)) * 1.000001f));
 }
 
 // ---- LayerNorm over the last dim (optionally of x + r), one wave per row, D <= 1024 -----------------
+// Optional outputs for the GEMM that reads the result: the row as two fp16 planes times the power of two that puts the
+// row's largest magnitude into [2^14, 2^15) (scale_out[row]: exact, the wave holds the whole row), and the scale the NEXT
+// GEMM's plane output may use for this row (bound_scale_out): |GELU(y W^T + b)| <= |y|_2 max_n |w_n|_2 + max |b|.
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         float* __restrict__ out, int64_t rows, int D, float eps,
                                                         const int64_t* __restrict__ out_row_start, int T,
-                                                        unsigned short* __restrict__ planes, int64_t plane, int panel) {
-    // panel != 0: the planes go out in the k16-panel layout of `rows` rows (gemm_bf16x6.h), staged through LDS so that the
+                                                        unsigned short* __restrict__ planes, int64_t plane, int panel,
+                                                        float* __restrict__ scale_out, const unsigned* __restrict__ bound_w,
+                                                        const unsigned* __restrict__ bound_b, float* __restrict__ bound_scale_out) {
+    // panel != 0: the planes go out in the k16-panel layout of `rows` rows (gemm_f16x3.h), staged through LDS so that the
     // four rows of the workgroup leave as full 128-byte lines per panel (scattering 8-byte pieces from the row layout cost
     // this kernel + 77 %)
-    __shared__ __attribute__((aligned(16))) unsigned short stg[3][4][1024];
+    __shared__ __attribute__((aligned(16))) unsigned short stg[2][4][1024];
     const int64_t row_raw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool valid = row_raw < rows;
     if (!valid && !(planes && panel)) return;
@@ -307,6 +340,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float4* o4 = out ? reinterpret_cast<float4*>(out + orow * D) : nullptr;
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const float4* b4 = reinterpret_cast<const float4*>(b);
+    float mx = 0.f, n2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = lane + 64 * i;
@@ -315,44 +349,53 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float4 y = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
                                          (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
             if (o4 && valid) o4[idx] = y;
-            if (planes) {                                  // the same values as three bf16 planes (A operand of the next GEMM)
-                const float yy[4] = {y.x, y.y, y.z, y.w};
-                unsigned short hh[4], mm[4], ll[4];
+            v[i] = y;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))));
+            n2 += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+        }
+    }
+    if (!planes) return;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    hh[k] = bf16_bits_w(yy[k]);
-                    const float r1 = yy[k] - bf16_to_f32_w(hh[k]);
-                    mm[k] = bf16_bits_w(r1);
-                    ll[k] = bf16_bits_w(r1 - bf16_to_f32_w(mm[k]));
-                }
-                const uint2 ph = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-                const uint2 pm = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
-                const uint2 pl = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
-                if (panel) {
-                    const int wq = threadIdx.x >> 6;
-                    *reinterpret_cast<uint2*>(&stg[0][wq][4 * idx]) = ph;
-                    *reinterpret_cast<uint2*>(&stg[1][wq][4 * idx]) = pm;
-                    *reinterpret_cast<uint2*>(&stg[2][wq][4 * idx]) = pl;
-                } else {
-                    unsigned short* pp = planes + row * D + 4 * idx;
-                    *reinterpret_cast<uint2*>(pp) = ph;
-                    *reinterpret_cast<uint2*>(pp + plane) = pm;
-                    *reinterpret_cast<uint2*>(pp + 2 * plane) = pl;
-                }
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float sc = f16x2_scale_for_bound(mx);
+    if (valid && lane == 0) scale_out[row] = sc;
+    if (bound_scale_out) {
+        const float nrm = sqrtf(wave_sum(n2)) * 1.000001f;
+        const float bound = nrm * __uint_as_float(bound_w[0]) * 1.000001f + (bound_b ? __uint_as_float(bound_b[1]) : 0.0f);
+        if (valid && lane == 0) bound_scale_out[row] = f16x2_scale_for_bound(bound);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < D4) {                                    // the same values as two fp16 planes (A operand of the next GEMM)
+            const float yy[4] = {v[i].x * sc, v[i].y * sc, v[i].z * sc, v[i].w * sc};
+            unsigned short hh[4], ll[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) split2_w(yy[k], hh[k], ll[k]);
+            const uint2 ph = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+            const uint2 pl = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+            if (panel) {
+                const int wq = threadIdx.x >> 6;
+                *reinterpret_cast<uint2*>(&stg[0][wq][4 * idx]) = ph;
+                *reinterpret_cast<uint2*>(&stg[1][wq][4 * idx]) = pl;
+            } else if (valid) {
+                unsigned short* pp = planes + row * D + 4 * idx;
+                *reinterpret_cast<uint2*>(pp) = ph;
+                *reinterpret_cast<uint2*>(pp + plane) = pl;
             }
         }
     }
-    if (planes && panel) {
+    if (panel) {
         __syncthreads();
         const int64_t row0 = (int64_t)blockIdx.x * 4;
         const int chunks = D >> 1;                          // 16-byte pieces per plane: D / 16 panels x 4 rows x 2 halves
         for (int c = threadIdx.x; c < chunks; c += 256) {
-            const int pn = c >> 3, r4 = (c & 7) >> 1, hf = c & 1;
-            if (row0 + r4 < rows) {
+            const int pn = c >> 3, rr = (c & 7) >> 1, hf = c & 1;
+            if (row0 + rr < rows) {
 #pragma unroll
-                for (int p3 = 0; p3 < 3; ++p3)
-                    *reinterpret_cast<uint4*>(planes + p3 * plane + (int64_t)pn * (rows * 16) + (row0 + r4) * 16 + 8 * hf) =
-                        *reinterpret_cast<const uint4*>(&stg[p3][r4][16 * pn + 8 * hf]);
+                for (int p2 = 0; p2 < 2; ++p2)
+                    *reinterpret_cast<uint4*>(planes + p2 * plane + (int64_t)pn * (rows * 16) + (row0 + rr) * 16 + 8 * hf) =
+                        *reinterpret_cast<const uint4*>(&stg[p2][rr][16 * pn + 8 * hf]);
             }
         }
     }
@@ -376,7 +419,8 @@ typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 typedef const __attribute__((address_space(1))) void* attn_glb_ptr;
 
 __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ planes,
-                                                            int64_t plane_stride, int64_t n_rows, int T, int NH, int Hd, float scale) {
+                                                            int64_t plane_stride, int64_t n_rows, int T, int NH, int Hd, float scale,
+                                                            const unsigned* __restrict__ v_amax, float* __restrict__ row_scale) {
     constexpr int HD = 64, KB = 128, TILE = KB * HD;                            // one staged block: 32 KB
     extern __shared__ __attribute__((aligned(1024))) float kvbuf[];             // two blocks
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -503,10 +547,12 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
         }
     }
     // C layout: column = lane & 31 (d), row = (e & 3) + 8 (e >> 2) + 4 h (query within the wave's 32).  The output only
-    // exists as the three bf16 planes the out-projection GEMM reads (no fp32 copy, no separate split pass).  Stored from
-    // the MFMA layout with 2-byte stores (32 lanes = 64 contiguous bytes of a row and plane): the kernel sits at its
-    // 256-register budget, and a transposing epilogue through LDS (16-byte stores) pushed two score tiles into scratch.
-    // k16 panels of n_rows rows (gemm_bf16x6.h): column head * 64 + 32 u + l31 -> panel 4 head + 2 u + (l31 >> 4), k = l31 & 15
+    // exists as the two fp16 planes the out-projection GEMM reads (no fp32 copy, no separate split pass), scaled by the
+    // window's power of two: an attention output is a convex combination of the window's value rows, so max |V| of the
+    // window (reported by the q/k/v projection's epilogue) bounds it.  Stored from the MFMA layout with 2-byte stores
+    // (32 lanes = 64 contiguous bytes of a row and plane): the kernel sits at its 256-register budget.
+    // k16 panels of n_rows rows (gemm_f16x3.h): column head * 64 + 32 u + l31 -> panel 4 head + 2 u + (l31 >> 4), k = l31 & 15
+    const float osc = f16x2_scale_for_bound(__uint_as_float(v_amax[win]) * 1.00001f);
     const int64_t panel_sz = n_rows * 16;
     unsigned short* op = planes + ((int64_t)(head * 4) + (l31 >> 4)) * panel_sz + ((int64_t)win * T) * 16 + (l31 & 15);
 #pragma unroll
@@ -514,16 +560,14 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
         const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (q < T) {
             unsigned short* d0 = op + (int64_t)q * 16;
+            if (head == 0 && l31 == 0) row_scale[(int64_t)win * T + q] = osc;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float x = u == 0 ? o0[e] : o1[e];
-                const unsigned short a2 = bf16_bits_w(x);
-                const float r1 = x - bf16_to_f32_w(a2);
-                const unsigned short b2 = bf16_bits_w(r1);
-                const unsigned short c2 = bf16_bits_w(r1 - bf16_to_f32_w(b2));
+                const float x = (u == 0 ? o0[e] : o1[e]) * osc;
+                unsigned short a2, b2;
+                split2_w(x, a2, b2);
                 d0[2 * u * panel_sz] = a2;
                 d0[plane_stride + 2 * u * panel_sz] = b2;
-                d0[2 * plane_stride + 2 * u * panel_sz] = c2;
             }
         }
     }
@@ -583,9 +627,11 @@ __global__ __launch_bounds__(256) void regroup_kernel(const float4* __restrict__
     }
 }
 
-// the same regrouping as three bf16 planes (A operand of the positional convolution on the bf16x6 GEMM)
+// the same regrouping as two fp16 planes (A operand of the positional convolution on the f16x3 GEMM), scaled per window by
+// the power of two that the window's largest |x| (reported by the feature projection's epilogue) asks for
 __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __restrict__ x, unsigned short* __restrict__ xg,
-                                                             int64_t plane, int n, int T, int Hd4, int G, int K) {
+                                                             int64_t plane, int n, int T, int Hd4, int G, int K,
+                                                             const unsigned* __restrict__ amax, float* __restrict__ win_scale) {
     const int cg4 = Hd4 / G;
     const int TT = T + K - 1;
     const int64_t total = (int64_t)n * G * TT * cg4;
@@ -596,48 +642,46 @@ __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __res
         const int g = (int)(r % G);
         const int64_t chunk = r / G;
         const int t = tt - K / 2;
+        const float sc = f16x2_scale_for_bound(__uint_as_float(amax[chunk]));
+        if (g == 0 && tt == 0 && ci == 0) win_scale[chunk] = sc;
         const float4 v = (t >= 0 && t < T) ? x[(chunk * T + t) * Hd4 + g * cg4 + ci] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        unsigned short hh[4], mm[4], ll[4];
+        const float vv[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+        unsigned short hh[4], ll[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            hh[k] = bf16_bits_w(vv[k]);
-            const float r1 = vv[k] - bf16_to_f32_w(hh[k]);
-            mm[k] = bf16_bits_w(r1);
-            ll[k] = bf16_bits_w(r1 - bf16_to_f32_w(mm[k]));
-        }
+        for (int k = 0; k < 4; ++k) split2_w(vv[k], hh[k], ll[k]);
         unsigned short* pp = xg + 4 * i;
         *reinterpret_cast<uint2*>(pp) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-        *reinterpret_cast<uint2*>(pp + plane) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
-        *reinterpret_cast<uint2*>(pp + 2 * plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+        *reinterpret_cast<uint2*>(pp + plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
     }
 }
 
 static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
               float eps, hipStream_t s, const int64_t* out_row_start = nullptr, int T = 1,
-              unsigned short* planes = nullptr, bool panel = false) {
+              unsigned short* planes = nullptr, bool panel = false, float* scale_out = nullptr,
+              const unsigned* bound_w = nullptr, const unsigned* bound_b = nullptr, float* bound_scale_out = nullptr) {
     const int64_t blocks = (rows + 3) / 4;
     RSAF_CHECK_ARG(blocks <= 0x7fffffffLL, "too many rows");
-    ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * (4 * (r ? 2 : 1) + (out ? 4 : 0) + (planes ? 6 : 0)));
+    RSAF_CHECK_ARG(!planes || scale_out, "planes need their scale array");
+    ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * (4 * (r ? 2 : 1) + (out ? 4 : 0) + (planes ? 4 : 0)));
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, r, g, b, out, rows, D, eps,
-                       out_row_start, T, planes, rows * D, panel ? 1 : 0);
+                       out_row_start, T, planes, rows * D, panel ? 1 : 0, scale_out, bound_w, bound_b, bound_scale_out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }
 
 template <bool APPLY>
-static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* part, const float* ab,
+static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* part, const float* ab, const float* scale,
                         unsigned short* outp, int64_t plane, int n, int len, int T0, int slab, int slabs, hipStream_t s) {
     const int threads = c.C <= 256 ? c.C : 256;
     const int cpt = c.C / threads;
     dim3 grid((unsigned)slabs, (unsigned)n);
-    // HBM-bound: the apply pass writes C channels x T0 frames per window as three bf16 planes (6 B per element: 49 MB per
+    // HBM-bound: the apply pass writes C channels x T0 frames per window as two fp16 planes (4 B per element: 33 MB per
     // 5 s window at C = 512) and reads the window once; the statistics pass only reads the window (both recompute the
     // 10-tap convolution: Cin = 1, 0.16 GFLOP per window)
     ProfScope prof(APPLY ? "w2v2_conv0_apply" : "w2v2_conv0_stats", s, 0.0,
-                   APPLY ? (double)n * ((double)c.C * T0 * 6.0 + 4.0 * (5.0 * T0 + 5.0)) : (double)n * 4.0 * (5.0 * T0 + 5.0));
+                   APPLY ? (double)n * ((double)c.C * T0 * 4.0 + 4.0 * (5.0 * T0 + 5.0)) : (double)n * 4.0 * (5.0 * T0 + 5.0));
 #define RSAF_C0(CPT)                                                                                       \
-    hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, outp, plane, len, T0, \
+    hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, scale, outp, plane, len, T0, \
                        c.C, slab, slabs)
     switch (cpt) {
         case 1: RSAF_C0(1); break;
@@ -726,113 +770,142 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     RSAF_CHECK_ARG(rows <= 0x7fffffffLL, "too many frames per call");
 
     auto planes_at = [&](int64_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
-    // helper: C = act(A B^T + bias (+ R)) on the bf16x6 kernel; A / B as planes
-    auto gemm6 = [&](const uint16_t* A, int64_t a_plane, int64_t lda, int64_t sA, const uint16_t* B, int M, int N, int K,
-                     float* Cf, int64_t sC, uint16_t* Cp, int64_t c_plane, int64_t sCp, const float* bias, const float* R,
-                     int nz, int act, const char* tag, bool a_panel = false, bool b_panel = false, bool cp_panel = false) {
-        Gemm6Params p{};
-        p.a_panel = a_panel; p.b_panel = b_panel; p.cp_panel = cp_panel;
-        p.A = A; p.a_plane = a_plane; p.lda = lda; p.sA = sA;
-        p.B = B; p.b_plane = (int64_t)N * K; p.ldb = K;
-        p.C = Cf; p.ldc = N; p.sC = sC;
-        p.Cp = Cp; p.c_plane = c_plane; p.ldcp = N; p.sCp = sCp;
-        p.bias = bias; p.R = R; p.ldr = N; p.sR = sC;
+    auto bits_at = [&](int64_t off) { return reinterpret_cast<unsigned*>(ws + off); };
+    auto wstat = [&](int idx) { return bits_at(W.wstat) + 2 * idx; };        // {max row norm, max |element|} of matrix idx
+    // helper: C = act(A B^T + bias (+ R)) on the f16x3 kernel; A / B as fp16 plane pairs with their scales
+    struct Out { float* Cf; int64_t sC; uint16_t* Cp; int64_t c_plane, sCp; const float* c_scale; int cs_zs, cs_ms; bool cp_panel; };
+    auto gemm3 = [&](const uint16_t* A, int64_t a_plane, int64_t lda, int64_t sA, const float* a_scale, int as_zs, int as_ms,
+                     const uint16_t* B, const float* b_scale, int M, int N, int K, const Out& o, const float* bias, const float* R,
+                     int nz, int act, const char* tag, bool a_panel, unsigned* amax = nullptr, int amax_zs = 0, int amax_div = 0,
+                     int amax_col_min = 0) {
+        GemmH3Params p{};
+        p.a_panel = a_panel; p.b_panel = 1; p.cp_panel = o.cp_panel;
+        p.A = A; p.a_plane = a_plane; p.lda = lda; p.sA = sA; p.a_scale = a_scale; p.a_scale_zs = as_zs; p.a_scale_ms = as_ms;
+        p.B = B; p.b_plane = (int64_t)N * K; p.ldb = 16; p.b_scale = b_scale;
+        p.C = o.Cf; p.ldc = N; p.sC = o.sC;
+        p.Cp = o.Cp; p.c_plane = o.c_plane; p.ldcp = N; p.sCp = o.sCp; p.c_scale = o.c_scale; p.c_scale_zs = o.cs_zs; p.c_scale_ms = o.cs_ms;
+        p.amax_out = amax; p.amax_zs = amax_zs; p.amax_div = amax_div; p.amax_col_min = amax_col_min;
+        p.bias = bias; p.R = R; p.ldr = N; p.sR = o.sC;
         p.M = M; p.N = N; p.K = K; p.nz = nz; p.act = act; p.alpha = 1.0f; p.group_m = 0;
-        return launch_gemm_bf16x6(p, s, tag);
+        return launch_gemm_f16x3(p, s, tag);
     };
-    // 0. weights of the dense layers as bf16 planes (once per call: 0.6 GB at base geometry, < 1 ms)
+    // 0. weights of the dense layers as fp16 plane pairs in the k16-panel layout, each row with its own power-of-two scale
+    //    (once per call: 0.4 GB at base geometry, < 1 ms), and per matrix the largest row norm: the Cauchy-Schwarz factor of
+    //    the bound behind the scale of a GEMM's PLANE output (conv1..5, ffn1)
+    RSAF_CHECK_HIP(hipMemsetAsync(ws + W.wstat, 0, sizeof(float) * 2 * (WSTAT_LAYER0 + 5 * c.L), s));
     {
-        // Every GEMM weight and every encoder activation that feeds a GEMM travel in the k16-panel layout
-        // (gemm_bf16x6.h): the ffn1 epilogue and the fused attention kernel address panels directly, LayerNorm stages
-        // its four rows through LDS so that they leave as full lines (scattering 8-byte pieces cost it + 77 %).  Only
-        // the conv activations stay row-major (strided im2col windows).
-        auto split_wp = [&](int64_t src_off, int64_t nrows, int K, int64_t dst_off) {
-            return launch_split_bf16x3_panels(Wt + src_off, nrows, K, planes_at(dst_off), nrows * K, s);
+        auto split_wp = [&](int64_t src_off, int64_t nrows, int K, int64_t dst_off, int64_t scale_off, int stat_idx) {
+            int r2 = launch_f16x2_row_scales(Wt + src_off, nrows, K, K, ws + scale_off, nullptr, wstat(stat_idx), s);
+            if (r2) return r2;
+            return launch_split_f16x2(Wt + src_off, nrows, K, K, ws + scale_off, 1, planes_at(dst_off), nrows * K, 1, s);
         };
         for (int i = 0; i < 6; ++i)
-            if ((rc = split_wp(L.conv[i], C, KERN[i + 1] * C, W.wp_conv[i]))) return rc;
-        if ((rc = split_wp(L.fpw, Hd, C, W.wp_fp))) return rc;
-        if ((Hd / c.PG) % 16 == 0) {                       // positional conv on the bf16x6 GEMM: [G cg][PK cg] as panels of Hd rows
-            if ((rc = split_wp(L.posw, Hd, c.PK * (Hd / c.PG), W.wp_pos))) return rc;
+            if ((rc = split_wp(L.conv[i], C, KERN[i + 1] * C, W.wp_conv[i], W.ws_conv[i], wstat_conv(i)))) return rc;
+        if ((rc = split_wp(L.fpw, Hd, C, W.wp_fp, W.ws_fp, WSTAT_FP))) return rc;
+        if ((Hd / c.PG) % 16 == 0) {                       // positional conv on the f16x3 GEMM: [G cg][PK cg] as panels of Hd rows
+            if ((rc = split_wp(L.posw, Hd, c.PK * (Hd / c.PG), W.wp_pos, W.ws_pos, WSTAT_POS))) return rc;
         }
         for (int l = 0; l < c.L; ++l) {
             const LayerOff& lo = L.layers[l];
-            if ((rc = split_wp(lo.wqkv, 3 * Hd, Hd, W.wp_qkv[l]))) return rc;
-            if ((rc = split_wp(lo.wo, Hd, Hd, W.wp_o[l]))) return rc;
-            if ((rc = split_wp(lo.w1, c.I, Hd, W.wp_1[l]))) return rc;
-            if ((rc = split_wp(lo.w2, Hd, c.I, W.wp_2[l]))) return rc;
+            const int b0 = WSTAT_LAYER0 + 5 * l;
+            if ((rc = split_wp(lo.wqkv, 3 * Hd, Hd, W.wp_qkv[l], W.ws_qkv[l], b0))) return rc;
+            if ((rc = split_wp(lo.wo, Hd, Hd, W.wp_o[l], W.ws_o[l], b0 + 1))) return rc;
+            if ((rc = split_wp(lo.w1, c.I, Hd, W.wp_1[l], W.ws_1[l], b0 + 2))) return rc;
+            if ((rc = split_wp(lo.w2, Hd, c.I, W.wp_2[l], W.ws_2[l], b0 + 3))) return rc;
+            // max |b1| (word 1 of the statistics of the bias seen as one row); the scale it writes goes to a scratch slot
+            if ((rc = launch_f16x2_row_scales(Wt + lo.b1, 1, c.I, c.I, ws + W.s_att, nullptr, wstat(b0 + 4), s))) return rc;
         }
     }
     // 1-3. feature encoder, CONV_GROUP windows at a time (its activations are the large ones: 15 999 x 512 per window)
     // window groups of (almost) equal size: ceil(n / G) groups instead of full ones and a small remainder
     const int n_groups = (n + W.G - 1) / W.G, gstep = (n + n_groups - 1) / n_groups;
+    float* cscale = ws + W.conv_scale;                       // [7][G]: scale of layer i's plane output, per window of the group
+    unsigned* camax = bits_at(W.conv_amax);                  // [7][G]: largest |output| of layer i (layer 0: its bound)
     for (int g0 = 0; g0 < n; g0 += gstep) {
         const int g = std::min(gstep, n - g0);
+        RSAF_CHECK_HIP(hipMemsetAsync(camax, 0, sizeof(unsigned) * 7 * W.G, s));
         // 1. per-chunk normalisation (HF feature extractor)
         {
             ProfScope prof("w2v2_normalize", s, 0.0, (double)g * chunk_len * 4 * 3);
             hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(256), 0, s, wav, chunk_start + g0, chunk_len, ws + W.xn);
             RSAF_CHECK_HIP(hipGetLastError());
         }
-        // 2. conv0 + GroupNorm + GELU (stats pass, finalize, apply pass); the apply pass writes bf16 planes
-        rc = conv0_launch<false>(c, ws + W.xn, Wt + L.conv0, ws + W.part, nullptr, nullptr, 0, g, chunk_len, T[0],
+        // 2. conv0 + GroupNorm + GELU (stats pass, finalize, apply pass); the apply pass writes fp16 plane pairs
+        rc = conv0_launch<false>(c, ws + W.xn, Wt + L.conv0, ws + W.part, nullptr, nullptr, nullptr, 0, g, chunk_len, T[0],
                                  STAT_SLAB, W.slabs, s);
         if (rc) return rc;
         {
             const int64_t tot = (int64_t)g * C;
             hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ws + W.part,
-                               Wt + L.gng, Wt + L.gnb, ws + W.ab, g, C, W.slabs, T[0]);
+                               Wt + L.gng, Wt + L.gnb, ws + W.ab, camax, g, C, W.slabs, T[0]);
             RSAF_CHECK_HIP(hipGetLastError());
+            if ((rc = launch_scale_from_bound(camax, g, nullptr, 1.0f, nullptr, cscale, s))) return rc;
         }
         {
             const int slab = 128;
-            rc = conv0_launch<true>(c, ws + W.xn, Wt + L.conv0, nullptr, ws + W.ab, planes_at(W.P), (int64_t)g * T[0] * C, g,
+            rc = conv0_launch<true>(c, ws + W.xn, Wt + L.conv0, nullptr, ws + W.ab, cscale, planes_at(W.P), (int64_t)g * T[0] * C, g,
                                     chunk_len, T[0], slab, (T[0] + slab - 1) / slab, s);
             if (rc) return rc;
         }
         // 3. conv1..6 as GEMMs over the channels-last sequence (lda = stride * C, K = taps * C) with fused GELU;
-        //    the output goes out as planes (the next layer's A), the last one as fp32 rows for the LayerNorm
+        //    the output goes out as planes (the next layer's A), the last one as fp32 rows for the LayerNorm.
+        //    Scale of layer i's output, per window: |GELU(x)| <= |x| <= |a|_2 |w|_2 <= sqrt(K) max|a| max_n |w_n|_2 with
+        //    max|a| = the largest |output| of layer i - 1, which that layer's epilogue reported (layer 0: the GroupNorm bound)
         uint16_t* cur = planes_at(W.P);
         uint16_t* nxt = planes_at(W.Q);
         for (int i = 1; i < 7; ++i) {
             const bool last = i == 6;
-            rc = gemm6(cur, (int64_t)g * T[i - 1] * C, (int64_t)STRD[i] * C, (int64_t)T[i - 1] * C, planes_at(W.wp_conv[i - 1]),
-                       T[i], C, KERN[i] * C, last ? ws + W.c6 + (int64_t)g0 * Tt * C : nullptr, (int64_t)T[i] * C,
-                       last ? nullptr : nxt, (int64_t)g * T[i] * C, (int64_t)T[i] * C, nullptr, nullptr, g, ACT_GELU, "w2v2_gemm",
-                       false, true);
+            const int K = KERN[i] * C;
+            Out o{};
+            if (last) { o.Cf = ws + W.c6 + (int64_t)g0 * Tt * C; o.sC = (int64_t)T[i] * C; }
+            else {
+                if ((rc = launch_scale_from_bound(camax + (int64_t)(i - 1) * W.G, g, reinterpret_cast<const float*>(wstat(wstat_conv(i - 1))),
+                                                  sqrtf((float)K) * 1.00001f, nullptr, cscale + (int64_t)i * W.G, s))) return rc;
+                o.Cp = nxt; o.c_plane = (int64_t)g * T[i] * C; o.sCp = (int64_t)T[i] * C; o.sC = (int64_t)T[i] * C;
+                o.c_scale = cscale + (int64_t)i * W.G; o.cs_zs = 1; o.cs_ms = 0;
+            }
+            rc = gemm3(cur, (int64_t)g * T[i - 1] * C, (int64_t)STRD[i] * C, (int64_t)T[i - 1] * C, cscale + (int64_t)(i - 1) * W.G, 1, 0,
+                       planes_at(W.wp_conv[i - 1]), ws + W.ws_conv[i - 1], T[i], C, K, o, nullptr, nullptr, g, ACT_GELU, "w2v2_gemm",
+                       false, last ? nullptr : camax + (int64_t)i * W.G, 1, 0);
             if (rc) return rc;
             std::swap(cur, nxt);
         }
     }
-    // 4. feature projection: LayerNorm (-> planes) + Linear
-    rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, 1, planes_at(W.lnfp), true);
+    // 4. feature projection: LayerNorm (-> planes, exact row scales) + Linear; its epilogue reports max |x| per window
+    RSAF_CHECK_HIP(hipMemsetAsync(ws + W.fp_amax, 0, sizeof(unsigned) * n, s));
+    rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, 1, planes_at(W.lnfp), true, ws + W.s_lnfp);
     if (rc) return rc;
-    rc = gemm6(planes_at(W.lnfp), rows * C, C, 0, planes_at(W.wp_fp), (int)rows, Hd, C, ws + W.x, 0, nullptr, 0, 0,
-               Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", true, true);
-    if (rc) return rc;
+    {
+        Out o{}; o.Cf = ws + W.x;
+        rc = gemm3(planes_at(W.lnfp), rows * C, C, 0, ws + W.s_lnfp, 0, 1, planes_at(W.wp_fp), ws + W.ws_fp, (int)rows, Hd, C, o,
+                   Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", true, bits_at(W.fp_amax), 0, Tt);
+        if (rc) return rc;
+    }
     // 5. positional conv embedding (grouped, weight norm folded), GELU, x = LN(x + pos)
     {
         const int cg = Hd / c.PG;
         const int TT = Tt + c.PK - 1;
         const int64_t tot4 = (int64_t)n * TT * (Hd / 4);
         if (cg % 16 == 0) {
-            // grouped conv as a two-level batched GEMM on the bf16x6 kernel's 256 x 64 tile: batch (window, group), M = T rows
+            // grouped conv as a two-level batched GEMM on the f16x3 kernel's 256 x 64 tile: batch (window, group), M = T rows
             // (overlapping windows of the regrouped sequence: lda = cg), N = cg output channels, K = PK cg
             const int64_t plane = (int64_t)n * TT * Hd;
             {
-                ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 40);
+                ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 32);
                 hipLaunchKernelGGL(regroup_planes_kernel, dim3((unsigned)std::min<int64_t>((tot4 + 255) / 256, 4096)), dim3(256),
                                    0, s, reinterpret_cast<const float4*>(ws + W.x), reinterpret_cast<unsigned short*>(planes_at(W.xg)),
-                                   plane, n, Tt, Hd / 4, c.PG, c.PK);
+                                   plane, n, Tt, Hd / 4, c.PG, c.PK, bits_at(W.fp_amax), ws + W.pos_scale);
                 RSAF_CHECK_HIP(hipGetLastError());
             }
-            Gemm6Params p{};
+            GemmH3Params p{};
             p.A = planes_at(W.xg); p.a_plane = plane; p.lda = cg; p.sA = (int64_t)c.PG * TT * cg; p.sA2 = (int64_t)TT * cg;
+            p.a_scale = ws + W.pos_scale; p.a_scale_zs = 1; p.a_scale_ms = 0;
             p.B = planes_at(W.wp_pos); p.b_plane = (int64_t)Hd * c.PK * cg; p.ldb = 16; p.b_panel = 1; p.b_panel_rows = Hd; p.sB2 = (int64_t)cg * 16;
+            p.b_scale = ws + W.ws_pos;
             p.C = ws + W.y; p.ldc = Hd; p.sC = (int64_t)Tt * Hd; p.sC2 = cg;
             p.bias = Wt + L.posb; p.sBias2 = cg;
             p.M = Tt; p.N = cg; p.K = c.PK * cg; p.nz = n * c.PG; p.nz2 = c.PG; p.act = ACT_GELU; p.alpha = 1.0f;
-            rc = launch_gemm_bf16x6(p, s, "w2v2_posconv_gemm");
+            rc = launch_gemm_f16x3(p, s, "w2v2_posconv_gemm");
             if (rc) return rc;
         } else {
         {
@@ -851,7 +924,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         rc = launch_gemm_f32(p, s, "w2v2_posconv_gemm");
         if (rc) return rc;
         }
-        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true);
+        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true, ws + W.s_x);
         if (rc) return rc;
     }
     // 6. encoder layers (post-LN)
@@ -860,21 +933,25 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     float* x = ws + W.x;
     for (int l = 0; l < c.L; ++l) {
         const LayerOff& lo = L.layers[l];
-        // fused q,k,v projection (A = the planes the previous LayerNorm wrote beside x)
-        rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_qkv[l]), (int)rows, 3 * Hd, Hd, ws + W.qkv, 0, nullptr, 0, 0,
-                   Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true, true);
-        if (rc) return rc;
+        const int b0 = WSTAT_LAYER0 + 5 * l;
         static const bool fused_attn = [] { const char* e = getenv("RSAF_W2V2_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
-        if (fused_attn && hd == 64 && Tt <= 256) {
+        const bool fused = fused_attn && hd == 64 && Tt <= 256;
+        // fused q,k,v projection (A = the planes the previous LayerNorm wrote beside x); its epilogue reports max |V| per window
+        RSAF_CHECK_HIP(hipMemsetAsync(ws + W.v_amax, 0, sizeof(unsigned) * n, s));
+        {
+            Out o{}; o.Cf = ws + W.qkv;
+            rc = gemm3(planes_at(W.xp), rows * Hd, Hd, 0, ws + W.s_x, 0, 1, planes_at(W.wp_qkv[l]), ws + W.ws_qkv[l], (int)rows, 3 * Hd, Hd, o,
+                       Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true, fused ? bits_at(W.v_amax) : nullptr, 0, Tt, 2 * Hd);
+            if (rc) return rc;
+        }
+        if (fused) {
             // 2 x 2 T^2 hd flops per (chunk, head)
             ProfScope prof("w2v2_attn_fused", s, 4.0 * (double)n * c.NH * (double)Tt * Tt * hd, 0.0);
-            static DeviceOnce attn_once;
-            if (attn_once.first()) {
-                RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   2 * 128 * 64 * (int)sizeof(float)));
-            }
+            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               2 * 128 * 64 * (int)sizeof(float)));
             hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256),
-                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, rows, Tt, c.NH, Hd, scale);
+                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, rows, Tt, c.NH, Hd, scale,
+                               bits_at(W.v_amax), ws + W.s_att);
             RSAF_CHECK_HIP(hipGetLastError());
         } else {
         {   // S = scale * Q K^T per (chunk, head)
@@ -906,27 +983,32 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
             // (the fused kernel writes the planes itself)
-            rc = launch_split_bf16x3_panels(ws + W.att, rows, Hd, planes_at(W.attp), rows * Hd, s);
+            if ((rc = launch_f16x2_row_scales(ws + W.att, rows, Hd, Hd, ws + W.s_att, nullptr, nullptr, s))) return rc;
+            rc = launch_split_f16x2(ws + W.att, rows, Hd, Hd, ws + W.s_att, 1, planes_at(W.attp), rows * Hd, 1, s);
             if (rc) return rc;
         }
         }
-        {   // y = attn Wo^T + bo + x ; x = LN(y)
-            rc = gemm6(planes_at(W.attp), rows * Hd, Hd, 0, planes_at(W.wp_o[l]), (int)rows, Hd, Hd, ws + W.y, 0, nullptr, 0, 0,
-                       Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", true, true);
+        {   // y = attn Wo^T + bo + x ; x = LN(y), with the bound behind the scale of the ffn1 output
+            Out o{}; o.Cf = ws + W.y;
+            rc = gemm3(planes_at(W.attp), rows * Hd, Hd, 0, ws + W.s_att, 0, 1, planes_at(W.wp_o[l]), ws + W.ws_o[l], (int)rows, Hd, Hd, o,
+                       Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", true);
             if (rc) return rc;
-            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true);
+            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true, ws + W.s_x,
+                    wstat(b0 + 2), wstat(b0 + 4), ws + W.s_ffn);
             if (rc) return rc;
         }
         {   // feed forward: the GELU output only exists as planes (A of the second GEMM)
-            rc = gemm6(planes_at(W.xp), rows * Hd, Hd, 0, planes_at(W.wp_1[l]), (int)rows, c.I, Hd, nullptr, 0,
-                       planes_at(W.ffnp), rows * c.I, 0, Wt + lo.b1, nullptr, 1, ACT_GELU, "w2v2_gemm", true, true, true);
+            Out o1{}; o1.Cp = planes_at(W.ffnp); o1.c_plane = rows * c.I; o1.c_scale = ws + W.s_ffn; o1.cs_zs = 0; o1.cs_ms = 1; o1.cp_panel = true;
+            rc = gemm3(planes_at(W.xp), rows * Hd, Hd, 0, ws + W.s_x, 0, 1, planes_at(W.wp_1[l]), ws + W.ws_1[l], (int)rows, c.I, Hd, o1,
+                       Wt + lo.b1, nullptr, 1, ACT_GELU, "w2v2_gemm", true);
             if (rc) return rc;
-            rc = gemm6(planes_at(W.ffnp), rows * c.I, c.I, 0, planes_at(W.wp_2[l]), (int)rows, Hd, c.I, ws + W.y, 0, nullptr, 0, 0,
-                       Wt + lo.b2, x, 1, ACT_NONE, "w2v2_gemm", true, true);
+            Out o2{}; o2.Cf = ws + W.y;
+            rc = gemm3(planes_at(W.ffnp), rows * c.I, c.I, 0, ws + W.s_ffn, 0, 1, planes_at(W.wp_2[l]), ws + W.ws_2[l], (int)rows, Hd, c.I, o2,
+                       Wt + lo.b2, x, 1, ACT_NONE, "w2v2_gemm", true);
             if (rc) return rc;
             const bool last = (l == c.L - 1);
             rc = ln(ws + W.y, nullptr, Wt + lo.ln2g, Wt + lo.ln2b, last ? out : x, rows, Hd, c.eps, s,
-                    last ? out_row_start : nullptr, Tt, last ? nullptr : planes_at(W.xp), true);
+                    last ? out_row_start : nullptr, Tt, last ? nullptr : planes_at(W.xp), true, ws + W.s_x);
             if (rc) return rc;
         }
     }
