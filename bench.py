@@ -287,7 +287,7 @@ def parity_vs_oracle(pipe, ref, stages, dev, model=None):
 def kernel_sha():
     """Identity of the GEMM / Wav2Vec2 kernel sources: a stored PMC traffic figure is attached only to the code it measured."""
     h = hashlib.sha256()
-    for f in ("gemm_bf16x6.hip", "gemm_bf16x6.h", "w2v2.hip"):
+    for f in ("gemm_f16x3.hip", "gemm_f16x3.h", "w2v2.hip"):
         with open(os.path.join(ROOT, "robust_speech_analysis_framework_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -490,9 +490,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 results throughout; the dense Wav2Vec2 layers obtain them from three-way bf16 splits of both "
-                          "operands (6 bf16 MFMA products per term, fp32 accumulation): error against float64 = that of an fp32 FMA "
-                          "chain (tests/test_gemm_gpu.py); MSHDS in f64, CNN-LSTM and the remaining GEMMs on the fp32 MFMA",
+            "dtype_note": "fp32 results throughout; the dense Wav2Vec2 layers obtain them from two-way fp16 splits of both "
+                          "operands under power-of-two row scales (3 fp16 MFMA products per term, fp32 accumulation): error against "
+                          "float64 at or below that of an fp32 FMA chain (tests/test_gemm_gpu.py); MSHDS in f64, CNN-LSTM and the "
+                          "remaining GEMMs on the fp32 MFMA",
             "config": {"workload": workload, "baseline_config": args.config, "clips_per_gpu": n_local, "clips_total": n_total,
                        "distinct_clips": len(set(members)), "clip_seconds": args.seconds, "stages": list(stages),
                        "sharding": f"clips/{world} ranks, all_gather of result rows",

@@ -31,7 +31,7 @@ extern "C" {
 #define RSAF_ERR_HIP 2      /* a HIP runtime call failed */
 #define RSAF_ERR_WORKSPACE 3 /* workspace too small */
 
-#define RSAF_ABI_VERSION 6   /* 6: params_host[18] of rsaf_mshds_pitch (per-depth Chebyshev tables behind sinc_cheb).  4: clip_info rows carry the sound's x1 / xmax (48 bytes); rsaf_resample_praat restates Sound_upsample for a rate ratio of 2.  5: the openSMILE-style chain is float64 end to end (lld / cand / functionals buffers are double) */
+#define RSAF_ABI_VERSION 7   /* 7: rsaf_gemm_f16x3 / rsaf_split_f16x2 / rsaf_f16x2_row_scales replace the bf16x6 entries (two fp16 planes with power-of-two row scales, three MFMA products).  6: params_host[18] of rsaf_mshds_pitch (per-depth Chebyshev tables behind sinc_cheb).  4: clip_info rows carry the sound's x1 / xmax (48 bytes); rsaf_resample_praat restates Sound_upsample for a rate ratio of 2.  5: the openSMILE-style chain is float64 end to end (lld / cand / functionals buffers are double) */
 
 typedef void* rsaf_stream_t;
 
@@ -113,35 +113,6 @@ int rsaf_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
                   int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr,
                   int nz, int nz2, const int64_t* strides8_host, int a_pad_k, int act, float alpha,
                   int b_kn, rsaf_stream_t stream);
-
-/* ---- fp32-accurate GEMM on the bf16 matrix pipe --------------------------------------------------------------
- * The same contraction as rsaf_gemm_f32 for the plain case (row-major A [M,K], B [N,K], K % 16 == 0), for the same
- * call sites (nn.Linear / nn.Conv1d inside Wav2Vec2Model, src/foundation_model_extractor.py:115), computed from
- * three-way bf16 splits of both operands: six v_mfma_f32_32x32x16_bf16 partial products per term with fp32
- * accumulation (csrc/gemm_bf16x6.hip).  The error against float64 is that of an fp32 FMA chain (a few fp32 roundings);
- * the matrix pipe spends 2.7x fewer cycles than the fp32 MFMA.  Operands are bf16 bit patterns in three planes
- * (`*_plane_stride` elements apart); rsaf_split_bf16x3 produces them (n % 4 == 0).  Outputs: C (fp32) and / or
- * C_planes (the next GEMM's A), either may be NULL; ldc is the row stride of both.  Supported combinations:
- * {act 0, C} {act 0, C, R} {act 0, C_planes} {act 0, C, C_planes} {act 1, C} {act 1, C_planes}.              */
-int rsaf_split_bf16x3(const float* src, int64_t n, uint16_t* planes, int64_t plane_stride, rsaf_stream_t stream);
-int rsaf_gemm_bf16x6(const uint16_t* A_planes, int64_t a_plane_stride, const uint16_t* B_planes,
-                     int64_t b_plane_stride, float* C, uint16_t* C_planes, int64_t c_plane_stride,
-                     const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
-                     int64_t ldc, int64_t ldr, int act, float alpha, rsaf_stream_t stream);
-/* The same two calls with operands in the k16-panel layout: a plane of R rows holds element (r, k) at
- * (k / 16) * (R * 16) + r * 16 + k % 16 (K / 16 panels of [R][16]), so that the 32 rows x 32 bytes one LDS-DMA instruction
- * moves are 1 KiB contiguous.  rsaf_split_bf16x3_panels: row-major fp32 src[rows][K] -> panel planes.
- * rsaf_gemm_bf16x6_panels: a_panels / b_panels / c_panels choose the layout per operand (R = M, N, M; a row-major operand
- * uses its lda / ldb / ldc as in rsaf_gemm_bf16x6; c_panels applies to C_planes, laid out as the A of a GEMM with K = N).
- * Results are bit-identical to the row-major call.                                                                      */
-int rsaf_split_bf16x3_panels(const float* src, int64_t rows, int K, uint16_t* planes, int64_t plane_stride,
-                             rsaf_stream_t stream);
-int rsaf_gemm_bf16x6_panels(const uint16_t* A_planes, int64_t a_plane_stride, const uint16_t* B_planes,
-                            int64_t b_plane_stride, float* C, uint16_t* C_planes, int64_t c_plane_stride,
-                            const float* bias, const float* R, int M, int N, int K, int64_t lda, int64_t ldb,
-                            int64_t ldc, int64_t ldr, int act, float alpha, int a_panels, int b_panels, int c_panels,
-                            rsaf_stream_t stream);
-
 
 /* ---- fp32-accurate GEMM on the fp16 matrix pipe: two-way operand splits, three products --------------------------
  * The same contraction and call sites as above (nn.Linear / nn.Conv1d inside Wav2Vec2Model,

@@ -42,10 +42,6 @@ SIGNATURES = {
     "rsaf_smile_functionals": (_I, [_P, _P, _I, _L, _I, _P, _P]),
     "rsaf_gemm_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I,
                            C.POINTER(_L), _I, _I, _F, _I, _P]),
-    "rsaf_split_bf16x3": (_I, [_P, _L, _P, _L, _P]),
-    "rsaf_gemm_bf16x6": (_I, [_P, _L, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _F, _P]),
-    "rsaf_split_bf16x3_panels": (_I, [_P, _L, _I, _P, _L, _P]),
-    "rsaf_gemm_bf16x6_panels": (_I, [_P, _L, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _F, _I, _I, _I, _P]),
     "rsaf_f16x2_row_scales": (_I, [_P, _L, _I, _L, _P, _P, _P]),
     "rsaf_split_f16x2": (_I, [_P, _L, _I, _L, _P, _I, _P, _L, _I, _P]),
     "rsaf_gemm_f16x3": (_I, [_P, _L, _P, _I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _F,

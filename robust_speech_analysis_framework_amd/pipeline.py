@@ -23,7 +23,8 @@ LATENCY_FAMILIES = {                  # one dependent step per frame: the figure
     "smile_viterbi": "Viterbi over 7 states, one wave per clip",
     "lstm_recurrent": "persistent bi-LSTM recurrence",
 }
-BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak
+F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
+SPLIT_PRODUCTS = 3                  # gemm_f16x3: fp16 MFMA products executed per algorithmic multiply-add
 
 
 def resolve_stages(spec: str):
@@ -195,20 +196,23 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
             continue
         if rec["flops"] > 0:
             fp64 = name.startswith("mshds_")
-            split6 = name in ("w2v2_gemm", "w2v2_posconv_gemm")      # both on gemm_bf16x6 (base geometry)
-            peak = f64_peak_tflops if fp64 else (BF16_MFMA_PEAK_TFLOPS if split6 else mfma_f32_peak_tflops)
+            split3 = name in ("w2v2_gemm", "w2v2_posconv_gemm")      # both on gemm_f16x3 (base geometry)
+            peak = f64_peak_tflops if fp64 else (F16_MFMA_PEAK_TFLOPS if split3 else mfma_f32_peak_tflops)
             alg = rec["flops"] / (rec["ms"] * 1e-3) / 1e12
-            # the bf16x6 GEMM executes six bf16 MFMA products per algorithmic multiply-add: its roofline is the bf16 matrix
-            # pipe, priced with the FLOPs the pipe actually executes; the algorithmic (fp32-equivalent) rate is kept beside it
-            ach = 6.0 * alg if split6 else alg
+            # the f16x3 GEMM executes three fp16 MFMA products per algorithmic multiply-add (two-way fp16 splits of both
+            # operands): its roofline is the fp16 matrix pipe, priced with the FLOPs the pipe actually executes; the
+            # algorithmic (fp32-equivalent) rate is kept beside it
+            ach = SPLIT_PRODUCTS * alg if split3 else alg
             r = {**base, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                  "arithmetic": ("f64 (v_mfma_f64_16x16x4_f64 issues at the fp64 vector rate)" if fp64 else
-                                ("fp32-accurate result from 6 bf16 MFMA products of three-way operand splits, fp32 accumulation"
-                                 if split6 else "f32 MFMA")),
+                                ("fp32-accurate result from 3 fp16 MFMA products of two-way operand splits (power-of-two row "
+                                 "scales), fp32 accumulation; rounds 2-3 needed 6 bf16 products for the same result"
+                                 if split3 else "f32 MFMA")),
                  "algorithmic_flops_per_launch": rec["flops"] / rec["launches"]}
-            if split6:
+            if split3:
                 r["fp32_equivalent_tflops"] = round(alg, 3)
                 r["fp32_equivalent_over_fp32_mfma_peak"] = round(alg / mfma_f32_peak_tflops, 4)
+                r["executed_products_per_multiply_add"] = SPLIT_PRODUCTS
             if name == "lstm_recurrent":
                 r["note"] = "latency-bound persistent recurrence: the figure that matters is the time per step"
             out.append(r)

@@ -28,7 +28,7 @@ def test_python_binding_covers_header(rsaf_lib):
 
 
 def test_abi_version_and_host_only_calls(rsaf_lib):
-    assert rsaf_lib.rsaf_abi_version() == 6
+    assert rsaf_lib.rsaf_abi_version() == 7
     # integer-exact frame-count contract (Androids.conf:73-78): no GPU needed
     for n, want in [(0, 0), (399, 0), (400, 1), (559, 1), (560, 2), (80000, 498), (480000, 2998)]:
         assert rsaf_lib.rsaf_smile_n_frames(n, 16000) == want

@@ -147,116 +147,6 @@ def test_argument_validation(rsaf_lib):
         ops.linear(a, w)                                   # K = 6 is not a multiple of 4
 
 
-# ---- fp32-accurate GEMM on the bf16 matrix pipe (six partial products of three-way bf16 splits) -----------------------
-def _split(t):
-    import torch
-    from robust_speech_analysis_framework_amd import _lib
-    lib = _lib.load()
-    n = t.numel()
-    planes = torch.empty((3,) + tuple(t.shape), dtype=torch.int16, device="cuda")
-    _lib.check(lib.rsaf_split_bf16x3(_lib.ptr(t), n, _lib.ptr(planes), n, None), "split")
-    return planes
-
-
-def _planes_to_f64(pl):
-    import torch
-    return sum((pl[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(3))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(300, 208, 64), (256, 256, 16), (1000, 144, 512), (513, 768, 3072), (257, 2304, 768)])
-def test_bf16x6_gemm_is_fp32_accurate(rsaf_lib, M, N, K):
-    """Every output mode of rsaf_gemm_bf16x6 against float64: the error is that of an fp32 FMA chain (same bar as, and
-    compared with, rsaf_gemm_f32 on the same operands); edges (M, N not multiples of the 256 x 256 tile) included."""
-    import torch
-    from robust_speech_analysis_framework_amd import _lib, ops
-    lib = _lib.load()
-    g = torch.Generator(device="cpu").manual_seed(M + N + K)
-    A = torch.randn((M, K), generator=g).cuda()
-    W = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
-    bias = torch.randn((N,), generator=g).cuda()
-    R = torch.randn((M, N), generator=g).cuda()
-    ap, wp = _split(A), _split(W)
-    assert ((_planes_to_f64(wp) - W.double()).abs() <= W.double().abs() * 2.0 ** -23).all()    # planes add back to the float
-    lin = A.double() @ W.double().T + bias.double()
-
-    def run(act, want_f32, want_planes, resid):
-        C = torch.full((M, N), float("nan"), device="cuda") if want_f32 else None
-        P = torch.zeros((3, M, N), dtype=torch.int16, device="cuda") if want_planes else None
-        _lib.check(lib.rsaf_gemm_bf16x6(_lib.ptr(ap), M * K, _lib.ptr(wp), N * K, _lib.ptr(C) if want_f32 else None,
-                                        _lib.ptr(P) if want_planes else None, M * N, _lib.ptr(bias),
-                                        _lib.ptr(R) if resid else None, M, N, K, K, K, N, N, act, 1.0, None), "gemm6")
-        torch.cuda.synchronize()
-        return C, P
-
-    ref_plain, ref_res = lin, lin + R.double()
-    ref_gelu = torch.nn.functional.gelu(lin)
-    e32 = (ops.linear(A, W, bias=bias).double() - ref_plain).abs().max().item() / ref_plain.abs().max().item()
-    bar = max(3 * e32, 2e-6)
-    C, _ = run(0, True, False, False)
-    assert (C.double() - ref_plain).abs().max().item() / ref_plain.abs().max().item() < bar
-    C, _ = run(0, True, False, True)
-    assert (C.double() - ref_res).abs().max().item() / ref_res.abs().max().item() < bar
-    C, _ = run(1, True, False, False)
-    assert (C.double() - ref_gelu).abs().max().item() / ref_gelu.abs().max().item() < bar
-    _, P = run(1, False, True, False)
-    assert (_planes_to_f64(P) - ref_gelu).abs().max().item() / ref_gelu.abs().max().item() < bar
-    C, P = run(0, True, True, False)
-    assert torch.equal(_planes_to_f64(P).float(), C)                    # the planes hold exactly the fp32 result
-    _, P2 = run(0, False, True, False)
-    assert torch.equal(P2, P)
-    with pytest.raises(_lib.RsafError):
-        run(2, True, False, False)                                       # SiLU is not one of the compiled epilogues
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(300, 208, 64), (513, 768, 3072), (256, 256, 16)])
-def test_bf16x6_panel_layout_is_bit_identical_to_row_major(rsaf_lib, M, N, K):
-    """k16-panel operands (rsaf_split_bf16x3_panels / rsaf_gemm_bf16x6_panels): the planes are a permutation of the
-    row-major planes, and every mix of panel / row-major operands gives the bits of the row-major call, the plane output
-    in panels included (it is what the Wav2Vec2 feed-forward hands from its first GEMM to the second)."""
-    import torch
-    from robust_speech_analysis_framework_amd import _lib
-    lib = _lib.load()
-    g = torch.Generator(device="cpu").manual_seed(7 * M + N + K)
-    A = torch.randn((M, K), generator=g).cuda()
-    W = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
-    bias = torch.randn((N,), generator=g).cuda()
-    ap, wp = _split(A), _split(W)
-
-    def split_panels(X):
-        rows, k = X.shape
-        P = torch.zeros((3, rows * k), dtype=torch.int16, device="cuda")
-        _lib.check(lib.rsaf_split_bf16x3_panels(_lib.ptr(X), rows, k, _lib.ptr(P), rows * k, None), "split panels")
-        return P
-
-    def to_row_major(P, rows, k):                                       # [3][k/16][rows][16] -> [3][rows][k]
-        return P.view(3, k // 16, rows, 16).permute(0, 2, 1, 3).reshape(3, rows, k).contiguous()
-
-    app, wpp = split_panels(A), split_panels(W)
-    torch.cuda.synchronize()
-    assert torch.equal(to_row_major(app, M, K), ap.view(3, M, K))
-    assert torch.equal(to_row_major(wpp, N, K), wp.view(3, N, K))
-
-    def run(a_pan, b_pan, c_pan, act, want_f32, want_planes):
-        C = torch.full((M, N), float("nan"), device="cuda") if want_f32 else None
-        P = torch.zeros((3, M * N), dtype=torch.int16, device="cuda") if want_planes else None
-        _lib.check(lib.rsaf_gemm_bf16x6_panels(_lib.ptr(app if a_pan else ap), M * K, _lib.ptr(wpp if b_pan else wp), N * K,
-                                               _lib.ptr(C) if want_f32 else None, _lib.ptr(P) if want_planes else None, M * N,
-                                               _lib.ptr(bias), None, M, N, K, K, K, N, N, act, 1.0, int(a_pan), int(b_pan),
-                                               int(c_pan), None), "gemm6 panels")
-        torch.cuda.synchronize()
-        return C, P
-
-    C0, _ = run(False, False, False, 0, True, False)
-    for a_pan, b_pan in ((True, True), (False, True), (True, False)):
-        C1, _ = run(a_pan, b_pan, False, 0, True, False)
-        assert torch.equal(C1, C0)
-    _, P0 = run(False, False, False, 1, False, True)
-    _, P1 = run(True, True, True, 1, False, True)
-    assert torch.equal(to_row_major(P1, M, N), P0.view(3, M, N))
-
-
 # ---- fp32-accurate GEMM on the fp16 matrix pipe (three products of two-way fp16 splits, power-of-two row scales) --------
 def _h3_scales(X, loose=1.0):
     """Per-row power-of-two scales from rsaf_f16x2_row_scales (+ row norms); loose > 1 shrinks them as a loose bound would."""

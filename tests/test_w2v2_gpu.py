@@ -90,7 +90,7 @@ def test_base_geometry_window_matches_oracle(rsaf_lib):
 
 
 def test_group_width_not_multiple_of_16_matches_oracle(rsaf_lib):
-    """The positional convolution runs on the bf16x6 GEMM when its group width is a multiple of 16 (base: 48, the small
+    """The positional convolution runs on the f16x3 GEMM when its group width is a multiple of 16 (base: 48, the small
     golden geometry: 16) and on the fp32 MFMA GEMM otherwise: a geometry with 8-wide groups (and 16-wide heads: the
     unfused attention with its panel split) against the oracle."""
     from robust_speech_analysis_framework_amd.w2v2 import W2V2Engine

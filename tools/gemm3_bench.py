@@ -1,4 +1,4 @@
-"""Speed of rsaf_gemm_f16x3 (two fp16 planes, three products) against rsaf_gemm_bf16x6-era numbers and rsaf_gemm_f32 on the
+"""Speed of rsaf_gemm_f16x3 (two fp16 planes, three products) against rsaf_gemm_f32 on the
 Wav2Vec2 shapes (both operands as k16 panels, as the encoder uses them; G3_A_ROW_MAJOR=1: A row-major as the conv layers)."""
 import os
 import sys

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_sha():
     h = hashlib.sha256()
-    for f in ("gemm_bf16x6.hip", "gemm_bf16x6.h", "w2v2.hip"):
+    for f in ("gemm_f16x3.hip", "gemm_f16x3.h", "w2v2.hip"):
         with open(os.path.join(ROOT, "robust_speech_analysis_framework_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -46,7 +46,7 @@ def collect(root, counter):
             k = row["Kernel_Name"]
             g = int(row.get("Grid_Size", 0) or 0)
             key = g
-            if "gemm_bf16x6" in k:
+            if "gemm_f16x3" in k:
                 key = (g, prev)
                 prev = g
             a = agg[k][key]
@@ -57,8 +57,8 @@ def collect(root, counter):
 
 def w2v2_shapes(n_windows, chunk_len=80000, conv_group=512):
     """Wav2Vec2-base GEMMs of one sub-batch of n equal windows: {grid size (threads): (label, algorithmic bytes per launch)}.
-    gemm_bf16x6: 256 x 256 tiles, 512 threads per workgroup; the conv GEMMs are batched over groups of 512 windows
-    (grid.y), the encoder GEMMs run on all rows at once.  Algorithmic bytes: every operand element once as three bf16
+    gemm_f16x3: 256 x 256 tiles, 512 threads per workgroup; the conv GEMMs are batched over groups of 512 windows
+    (grid.y), the encoder GEMMs run on all rows at once.  Algorithmic bytes: every operand element once as two fp16
     planes (6 B), outputs as fp32 (4 B) or planes (6 B), fp32 residual 4 B."""
     T, t = [], chunk_len
     for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--command", default="")
     a = ap.parse_args()
     fe, wr = collect(a.fetch_dir, "FETCH_SIZE"), collect(a.write_dir, "WRITE_SIZE")
-    gemm = [k for k in set(fe) | set(wr) if "gemm_bf16x6" in k]
+    gemm = [k for k in set(fe) | set(wr) if "gemm_f16x3" in k]
     shapes = w2v2_shapes(a.shape_windows or a.windows)
     per_shape, tot_f, tot_w, tot_l = [], 0.0, 0.0, 0
     grids = sorted({g for k in gemm for g in list(fe.get(k, {})) + list(wr.get(k, {}))}, key=str)
@@ -135,7 +135,7 @@ def main():
                    "kernel_sha": kernel_sha()},
            "gemm_kernels": gemm_names, "gemm_launches": tot_l, "fetch_KB_raw": tot_f, "write_KB": tot_w,
            "traffic_bytes_per_launch_fetch_x2_plus_write": (2.0 * tot_f + tot_w) * 1024.0 / max(tot_l, 1),
-           "note": "all gemm_bf16x6 dispatches of the run (full-window and tail-window sub-batches); "
+           "note": "all gemm_f16x3 dispatches of the run (full-window and tail-window sub-batches); "
                    "per_shape separates them by grid size, shapes of the full-window sub-batches are labelled",
            "per_shape": per_shape}
     with open(a.out, "w") as f:
