@@ -93,9 +93,12 @@ def launcher_selftest(args) -> None:
     first, n_local, n_total, scaling = benchlib.shard_plan(rank, world, args.clips if args.clips is not None else 5, args.total_clips)
     width = 940
 
+    pool = 4                                                   # fabricated rows depend on the pool member only: g mod pool
+
     def step():
-        idx = torch.arange(first, first + n_local, dtype=torch.float32)[:, None]
-        return gather_rows(idx * 10.0 + torch.arange(width, dtype=torch.float32)[None, :], n_total)
+        idx = torch.as_tensor(benchlib.pool_members(first, n_local, pool), dtype=torch.float32)[:, None]
+        rows = idx * 10.0 + torch.arange(width, dtype=torch.float32)[None, :]
+        return gather_rows(benchlib.tag_rows(rows, rank), n_total)
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -110,13 +113,17 @@ def launcher_selftest(args) -> None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    want = torch.arange(n_total, dtype=torch.float32)[:, None] * 10.0 + torch.arange(width, dtype=torch.float32)[None, :]
-    assert torch.equal(out, want), "gathered rows are not in global clip order"
+    rows, gathered = benchlib.check_gathered(out, world, args.clips if args.clips is not None else 5, args.total_clips, pool)
+    want = torch.as_tensor(benchlib.pool_members(0, n_total, pool), dtype=torch.float32)[:, None] * 10.0 + torch.arange(width, dtype=torch.float32)[None, :]
+    assert torch.equal(rows, want), "gathered rows are not in global clip order"
+    assert gathered["rows_at_their_global_position_from_their_owner_rank"] and gathered["duplicate_clips_bit_identical_across_the_gathered_table"]
+    assert gathered["ranks_contributing"] == gathered["ranks_with_a_shard"], "a rank's rows did not arrive"
     if rank == 0:
         print(json.dumps({"metric": "launcher selftest: NOT a measurement (no GPU work, fabricated rows on the CPU, gloo)",
                           "value": None, "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * dt / max(args.steps, 1), 3), "scaling": scaling, "data": "none",
-                          "config": {"workload": "launcher selftest", "clips_total": n_total, "clips_per_rank": n_local}}), flush=True)
+                          "config": {"workload": "launcher selftest", "clips_total": n_total, "clips_per_rank": n_local},
+                          "checks": {"gathered": gathered}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -382,7 +389,8 @@ def main():
         audio_s_per_step = n_total * args.seconds
 
     def step():
-        return gather_rows(run_local(), n_total)             # one RCCL all-gather of the result rows
+        # one RCCL all-gather of the result rows; the producing rank rides in a last column (benchlib.tag_rows)
+        return gather_rows(benchlib.tag_rows(run_local(), rank), n_total)
 
     if rank == 0:
         log(f"setup done: config {args.config}, stages {stages}, {n_local} clips on this rank of {n_total} ({scaling}), "
@@ -412,6 +420,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    out, gathered = benchlib.check_gathered(out, world, clips_per_gpu, args.total_clips, args.pool)
+    assert gathered["rows_at_their_global_position_from_their_owner_rank"], "gathered rows are not at their global positions"
+    assert gathered["ranks_contributing"] == gathered["ranks_with_a_shard"], "a rank's rows did not arrive"
+    assert gathered["duplicate_clips_bit_identical_across_the_gathered_table"], "rows of one clip differ between ranks / batch positions"
     local = out[first:first + n_local] if world > 1 else out
     m_cols = 25 if (not c4 and "mshds" in stages) else 0    # MSHDS cells may be NaN by contract (failed helper -> NaN)
     assert torch.isfinite(local[:, m_cols:]).all(), "non-finite results in the timed region"
@@ -442,6 +454,31 @@ def main():
                      "h2d_bytes": int(pcm.numel() * 2), "d2h_bytes": int(rows.numel() * 4), "ranks": 1,
                      "what": "rank 0's shard: pinned int16 PCM -> H2D -> rsaf_pcm_to_mono_f32 -> hot path -> D2H rows (best of 2)"}
 
+    # MSHDS runs its analyses on three HIP streams in the product (mshds.py), so a family's event bracket in the timed region
+    # contains the time its kernels waited for the others: those brackets are not kernel times.  One more pass of the
+    # DSP stages, AFTER the timed region, with every analysis on ONE stream and the event brackets on: the MSHDS / smile /
+    # resampling families of `other_rooflines` and the C2-level entry come from this pass, the Wav2Vec2 / CNN-LSTM families
+    # (one stream anyway) from the timed region itself.
+    prof_one, one_wall = None, None
+    dsp = tuple(st for st in ("mshds", "smile") if st in stages)
+    if rank == 0 and world == 1 and pipe is not None and dsp and n_local:
+        keep_streams = pipe.mshds.n_streams if pipe.mshds is not None else None
+        if pipe.mshds is not None:
+            pipe.mshds.n_streams = 1
+        try:
+            pipe.run(wav, only=dsp)
+            torch.cuda.synchronize()
+            _lib.prof_begin()
+            t1 = time.perf_counter()
+            pipe.run(wav, only=dsp)
+            torch.cuda.synchronize()
+            one_wall = time.perf_counter() - t1
+            prof_one = _lib.prof_end()
+        finally:
+            if pipe.mshds is not None:
+                pipe.mshds.n_streams = keep_streams
+        log(f"one-stream pass of {dsp}: {1e3 * one_wall:.1f} ms, {sum(v['ms'] for v in prof_one.values()):.1f} ms of family brackets")
+
     # BASELINE configs C2 / C3 / C4 on their own, same process, after the timed region (N = 1, e2e only): the same code
     # paths as `--config C2|C3|C4`, 1 warm-up + 2 timed steps each, so that the per-config table is driver-visible
     per_config = None
@@ -471,8 +508,17 @@ def main():
     if rank == 0:
         value = audio_s_per_step * args.steps / dt
         frames = {"mshds_pitch_path": 6000.0 * args.seconds / 30.0, "smile_viterbi": 2998.0 * args.seconds / 30.0}
-        roofs = pipeline.rooflines(prof, stages, n_local, args.seconds, args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS,
+        main_prof = {k: v for k, v in prof.items() if prof_one is None or k not in prof_one}
+        roofs = pipeline.rooflines(main_prof, stages, n_local, args.seconds, args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS,
                                    F64_VECTOR_PEAK_TFLOPS, wall_ms=1e3 * dt, frames_per_launch=frames)
+        c2_level = None
+        if prof_one is not None:
+            one = pipeline.rooflines(prof_one, stages, n_local, args.seconds, 1, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS,
+                                     F64_VECTOR_PEAK_TFLOPS, wall_ms=1e3 * one_wall, frames_per_launch=frames)
+            for r in one:
+                r["timed_in"] = "one-stream pass after the timed region (share_of_step_wall = share of that pass)"
+            roofs += one
+            c2_level = pipeline.c2_level_roofline(prof_one, n_local, args.seconds, one_wall, HBM_PEAK_GBS, F64_VECTOR_PEAK_TFLOPS)
         roofs = [r for r in roofs if r.get("bound") != "latency"] + [r for r in roofs if r.get("bound") == "latency"]
         roof = roofs[0] if roofs else None
         for r in roofs:                                      # the recurrence is latency-bound: report the time per step
@@ -498,17 +544,28 @@ def main():
                        "distinct_clips": len(set(members)), "clip_seconds": args.seconds, "stages": list(stages),
                        "sharding": f"clips/{world} ranks, all_gather of result rows",
                        "w2v2_windows_per_call": args.w2v2_chunks_per_call},
-            "roofline": roof, "other_rooflines": roofs[1:], "per_config": per_config,
+            "roofline": roof, "other_rooflines": roofs[1:], "c2_level_roofline": c2_level, "per_config": per_config,
             "inclusive_of_pcie_and_decode": inclusive,
-            "checks": {"finite": True, "duplicate_clips_bit_identical": dup_ok,
+            "checks": {"finite": True, "duplicate_clips_bit_identical": dup_ok, "gathered": gathered,
                        "rccl_all_gather_executed": bool(world > 1 or force_collective),
                        "note": "parity vs the CPU oracle is asserted by tests/ (-m gpu) and smoke(); parity_vs_oracle below reports it "
                                "for the cpu_baseline sample, outside the timed run"},
-            "kernel_time_note": "per-family HIP-event times; the MSHDS analyses run on two streams beside each other, so the "
-                                "family times overlap in wall time and their sum exceeds the timed region",
+            "kernel_time_note": "per-family HIP-event brackets on the launch stream.  `kernels` = the timed region: Wav2Vec2 / "
+                                "CNN-LSTM families run on one stream (bracket = kernel time); the MSHDS analyses run on three "
+                                "streams beside each other there, so THOSE brackets include waiting and are flagged multi_stream; "
+                                "`kernels_one_stream_pass` = the DSP stages once more on ONE stream after the timed region "
+                                "(bracket = kernel time), which is what other_rooflines and c2_level_roofline use",
             "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "share_of_step_wall": round(v["ms"] / (1e3 * dt), 4),
+                            **({"multi_stream": True} if prof_one is not None and k in prof_one and k.startswith(("mshds", "praat")) else {}),
                             **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 and v["ms"] > 0 else {})}
                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernels_one_stream_pass": None if prof_one is None else {
+                "wall_ms": round(1e3 * one_wall, 3), "sum_of_family_ms": round(sum(v["ms"] for v in prof_one.values()), 3),
+                "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3)}
+                             for k, v in sorted(prof_one.items(), key=lambda kv: -kv[1]["ms"])}},
+            "family_time_sums": {"timed_region_wall_ms": round(1e3 * dt, 3),
+                                 "single_stream_families_ms": round(sum(v["ms"] for k, v in prof.items()
+                                                                        if not k.startswith(("mshds", "praat"))), 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             ref, line["cpu_baseline"] = cpu_baseline(args.config, stages, args.seconds, args.cpu_sample_clips)

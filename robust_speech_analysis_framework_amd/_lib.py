@@ -133,10 +133,18 @@ def check(rc: int, what: str = "") -> None:
 
 
 def stream_ptr(stream=None):
-    """hipStream_t of a torch stream (default: torch's current stream) as void*."""
+    """hipStream_t of a torch stream (default: torch's current stream) as void*.
+
+    Contract of every ``stream=`` parameter of this package: the stream, if given, must BE torch's current stream (enter it
+    with ``with torch.cuda.stream(s):``).  Host-built tables travel through pinned staging buffers queued on the current
+    stream and temporaries return to the current stream's allocator pool, so a kernel launched on any other stream could
+    read a table before its copy lands; that is refused here instead of left as a race."""
     import torch
-    s = torch.cuda.current_stream() if stream is None else stream
-    return C.c_void_p(s.cuda_stream)
+    cur = torch.cuda.current_stream()
+    if stream is not None and stream.cuda_stream != cur.cuda_stream:
+        raise RsafError("stream= must be torch's current stream: enter it with `with torch.cuda.stream(s):` "
+                        "(host tables are staged on the current stream)")
+    return C.c_void_p(cur.cuda_stream)
 
 
 def ptr(t):

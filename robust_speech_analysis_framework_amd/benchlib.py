@@ -50,6 +50,35 @@ def duplicates_bit_identical(rows, members) -> bool:
     return bool(same.all().item())
 
 
+def tag_rows(rows, rank: int):
+    """rows [n_local, width] -> [n_local, width + 1]: the producing rank rides in a last column, so that the gathered table
+    itself says which rank computed each row (the tag is bench bookkeeping, not part of the result row)."""
+    import torch
+    tag = torch.full((rows.shape[0], 1), float(rank), dtype=rows.dtype, device=rows.device)
+    return torch.cat([rows, tag], dim=1)
+
+
+def check_gathered(out_tagged, world: int, clips_per_gpu: int, total_clips, pool: int):
+    """What an N-rank line has to prove about the GATHERED table (rank 0, after the timed region): every global row sits
+    at its global position and was produced by the rank that owns it under the sharding plan (tag column), every rank with
+    a non-empty shard contributed, and rows of the same pool member are bit-identical across the whole table, i.e. across
+    GPUs.  Returns (rows without the tag column, checks dict)."""
+    tags = out_tagged[:, -1].cpu().tolist()
+    rows = out_tagged[:, :-1]
+    want = []
+    owners = 0
+    for r in range(world):
+        _, n_local, n_total, _ = shard_plan(r, world, clips_per_gpu, total_clips)
+        want += [float(r)] * n_local
+        owners += 1 if n_local > 0 else 0
+    order_ok = len(want) == len(tags) and all(a == b for a, b in zip(tags, want))
+    contributing = len(set(tags))
+    dup_ok = duplicates_bit_identical(rows, pool_members(0, rows.shape[0], pool))
+    return rows, {"gathered_rows": int(rows.shape[0]), "rows_at_their_global_position_from_their_owner_rank": bool(order_ok),
+                  "ranks_contributing": int(contributing), "ranks_with_a_shard": int(owners),
+                  "duplicate_clips_bit_identical_across_the_gathered_table": bool(dup_ok)}
+
+
 def usable_cpus() -> int:
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota and by RSAF_CPU_THREADS
     (default 16 = the CPU share of a one-GPU box; the host may show 256 CPUs it does not grant)."""

@@ -442,11 +442,9 @@ static int launch_glds_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int THREADS = (BM / 64) * (BN / 64) * 64;
     const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
     const int lds = 2 * (BM + BN) * 32 * (int)sizeof(float);
-    static DeviceOnce attr_once;
-    if (attr_once.first()) {
-        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f32_glds_kernel<BM, BN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
+    // (set on every launch: the attribute holds per device, a process may drive several, and a once-flag would have to be
+    // per device, set only after success and thread-safe)
+    RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f32_glds_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN>), dim3((unsigned)tiles, (unsigned)p.nz), dim3(THREADS), lds, s, p);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;

@@ -2698,6 +2698,13 @@ __device__ double max_correlation_wave(const float* __restrict__ x, int n, doubl
             for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
             norm1 = n1_all;
             norm2 = n20 + (incl - dsc);                            // exclusive prefix of the differences
+            // The sliding sum is exact for 16-bit PCM (the squares add exactly); on resampled or float clips it can cancel
+            // when the energy drops sharply inside the batch.  A lane whose sum has lost its digits takes the direct sum.
+            if (in && !(norm2 > 1e-9 * n20)) {
+                double d2 = 0.0;
+                for (int i = 0; i < wlen; ++i) { const double a = ps2[o2 + i]; d2 = fma(a, a, d2); }
+                norm2 = d2;
+            }
             if (in) {
                 double p0 = 0.0, p1 = 0.0;
                 int i = 0;
@@ -2835,7 +2842,8 @@ __global__ __launch_bounds__(256) void pulse_stretches_kernel(const float* __res
         const float* x = wav + c.sample_off;
         float gp = 0.0f;                                      // |x| of float samples: exact in float
         const int n4 = c.n_samples >> 2;
-        const bool al = ((c.sample_off & 3) == 0);            // 16-byte loads when the clip starts on a 16-byte boundary
+        const bool al = (reinterpret_cast<uintptr_t>(x) & 15) == 0;   // 16-byte loads when the clip's first sample is 16-byte aligned
+                                                                      // (the address itself: `wav` may be any float*, e.g. a sliced view)
         if (al) {
             const float4* x4 = reinterpret_cast<const float4*>(x);
             for (int i = threadIdx.x; i < n4; i += 256) {
@@ -3481,8 +3489,15 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
             }
             RSAF_CHECK_HIP(hipGetLastError());
             }
-            // family "mshds_pitch_cand": maxima, candidate lists, Brent refinement (latency / issue bound, no FLOP model)
-            ProfScope prof(cheb ? "mshds_pitch_cand_cheb" : "mshds_pitch_cand_direct", s, 0.0, 0.0);
+            // family "mshds_pitch_cand": maxima, candidate lists, Brent refinement.  Work model: every frame's normalised
+            // correlation row comes back from the HBM workspace ((Lr + 2) doubles); on the Chebyshev path the coefficient build
+            // of the frame's candidates runs on the fp64 matrix pipe: ceil(2 depth / 4) tap groups x 2 column tiles of
+            // v_mfma_f64_16x16x4_f64 (2 048 flops each).  The Brent iterations themselves (a dozen polynomial evaluations per
+            // candidate) and the direct path's sinc sums are not counted.
+            const double cand_rows = (double)max_frames * (double)nc;
+            ProfScope prof(cheb ? "mshds_pitch_cand_cheb" : "mshds_pitch_cand_direct", s,
+                           cheb ? cand_rows * 2048.0 * 2.0 * ceil(2.0 * P.refine_depth / 4.0) : 0.0,
+                           cand_rows * (double)(Lr + 2) * 8.0);
             hipLaunchKernelGGL(pitch_cand_kernel, dim3(max_frames, nc), dim3(CT), lds_cand, s, cig, gpeak + c0, P,
                                (const double*)workspace, rstride, max_frames, (FrameOut*)frame_out,
                                dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb);

@@ -357,12 +357,12 @@ __global__ __launch_bounds__(256) void cepstrum_kernel(const Seg* __restrict__ s
                                                        const double* __restrict__ res, int cap_res, int cap_frames,
                                                        const double* __restrict__ win1000, const double2* __restrict__ tw,
                                                        double preemph, double* __restrict__ ceps, const int* __restrict__ list,
-                                                       const int* __restrict__ list_count) {
+                                                       const int* __restrict__ list_count, int list_cap) {
     __shared__ double2 a[NFFT_MAX / 2];
     __shared__ double xs[NFFT_MAX + 1];                 // windowed frame, then the ln-power half spectrum
     __shared__ double s_red[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int count = *list_count;
+    const int count = min(*list_count, list_cap);       // (the producers drop what does not fit; the host sizes the list so that nothing is dropped)
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
     __syncthreads();                                    // the previous frame's readers of a / xs / s_red are done
     const int clip = list[2 * item], f = list[2 * item + 1];
@@ -655,13 +655,13 @@ __global__ __launch_bounds__(256) void cpp_frame_kernel(const Seg* __restrict__ 
                                                         const double* __restrict__ ceps, int cap_frames, int n_time,
                                                         int n_quef, double pitch_floor, double pitch_ceiling,
                                                         double* __restrict__ cpp_out, const int* __restrict__ list,
-                                                        const int* __restrict__ list_count) {
+                                                        const int* __restrict__ list_count, int list_cap) {
     __shared__ double zt[NQ_MAX + 3], db[NQ_MAX + 3], srt[NFFT_MAX];
     __shared__ double s_val[4];
     __shared__ int s_ord[4];
     __shared__ double s_xq[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int count = *list_count;
+    const int count = min(*list_count, list_cap);       // (the producers drop what does not fit; the host sizes the list so that nothing is dropped)
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
     __syncthreads();                                    // the previous frame's readers of the shared arrays are done
     const int clip = list[2 * item], f = list[2 * item + 1];
@@ -1091,6 +1091,8 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
         int* list = reinterpret_cast<int*>(lp_work);
         int* list_count = list + 2 * (lp_doubles - 1);
         const int list_cap = (int)std::min<int64_t>(lp_doubles - 1, 0x7fffffff);
+        // every frame of every clip may be listed at most once: the list holds them all, nothing can be dropped
+        RSAF_CHECK_ARG((int64_t)n_clips * cap_frames <= list_cap, "frame list smaller than the frame count");
         RSAF_CHECK_HIP(hipMemsetAsync(list_count, 0, sizeof(int), s));
         const double pre = exp(-2.0 * PI * 50.0 * DXO);
         hipLaunchKernelGGL(cepstrum_wave_kernel, dim3((cap_frames + CEP_FRAMES - 1) / CEP_FRAMES, n_clips), dim3(64), 0, s, segs,
@@ -1098,7 +1100,7 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
                            list, list_count, list_cap, force_list & 1);
         RSAF_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(cepstrum_kernel, dim3(2048), dim3(256), 0, s, segs, max_seg, hdr, resampled, cap_res, cap_frames,
-                           window1000, (const double2*)twiddle1024, pre, cepstrogram, list, list_count);
+                           window1000, (const double2*)twiddle1024, pre, cepstrogram, list, list_count, list_cap);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     {
@@ -1113,7 +1115,7 @@ int rsaf_mshds_cpp(const float* wav, const void* clip_info, int n_clips, const d
                            cpp_frames, list, list_count, list_cap, force_list & 2);
         RSAF_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(cpp_frame_kernel, dim3(2048), dim3(256), 0, s, segs, max_seg, hdr, cepstrogram, cap_frames,
-                           (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0, cpp_frames, list, list_count);
+                           (int)floor(0.01 / DT), (int)floor(0.001 / DQ), 60.0, 330.0, cpp_frames, list, list_count, list_cap);
         RSAF_CHECK_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(n_clips), dim3(256), 0, s, segs, max_seg, hdr, cpp_frames, cap_frames, 4.0, out);

@@ -30,19 +30,6 @@ void set_error(const std::string& msg);
         }                                                                           \
     } while (0)
 
-// hipFuncSetAttribute (dynamic LDS above 48 KB) holds per DEVICE: one process may drive several GPUs (rsaf_init_device),
-// so the "already set" flag of a kernel is kept per device.  `static DeviceOnce once; if (once.first()) set...`
-struct DeviceOnce {
-    bool done[64] = {};
-    bool first() {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;   // unknown device: set the attribute again
-        const bool f = !done[dev];
-        done[dev] = true;
-        return f;
-    }
-};
-
 // Per-kernel-family event timing (rsaf_prof_begin/end).  No-ops unless profiling is on.
 struct ProfScope {
     ProfScope(const char* name, hipStream_t s, double flops, double bytes);

@@ -20,6 +20,19 @@ struct ProfEntry {
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfEntry> g_prof;
+// Events are pooled: created in rsaf_prof_begin (outside any timed region) or on first need, returned by rsaf_prof_end, so
+// that a profiled launch costs two hipEventRecord calls and no hipEventCreate (~1 000 creations per step before).
+static std::vector<hipEvent_t> g_event_pool;
+constexpr size_t EVENT_POOL_PREFILL = 8192;
+
+static bool take_event(hipEvent_t* e) {
+    if (!g_event_pool.empty()) {
+        *e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return true;
+    }
+    return hipEventCreate(e) == hipSuccess;
+}
 
 ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes)
     : slot(-1), pair(-1), stream(s) {
@@ -38,10 +51,8 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes
     e.flops += flops;
     e.bytes += bytes;
     hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
-        slot = -1;
-        return;
-    }
+    if (!take_event(&a)) { slot = -1; return; }
+    if (!take_event(&b)) { g_event_pool.push_back(a); slot = -1; return; }
     e.events.emplace_back(a, b);
     pair = (int)e.events.size() - 1;          // this scope's own event pair: other threads may open the same family meanwhile
     (void)hipEventRecord(a, stream);
@@ -68,10 +79,15 @@ int rsaf_prof_begin(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& e : g_prof)
         for (auto& p : e.events) {
-            (void)hipEventDestroy(p.first);
-            (void)hipEventDestroy(p.second);
+            g_event_pool.push_back(p.first);
+            g_event_pool.push_back(p.second);
         }
     g_prof.clear();
+    while (g_event_pool.size() < EVENT_POOL_PREFILL) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        g_event_pool.push_back(e);
+    }
     g_prof_on = true;
     return RSAF_OK;
 }
@@ -88,8 +104,8 @@ int rsaf_prof_end(rsaf_prof_record* records_host, int cap, int* n_records_host) 
             float t = 0;
             RSAF_CHECK_HIP(hipEventElapsedTime(&t, p.first, p.second));
             ms += t;
-            (void)hipEventDestroy(p.first);
-            (void)hipEventDestroy(p.second);
+            g_event_pool.push_back(p.first);
+            g_event_pool.push_back(p.second);
         }
         e.events.clear();
         if (records_host && n < cap) {

@@ -1,5 +1,5 @@
 // Complex fp64 FFT of S = 64 R points held by ONE wavefront, R points per lane (R = 8, 16, 32: S = 512, 1024, 2048),
-// for the MSHDS pitch analyses (Sound: To Pitch (ac/cc) as src/MSHDS_pitch_features.py and its siblings call it).
+// for the MSHDS pitch analyses (Sound: To Pitch (ac/cc) as src/mshds_extractor.py:143,178,221 of the reference call it).
 //
 // Layout in and out: lane l, register m holds element l + 64 m.  Three passes, all arithmetic in registers:
 //   pass A   DFT_R over m (stride 64 in the sequence), twiddle W_S^(l k1)              -> y[l][k1]

@@ -230,3 +230,24 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
             out.append({**base, "bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s",
                         "frac": round(ach / hbm_peak_gbs, 5), "algorithmic_bytes_per_launch": per_launch})
     return out
+
+
+def c2_level_roofline(prof_one, clips, seconds, wall_s, hbm_peak_gbs, f64_peak_tflops):
+    """One entry for BASELINE config C2 as a whole (MSHDS + openSMILE-style stages, one-stream pass).  SURVEY.md 8d assigns
+    the stage the HBM roof at 64 000 B per audio-second (the waveform read once): that figure is kept, and beside it the
+    fp64 work model the stage really lives on - the summed algorithmic FLOPs of its families that carry one (correlation
+    FFTs, Chebyshev coefficient builds: Praat's arithmetic is float64 on the vector / fp64 matrix pipe) over the pass."""
+    audio_s = clips * seconds
+    flops = sum(v["flops"] for k, v in prof_one.items() if k.startswith("mshds") and v["flops"] > 0)
+    counted = sorted(k for k, v in prof_one.items() if k.startswith("mshds") and v["flops"] > 0)
+    tf = flops / wall_s / 1e12
+    hbm = 64000.0 * audio_s / wall_s / 1e9
+    return {"kernel": "C2 (MSHDS + openSMILE-style) as a whole, one-stream pass", "wall_ms": round(1e3 * wall_s, 3),
+            "bound": "fp64_vector", "achieved": round(tf, 3), "peak": f64_peak_tflops, "unit": "TFLOP/s",
+            "frac": round(tf / f64_peak_tflops, 4), "algorithmic_fp64_flops": flops, "families_counted": counted,
+            "families_not_counted": "Brent iterations, path finder, pulse walker, Burg / root finder, CPPS, intensity, "
+                                    "openSMILE-style chain (latency- or issue-bound, no closed FLOP count)",
+            "survey_8d_hbm_reading": {"bytes_per_audio_s": 64000, "achieved_GBs": round(hbm, 2), "peak_GBs": hbm_peak_gbs,
+                                      "frac": round(hbm / hbm_peak_gbs, 6),
+                                      "note": "the stage reads each sample a few dozen times from L2 / LDS and computes in fp64: "
+                                              "the HBM roof SURVEY.md assigned is not what bounds it"}}

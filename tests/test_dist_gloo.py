@@ -158,6 +158,49 @@ def test_bench_gpus_n_starts_its_own_ranks():
         assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
         assert line["config"]["clips_total"] == n_total and line["value"] is None
         assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+        g = line["checks"]["gathered"]                                      # the line proves that both ranks' rows arrived
+        assert g["gathered_rows"] == n_total and g["ranks_contributing"] == 2 == g["ranks_with_a_shard"]
+        assert g["rows_at_their_global_position_from_their_owner_rank"] and g["duplicate_clips_bit_identical_across_the_gathered_table"]
+
+
+def test_bench_selftest_world3_uneven_shard_proves_every_rank_contributed():
+    """World 3 with an uneven last shard (10 clips: 4 + 4 + 2) and with a rank that owns nothing (2 clips: 1 + 1 + 0): rank 0's
+    line carries, for the GATHERED table, the owner-rank order check, the number of contributing ranks and the cross-rank
+    duplicate check."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for total, owners in ((10, 3), (2, 2)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0",
+                            "--launcher-selftest", "--total-clips", str(total)], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        g = line["checks"]["gathered"]
+        assert line["n_gpus"] == 3 and g["gathered_rows"] == total
+        assert g["ranks_contributing"] == owners == g["ranks_with_a_shard"]
+        assert g["rows_at_their_global_position_from_their_owner_rank"] and g["duplicate_clips_bit_identical_across_the_gathered_table"]
+
+
+def test_check_gathered_notices_a_missing_or_misplaced_shard():
+    from robust_speech_analysis_framework_amd import benchlib
+    world, per, pool = 3, 4, 3
+    parts = []
+    for r in range(world):
+        m = torch.as_tensor(benchlib.pool_members(r * per, per, pool), dtype=torch.float32)[:, None]
+        parts.append(benchlib.tag_rows(m * 2.0 + torch.arange(6, dtype=torch.float32)[None, :], r))
+    good = torch.cat(parts)
+    rows, g = benchlib.check_gathered(good, world, per, None, pool)
+    assert rows.shape == (12, 6) and g["ranks_contributing"] == 3 and g["rows_at_their_global_position_from_their_owner_rank"]
+    assert g["duplicate_clips_bit_identical_across_the_gathered_table"]
+    swapped = torch.cat([parts[1], parts[0], parts[2]])                      # shards in the wrong order
+    assert not benchlib.check_gathered(swapped, world, per, None, pool)[1]["rows_at_their_global_position_from_their_owner_rank"]
+    lost = torch.cat([parts[0], parts[0], parts[2]])                         # rank 1's rows never arrived
+    g = benchlib.check_gathered(lost, world, per, None, pool)[1]
+    assert g["ranks_contributing"] == 2 and not g["rows_at_their_global_position_from_their_owner_rank"]
+    parts[2][1, 0] += 1e-3                                                   # one GPU computes a different value for the same clip
+    assert not benchlib.check_gathered(torch.cat(parts), world, per, None, pool)[1]["duplicate_clips_bit_identical_across_the_gathered_table"]
 
 
 def test_bench_under_an_existing_launcher_does_not_spawn_again():
