@@ -502,6 +502,27 @@ def main():
         per_config["C4"] = {**timed(lambda: pipe.model(x4), 256 * 30.0),
                             "workload": "CNN-LSTM-attn forward on randn(256, 1500, 768) seed 1234 (7 680 audio-s per batch)"}
         del x4
+        # C3 on a corpus-shaped batch: clip lengths U[5, 60] s (seeded), about the same audio as the equal-length C3, so every
+        # clip ends in a tail window of its own length (the reference's loop, src/foundation_model_extractor.py:103-108); all
+        # windows of all clips go through rsaf_w2v2_forward_ragged in balanced sub-batches
+        if pipe.w2v2 is not None:
+            rng = np.random.default_rng(20261005)
+            secs_r = []
+            while sum(secs_r) < n_local * args.seconds:
+                secs_r.append(float(rng.uniform(5.0, 60.0)))
+            long_pool = {m: synth.synth_clip(m, 60.0) for m in range(min(args.pool, 16))}
+            lens_r = [int(round(sr_ * 16000)) for sr_ in secs_r]
+            offs_r = np.concatenate([[0], np.cumsum(lens_r)])
+            wav_r = torch.from_numpy(np.concatenate([long_pool[k % len(long_pool)][:ln] for k, ln in enumerate(lens_r)])).to(dev)
+            audio_r = float(offs_r[-1]) / 16000.0
+            n_win = sum(len(pl) for pl in pipe.w2v2.plan(lens_r)[0])
+            tails = len({pl[-1][1] for pl in pipe.w2v2.plan(lens_r)[0]})
+            per_config["C3_ragged"] = {**timed(lambda: pipe.w2v2.extract_packed(wav_r, offs_r[:-1], lens_r), audio_r),
+                                       "workload": f"Wav2Vec2-base frame embeddings on {len(lens_r)} clips of U[5, 60] s (seed 20261005, "
+                                                   f"{audio_r:.0f} audio-s, {n_win} windows, {tails} distinct tail-window lengths), all windows "
+                                                   "through rsaf_w2v2_forward_ragged"}
+            per_config["C3_ragged"]["relative_to_equal_length_C3"] = round(per_config["C3_ragged"]["value"] / per_config["C3"]["value"], 4)
+            del wav_r
         per_config["note"] = "measured after the timed region in the same process (resident inputs, no CPU baseline); the headline value is the e2e line"
         log("per-config lines: " + ", ".join(f"{k} {v['value']}" for k, v in per_config.items() if k != "note"))
 

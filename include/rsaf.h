@@ -242,6 +242,19 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
                       int pos_groups, float layer_norm_eps, const float* weights, void* workspace,
                       int64_t workspace_bytes, float* out, const int64_t* out_row_start,
                       rsaf_stream_t stream);
+/* The same forward for windows of DIFFERENT lengths in one call (the reference's loop ends every file in a tail window of
+ * its own length, src/foundation_model_extractor.py:103-108): chunk i has chunk_len[i] samples (device int32 array) and
+ * T_i = rsaf_w2v2_frames(chunk_len[i]) frames, written to rows out_row_start[i] .. +T_i (or packed, window after window,
+ * when out_row_start is NULL).  chunk_len_host: the same lengths on the host (launch geometry); they must be
+ * NON-INCREASING.  Every window is normalised, GroupNorm-ed, zero-padded (positional conv) and attended over its own
+ * frames only: the values are those of the per-window call.                                                          */
+int64_t rsaf_w2v2_workspace_bytes_ragged(const int* chunk_len_host, int n_chunks, int conv_dim, int hidden, int layers,
+                                         int heads, int intermediate, int pos_kernel, int pos_groups);
+int rsaf_w2v2_forward_ragged(const float* wav, const int64_t* chunk_start, const int* chunk_len,
+                             const int* chunk_len_host, int n_chunks, int conv_dim, int hidden, int layers, int heads,
+                             int intermediate, int pos_kernel, int pos_groups, float layer_norm_eps,
+                             const float* weights, void* workspace, int64_t workspace_bytes, float* out,
+                             const int64_t* out_row_start, rsaf_stream_t stream);
 
 /* ---- Praat-style analyses behind the MSHDS features (float64) ---------------------------------------
  * Replace the parselmouth/Praat calls of src/mshds_extractor.py: To Intensity (:41,198), To Pitch

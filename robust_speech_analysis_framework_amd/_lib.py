@@ -94,6 +94,8 @@ SIGNATURES = {
     "rsaf_w2v2_weight_offsets": (_I, [_I] * 7 + [C.POINTER(_L), _I, C.POINTER(_I)]),
     "rsaf_w2v2_workspace_bytes": (_L, [_I] * 9),
     "rsaf_w2v2_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _L, _P, _P, _P]),
+    "rsaf_w2v2_workspace_bytes_ragged": (_L, [C.POINTER(_I), _I] + [_I] * 7),
+    "rsaf_w2v2_forward_ragged": (_I, [_P, _P, _P, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _L, _P, _P, _P]),
 }
 
 _lib = None

@@ -23,14 +23,16 @@ struct GemmH3Params {
     const float* c_scale;    // forward scale of the plane output: c_scale[z1 * c_scale_zs + m * c_scale_ms] (must bound the
     int c_scale_zs, c_scale_ms;   // output: |x| * scale < 65504; the callers derive it from a Cauchy-Schwarz bound)
     unsigned* amax_out;      // optional: atomicMax of the bit pattern of |x| (x = what is written) into
-    int amax_zs, amax_div;   //   amax_out[z1 * amax_zs + (amax_row_slot ? amax_row_slot[m] : (amax_div > 0 ? m / amax_div : 0))]
+    int amax_zs;             //   amax_out[z1 * amax_zs + (amax_row_slot ? amax_row_slot[m] : 0)]
     const int* amax_row_slot;
     int amax_col_min;        // only columns >= amax_col_min take part (the V third of a fused q/k/v projection)
     const float* bias;       // [N] or nullptr
     const float* R;          // fp32 residual [M][ldr] or nullptr
     int64_t ldr, sR;
     int M, N, K, nz;
-    const int* m_per_z;      // optional: rows of batch z1 (<= M); tiles past it exit (ragged windows of one launch)
+    // optional, ragged windows of one launch: ztab[2 z1] = rows of batch z1 (<= M; tiles past it are skipped),
+    // ztab[2 z1 + 1] = element offset of the batch's fp32 output (packed windows), or -1 for z1 * sC
+    const int64_t* ztab;
     int act;
     float alpha;
     int group_m;             // row-tiles per L2 group of the tile order (0 = default)
@@ -43,7 +45,6 @@ struct GemmH3Params {
     int nz2;
     int64_t sA2, sB2, sC2, sBias2;
     int b_panel_rows;
-    int dbg;                 // measurement knobs (RSAF_G3_DBG): bit 0 = skip the epilogue (timing only, wrong results)
 };
 
 int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag);

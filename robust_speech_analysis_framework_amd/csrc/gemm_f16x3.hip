@@ -91,14 +91,15 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
 
     // Persistent workgroups: workgroup b walks tiles b, b + gridDim.x, ...  Tile t -> batch z = t / nwg and, inside the batch,
     // the XCD-aware bijective remap of the index, then GROUP_M row-tiles x all column-tiles walked column by column.
-    struct Tile { int m0, n0, Mz; int64_t z, z1, z2; };
+    struct Tile { int m0, n0, Mz; int64_t z, z1, z2, coff; };
     auto tile_at = [&](int64_t t) {
         Tile T;
         T.z = t / nwg;
         const int orig = (int)(t - T.z * nwg);
         T.z1 = p.nz2 > 1 ? T.z / p.nz2 : T.z;
         T.z2 = p.nz2 > 1 ? T.z % p.nz2 : 0;                              // (window, group) of a grouped convolution
-        T.Mz = p.m_per_z ? p.m_per_z[T.z1] : p.M;                        // rows of this batch (ragged windows)
+        T.Mz = p.ztab ? (int)p.ztab[2 * T.z1] : p.M;                     // rows of this batch (ragged windows)
+        T.coff = p.ztab ? p.ztab[2 * T.z1 + 1] : -1;
         const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
         const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
         const int GROUP_M = p.group_m;
@@ -310,7 +311,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     // sub-tile is fetched in front of the current one's stores, and the next tile's first DMA instructions go out in
     // front of the first store.
     const Tile done = cur;
-    const bool epi = !(p.dbg & 1);
     // fp32 output: 4 columns per lane (8 lanes = one 128-byte line of a row, 8 rows per instruction).  Planes only: 8 columns
     // per lane (16 bytes per plane: 2 lanes = one 32-byte panel row, 16 rows per instruction = 512 contiguous bytes per panel).
     constexpr int CW = (OUT_PLANES && !OUT_F32) ? 8 : 4, LPR = 32 / CW, RPI = 64 / LPR, NQ = 32 / RPI;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         }
     };
     if (tid < BM + BN) { tab0[tid] = e0; tab1[tid] = e1; }
-    if (epi && HAS_R) load_r(0, 0);
+    if (HAS_R) load_r(0, 0);
 
     // ---- next tile: its first two k-tiles travel while this tile's epilogue runs ----
     __syncthreads();                                     // every wave is done reading the stages; the tables are filed
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         if (nk > 1) H3_DMA(1, 1);
     }
 
-    if (epi) {
+    {
     const int m0 = done.m0, n0 = done.n0, Mz = done.Mz;
     const int64_t z = done.z, z1 = done.z1, z2 = done.z2;
     static_assert(!HAS_R || CW == 4, "the residual comes with the fp32 output");
@@ -368,7 +368,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             }
             constexpr int LAST = TM * TN - 1;
             const int sub = mt * TN + nt;
-            if (!(p.dbg & 4))
 #pragma unroll
             for (int e = 0; e < 16; ++e) patch[(4 * h + (e & 3) + 8 * (e >> 2)) * PATCH_LD + l31] = acc[mt][nt][e];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -406,8 +405,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
 #pragma unroll
                     for (int j = 0; j < CW; ++j) row_amax[q] = fmaxf(row_amax[q], fabsf(v[q][j]));
                 }
-                if (ok && !(p.dbg & 2)) {
-                    if (OUT_F32) *reinterpret_cast<float4*>(p.C + z1 * p.sC + z2 * p.sC2 + (int64_t)row * p.ldc + gc) =
+                if (ok) {
+                    if (OUT_F32) *reinterpret_cast<float4*>(p.C + (done.coff >= 0 ? done.coff : z1 * p.sC) + z2 * p.sC2 + (int64_t)row * p.ldc + gc) =
                         make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
                     if (OUT_PLANES) {
                         const float cs = csc[q];
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             for (int q = 0; q < NQ; ++q) {
                 const int row = tm + RPI * q + lr;
                 const bool r_ok = row < Mz;
-                const int slot = !r_ok ? -1 : (int)(z1 * p.amax_zs) + (p.amax_row_slot ? p.amax_row_slot[row] : (p.amax_div > 0 ? row / p.amax_div : 0));
+                const int slot = !r_ok ? -1 : (int)(z1 * p.amax_zs) + (p.amax_row_slot ? p.amax_row_slot[row] : 0);
                 unsigned long long todo = __ballot(r_ok);
                 while (todo) {
                     const int first = __ffsll((long long)todo) - 1;
@@ -601,12 +600,6 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     } while (0)
     GemmH3Params pp = p;
     if (pp.group_m <= 0) pp.group_m = 2;
-    {
-        static const int dbg = [] { const char* e = getenv("RSAF_G3_DBG"); return e ? atoi(e) : 0; }();
-        static const int gm = [] { const char* e = getenv("RSAF_G3_GROUP_M"); return e ? atoi(e) : 0; }();
-        pp.dbg = dbg;
-        if (gm > 0) pp.group_m = gm;
-    }
     // persistent workgroups, one per CU (RSAF_GEMM_WGS overrides the count: a measurement knob)
     int persistent_wgs = 256;
     {
@@ -662,7 +655,7 @@ extern "C" int rsaf_gemm_f16x3(const uint16_t* A_planes, int64_t a_plane_stride,
     p.C = C; p.ldc = ldc; p.sC = 0;
     p.Cp = C_planes; p.c_plane = c_plane_stride; p.ldcp = c_panels ? 16 : ldc; p.sCp = 0;
     p.c_scale = c_scale; p.c_scale_zs = 0; p.c_scale_ms = c_scale_stride;
-    p.amax_out = amax_out; p.amax_zs = 0; p.amax_div = 0; p.amax_row_slot = nullptr; p.amax_col_min = 0;
+    p.amax_out = amax_out; p.amax_zs = 0; p.amax_row_slot = nullptr; p.amax_col_min = 0;
     p.bias = bias; p.R = R; p.ldr = ldr; p.sR = 0;
     p.M = M; p.N = N; p.K = K; p.nz = 1; p.act = act; p.alpha = alpha;
     p.a_panel = a_panels != 0; p.b_panel = b_panels != 0; p.cp_panel = c_panels != 0;

@@ -100,6 +100,7 @@ struct Workspace {
     // scales of the activations: per window of the current conv group (conv_scale[7][G], conv_amax[7][G]), per window of
     // the call (pos_scale, fp_amax, v_amax) and per frame (ln scale, ffn scale, attention scale)
     int64_t conv_scale, conv_amax, pos_scale, fp_amax, v_amax, s_lnfp, s_x, s_ffn, s_att;
+    int64_t t_Tw, t_row0, t_ztab, t_rowwin;              // window tables (int32 / int64 views of the float workspace)
     int slabs, Tp, G;
 };
 constexpr int STAT_SLAB = 512;
@@ -111,33 +112,65 @@ static inline int64_t planes_floats(int64_t n) { return pad4(n); }
 static inline int wstat_conv(int i) { return i; }                       // i = 0..5 (conv1..6)
 constexpr int WSTAT_FP = 6, WSTAT_POS = 7, WSTAT_LAYER0 = 8;             // layer l: qkv, o, ffn1, ffn2, ffn1 bias
 
-static Workspace make_ws(const Cfg& c, int n, int len) {
-    int T[7];
-    chunk_lengths(len, T);
+// Window geometry of one call (host side): lengths are NON-INCREASING (the caller sorts), so windows of equal frame count
+// are contiguous and a group of CONV_GROUP consecutive windows wastes few tile rows.
+struct Rag {
+    int n = 0, maxlen = 0, Tmax[7] = {};
+    int64_t rows = 0;                                    // frames of all windows (rows of the encoder)
+    std::vector<int> len;
+    std::vector<int64_t> row0;                           // [n + 1] first encoder row of each window
+    std::vector<std::pair<int, int>> tgroups;            // [begin, end) of windows with equal T[6]
+    std::vector<int> T6;
+};
+
+static int make_rag(const int* len_host, int n, Rag& R) {
+    R.n = n;
+    R.len.assign(len_host, len_host + n);
+    R.row0.assign(n + 1, 0);
+    R.T6.resize(n);
+    for (int w = 0; w < n; ++w) {
+        RSAF_CHECK_ARG(w == 0 || R.len[w] <= R.len[w - 1], "window lengths must be non-increasing");
+        int T[7];
+        chunk_lengths(R.len[w], T);
+        RSAF_CHECK_ARG(T[6] >= 1, "chunk shorter than the receptive field of the feature encoder");
+        R.T6[w] = T[6];
+        R.row0[w + 1] = R.row0[w] + T[6];
+        if (w == 0) { R.maxlen = R.len[0]; for (int i = 0; i < 7; ++i) R.Tmax[i] = T[i]; }
+        if (w == 0 || T[6] != R.T6[w - 1]) R.tgroups.emplace_back(w, w + 1);
+        else R.tgroups.back().second = w + 1;
+    }
+    R.rows = R.row0[n];
+    return RSAF_OK;
+}
+
+static Workspace make_ws(const Cfg& c, const Rag& R) {
+    const int n = R.n;
+    const int* T = R.Tmax;
     Workspace w{};
     int64_t o = 0;
     auto take = [&](int64_t k) { int64_t s = o; o += pad4(k); return s; };
     const int Tt = T[6];
+    const int64_t rows = R.rows;
     const int G = n < CONV_GROUP ? n : CONV_GROUP;
     w.G = G;
     w.slabs = (T[0] + STAT_SLAB - 1) / STAT_SLAB;
     w.Tp = (int)pad4(Tt);
-    w.xn = take((int64_t)G * len);
+    w.xn = take((int64_t)G * R.maxlen);
     w.part = take((int64_t)G * w.slabs * 3 * c.C);
     w.ab = take((int64_t)G * 2 * c.C);
     w.P = take(planes_floats((int64_t)G * T[0] * c.C));
     w.Q = take(planes_floats((int64_t)G * T[1] * c.C));
-    w.c6 = take((int64_t)n * Tt * c.C);
-    w.lnfp = take(planes_floats((int64_t)n * Tt * c.C));
-    w.x = take((int64_t)n * Tt * c.Hd);
-    w.xp = take(planes_floats((int64_t)n * Tt * c.Hd));
-    w.y = take((int64_t)n * Tt * c.Hd);
-    w.att = take((int64_t)n * Tt * c.Hd);
-    w.attp = take(planes_floats((int64_t)n * Tt * c.Hd));
+    w.c6 = take(rows * c.C);
+    w.lnfp = take(planes_floats(rows * c.C));
+    w.x = take(rows * c.Hd);
+    w.xp = take(planes_floats(rows * c.Hd));
+    w.y = take(rows * c.Hd);
+    w.att = take(rows * c.Hd);
+    w.attp = take(planes_floats(rows * c.Hd));
     w.xg = take((int64_t)n * (Tt + c.PK - 1) * c.Hd);                     // fp32 or two fp16 planes (same size)
-    w.qkv = take((int64_t)n * Tt * 3 * c.Hd);
-    w.S = take((int64_t)n * c.NH * Tt * w.Tp);
-    w.ffnp = take(planes_floats((int64_t)n * Tt * c.I));
+    w.qkv = take(rows * 3 * c.Hd);
+    w.S = take((c.Hd / c.NH == 64 && Tt <= 256) ? 4 : (int64_t)n * c.NH * Tt * w.Tp);   // scores: only the three-launch attention
+    w.ffnp = take(planes_floats(rows * c.I));
     // weight planes and row scales (built once per forward call)
     for (int i = 0; i < 6; ++i) {
         w.wp_conv[i] = take(planes_floats((int64_t)c.C * KERN[i + 1] * c.C));
@@ -155,20 +188,57 @@ static Workspace make_ws(const Cfg& c, int n, int len) {
     w.conv_scale = take((int64_t)7 * G);
     w.conv_amax = take((int64_t)7 * G);
     w.pos_scale = take(n); w.fp_amax = take(n); w.v_amax = take(n);
-    const int64_t rows = (int64_t)n * Tt;
     w.s_lnfp = take(rows); w.s_x = take(rows); w.s_ffn = take(rows); w.s_att = take(rows);
+    // window tables (device): Tw[7][n] frames per layer, row0[n + 1] (int64), ztab[7][n][2] (int64: the GEMM's per-batch
+    // {rows, output offset} of conv1..6 and of the positional conv), rowwin[rows] window of every encoder row
+    w.t_Tw = take((int64_t)7 * n); w.t_row0 = take(2 * ((int64_t)n + 1)); w.t_ztab = take((int64_t)7 * n * 2 * 2);
+    w.t_rowwin = take(rows);
     w.total = o;
     return w;
 }
 
+// Tw[i][w], row0, the packed-output offsets and the row -> window map from the device copy of the lengths
+__global__ __launch_bounds__(256) void w2v2_tables_kernel(const int* __restrict__ len, int n, int C, int Hd, int* __restrict__ Tw,
+                                                          int64_t* __restrict__ row0, int64_t* __restrict__ ztab) {
+    const int KERN_[7] = {10, 3, 3, 3, 3, 2, 2}, STRD_[7] = {5, 2, 2, 2, 2, 2, 2};
+    for (int w = threadIdx.x; w < n; w += 256) {
+        int m = len[w];
+        for (int i = 0; i < 7; ++i) { m = m >= KERN_[i] ? (m - KERN_[i]) / STRD_[i] + 1 : 0; Tw[(int64_t)i * n + w] = m; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t r = 0;
+        for (int w = 0; w < n; ++w) { row0[w] = r; r += Tw[(int64_t)6 * n + w]; }
+        row0[n] = r;
+    }
+    __syncthreads();
+    // ztab[j][w] = {rows of window w, element offset of its fp32 output or -1}: j = 0..4 conv1..5 (plane outputs at the batch
+    // stride), j = 5 conv6 (packed rows of C floats), j = 6 positional conv (packed rows of Hd floats)
+    for (int w = threadIdx.x; w < n; w += 256) {
+        for (int j = 0; j < 5; ++j) { ztab[((int64_t)j * n + w) * 2] = Tw[(int64_t)(j + 1) * n + w]; ztab[((int64_t)j * n + w) * 2 + 1] = -1; }
+        ztab[((int64_t)5 * n + w) * 2] = Tw[(int64_t)6 * n + w]; ztab[((int64_t)5 * n + w) * 2 + 1] = row0[w] * C;
+        ztab[((int64_t)6 * n + w) * 2] = Tw[(int64_t)6 * n + w]; ztab[((int64_t)6 * n + w) * 2 + 1] = row0[w] * Hd;
+    }
+}
+__global__ __launch_bounds__(256) void w2v2_rowwin_kernel(const int64_t* __restrict__ row0, int* __restrict__ rowwin) {
+    const int w = blockIdx.x;
+    const int64_t a = row0[w], b = row0[w + 1];
+    for (int64_t r = a + threadIdx.x; r < b; r += 256) rowwin[r] = w;
+}
+__global__ __launch_bounds__(256) void fill_i32_kernel(int* __restrict__ p, int n, int v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // ---- per-chunk zero-mean / unit-variance normalisation -------------------------------------------
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ wav,
-                                                        const int64_t* __restrict__ starts, int len,
-                                                        float* __restrict__ xn) {
+                                                        const int64_t* __restrict__ starts, const int* __restrict__ wlen,
+                                                        int maxlen, float* __restrict__ xn) {
     __shared__ double red[4];
     __shared__ double bc;
     const float* x = wav + starts[blockIdx.x];
-    float* o = xn + (int64_t)blockIdx.x * len;
+    const int len = wlen[blockIdx.x];                        // every window is normalised over its own samples
+    float* o = xn + (int64_t)blockIdx.x * maxlen;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double s = 0.0;
     for (int i = threadIdx.x; i < len; i += 256) s += (double)x[i];
@@ -207,9 +277,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
                                                     float* __restrict__ part, const float* __restrict__ ab,
                                                     const float* __restrict__ scale,
                                                     unsigned short* __restrict__ outp, int64_t plane, int len,
-                                                    int T0, int C, int slab, int slabs) {
+                                                    const int* __restrict__ T0w, int T0, int C, int slab, int slabs) {
+    // len / T0: the longest window's samples / frames (strides of xn and of the output); T0w: frames of every window
     const int chunk = blockIdx.y, sl = blockIdx.x;
-    const int t0 = sl * slab, t1 = min(T0, t0 + slab);
+    const int t0 = sl * slab, t1 = min(T0w[chunk], t0 + slab);
     const float* __restrict__ x = xn + (int64_t)chunk * len;
     float wr[CPT][10], a[CPT], b[CPT], s[CPT], q[CPT], mx[CPT];
     int ch[CPT];
@@ -267,10 +338,12 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
 // GroupNorm coefficients per (window, channel) and the window's bound: |GELU(a y + b)| <= |a| max|y| + |b|
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ g,
                                                           const float* __restrict__ be, float* __restrict__ ab,
-                                                          unsigned* __restrict__ amax, int n, int C, int slabs, int T0) {
+                                                          unsigned* __restrict__ amax, int n, int C, int slabs,
+                                                          const int* __restrict__ T0w) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)n * C) return;
     const int chunk = (int)(i / C), c = (int)(i % C);
+    const int T0 = T0w[chunk];
     double s = 0.0, q = 0.0;
     float mx = 0.f;
     for (int sl = 0; sl < slabs; ++sl) {
@@ -296,7 +369,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         float* __restrict__ out, int64_t rows, int D, float eps,
-                                                        const int64_t* __restrict__ out_row_start, int T,
+                                                        const int64_t* __restrict__ out_row_start, const int* __restrict__ rowwin,
+                                                        const int64_t* __restrict__ row0,
                                                         unsigned short* __restrict__ planes, int64_t plane, int panel,
                                                         float* __restrict__ scale_out, const unsigned* __restrict__ bound_w,
                                                         const unsigned* __restrict__ bound_b, float* __restrict__ bound_scale_out) {
@@ -309,8 +383,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (!valid && !(planes && panel)) return;
     const int64_t row = valid ? row_raw : rows - 1;
     const int lane = threadIdx.x & 63;
-    // optional scatter: row r of chunk i lands at output row out_row_start[i] + r (vstack order)
-    const int64_t orow = out_row_start ? out_row_start[row / T] + row % T : row;
+    // optional scatter: frame t of window w lands at output row out_row_start[w] + t (vstack order)
+    int64_t orow = row;
+    if (out_row_start) { const int w = rowwin[row]; orow = out_row_start[w] + (row - row0[w]); }
     const int D4 = D >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x + row * D);
     const float4* r4 = r ? reinterpret_cast<const float4*>(r + row * D) : nullptr;
@@ -419,15 +494,19 @@ typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 typedef const __attribute__((address_space(1))) void* attn_glb_ptr;
 
 __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ planes,
-                                                            int64_t plane_stride, int64_t n_rows, int T, int NH, int Hd, float scale,
+                                                            int64_t plane_stride, int64_t n_rows, const int* __restrict__ Tw,
+                                                            const int64_t* __restrict__ row0, int NH, int Hd, float scale,
                                                             const unsigned* __restrict__ v_amax, float* __restrict__ row_scale) {
     constexpr int HD = 64, KB = 128, TILE = KB * HD;                            // one staged block: 32 KB
     extern __shared__ __attribute__((aligned(1024))) float kvbuf[];             // two blocks
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int win = blockIdx.x / NH, head = blockIdx.x - win * NH;
+    const int T = Tw[win];                                                      // frames of this window (windows are ragged)
+    if (blockIdx.y * 128 >= T) return;                                          // (workgroup-uniform)
+    const int64_t wrow0 = row0[win];
     const int64_t ld = 3 * (int64_t)Hd;
-    const float* base = qkv + (int64_t)win * T * ld + (int64_t)head * HD;      // q of this window and head
+    const float* base = qkv + wrow0 * ld + (int64_t)head * HD;                 // q of this window and head
     const int q0 = blockIdx.y * 128 + wv * 32;
     const int nblk = (T + KB - 1) / KB;                                         // 1 or 2 key blocks
 
@@ -554,13 +633,13 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
     // k16 panels of n_rows rows (gemm_f16x3.h): column head * 64 + 32 u + l31 -> panel 4 head + 2 u + (l31 >> 4), k = l31 & 15
     const float osc = f16x2_scale_for_bound(__uint_as_float(v_amax[win]) * 1.00001f);
     const int64_t panel_sz = n_rows * 16;
-    unsigned short* op = planes + ((int64_t)(head * 4) + (l31 >> 4)) * panel_sz + ((int64_t)win * T) * 16 + (l31 & 15);
+    unsigned short* op = planes + ((int64_t)(head * 4) + (l31 >> 4)) * panel_sz + wrow0 * 16 + (l31 & 15);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (q < T) {
             unsigned short* d0 = op + (int64_t)q * 16;
-            if (head == 0 && l31 == 0) row_scale[(int64_t)win * T + q] = osc;
+            if (head == 0 && l31 == 0) row_scale[wrow0 + q] = osc;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const float x = (u == 0 ? o0[e] : o1[e]) * osc;
@@ -630,10 +709,12 @@ __global__ __launch_bounds__(256) void regroup_kernel(const float4* __restrict__
 // the same regrouping as two fp16 planes (A operand of the positional convolution on the f16x3 GEMM), scaled per window by
 // the power of two that the window's largest |x| (reported by the feature projection's epilogue) asks for
 __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __restrict__ x, unsigned short* __restrict__ xg,
-                                                             int64_t plane, int n, int T, int Hd4, int G, int K,
+                                                             int64_t plane, int n, int Tmax, int Hd4, int G, int K,
+                                                             const int* __restrict__ Tw, const int64_t* __restrict__ row0,
                                                              const unsigned* __restrict__ amax, float* __restrict__ win_scale) {
+    // destination [window][group][Tmax + K - 1][cg]: frame t of window w at tt = t + K / 2, zeros around its T_w frames
     const int cg4 = Hd4 / G;
-    const int TT = T + K - 1;
+    const int TT = Tmax + K - 1;
     const int64_t total = (int64_t)n * G * TT * cg4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ci = (int)(i % cg4);
@@ -644,7 +725,7 @@ __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __res
         const int t = tt - K / 2;
         const float sc = f16x2_scale_for_bound(__uint_as_float(amax[chunk]));
         if (g == 0 && tt == 0 && ci == 0) win_scale[chunk] = sc;
-        const float4 v = (t >= 0 && t < T) ? x[(chunk * T + t) * Hd4 + g * cg4 + ci] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = (t >= 0 && t < Tw[chunk]) ? x[(row0[chunk] + t) * Hd4 + g * cg4 + ci] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float vv[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
         unsigned short hh[4], ll[4];
 #pragma unroll
@@ -656,22 +737,22 @@ __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __res
 }
 
 static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
-              float eps, hipStream_t s, const int64_t* out_row_start = nullptr, int T = 1,
-              unsigned short* planes = nullptr, bool panel = false, float* scale_out = nullptr,
+              float eps, hipStream_t s, const int64_t* out_row_start = nullptr, const int* rowwin = nullptr,
+              const int64_t* row0 = nullptr, unsigned short* planes = nullptr, bool panel = false, float* scale_out = nullptr,
               const unsigned* bound_w = nullptr, const unsigned* bound_b = nullptr, float* bound_scale_out = nullptr) {
     const int64_t blocks = (rows + 3) / 4;
     RSAF_CHECK_ARG(blocks <= 0x7fffffffLL, "too many rows");
     RSAF_CHECK_ARG(!planes || scale_out, "planes need their scale array");
     ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * (4 * (r ? 2 : 1) + (out ? 4 : 0) + (planes ? 4 : 0)));
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, r, g, b, out, rows, D, eps,
-                       out_row_start, T, planes, rows * D, panel ? 1 : 0, scale_out, bound_w, bound_b, bound_scale_out);
+                       out_row_start, rowwin, row0, planes, rows * D, panel ? 1 : 0, scale_out, bound_w, bound_b, bound_scale_out);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }
 
 template <bool APPLY>
 static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* part, const float* ab, const float* scale,
-                        unsigned short* outp, int64_t plane, int n, int len, int T0, int slab, int slabs, hipStream_t s) {
+                        unsigned short* outp, int64_t plane, int n, int len, const int* T0w, int T0, int slab, int slabs, hipStream_t s) {
     const int threads = c.C <= 256 ? c.C : 256;
     const int cpt = c.C / threads;
     dim3 grid((unsigned)slabs, (unsigned)n);
@@ -681,7 +762,7 @@ static int conv0_launch(const Cfg& c, const float* xn, const float* w0, float* p
     ProfScope prof(APPLY ? "w2v2_conv0_apply" : "w2v2_conv0_stats", s, 0.0,
                    APPLY ? (double)n * ((double)c.C * T0 * 4.0 + 4.0 * (5.0 * T0 + 5.0)) : (double)n * 4.0 * (5.0 * T0 + 5.0));
 #define RSAF_C0(CPT)                                                                                       \
-    hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, scale, outp, plane, len, T0, \
+    hipLaunchKernelGGL((conv0_kernel<CPT, APPLY>), grid, dim3(threads), 0, s, xn, w0, part, ab, scale, outp, plane, len, T0w, T0, \
                        c.C, slab, slabs)
     switch (cpt) {
         case 1: RSAF_C0(1); break;
@@ -735,12 +816,28 @@ int rsaf_w2v2_weight_offsets(int conv_dim, int hidden, int layers, int heads, in
     return RSAF_OK;
 }
 
+static int forward_impl(const float* wav, const int64_t* chunk_start, const int* len_dev_or_null, const Rag& R, const Cfg& c,
+                        const float* weights, void* workspace, int64_t workspace_bytes, float* out, const int64_t* out_row_start,
+                        hipStream_t s);
+
 int64_t rsaf_w2v2_workspace_bytes(int n_chunks, int chunk_len, int conv_dim, int hidden, int layers, int heads,
                                   int intermediate, int pos_kernel, int pos_groups) {
     Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, 1e-5f};
     if (check_cfg(c) != RSAF_OK || n_chunks <= 0) return -1;
     if (rsaf_w2v2_frames(chunk_len) <= 0) return -1;
-    return make_ws(c, n_chunks, chunk_len).total * (int64_t)sizeof(float);
+    std::vector<int> len((size_t)n_chunks, chunk_len);
+    Rag R;
+    if (make_rag(len.data(), n_chunks, R) != RSAF_OK) return -1;
+    return make_ws(c, R).total * (int64_t)sizeof(float);
+}
+
+int64_t rsaf_w2v2_workspace_bytes_ragged(const int* chunk_len_host, int n_chunks, int conv_dim, int hidden, int layers, int heads,
+                                         int intermediate, int pos_kernel, int pos_groups) {
+    Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, 1e-5f};
+    if (check_cfg(c) != RSAF_OK || n_chunks <= 0 || !chunk_len_host) return -1;
+    Rag R;
+    if (make_rag(chunk_len_host, n_chunks, R) != RSAF_OK) return -1;
+    return make_ws(c, R).total * (int64_t)sizeof(float);
 }
 
 int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks, int chunk_len, int conv_dim,
@@ -750,43 +847,85 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, layer_norm_eps};
     int rc = check_cfg(c);
     if (rc != RSAF_OK) return rc;
-    RSAF_CHECK_ARG(n_chunks >= 0 && n_chunks <= 65535 / std::max(c.NH, c.PG), "too many chunks per call");
+    RSAF_CHECK_ARG(n_chunks >= 0, "negative chunk count");
     if (n_chunks == 0) return RSAF_OK;
+    std::vector<int> len((size_t)n_chunks, chunk_len);
+    Rag R;
+    if ((rc = make_rag(len.data(), n_chunks, R))) return rc;
+    return forward_impl(wav, chunk_start, nullptr, R, c, weights, workspace, workspace_bytes, out, out_row_start, (hipStream_t)stream);
+}
+
+int rsaf_w2v2_forward_ragged(const float* wav, const int64_t* chunk_start, const int* chunk_len, const int* chunk_len_host,
+                             int n_chunks, int conv_dim, int hidden, int layers, int heads, int intermediate, int pos_kernel,
+                             int pos_groups, float layer_norm_eps, const float* weights, void* workspace,
+                             int64_t workspace_bytes, float* out, const int64_t* out_row_start, rsaf_stream_t stream) {
+    Cfg c{conv_dim, hidden, layers, heads, intermediate, pos_kernel, pos_groups, layer_norm_eps};
+    int rc = check_cfg(c);
+    if (rc != RSAF_OK) return rc;
+    RSAF_CHECK_ARG(n_chunks >= 0, "negative chunk count");
+    if (n_chunks == 0) return RSAF_OK;
+    RSAF_CHECK_ARG(chunk_len && chunk_len_host, "NULL length table");
+    Rag R;
+    if ((rc = make_rag(chunk_len_host, n_chunks, R))) return rc;
+    return forward_impl(wav, chunk_start, chunk_len, R, c, weights, workspace, workspace_bytes, out, out_row_start, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+static int forward_impl(const float* wav, const int64_t* chunk_start, const int* len_dev_or_null, const Rag& R, const Cfg& c,
+                        const float* weights, void* workspace, int64_t workspace_bytes, float* out, const int64_t* out_row_start,
+                        hipStream_t s) {
+    int rc = RSAF_OK;
+    const int n_chunks = R.n;
+    RSAF_CHECK_ARG(n_chunks <= 65535 / std::max(c.NH, c.PG), "too many chunks per call");
     RSAF_CHECK_ARG(wav && chunk_start && weights && workspace && out, "NULL pointer");
-    int T[7];
-    chunk_lengths(chunk_len, T);
-    RSAF_CHECK_ARG(T[6] >= 1, "chunk shorter than the receptive field of the feature encoder");
-    const Workspace W = make_ws(c, n_chunks, chunk_len);
+    const int* T = R.Tmax;                                   // frames of the LONGEST window per layer (strides, grids)
+    const Workspace W = make_ws(c, R);
     if (workspace_bytes < W.total * (int64_t)sizeof(float)) {
         set_error("rsaf_w2v2_forward: workspace too small");
         return RSAF_ERR_WORKSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
     const Layout L = make_layout(c);
     float* ws = static_cast<float*>(workspace);
     const float* Wt = weights;
     const int n = n_chunks, C = c.C, Hd = c.Hd, Tt = T[6];
-    const int64_t rows = (int64_t)n * Tt;
+    const int64_t rows = R.rows;
     RSAF_CHECK_ARG(rows <= 0x7fffffffLL, "too many frames per call");
 
     auto planes_at = [&](int64_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
     auto bits_at = [&](int64_t off) { return reinterpret_cast<unsigned*>(ws + off); };
     auto wstat = [&](int idx) { return bits_at(W.wstat) + 2 * idx; };        // {max row norm, max |element|} of matrix idx
+    // window tables on the device (every window has its own length: the reference's tail windows)
+    int* Tw = reinterpret_cast<int*>(ws + W.t_Tw);           // [7][n]
+    int64_t* row0 = reinterpret_cast<int64_t*>(ws + W.t_row0);
+    int64_t* ztab = reinterpret_cast<int64_t*>(ws + W.t_ztab);   // [7][n][2]
+    int* rowwin = reinterpret_cast<int*>(ws + W.t_rowwin);
+    const int* wlen = len_dev_or_null;
+    {
+        if (!wlen) {                                         // equal windows: the length table is filled here
+            int* wl = reinterpret_cast<int*>(ws + W.s_att);  // (scratch: the attention scales are written much later)
+            hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, wl, n, R.maxlen);
+            wlen = wl;
+        }
+        hipLaunchKernelGGL(w2v2_tables_kernel, dim3(1), dim3(256), 0, s, wlen, n, C, Hd, Tw, row0, ztab);
+        hipLaunchKernelGGL(w2v2_rowwin_kernel, dim3(n), dim3(256), 0, s, row0, rowwin);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
     // helper: C = act(A B^T + bias (+ R)) on the f16x3 kernel; A / B as fp16 plane pairs with their scales
     struct Out { float* Cf; int64_t sC; uint16_t* Cp; int64_t c_plane, sCp; const float* c_scale; int cs_zs, cs_ms; bool cp_panel; };
     auto gemm3 = [&](const uint16_t* A, int64_t a_plane, int64_t lda, int64_t sA, const float* a_scale, int as_zs, int as_ms,
-                     const uint16_t* B, const float* b_scale, int M, int N, int K, const Out& o, const float* bias, const float* R,
-                     int nz, int act, const char* tag, bool a_panel, unsigned* amax = nullptr, int amax_zs = 0, int amax_div = 0,
-                     int amax_col_min = 0) {
+                     const uint16_t* B, const float* b_scale, int M, int N, int K, const Out& o, const float* bias, const float* Rr,
+                     int nz, int act, const char* tag, bool a_panel, unsigned* amax = nullptr, int amax_zs = 0,
+                     const int* amax_row_slot = nullptr, int amax_col_min = 0, const int64_t* ztab = nullptr) {
         GemmH3Params p{};
         p.a_panel = a_panel; p.b_panel = 1; p.cp_panel = o.cp_panel;
         p.A = A; p.a_plane = a_plane; p.lda = lda; p.sA = sA; p.a_scale = a_scale; p.a_scale_zs = as_zs; p.a_scale_ms = as_ms;
         p.B = B; p.b_plane = (int64_t)N * K; p.ldb = 16; p.b_scale = b_scale;
         p.C = o.Cf; p.ldc = N; p.sC = o.sC;
         p.Cp = o.Cp; p.c_plane = o.c_plane; p.ldcp = N; p.sCp = o.sCp; p.c_scale = o.c_scale; p.c_scale_zs = o.cs_zs; p.c_scale_ms = o.cs_ms;
-        p.amax_out = amax; p.amax_zs = amax_zs; p.amax_div = amax_div; p.amax_col_min = amax_col_min;
-        p.bias = bias; p.R = R; p.ldr = N; p.sR = o.sC;
-        p.M = M; p.N = N; p.K = K; p.nz = nz; p.act = act; p.alpha = 1.0f; p.group_m = 0;
+        p.amax_out = amax; p.amax_zs = amax_zs; p.amax_row_slot = amax_row_slot; p.amax_col_min = amax_col_min;
+        p.bias = bias; p.R = Rr; p.ldr = N; p.sR = o.sC;
+        p.M = M; p.N = N; p.K = K; p.nz = nz; p.ztab = ztab; p.act = act; p.alpha = 1.0f; p.group_m = 0;
         return launch_gemm_f16x3(p, s, tag);
     };
     // 0. weights of the dense layers as fp16 plane pairs in the k16-panel layout, each row with its own power-of-two scale
@@ -813,7 +952,7 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             if ((rc = split_wp(lo.w1, c.I, Hd, W.wp_1[l], W.ws_1[l], b0 + 2))) return rc;
             if ((rc = split_wp(lo.w2, Hd, c.I, W.wp_2[l], W.ws_2[l], b0 + 3))) return rc;
             // max |b1| (word 1 of the statistics of the bias seen as one row); the scale it writes goes to a scratch slot
-            if ((rc = launch_f16x2_row_scales(Wt + lo.b1, 1, c.I, c.I, ws + W.s_att, nullptr, wstat(b0 + 4), s))) return rc;
+            if ((rc = launch_f16x2_row_scales(Wt + lo.b1, 1, c.I, c.I, ws + W.pos_scale, nullptr, wstat(b0 + 4), s))) return rc;
         }
     }
     // 1-3. feature encoder, CONV_GROUP windows at a time (its activations are the large ones: 15 999 x 512 per window)
@@ -823,62 +962,68 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
     unsigned* camax = bits_at(W.conv_amax);                  // [7][G]: largest |output| of layer i (layer 0: its bound)
     for (int g0 = 0; g0 < n; g0 += gstep) {
         const int g = std::min(gstep, n - g0);
+        // the group's longest window is its first (lengths are non-increasing): its frame counts size the group's launches
+        int Tg[7];
+        chunk_lengths(R.len[g0], Tg);
         RSAF_CHECK_HIP(hipMemsetAsync(camax, 0, sizeof(unsigned) * 7 * W.G, s));
         // 1. per-chunk normalisation (HF feature extractor)
         {
-            ProfScope prof("w2v2_normalize", s, 0.0, (double)g * chunk_len * 4 * 3);
-            hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(256), 0, s, wav, chunk_start + g0, chunk_len, ws + W.xn);
+            ProfScope prof("w2v2_normalize", s, 0.0, (double)g * R.len[g0] * 4 * 3);
+            hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(256), 0, s, wav, chunk_start + g0, wlen + g0, R.maxlen, ws + W.xn);
             RSAF_CHECK_HIP(hipGetLastError());
         }
         // 2. conv0 + GroupNorm + GELU (stats pass, finalize, apply pass); the apply pass writes fp16 plane pairs
-        rc = conv0_launch<false>(c, ws + W.xn, Wt + L.conv0, ws + W.part, nullptr, nullptr, nullptr, 0, g, chunk_len, T[0],
-                                 STAT_SLAB, W.slabs, s);
+        const int slabs_g = (Tg[0] + STAT_SLAB - 1) / STAT_SLAB;
+        rc = conv0_launch<false>(c, ws + W.xn, Wt + L.conv0, ws + W.part, nullptr, nullptr, nullptr, 0, g, R.maxlen, Tw + g0, T[0],
+                                 STAT_SLAB, slabs_g, s);
         if (rc) return rc;
         {
             const int64_t tot = (int64_t)g * C;
             hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ws + W.part,
-                               Wt + L.gng, Wt + L.gnb, ws + W.ab, camax, g, C, W.slabs, T[0]);
+                               Wt + L.gng, Wt + L.gnb, ws + W.ab, camax, g, C, slabs_g, Tw + g0);
             RSAF_CHECK_HIP(hipGetLastError());
             if ((rc = launch_scale_from_bound(camax, g, nullptr, 1.0f, nullptr, cscale, s))) return rc;
         }
         {
             const int slab = 128;
-            rc = conv0_launch<true>(c, ws + W.xn, Wt + L.conv0, nullptr, ws + W.ab, cscale, planes_at(W.P), (int64_t)g * T[0] * C, g,
-                                    chunk_len, T[0], slab, (T[0] + slab - 1) / slab, s);
+            rc = conv0_launch<true>(c, ws + W.xn, Wt + L.conv0, nullptr, ws + W.ab, cscale, planes_at(W.P), (int64_t)W.G * T[0] * C, g,
+                                    R.maxlen, Tw + g0, T[0], slab, (Tg[0] + slab - 1) / slab, s);
             if (rc) return rc;
         }
         // 3. conv1..6 as GEMMs over the channels-last sequence (lda = stride * C, K = taps * C) with fused GELU;
         //    the output goes out as planes (the next layer's A), the last one as fp32 rows for the LayerNorm.
         //    Scale of layer i's output, per window: |GELU(x)| <= |x| <= |a|_2 |w|_2 <= sqrt(K) max|a| max_n |w_n|_2 with
-        //    max|a| = the largest |output| of layer i - 1, which that layer's epilogue reported (layer 0: the GroupNorm bound)
+        //    max|a| = the largest |output| of layer i - 1, which that layer's epilogue reported (layer 0: the GroupNorm bound).
+        //    Every window keeps the longest window's row allotment (batch stride T[i] rows) and has its own row count
+        //    (ztab); the last layer writes its rows packed (window w at row row0[w]).
         uint16_t* cur = planes_at(W.P);
         uint16_t* nxt = planes_at(W.Q);
         for (int i = 1; i < 7; ++i) {
             const bool last = i == 6;
             const int K = KERN[i] * C;
             Out o{};
-            if (last) { o.Cf = ws + W.c6 + (int64_t)g0 * Tt * C; o.sC = (int64_t)T[i] * C; }
+            if (last) { o.Cf = ws + W.c6; o.sC = 0; }
             else {
                 if ((rc = launch_scale_from_bound(camax + (int64_t)(i - 1) * W.G, g, reinterpret_cast<const float*>(wstat(wstat_conv(i - 1))),
                                                   sqrtf((float)K) * 1.00001f, nullptr, cscale + (int64_t)i * W.G, s))) return rc;
-                o.Cp = nxt; o.c_plane = (int64_t)g * T[i] * C; o.sCp = (int64_t)T[i] * C; o.sC = (int64_t)T[i] * C;
+                o.Cp = nxt; o.c_plane = (int64_t)W.G * T[i] * C; o.sCp = (int64_t)T[i] * C; o.sC = (int64_t)T[i] * C;
                 o.c_scale = cscale + (int64_t)i * W.G; o.cs_zs = 1; o.cs_ms = 0;
             }
-            rc = gemm3(cur, (int64_t)g * T[i - 1] * C, (int64_t)STRD[i] * C, (int64_t)T[i - 1] * C, cscale + (int64_t)(i - 1) * W.G, 1, 0,
-                       planes_at(W.wp_conv[i - 1]), ws + W.ws_conv[i - 1], T[i], C, K, o, nullptr, nullptr, g, ACT_GELU, "w2v2_gemm",
-                       false, last ? nullptr : camax + (int64_t)i * W.G, 1, 0);
+            rc = gemm3(cur, (int64_t)W.G * T[i - 1] * C, (int64_t)STRD[i] * C, (int64_t)T[i - 1] * C, cscale + (int64_t)(i - 1) * W.G, 1, 0,
+                       planes_at(W.wp_conv[i - 1]), ws + W.ws_conv[i - 1], Tg[i], C, K, o, nullptr, nullptr, g, ACT_GELU, "w2v2_gemm",
+                       false, last ? nullptr : camax + (int64_t)i * W.G, 1, nullptr, 0, ztab + ((int64_t)(i - 1) * n + g0) * 2);
             if (rc) return rc;
             std::swap(cur, nxt);
         }
     }
     // 4. feature projection: LayerNorm (-> planes, exact row scales) + Linear; its epilogue reports max |x| per window
     RSAF_CHECK_HIP(hipMemsetAsync(ws + W.fp_amax, 0, sizeof(unsigned) * n, s));
-    rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, 1, planes_at(W.lnfp), true, ws + W.s_lnfp);
+    rc = ln(ws + W.c6, nullptr, Wt + L.fplg, Wt + L.fplb, nullptr, rows, C, c.eps, s, nullptr, nullptr, nullptr, planes_at(W.lnfp), true, ws + W.s_lnfp);
     if (rc) return rc;
     {
         Out o{}; o.Cf = ws + W.x;
         rc = gemm3(planes_at(W.lnfp), rows * C, C, 0, ws + W.s_lnfp, 0, 1, planes_at(W.wp_fp), ws + W.ws_fp, (int)rows, Hd, C, o,
-                   Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", true, bits_at(W.fp_amax), 0, Tt);
+                   Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", true, bits_at(W.fp_amax), 0, rowwin);
         if (rc) return rc;
     }
     // 5. positional conv embedding (grouped, weight norm folded), GELU, x = LN(x + pos)
@@ -887,14 +1032,14 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         const int TT = Tt + c.PK - 1;
         const int64_t tot4 = (int64_t)n * TT * (Hd / 4);
         if (cg % 16 == 0) {
-            // grouped conv as a two-level batched GEMM on the f16x3 kernel's 256 x 64 tile: batch (window, group), M = T rows
+            // grouped conv as a two-level batched GEMM on the f16x3 kernel's 256 x 64 tile: batch (window, group), M = T_w rows
             // (overlapping windows of the regrouped sequence: lda = cg), N = cg output channels, K = PK cg
             const int64_t plane = (int64_t)n * TT * Hd;
             {
                 ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 32);
                 hipLaunchKernelGGL(regroup_planes_kernel, dim3((unsigned)std::min<int64_t>((tot4 + 255) / 256, 4096)), dim3(256),
                                    0, s, reinterpret_cast<const float4*>(ws + W.x), reinterpret_cast<unsigned short*>(planes_at(W.xg)),
-                                   plane, n, Tt, Hd / 4, c.PG, c.PK, bits_at(W.fp_amax), ws + W.pos_scale);
+                                   plane, n, Tt, Hd / 4, c.PG, c.PK, Tw + (int64_t)6 * n, row0, bits_at(W.fp_amax), ws + W.pos_scale);
                 RSAF_CHECK_HIP(hipGetLastError());
             }
             GemmH3Params p{};
@@ -902,29 +1047,35 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
             p.a_scale = ws + W.pos_scale; p.a_scale_zs = 1; p.a_scale_ms = 0;
             p.B = planes_at(W.wp_pos); p.b_plane = (int64_t)Hd * c.PK * cg; p.ldb = 16; p.b_panel = 1; p.b_panel_rows = Hd; p.sB2 = (int64_t)cg * 16;
             p.b_scale = ws + W.ws_pos;
-            p.C = ws + W.y; p.ldc = Hd; p.sC = (int64_t)Tt * Hd; p.sC2 = cg;
+            p.C = ws + W.y; p.ldc = Hd; p.sC = 0; p.sC2 = cg;
             p.bias = Wt + L.posb; p.sBias2 = cg;
-            p.M = Tt; p.N = cg; p.K = c.PK * cg; p.nz = n * c.PG; p.nz2 = c.PG; p.act = ACT_GELU; p.alpha = 1.0f;
+            p.M = Tt; p.ztab = ztab + (int64_t)6 * n * 2; p.N = cg; p.K = c.PK * cg; p.nz = n * c.PG; p.nz2 = c.PG; p.act = ACT_GELU; p.alpha = 1.0f;
             rc = launch_gemm_f16x3(p, s, "w2v2_posconv_gemm");
             if (rc) return rc;
         } else {
-        {
-            ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 32);
-            hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)std::min<int64_t>((tot4 + 255) / 256, 4096)), dim3(256),
-                               0, s, reinterpret_cast<const float4*>(ws + W.x), reinterpret_cast<float4*>(ws + W.xg),
-                               n, Tt, Hd / 4, c.PG, c.PK);
-            RSAF_CHECK_HIP(hipGetLastError());
+            // group widths that are no multiple of 16 (test geometries): exact-fp32 GEMM, one launch per run of equal windows
+            for (const auto& tg : R.tgroups) {
+                const int nw = tg.second - tg.first, Tq = R.T6[tg.first], TTq = Tq + c.PK - 1;
+                const int64_t r0 = R.row0[tg.first];
+                const int64_t t4 = (int64_t)nw * TTq * (Hd / 4);
+                {
+                    ProfScope prof("w2v2_regroup", s, 0.0, (double)t4 * 32);
+                    hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)std::min<int64_t>((t4 + 255) / 256, 4096)), dim3(256),
+                                       0, s, reinterpret_cast<const float4*>(ws + W.x + r0 * Hd), reinterpret_cast<float4*>(ws + W.xg),
+                                       nw, Tq, Hd / 4, c.PG, c.PK);
+                    RSAF_CHECK_HIP(hipGetLastError());
+                }
+                GemmParams p = gemm_params_plain(ws + W.xg, Wt + L.posw, ws + W.y + r0 * Hd, Tq, cg, c.PK * cg, cg, (int64_t)c.PK * cg, Hd);
+                p.nz = nw * c.PG; p.nz2 = c.PG;
+                p.sA1 = (int64_t)c.PG * TTq * cg; p.sA2 = (int64_t)TTq * cg;
+                p.sB1 = 0; p.sB2 = (int64_t)cg * c.PK * cg;
+                p.sC1 = (int64_t)Tq * Hd; p.sC2 = cg;
+                p.bias = Wt + L.posb; p.sBias2 = cg; p.act = ACT_GELU;
+                rc = launch_gemm_f32(p, s, "w2v2_posconv_gemm");
+                if (rc) return rc;
+            }
         }
-        GemmParams p = gemm_params_plain(ws + W.xg, Wt + L.posw, ws + W.y, Tt, cg, c.PK * cg, cg, (int64_t)c.PK * cg, Hd);
-        p.nz = n * c.PG; p.nz2 = c.PG;
-        p.sA1 = (int64_t)c.PG * TT * cg; p.sA2 = (int64_t)TT * cg;
-        p.sB1 = 0; p.sB2 = (int64_t)cg * c.PK * cg;
-        p.sC1 = (int64_t)Tt * Hd; p.sC2 = cg;
-        p.bias = Wt + L.posb; p.sBias2 = cg; p.act = ACT_GELU;
-        rc = launch_gemm_f32(p, s, "w2v2_posconv_gemm");
-        if (rc) return rc;
-        }
-        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true, ws + W.s_x);
+        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, nullptr, nullptr, planes_at(W.xp), true, ws + W.s_x);
         if (rc) return rc;
     }
     // 6. encoder layers (post-LN)
@@ -941,59 +1092,67 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
         {
             Out o{}; o.Cf = ws + W.qkv;
             rc = gemm3(planes_at(W.xp), rows * Hd, Hd, 0, ws + W.s_x, 0, 1, planes_at(W.wp_qkv[l]), ws + W.ws_qkv[l], (int)rows, 3 * Hd, Hd, o,
-                       Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true, fused ? bits_at(W.v_amax) : nullptr, 0, Tt, 2 * Hd);
+                       Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true, fused ? bits_at(W.v_amax) : nullptr, 0, rowwin, 2 * Hd);
             if (rc) return rc;
         }
         if (fused) {
             // 2 x 2 T^2 hd flops per (chunk, head)
-            ProfScope prof("w2v2_attn_fused", s, 4.0 * (double)n * c.NH * (double)Tt * Tt * hd, 0.0);
+            double att_flops = 0.0;
+            for (const auto& tg : R.tgroups) att_flops += 4.0 * (tg.second - tg.first) * c.NH * (double)R.T6[tg.first] * R.T6[tg.first] * hd;
+            ProfScope prof("w2v2_attn_fused", s, att_flops, 0.0);
             RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                2 * 128 * 64 * (int)sizeof(float)));
             hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256),
-                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, rows, Tt, c.NH, Hd, scale,
-                               bits_at(W.v_amax), ws + W.s_att);
+                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, rows, Tw + (int64_t)6 * n, row0,
+                               c.NH, Hd, scale, bits_at(W.v_amax), ws + W.s_att);
             RSAF_CHECK_HIP(hipGetLastError());
         } else {
+        // three launches per run of equal windows (head widths other than 64: test geometries)
+        for (const auto& tg : R.tgroups) {
+            const int nw = tg.second - tg.first, Tq = R.T6[tg.first], Tpq = (int)pad4(Tq);
+            const int64_t r0 = R.row0[tg.first];
+            const float* qkvg = ws + W.qkv + r0 * 3 * Hd;
         {   // S = scale * Q K^T per (chunk, head)
-            GemmParams p = gemm_params_plain(ws + W.qkv, ws + W.qkv + Hd, ws + W.S, Tt, Tt, hd, 3 * Hd, 3 * Hd, W.Tp);
-            p.nz = n * c.NH; p.nz2 = c.NH;
-            p.sA1 = (int64_t)Tt * 3 * Hd; p.sA2 = hd; p.sB1 = p.sA1; p.sB2 = hd;
-            p.sC1 = (int64_t)c.NH * Tt * W.Tp; p.sC2 = (int64_t)Tt * W.Tp;
+            GemmParams p = gemm_params_plain(qkvg, qkvg + Hd, ws + W.S, Tq, Tq, hd, 3 * Hd, 3 * Hd, Tpq);
+            p.nz = nw * c.NH; p.nz2 = c.NH;
+            p.sA1 = (int64_t)Tq * 3 * Hd; p.sA2 = hd; p.sB1 = p.sA1; p.sB2 = hd;
+            p.sC1 = (int64_t)c.NH * Tq * Tpq; p.sC2 = (int64_t)Tq * Tpq;
             p.alpha = scale;
             rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
         }
         {
-            const int64_t srows = (int64_t)n * c.NH * Tt;
-            ProfScope prof("w2v2_softmax", s, 0.0, (double)srows * W.Tp * 8);
-            if (W.Tp <= 256)
+            const int64_t srows = (int64_t)nw * c.NH * Tq;
+            ProfScope prof("w2v2_softmax", s, 0.0, (double)srows * Tpq * 8);
+            if (Tpq <= 256)
                 hipLaunchKernelGGL(softmax_kernel<true>, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, s, ws + W.S,
-                                   srows, Tt, W.Tp);
+                                   srows, Tq, Tpq);
             else
                 hipLaunchKernelGGL(softmax_kernel<false>, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, s, ws + W.S,
-                                   srows, Tt, W.Tp);
+                                   srows, Tq, Tpq);
             RSAF_CHECK_HIP(hipGetLastError());
         }
         {   // O = P V per (chunk, head), V is [T, hd] with N contiguous
-            GemmParams p = gemm_params_plain(ws + W.S, ws + W.qkv + 2 * Hd, ws + W.att, Tt, hd, Tt, W.Tp, 3 * Hd, Hd);
-            p.nz = n * c.NH; p.nz2 = c.NH; p.b_kn = 1;
-            p.sA1 = (int64_t)c.NH * Tt * W.Tp; p.sA2 = (int64_t)Tt * W.Tp;
-            p.sB1 = (int64_t)Tt * 3 * Hd; p.sB2 = hd;
-            p.sC1 = (int64_t)Tt * Hd; p.sC2 = hd;
+            GemmParams p = gemm_params_plain(ws + W.S, qkvg + 2 * Hd, ws + W.att + r0 * Hd, Tq, hd, Tq, Tpq, 3 * Hd, Hd);
+            p.nz = nw * c.NH; p.nz2 = c.NH; p.b_kn = 1;
+            p.sA1 = (int64_t)c.NH * Tq * Tpq; p.sA2 = (int64_t)Tq * Tpq;
+            p.sB1 = (int64_t)Tq * 3 * Hd; p.sB2 = hd;
+            p.sC1 = (int64_t)Tq * Hd; p.sC2 = hd;
             rc = launch_gemm_f32(p, s, "w2v2_attn_gemm");
             if (rc) return rc;
+        }
+        }
             // (the fused kernel writes the planes itself)
             if ((rc = launch_f16x2_row_scales(ws + W.att, rows, Hd, Hd, ws + W.s_att, nullptr, nullptr, s))) return rc;
             rc = launch_split_f16x2(ws + W.att, rows, Hd, Hd, ws + W.s_att, 1, planes_at(W.attp), rows * Hd, 1, s);
             if (rc) return rc;
-        }
         }
         {   // y = attn Wo^T + bo + x ; x = LN(y), with the bound behind the scale of the ffn1 output
             Out o{}; o.Cf = ws + W.y;
             rc = gemm3(planes_at(W.attp), rows * Hd, Hd, 0, ws + W.s_att, 0, 1, planes_at(W.wp_o[l]), ws + W.ws_o[l], (int)rows, Hd, Hd, o,
                        Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", true);
             if (rc) return rc;
-            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, 1, planes_at(W.xp), true, ws + W.s_x,
+            rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, nullptr, nullptr, planes_at(W.xp), true, ws + W.s_x,
                     wstat(b0 + 2), wstat(b0 + 4), ws + W.s_ffn);
             if (rc) return rc;
         }
@@ -1007,12 +1166,11 @@ int rsaf_w2v2_forward(const float* wav, const int64_t* chunk_start, int n_chunks
                        Wt + lo.b2, x, 1, ACT_NONE, "w2v2_gemm", true);
             if (rc) return rc;
             const bool last = (l == c.L - 1);
+            // the last LayerNorm writes frame t of window w at out_row_start[w] + t (or packed, window after window)
             rc = ln(ws + W.y, nullptr, Wt + lo.ln2g, Wt + lo.ln2b, last ? out : x, rows, Hd, c.eps, s,
-                    last ? out_row_start : nullptr, Tt, last ? nullptr : planes_at(W.xp), true, ws + W.s_x);
+                    last ? out_row_start : nullptr, rowwin, row0, last ? nullptr : planes_at(W.xp), true, ws + W.s_x);
             if (rc) return rc;
         }
     }
     return RSAF_OK;
 }
-
-}  // extern "C"

@@ -88,40 +88,55 @@ class W2V2Engine:
         lim = 65535 // max(cfg.num_attention_heads, cfg.num_conv_pos_embedding_groups)
         self.max_chunks = max(1, min(max_chunks_per_call, lim))
         self._ws = None
+        self._keep = None
 
-    def _workspace(self, n, chunk_len):
+    def _workspace(self, lens_c, n):
         import torch
-        need = _lib.load().rsaf_w2v2_workspace_bytes(n, chunk_len, *_cfg_args(self.cfg))
+        need = _lib.load().rsaf_w2v2_workspace_bytes_ragged(lens_c, n, *_cfg_args(self.cfg))
         if need < 0:
-            raise _lib.RsafError(f"window of {chunk_len} samples is shorter than the encoder's receptive field")
+            raise _lib.RsafError("a window is shorter than the encoder's receptive field (or the lengths are not non-increasing)")
         if self._ws is None or self._ws.numel() * 4 < need:
             self._ws = None
             self._ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=self.device)
         return self._ws
 
-    def forward_windows(self, wav, starts, chunk_len, out, out_rows, stream=None):
-        """wav: 1-D float32 device tensor; starts/out_rows: int64 host arrays (sample offset of each
-        window in ``wav``; first output row of each window in ``out`` [rows, hidden])."""
+    def forward_windows(self, wav, starts, lens, out, out_rows, stream=None):
+        """wav: 1-D float32 device tensor; starts / lens / out_rows: host arrays (sample offset and length of each window in
+        ``wav``; first output row of each window in ``out`` [rows, hidden]).  Windows of any mix of lengths run together
+        (``rsaf_w2v2_forward_ragged``): they are ordered by length here, longest first, and cut into balanced sub-batches."""
         import torch
         lib = _lib.load()
         cfg = self.cfg
+        starts = np.asarray(starts, dtype=np.int64)
+        lens = np.asarray(lens, dtype=np.int32)
+        out_rows = np.asarray(out_rows, dtype=np.int64)
         n_total = len(starts)
+        if n_total == 0:
+            return out
+        order = np.argsort(-lens.astype(np.int64), kind="stable")
+        starts, lens, out_rows = starts[order], lens[order], out_rows[order]
         # balanced sub-batches: ceil(n / max) calls of (almost) equal size instead of full ones and a remainder (7 000 windows
         # with a maximum of 2 048: 4 x 1 750, whose GEMM tile counts fill the 256 CUs to 99.8 % where 2 048 left the last round
         # of every N = 768 GEMM a third full)
         n_calls = max(1, -(-n_total // self.max_chunks))
         per = max(1, -(-n_total // n_calls))
-        per = min(self.max_chunks, (per + 3) & ~3)           # rows = windows x frames: a multiple of 4 windows keeps the GEMM
-                                                              # operand panels (32 bytes per row) aligned to 128-byte lines
+        per = min(self.max_chunks, (per + 3) & ~3)
+        # one pinned staging buffer per call for the three small tables, queued on the current stream (no host wait)
         for b0 in range(0, n_total, per):
             n = min(per, n_total - b0)
-            st = torch.from_numpy(np.ascontiguousarray(starts[b0:b0 + n], dtype=np.int64)).to(self.device)
-            rows = torch.from_numpy(np.ascontiguousarray(out_rows[b0:b0 + n], dtype=np.int64)).to(self.device)
-            ws = self._workspace(n, chunk_len)
-            _lib.check(lib.rsaf_w2v2_forward(
-                _lib.ptr(wav), _lib.ptr(st), n, int(chunk_len), *_cfg_args(cfg), float(cfg.layer_norm_eps),
-                _lib.ptr(self.blob), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(out), _lib.ptr(rows),
-                _lib.stream_ptr(stream)), "rsaf_w2v2_forward")
+            host = torch.empty(5 * n, dtype=torch.int32).pin_memory()          # starts (int64) | out rows (int64) | lengths (int32)
+            hv = host.numpy()
+            hv[:2 * n].view(np.int64)[:] = starts[b0:b0 + n]
+            hv[2 * n:4 * n].view(np.int64)[:] = out_rows[b0:b0 + n]
+            hv[4 * n:] = lens[b0:b0 + n]
+            dev = host.to(self.device, non_blocking=True)
+            lens_c = (C.c_int * n)(*[int(v) for v in lens[b0:b0 + n]])
+            ws = self._workspace(lens_c, n)
+            _lib.check(lib.rsaf_w2v2_forward_ragged(
+                _lib.ptr(wav), C.c_void_p(dev.data_ptr()), C.c_void_p(dev.data_ptr() + 16 * n), lens_c, n,
+                *_cfg_args(cfg), float(cfg.layer_norm_eps), _lib.ptr(self.blob), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(out),
+                C.c_void_p(dev.data_ptr() + 8 * n), _lib.stream_ptr(stream)), "rsaf_w2v2_forward_ragged")
+            self._keep = (host, dev)                                           # alive until the next call's copy is queued
         return out
 
     def plan(self, lengths, chunk_seconds=5, overlap_seconds=1):
@@ -143,17 +158,15 @@ class W2V2Engine:
         frame_off = np.zeros(len(lengths) + 1, dtype=np.int64)
         frame_off[1:] = np.cumsum(totals)
         out = torch.empty((max(int(frame_off[-1]), 1), self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        groups = {}
+        starts, lens, rows = [], [], []
         for c, pl in enumerate(per_clip):
             row = int(frame_off[c])
             for s, l, f in pl:
-                groups.setdefault(l, ([], []))
-                groups[l][0].append(int(clip_offsets[c]) + s)
-                groups[l][1].append(row)
+                starts.append(int(clip_offsets[c]) + s)
+                lens.append(l)
+                rows.append(row)
                 row += f
-        for l in sorted(groups, reverse=True):
-            starts, rows = groups[l]
-            self.forward_windows(wav, np.asarray(starts), l, out, np.asarray(rows), stream)
+        self.forward_windows(wav, starts, lens, out, rows, stream)
         return out[:int(frame_off[-1])], frame_off
 
 

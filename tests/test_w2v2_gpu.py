@@ -31,7 +31,7 @@ def _windows(eng, wav_np, starts, length):
     T = eng.cfg.frames(length)
     wav = torch.from_numpy(np.ascontiguousarray(wav_np, dtype=np.float32)).cuda()
     out = torch.empty((len(starts) * T, eng.cfg.hidden_size), dtype=torch.float32, device="cuda")
-    eng.forward_windows(wav, np.asarray(starts), length, out, np.arange(len(starts)) * T)
+    eng.forward_windows(wav, np.asarray(starts), [length] * len(starts), out, np.arange(len(starts)) * T)
     torch.cuda.synchronize()
     return out.cpu().numpy().reshape(len(starts), T, -1)
 
@@ -145,3 +145,67 @@ def test_dropin_sequences_and_embeddings(rsaf_lib, tmp_path, monkeypatch):
     monkeypatch.delenv("RSAF_W2V2_RANDOM_SEED", raising=False)
     assert w2v2.extract_wav2vec2_sequences(df, model_name="facebook/wav2vec2-base-960h", verbose=False) == {}
     assert w2v2.extract_wav2vec2_embeddings(df, model_name="facebook/wav2vec2-base-960h", verbose=False).empty
+
+
+def test_twelve_ragged_clips_in_one_call_match_the_oracle_at_base_geometry(rsaf_lib):
+    """The reference ends every file in a tail window of its own length (src/foundation_model_extractor.py:103-108): twelve
+    clips of 0.6 - 11 s give 12 distinct tail lengths beside the full windows.  All of them run in ONE
+    rsaf_w2v2_forward_ragged call (per-window normalisation, GroupNorm statistics, zero padding of the positional
+    convolution and attention over each window's own frames) and match the per-window torch-CPU restatement."""
+    import torch
+    from robust_speech_analysis_framework_amd import _lib
+    from robust_speech_analysis_framework_amd.w2v2 import W2V2Engine
+    cfg = W2V2Config()
+    sd = random_state_dict(cfg, seed=0)
+    eng = W2V2Engine(cfg, sd, max_chunks_per_call=64)
+    secs = [0.6, 1.3, 2.05, 3.3, 4.4, 5.0, 5.35, 6.7, 7.9, 9.0, 10.1, 11.0]
+    clips = [synth.synth_clip(500 + i, s) for i, s in enumerate(secs)]
+    lengths = [len(c) for c in clips]
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    wav = torch.from_numpy(np.concatenate(clips)).cuda()
+    calls = []
+    lib = _lib.load()
+    real = lib.rsaf_w2v2_forward_ragged
+
+    class Spy:                                                  # counts the library calls and the windows each one took
+        def __call__(self, *a):
+            calls.append(int(a[4]))
+            return real(*a)
+    lib.rsaf_w2v2_forward_ragged = Spy()
+    try:
+        out, frame_off = eng.extract_packed(wav, offs[:-1], lengths)
+        torch.cuda.synchronize()
+    finally:
+        lib.rsaf_w2v2_forward_ragged = real
+    n_windows = sum(len(eng.plan([n])[0][0]) for n in lengths)
+    assert calls == [n_windows] and n_windows >= 20           # every window of every clip in one call
+    host = out.cpu().numpy()
+    worst = 0.0
+    for i, c in enumerate(clips):
+        ref = wo.extract_sequence(sd, cfg, c)
+        a, b = int(frame_off[i]), int(frame_off[i + 1])
+        assert (b - a, cfg.hidden_size) == ref.shape          # integer-exact frame counts
+        worst = max(worst, _rel(host[a:b], ref))
+        rows = np.abs(host[a:b] - ref).max(axis=1) / np.abs(ref).max(axis=1)
+        assert rows.max() < TOL, (i, int(np.argmax(rows)))
+    assert worst < TOL
+
+
+def test_ragged_call_returns_the_bits_of_the_per_length_calls(rsaf_lib):
+    """A window's frames must not depend on its batch mates: the mixed-length call and one call per window give the same bits."""
+    import torch
+    from robust_speech_analysis_framework_amd.w2v2 import W2V2Engine
+    z, cfg, sd = _small()
+    eng = W2V2Engine(cfg, sd)
+    clip = synth.synth_clip(77, 7.0)
+    spec = [(0, 80000), (1000, 52000), (64000, 48000), (30000, 9000), (5, 80000), (200, 400)]
+    T = [cfg.frames(l) for _, l in spec]
+    rows = np.concatenate([[0], np.cumsum(T)])
+    wav = torch.from_numpy(clip).cuda()
+    together = torch.zeros((int(rows[-1]), cfg.hidden_size), device="cuda")
+    eng.forward_windows(wav, [s for s, _ in spec], [l for _, l in spec], together, rows[:-1])
+    alone = torch.zeros_like(together)
+    for k, (s0, l) in enumerate(spec):
+        eng.forward_windows(wav, [s0], [l], alone, [int(rows[k])])
+    torch.cuda.synchronize()
+    assert torch.equal(together, alone)

@@ -1,5 +1,5 @@
 """K / N sweep of rsaf_gemm_f16x3 (fp32 output, panels): time = a + b * (K / 16) per tile -> fixed cost per tile and
-asymptotic rate.  RSAF_G3_DBG=1 skips the epilogue (timing only)."""
+asymptotic rate."""
 import os
 import sys
 
