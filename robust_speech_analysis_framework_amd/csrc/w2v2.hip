@@ -98,8 +98,8 @@ struct Workspace {
     int64_t ws_conv[6], ws_fp, ws_pos, wstat;            // wstat: [6 + 2 + 4 L][2] (+ [L][2] for the ffn1 biases)
     std::vector<int64_t> ws_qkv, ws_o, ws_1, ws_2;
     // scales of the activations: per window of the current conv group (conv_scale[7][G], conv_amax[7][G]), per window of
-    // the call (pos_scale, fp_amax, v_amax) and per frame (ln scale, ffn scale, attention scale)
-    int64_t conv_scale, conv_amax, pos_scale, fp_amax, v_amax, s_lnfp, s_x, s_ffn, s_att;
+    // the call (pos_scale, fp_amax, win_norm; wlen: the length table of an equal-window call) and per frame (ln / ffn / qkv scales)
+    int64_t conv_scale, conv_amax, pos_scale, fp_amax, wlen, win_norm, s_lnfp, s_x, s_ffn, s_att, s_qkv;
     int64_t t_Tw, t_row0, t_ztab, t_rowwin;              // window tables (int32 / int64 views of the float workspace)
     int slabs, Tp, G;
 };
@@ -110,7 +110,7 @@ static inline int64_t planes_floats(int64_t n) { return pad4(n); }
 
 // index of a weight matrix in the wstat table
 static inline int wstat_conv(int i) { return i; }                       // i = 0..5 (conv1..6)
-constexpr int WSTAT_FP = 6, WSTAT_POS = 7, WSTAT_LAYER0 = 8;             // layer l: qkv, o, ffn1, ffn2, ffn1 bias
+constexpr int WSTAT_FP = 6, WSTAT_POS = 7, WSTAT_LAYER0 = 8, WSTAT_PER_LAYER = 6;   // layer l: qkv, o, ffn1, ffn2, ffn1 bias, qkv bias
 
 // Window geometry of one call (host side): lengths are NON-INCREASING (the caller sorts), so windows of equal frame count
 // are contiguous and a group of CONV_GROUP consecutive windows wastes few tile rows.
@@ -184,11 +184,11 @@ static Workspace make_ws(const Cfg& c, const Rag& R) {
         w.wp_1.push_back(take(planes_floats((int64_t)c.I * c.Hd))); w.ws_1.push_back(take(c.I));
         w.wp_2.push_back(take(planes_floats((int64_t)c.Hd * c.I))); w.ws_2.push_back(take(c.Hd));
     }
-    w.wstat = take((int64_t)(WSTAT_LAYER0 + 5 * c.L) * 2);
+    w.wstat = take((int64_t)(WSTAT_LAYER0 + WSTAT_PER_LAYER * c.L) * 2);
     w.conv_scale = take((int64_t)7 * G);
     w.conv_amax = take((int64_t)7 * G);
-    w.pos_scale = take(n); w.fp_amax = take(n); w.v_amax = take(n);
-    w.s_lnfp = take(rows); w.s_x = take(rows); w.s_ffn = take(rows); w.s_att = take(rows);
+    w.pos_scale = take(n); w.fp_amax = take(n); w.wlen = take(n); w.win_norm = take(n);
+    w.s_lnfp = take(rows); w.s_x = take(rows); w.s_ffn = take(rows); w.s_att = take(rows); w.s_qkv = take(rows);
     // window tables (device): Tw[7][n] frames per layer, row0[n + 1] (int64), ztab[7][n][2] (int64: the GEMM's per-batch
     // {rows, output offset} of conv1..6 and of the positional conv), rowwin[rows] window of every encoder row
     w.t_Tw = take((int64_t)7 * n); w.t_row0 = take(2 * ((int64_t)n + 1)); w.t_ztab = take((int64_t)7 * n * 2 * 2);
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const int64_t* __restrict__ row0,
                                                         unsigned short* __restrict__ planes, int64_t plane, int panel,
                                                         float* __restrict__ scale_out, const unsigned* __restrict__ bound_w,
-                                                        const unsigned* __restrict__ bound_b, float* __restrict__ bound_scale_out) {
+                                                        const unsigned* __restrict__ bound_b, float* __restrict__ bound_scale_out,
+                                                        unsigned* __restrict__ win_norm) {
     // panel != 0: the planes go out in the k16-panel layout of `rows` rows (gemm_f16x3.h), staged through LDS so that the
     // four rows of the workgroup leave as full 128-byte lines per panel (scattering 8-byte pieces from the row layout cost
     // this kernel + 77 %)
@@ -434,10 +435,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     const float sc = f16x2_scale_for_bound(mx);
     if (valid && lane == 0) scale_out[row] = sc;
-    if (bound_scale_out) {
+    if (bound_scale_out || win_norm) {
         const float nrm = sqrtf(wave_sum(n2)) * 1.000001f;
-        const float bound = nrm * __uint_as_float(bound_w[0]) * 1.000001f + (bound_b ? __uint_as_float(bound_b[1]) : 0.0f);
-        if (valid && lane == 0) bound_scale_out[row] = f16x2_scale_for_bound(bound);
+        if (bound_scale_out) {
+            const float bound = nrm * __uint_as_float(bound_w[0]) * 1.000001f + (bound_b ? __uint_as_float(bound_b[1]) : 0.0f);
+            if (valid && lane == 0) bound_scale_out[row] = f16x2_scale_for_bound(bound);
+        }
+        // the largest row norm of the window (behind the per-window scale of the next q / k / v projection's plane output)
+        if (win_norm && valid && lane == 0) atomicMax(win_norm + rowwin[row], __float_as_uint(nrm));
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -476,47 +481,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// ---- fused attention for windows of at most 256 frames (every Wav2Vec2 window: T <= 249) -------------------
-// One workgroup = 128 queries of one (window, head); wave = 32 queries.  Exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
-//   S^T = K Q^T : keys are the MFMA rows, queries the columns, so a lane holds ONE query's scores for 16 keys per
-//                 tile: the softmax over keys is in-lane plus one exchange with lane ^ 32, and the probabilities
-//                 already sit in the register layout the next MFMA wants as its A operand (row = lane & 31 =
-//                 query, k slot = lane >> 5): register e of key tile kt pairs keys a_e and a_e + 4, and the V
-//                 fragment simply reads those two keys.  No score or probability ever goes to memory
-//                 (the three-launch path wrote and re-read 762 MB per layer and 256 windows).
-//   K and V are staged in blocks of 128 keys by LDS-DMA (global_load_lds, two 32 KB buffers, the next block in
-//   flight during the multiply; K chunks XOR-swizzled on the source address so the float4 fragment reads are
-//   conflict-free); all 256 scores of a query stay in registers, so the softmax is the plain two-pass form, not an
-//   online rescaling.
 using af32x16 = __attribute__((ext_vector_type(16))) float;
 
 typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 typedef const __attribute__((address_space(1))) void* attn_glb_ptr;
 
-__global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ planes,
-                                                            int64_t plane_stride, int64_t n_rows, const int* __restrict__ Tw,
+// ---- fused attention on the fp16 matrix pipe (two-way fp16 splits, three products: gemm_f16x3.hip's arithmetic) --------
+// For windows of at most 256 frames (every Wav2Vec2 window: T <= 249).  One workgroup = 128 queries of one (window, head);
+// wave = 32 queries.  S^T = K Q^T: keys are the MFMA rows, queries the columns, so a lane holds ONE query's scores for 16 keys
+// per tile: the softmax over keys is in-lane plus one exchange with lane ^ 32, and no score or probability ever goes to memory;
+// all 256 scores of a query stay in registers, so the softmax is the plain two-pass form, not an online rescaling.  K and V are
+// staged in blocks of 128 keys by LDS-DMA (two 32 KB buffers, the next block in flight during the multiply).
+// (Rounds 1-3 ran this on the fp32 matrix pipe, v_mfma_f32_32x32x2_f32: 78 TFLOP/s; now 161.)  Every product runs on
+// v_mfma_f32_32x32x16_f16:
+//   * q, k, v arrive as the fp16 plane pair the q/k/v projection's epilogue wrote, scaled by ONE power of two per window
+//     (s_w: the bound |x|_2 max|w_n|_2 + max|b| over the window's rows), so S = acc / s_w^2 and the value scale factors out
+//     of the sum over keys; no conversion work in this kernel except for the probabilities;
+//   * K blocks of 128 keys x 64 halfs x 2 planes (32 KB) by LDS-DMA, 16-byte chunks XOR-swizzled on the source address
+//     (chunk ^ ((row >> 1) & 7): the ds_read_b128 fragment reads of 16 consecutive rows cover all 64 banks);
+//   * the score tile's register layout is the A operand of P V (element j of lane half h = key 16 s + 8 (j >> 2) + 4 h + (j & 3)),
+//     P = p * 2^14 split into hi + lo; the V fragment (B operand, the same key order) comes out of row-major V by two
+//     ds_read_b64_tr_b16 (4 keys x 16 columns per 16-lane group, delivered column-major), V chunks swizzled by
+//     ((row >> 1) & 1) << 2 so that the four rows of a transposed read sit on disjoint banks;
+//   * O = acc 2^-14 is already in the window's scale: it leaves as the plane pair of the out-projection's A operand.
+// Matrix cycles: 192 MFMAs of 32 cycles per wave against 512 of 64 on the fp32 pipe.
+using ah8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef short atr4 __attribute__((__vector_size__(4 * sizeof(short))));
+
+__global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const unsigned short* __restrict__ qkvp, int64_t in_plane,
+                                                            unsigned short* __restrict__ planes, int64_t plane_stride,
+                                                            int64_t n_rows, const int* __restrict__ Tw,
                                                             const int64_t* __restrict__ row0, int NH, int Hd, float scale,
-                                                            const unsigned* __restrict__ v_amax, float* __restrict__ row_scale) {
-    constexpr int HD = 64, KB = 128, TILE = KB * HD;                            // one staged block: 32 KB
-    extern __shared__ __attribute__((aligned(1024))) float kvbuf[];             // two blocks
+                                                            const float* __restrict__ row_scale) {
+    constexpr int HD = 64, KB = 128, PLANE = KB * HD, TILE = 2 * PLANE;          // one staged block: 2 planes x 16 KB (halfs)
+    extern __shared__ __attribute__((aligned(1024))) unsigned short kvh[];      // two blocks
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int win = blockIdx.x / NH, head = blockIdx.x - win * NH;
-    const int T = Tw[win];                                                      // frames of this window (windows are ragged)
+    const int T = Tw[win];
     if (blockIdx.y * 128 >= T) return;                                          // (workgroup-uniform)
     const int64_t wrow0 = row0[win];
-    const int64_t ld = 3 * (int64_t)Hd;
-    const float* base = qkv + wrow0 * ld + (int64_t)head * HD;                 // q of this window and head
+    const int64_t ld = 3 * (int64_t)Hd;                                         // halfs per row of a plane
+    const unsigned short* base = qkvp + wrow0 * ld + (int64_t)head * HD;       // q of this window and head, plane 0
     const int q0 = blockIdx.y * 128 + wv * 32;
     const int nblk = (T + KB - 1) / KB;                                         // 1 or 2 key blocks
+    const float sw = row_scale[wrow0];                                          // the window's power of two
+    const float sinv = pow2_inverse(sw);
 
-    // Q fragments: lane (query l31, half h) holds d = 8g + 4h + j  (the pairing both MFMA operands use)
-    float4 qf[8];
+    // Q fragments (B operand of S^T = K Q^T): lane (query l31, half h) holds d = 16 s + 8 h + j, both planes
+    ah8 qh[4], ql[4];
     {
         const int q = q0 + l31 < T ? q0 + l31 : T - 1;
-        const float* qp = base + (int64_t)q * ld + 4 * h;
+        const unsigned short* qp = base + (int64_t)q * ld + 8 * h;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const float4*>(qp + 8 * g);
+        for (int s4 = 0; s4 < 4; ++s4) {
+            qh[s4] = *reinterpret_cast<const ah8*>(qp + 16 * s4);
+            ql[s4] = *reinterpret_cast<const ah8*>(qp + in_plane + 16 * s4);
+        }
     }
     af32x16 sc[8];
 #pragma unroll
@@ -524,48 +545,47 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
 
-    // LDS-DMA staging of a 128-key block: one wave-instruction writes 4 rows of 256 B linearly; for K the 16-byte
-    // chunk c of row r is fetched into slot c ^ (r & 15) (swizzle on the source address) so that the float4 fragment
-    // reads of 16 consecutive rows hit 16 different chunk slots; V is read row-contiguously and stays unswizzled.
-    // Rows past the window re-read the last row (their scores are masked / their probabilities are zero).
-    auto stage = [&](const float* src0, int key0, float* dst, bool swz) {
+    // LDS-DMA staging of a 128-key block of K (col0 = Hd) or V (col0 = 2 Hd): one wave-instruction writes 8 rows of 128 B of
+    // one plane linearly; chunk c' of row r is fetched from source chunk c' ^ f(r).  Rows past the window re-read its last row.
+    auto stage = [&](int col0, int key0, unsigned short* dst, bool is_v) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ins = wv * 8 + i;                                         // 32 wave-instructions per block
-            const int r = 4 * ins + (lane >> 4), pc = lane & 15;
+            const int pl = ins >> 4, r = 8 * (ins & 15) + (lane >> 3), pc = lane & 7;
             const int key = key0 + r < T ? key0 + r : T - 1;
-            const int c = swz ? (pc ^ (r & 15)) : pc;
-            __builtin_amdgcn_global_load_lds((attn_glb_ptr)(src0 + (int64_t)key * ld + 4 * c),
-                                             (attn_lds_ptr)(dst + ins * 256), 16, 0, 0);
+            const int c = pc ^ (is_v ? (((r >> 1) & 1) << 2) : ((r >> 1) & 7));
+            __builtin_amdgcn_global_load_lds((attn_glb_ptr)(base + col0 + pl * in_plane + (int64_t)key * ld + 8 * c),
+                                             (attn_lds_ptr)(dst + ins * 512), 16, 0, 0);
         }
     };
     auto drain = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    float* buf0 = kvbuf;
-    float* buf1 = kvbuf + TILE;
+    unsigned short* buf0 = kvh;
+    unsigned short* buf1 = kvh + TILE;
 
     // ---- scores: block b of K lives in buf[b]; the next block (K1, then V0) is in flight during the multiply ----
-    stage(base + Hd, 0, buf0, true);
+    stage(Hd, 0, buf0, false);
     drain();
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b < nblk) {
-            float* cur = b == 0 ? buf0 : buf1;
-            if (b + 1 < nblk) stage(base + Hd, KB * (b + 1), buf1, true);      // K1 -> buf1 while K0 is multiplied
-            else stage(base + 2 * Hd, 0, b == 0 ? buf1 : buf0, false);        // last K block: V0 -> the other buffer
+            const unsigned short* cur = b == 0 ? buf0 : buf1;
+            if (b + 1 < nblk) stage(Hd, KB * (b + 1), buf1, false);            // K1 -> buf1 while K0 is multiplied
+            else stage(2 * Hd, 0, b == 0 ? buf1 : buf0, true);                 // last K block: V0 -> the other buffer
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const int kt = 4 * b + t4;
                 const int row = 32 * t4 + l31;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const float4 kf = *reinterpret_cast<const float4*>(&cur[row * HD + 4 * ((2 * g + h) ^ (row & 15))]);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g].x, sc[kt], 0, 0, 0);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g].y, sc[kt], 0, 0, 0);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g].z, sc[kt], 0, 0, 0);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g].w, sc[kt], 0, 0, 0);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int off = row * HD + 8 * ((2 * s4 + h) ^ ((row >> 1) & 7));
+                    const ah8 kh = *reinterpret_cast<const ah8*>(cur + off);
+                    const ah8 kl = *reinterpret_cast<const ah8*>(cur + PLANE + off);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s4], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s4], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s4], sc[kt], 0, 0, 0);
                 }
             }
             drain();
@@ -573,13 +593,14 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
     }
     // V0 now sits in buf1 (one key block) or buf0 (two key blocks)
     // ---- softmax over the keys of this lane's query: key = 32 kt + (e & 3) + 8 (e >> 2) + 4 h ----
+    const float sscale = scale * sinv * sinv;                                   // q and k both carry s_w
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float v = key < T ? sc[kt][e] * scale : -INFINITY;
+            const float v = key < T ? sc[kt][e] * sscale : -INFINITY;
             sc[kt][e] = v;
             m = fmaxf(m, v);
         }
@@ -594,44 +615,75 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
             sum += ev;
         }
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sc[kt][e] *= inv;
+    const float inv = 16384.0f / sum;                                           // probabilities travel as p * 2^14 (hi + lo)
 
     // ---- O = P V ----
     af32x16 o0, o1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.0f; o1[e] = 0.0f; }
+    // transposed-read addressing: 16-lane group gq covers columns 16 (gq & 1) .. + 15 of a column tile and the 4 keys of lane
+    // half h = gq >> 1; lane 4 q + p of the group supplies row q, columns 4 p .. 4 p + 3
+    const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b < nblk) {
             // V block b: V0 is where the score phase left it, V1 goes to the other buffer while V0 is multiplied
-            float* v0buf = nblk == 1 ? buf1 : buf0;
-            float* cur = b == 0 ? v0buf : (v0buf == buf0 ? buf1 : buf0);
-            if (b == 0 && nblk > 1) stage(base + 2 * Hd, KB, v0buf == buf0 ? buf1 : buf0, false);
+            unsigned short* v0buf = nblk == 1 ? buf1 : buf0;
+            const unsigned short* cur = b == 0 ? v0buf : (v0buf == buf0 ? buf1 : buf0);
+            if (b == 0 && nblk > 1) stage(2 * Hd, KB, v0buf == buf0 ? buf1 : buf0, true);
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const int kt = 4 * b + t4;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;   // within the staged block
-                    const float v0 = cur[key * HD + l31], v1 = cur[key * HD + 32 + l31];
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], v0, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], v1, o1, 0, 0, 0);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    ah8 ph, pl;                                                 // A operand: this lane's query, keys of k-step s2
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pn = sc[kt][8 * s2 + j] * inv;
+                        const _Float16 hi = (_Float16)pn;
+                        ph[j] = hi;
+                        pl[j] = (_Float16)(pn - (float)hi);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        // (volatile asm with a memory clobber: the reads stay behind the barrier that publishes the staged
+                        // block, the wait for the four results is explicit and tied to them)
+                        atr4 th0, th1, tl0, tl1;
+                        {
+                            const int rowa = 32 * t4 + 16 * s2 + 4 * (gq >> 1) + tq, rowb = rowa + 8;      // keys within the staged block
+                            const int cha = (4 * ct + 2 * (gq & 1) + (tp >> 1)) ^ (((rowa >> 1) & 1) << 2);
+                            const int chb = (4 * ct + 2 * (gq & 1) + (tp >> 1)) ^ (((rowb >> 1) & 1) << 2);
+                            const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)(cur + rowa * HD + 8 * cha + 4 * (tp & 1));
+                            const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)(cur + rowb * HD + 8 * chb + 4 * (tp & 1));
+                            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(th0) : "v"(a0) : "memory");
+                            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(th1) : "v"(a1) : "memory");
+                            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tl0) : "v"(a0), "n"(2 * PLANE) : "memory");
+                            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tl1) : "v"(a1), "n"(2 * PLANE) : "memory");
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(th0), "+v"(th1), "+v"(tl0), "+v"(tl1) : : "memory");
+                        }
+                        // (whole-vector moves: rebuilding the fragments element by element from the 4-element results,
+                        // `vh[j] = bit_cast(th0[j])`, came out of hipcc 7.2 as a broadcast of element 0)
+                        typedef short atr8 __attribute__((__vector_size__(8 * sizeof(short))));
+                        const ah8 vh = __builtin_bit_cast(ah8, __builtin_shufflevector(th0, th1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        const ah8 vl = __builtin_bit_cast(ah8, __builtin_shufflevector(tl0, tl1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        if (ct == 0) {
+                            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o0, 0, 0, 0);
+                            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o0, 0, 0, 0);
+                            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o0, 0, 0, 0);
+                        } else {
+                            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o1, 0, 0, 0);
+                            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o1, 0, 0, 0);
+                            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o1, 0, 0, 0);
+                        }
+                    }
                 }
             }
             if (b == 0 && nblk > 1) drain();
         }
     }
-    // C layout: column = lane & 31 (d), row = (e & 3) + 8 (e >> 2) + 4 h (query within the wave's 32).  The output only
-    // exists as the two fp16 planes the out-projection GEMM reads (no fp32 copy, no separate split pass), scaled by the
-    // window's power of two: an attention output is a convex combination of the window's value rows, so max |V| of the
-    // window (reported by the q/k/v projection's epilogue) bounds it.  Stored from the MFMA layout with 2-byte stores
-    // (32 lanes = 64 contiguous bytes of a row and plane): the kernel sits at its 256-register budget.
+    // C layout: column = lane & 31 (d), row = (e & 3) + 8 (e >> 2) + 4 h (query within the wave's 32).  acc * 2^-14 = o * s_w:
+    // already the out-projection's A operand in the window's scale (|o| <= max |v| of the window, and v * s_w < 2^15).
     // k16 panels of n_rows rows (gemm_f16x3.h): column head * 64 + 32 u + l31 -> panel 4 head + 2 u + (l31 >> 4), k = l31 & 15
-    const float osc = f16x2_scale_for_bound(__uint_as_float(v_amax[win]) * 1.00001f);
     const int64_t panel_sz = n_rows * 16;
     unsigned short* op = planes + ((int64_t)(head * 4) + (l31 >> 4)) * panel_sz + wrow0 * 16 + (l31 & 15);
 #pragma unroll
@@ -639,10 +691,9 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
         const int q = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (q < T) {
             unsigned short* d0 = op + (int64_t)q * 16;
-            if (head == 0 && l31 == 0) row_scale[wrow0 + q] = osc;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float x = (u == 0 ? o0[e] : o1[e]) * osc;
+                const float x = (u == 0 ? o0[e] : o1[e]) * (1.0f / 16384.0f);
                 unsigned short a2, b2;
                 split2_w(x, a2, b2);
                 d0[2 * u * panel_sz] = a2;
@@ -650,6 +701,17 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const float* __restr
             }
         }
     }
+}
+
+// one power of two per window for the q / k / v projection's plane output: the bound of the window's rows,
+// max_rows |y|_2 * max_n |w_n|_2 + max |b|, written per row (the GEMM's c_scale / the attention's scale / the out-projection's a_scale)
+__global__ __launch_bounds__(256) void qkv_scale_kernel(const unsigned* __restrict__ win_norm, const int* __restrict__ rowwin,
+                                                        int64_t rows, const unsigned* __restrict__ wst, const unsigned* __restrict__ bst,
+                                                        float* __restrict__ row_scale) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float bound = __uint_as_float(win_norm[rowwin[r]]) * __uint_as_float(wst[0]) * 1.000001f + __uint_as_float(bst[1]);
+    row_scale[r] = f16x2_scale_for_bound(bound);
 }
 
 // ---- row softmax in place, one wave per row of length T (row stride Tp, pad columns zeroed) ---------
@@ -739,13 +801,15 @@ __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __res
 static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
               float eps, hipStream_t s, const int64_t* out_row_start = nullptr, const int* rowwin = nullptr,
               const int64_t* row0 = nullptr, unsigned short* planes = nullptr, bool panel = false, float* scale_out = nullptr,
-              const unsigned* bound_w = nullptr, const unsigned* bound_b = nullptr, float* bound_scale_out = nullptr) {
+              const unsigned* bound_w = nullptr, const unsigned* bound_b = nullptr, float* bound_scale_out = nullptr,
+              unsigned* win_norm = nullptr) {
     const int64_t blocks = (rows + 3) / 4;
     RSAF_CHECK_ARG(blocks <= 0x7fffffffLL, "too many rows");
     RSAF_CHECK_ARG(!planes || scale_out, "planes need their scale array");
+    RSAF_CHECK_ARG(!win_norm || rowwin, "the per-window norm needs the row -> window map");
     ProfScope prof("w2v2_layernorm", s, 0.0, (double)rows * D * (4 * (r ? 2 : 1) + (out ? 4 : 0) + (planes ? 4 : 0)));
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, r, g, b, out, rows, D, eps,
-                       out_row_start, rowwin, row0, planes, rows * D, panel ? 1 : 0, scale_out, bound_w, bound_b, bound_scale_out);
+                       out_row_start, rowwin, row0, planes, rows * D, panel ? 1 : 0, scale_out, bound_w, bound_b, bound_scale_out, win_norm);
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }
@@ -903,7 +967,7 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
     const int* wlen = len_dev_or_null;
     {
         if (!wlen) {                                         // equal windows: the length table is filled here
-            int* wl = reinterpret_cast<int*>(ws + W.s_att);  // (scratch: the attention scales are written much later)
+            int* wl = reinterpret_cast<int*>(ws + W.wlen);
             hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, wl, n, R.maxlen);
             wlen = wl;
         }
@@ -931,7 +995,7 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
     // 0. weights of the dense layers as fp16 plane pairs in the k16-panel layout, each row with its own power-of-two scale
     //    (once per call: 0.4 GB at base geometry, < 1 ms), and per matrix the largest row norm: the Cauchy-Schwarz factor of
     //    the bound behind the scale of a GEMM's PLANE output (conv1..5, ffn1)
-    RSAF_CHECK_HIP(hipMemsetAsync(ws + W.wstat, 0, sizeof(float) * 2 * (WSTAT_LAYER0 + 5 * c.L), s));
+    RSAF_CHECK_HIP(hipMemsetAsync(ws + W.wstat, 0, sizeof(float) * 2 * (WSTAT_LAYER0 + WSTAT_PER_LAYER * c.L), s));
     {
         auto split_wp = [&](int64_t src_off, int64_t nrows, int K, int64_t dst_off, int64_t scale_off, int stat_idx) {
             int r2 = launch_f16x2_row_scales(Wt + src_off, nrows, K, K, ws + scale_off, nullptr, wstat(stat_idx), s);
@@ -946,13 +1010,14 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
         }
         for (int l = 0; l < c.L; ++l) {
             const LayerOff& lo = L.layers[l];
-            const int b0 = WSTAT_LAYER0 + 5 * l;
+            const int b0 = WSTAT_LAYER0 + WSTAT_PER_LAYER * l;
             if ((rc = split_wp(lo.wqkv, 3 * Hd, Hd, W.wp_qkv[l], W.ws_qkv[l], b0))) return rc;
             if ((rc = split_wp(lo.wo, Hd, Hd, W.wp_o[l], W.ws_o[l], b0 + 1))) return rc;
             if ((rc = split_wp(lo.w1, c.I, Hd, W.wp_1[l], W.ws_1[l], b0 + 2))) return rc;
             if ((rc = split_wp(lo.w2, Hd, c.I, W.wp_2[l], W.ws_2[l], b0 + 3))) return rc;
             // max |b1| (word 1 of the statistics of the bias seen as one row); the scale it writes goes to a scratch slot
             if ((rc = launch_f16x2_row_scales(Wt + lo.b1, 1, c.I, c.I, ws + W.pos_scale, nullptr, wstat(b0 + 4), s))) return rc;
+            if ((rc = launch_f16x2_row_scales(Wt + lo.bqkv, 1, 3 * Hd, 3 * Hd, ws + W.pos_scale, nullptr, wstat(b0 + 5), s))) return rc;
         }
     }
     // 1-3. feature encoder, CONV_GROUP windows at a time (its activations are the large ones: 15 999 x 512 per window)
@@ -1026,6 +1091,10 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
                    Wt + L.fpb, nullptr, 1, ACT_NONE, "w2v2_gemm", true, bits_at(W.fp_amax), 0, rowwin);
         if (rc) return rc;
     }
+    const int hd = Hd / c.NH;
+    const float scale = 1.0f / sqrtf((float)hd);
+    static const bool fused_attn = [] { const char* e = getenv("RSAF_W2V2_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
+    const bool fused = fused_attn && hd == 64 && Tt <= 256;  // attention on the fp16 matrix pipe, q / k / v as plane pairs
     // 5. positional conv embedding (grouped, weight norm folded), GELU, x = LN(x + pos)
     {
         const int cg = Hd / c.PG;
@@ -1075,24 +1144,31 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
                 if (rc) return rc;
             }
         }
-        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, nullptr, nullptr, planes_at(W.xp), true, ws + W.s_x);
+        // (fused attention: this LayerNorm also reports the window's largest row norm, behind the scale of layer 0's q / k / v)
+        if (fused) RSAF_CHECK_HIP(hipMemsetAsync(ws + W.win_norm, 0, sizeof(unsigned) * n, s));
+        rc = ln(ws + W.x, ws + W.y, Wt + L.elng, Wt + L.elnb, ws + W.x, rows, Hd, c.eps, s, nullptr, rowwin, row0, planes_at(W.xp), true, ws + W.s_x,
+                nullptr, nullptr, nullptr, fused ? bits_at(W.win_norm) : nullptr);
         if (rc) return rc;
     }
     // 6. encoder layers (post-LN)
-    const int hd = Hd / c.NH;
-    const float scale = 1.0f / sqrtf((float)hd);
     float* x = ws + W.x;
     for (int l = 0; l < c.L; ++l) {
         const LayerOff& lo = L.layers[l];
-        const int b0 = WSTAT_LAYER0 + 5 * l;
-        static const bool fused_attn = [] { const char* e = getenv("RSAF_W2V2_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
-        const bool fused = fused_attn && hd == 64 && Tt <= 256;
-        // fused q,k,v projection (A = the planes the previous LayerNorm wrote beside x); its epilogue reports max |V| per window
-        RSAF_CHECK_HIP(hipMemsetAsync(ws + W.v_amax, 0, sizeof(unsigned) * n, s));
-        {
+        const int b0 = WSTAT_LAYER0 + WSTAT_PER_LAYER * l;
+        // fused q,k,v projection (A = the planes the previous LayerNorm wrote beside x).  Fused attention: the output leaves as
+        // the fp16 plane pair the attention kernel multiplies, under one power of two per window (the bound over its rows)
+        if (fused) {
+            hipLaunchKernelGGL(qkv_scale_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, bits_at(W.win_norm), rowwin, rows,
+                               wstat(b0), wstat(b0 + 5), ws + W.s_qkv);
+            RSAF_CHECK_HIP(hipGetLastError());
+            Out o{}; o.Cp = planes_at(W.qkv); o.c_plane = rows * 3 * Hd; o.c_scale = ws + W.s_qkv; o.cs_zs = 0; o.cs_ms = 1;
+            rc = gemm3(planes_at(W.xp), rows * Hd, Hd, 0, ws + W.s_x, 0, 1, planes_at(W.wp_qkv[l]), ws + W.ws_qkv[l], (int)rows, 3 * Hd, Hd, o,
+                       Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true);
+            if (rc) return rc;
+        } else {
             Out o{}; o.Cf = ws + W.qkv;
             rc = gemm3(planes_at(W.xp), rows * Hd, Hd, 0, ws + W.s_x, 0, 1, planes_at(W.wp_qkv[l]), ws + W.ws_qkv[l], (int)rows, 3 * Hd, Hd, o,
-                       Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true, fused ? bits_at(W.v_amax) : nullptr, 0, rowwin, 2 * Hd);
+                       Wt + lo.bqkv, nullptr, 1, ACT_NONE, "w2v2_gemm", true);
             if (rc) return rc;
         }
         if (fused) {
@@ -1100,11 +1176,10 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
             double att_flops = 0.0;
             for (const auto& tg : R.tgroups) att_flops += 4.0 * (tg.second - tg.first) * c.NH * (double)R.T6[tg.first] * R.T6[tg.first] * hd;
             ProfScope prof("w2v2_attn_fused", s, att_flops, 0.0);
-            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               2 * 128 * 64 * (int)sizeof(float)));
-            hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256),
-                               2 * 128 * 64 * sizeof(float), s, ws + W.qkv, planes_at(W.attp), rows * Hd, rows, Tw + (int64_t)6 * n, row0,
-                               c.NH, Hd, scale, bits_at(W.v_amax), ws + W.s_att);
+            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 64 * 2));
+            hipLaunchKernelGGL(attn_f16x3_kernel, dim3((unsigned)(n * c.NH), (unsigned)((Tt + 127) / 128)), dim3(256), 2 * 2 * 128 * 64 * 2, s,
+                               planes_at(W.qkv), rows * 3 * Hd, planes_at(W.attp), rows * Hd, rows, Tw + (int64_t)6 * n, row0, c.NH, Hd, scale,
+                               ws + W.s_qkv);
             RSAF_CHECK_HIP(hipGetLastError());
         } else {
         // three launches per run of equal windows (head widths other than 64: test geometries)
@@ -1149,7 +1224,7 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
         }
         {   // y = attn Wo^T + bo + x ; x = LN(y), with the bound behind the scale of the ffn1 output
             Out o{}; o.Cf = ws + W.y;
-            rc = gemm3(planes_at(W.attp), rows * Hd, Hd, 0, ws + W.s_att, 0, 1, planes_at(W.wp_o[l]), ws + W.ws_o[l], (int)rows, Hd, Hd, o,
+            rc = gemm3(planes_at(W.attp), rows * Hd, Hd, 0, fused ? ws + W.s_qkv : ws + W.s_att, 0, 1, planes_at(W.wp_o[l]), ws + W.ws_o[l], (int)rows, Hd, Hd, o,
                        Wt + lo.bo, x, 1, ACT_NONE, "w2v2_gemm", true);
             if (rc) return rc;
             rc = ln(ws + W.y, nullptr, Wt + lo.ln1g, Wt + lo.ln1b, x, rows, Hd, c.eps, s, nullptr, nullptr, nullptr, planes_at(W.xp), true, ws + W.s_x,
@@ -1167,8 +1242,10 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
             if (rc) return rc;
             const bool last = (l == c.L - 1);
             // the last LayerNorm writes frame t of window w at out_row_start[w] + t (or packed, window after window)
+            if (fused && !last) RSAF_CHECK_HIP(hipMemsetAsync(ws + W.win_norm, 0, sizeof(unsigned) * n, s));
             rc = ln(ws + W.y, nullptr, Wt + lo.ln2g, Wt + lo.ln2b, last ? out : x, rows, Hd, c.eps, s,
-                    last ? out_row_start : nullptr, rowwin, row0, last ? nullptr : planes_at(W.xp), true, ws + W.s_x);
+                    last ? out_row_start : nullptr, rowwin, row0, last ? nullptr : planes_at(W.xp), true, ws + W.s_x,
+                    nullptr, nullptr, nullptr, (fused && !last) ? bits_at(W.win_norm) : nullptr);
             if (rc) return rc;
         }
     }
