@@ -306,7 +306,7 @@ def attach_traffic(roof, args, n_local):
     attached only when that profile was taken with this run's shape and kernel sources."""
     if not roof:
         return
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_bench_traffic.json")
         if not os.path.exists(path):
             continue
