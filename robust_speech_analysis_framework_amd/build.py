@@ -48,6 +48,10 @@ def _digest(paths) -> str:
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
                 "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
                 "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+# RSAF_BUILD_TEST_KERNELS=1: also compile the kernels that newer ones superseded in the product (the workgroup-FFT pitch
+# correlation kernels for transforms of up to 2 048 points), which some tests run as an independent A/B check
+if os.environ.get("RSAF_BUILD_TEST_KERNELS", "0") == "1":
+    COMMON_FLAGS.append("-DRSAF_TEST_KERNELS")
 
 
 def _compile_one(src: str, hdr_digest: str, force: bool, verbose: bool) -> str:

@@ -18,9 +18,11 @@
 // and cell update are lane-local (all four gates of a (row, unit) pair land in the same lane and
 // register index), h_t goes to LDS (double-buffered, one barrier per step) and to HBM.
 #include <algorithm>
+#include <cstdlib>
 
 #include "cnnlstm_kernels.h"
 #include "gemm_f32.h"
+#include "gemm_f16x3.h"
 
 namespace rsaf {
 namespace cnnlstm {
@@ -399,6 +401,281 @@ static int conv3(const float* x, const float* wk, const float* bias, const float
     return launch_gemm_f32(p, s, "cnn_conv_gemm");
 }
 
+
+static int tap_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
+    if (dst) RSAF_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return RSAF_OK;
+}
+
+// ---- the same forward with the convolutions and the LSTM input projections on the fp16-split GEMM (gemm_f16x3.hip) -------
+// Every GEMM operand is a pair of fp16 planes under a power-of-two scale.  A k = 3 / pad = 1 convolution reads three
+// consecutive rows of a sequence, so its A operand is stored with one zero row in front of and behind every sequence
+// ([B][T + 2][C]: the convolution is then a plain GEMM with lda = C, K = 3 C over the padded rows) and carries ONE scale per
+// sequence: the input's exact maximum, or for a convolution's own output the bound sqrt(K) max|a| max_n |w_n|_2 + max|b|
+// (+ max |residual|) with max|a| the largest |input| that the producing epilogue reported.
+__device__ __forceinline__ void split2_c(float xs, unsigned short& h, unsigned short& l) {
+    const _Float16 hh = (_Float16)xs;
+    h = __builtin_bit_cast(unsigned short, hh);
+    l = __builtin_bit_cast(unsigned short, (_Float16)(xs - (float)hh));
+}
+
+// largest |x| of every sequence (bit pattern of the float: non-negative floats order like unsigned integers)
+__global__ __launch_bounds__(256) void seq_absmax_kernel(const float4* __restrict__ x, int64_t n4_per_seq, int chunks,
+                                                         unsigned* __restrict__ amax) {
+    const int z = blockIdx.y;
+    const float4* p = x + (int64_t)z * n4_per_seq;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4_per_seq; i += (int64_t)chunks * 256) {
+        const float4 v = p[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max_nonneg(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(amax + z, __float_as_uint(m));
+}
+
+// scale[z] = the power of two for bound_z = amax_in[z] * factor_host * wstat[0] + bstat[1] (+ amax_res[z]); a NULL wstat = 1
+__global__ __launch_bounds__(256) void cnn_scale_kernel(const unsigned* __restrict__ amax_in, const unsigned* __restrict__ amax_res,
+                                                        const unsigned* __restrict__ wstat, const unsigned* __restrict__ bstat,
+                                                        float factor_host, float* __restrict__ scale, int n) {
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    if (z >= n) return;
+    float b = __uint_as_float(amax_in[z]) * factor_host * (wstat ? __uint_as_float(wstat[0]) * 1.000001f : 1.0f);
+    if (bstat) b += __uint_as_float(bstat[1]);
+    if (amax_res) b += __uint_as_float(amax_res[z]);
+    scale[z] = f16x2_scale_for_bound(b * 1.000001f);
+}
+
+// fp32 [B][T][C] -> plane pair [B][T + 2][C] (zero rows around every sequence), times scale[z]; POOL: the rows are first
+// max-pooled in pairs (src is [B][2 T (+1)][C]) and the pooled fp32 rows are kept as well (the residual of res_block2)
+template <bool POOL>
+__global__ __launch_bounds__(256) void split_padded_kernel(const float4* __restrict__ src, int B, int T, int Tsrc, int C4,
+                                                           const float* __restrict__ scale, unsigned short* __restrict__ planes,
+                                                           int64_t plane, float4* __restrict__ pooled) {
+    const int64_t n = (int64_t)B * (T + 2) * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const int64_t bt = i / C4;
+        const int tp = (int)(bt % (T + 2));
+        const int64_t b = bt / (T + 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tp >= 1 && tp <= T) {
+            const int t = tp - 1;
+            if (POOL) {
+                const float4 a = src[(b * Tsrc + 2 * t) * C4 + c], d = src[(b * Tsrc + 2 * t + 1) * C4 + c];
+                v = make_float4(fmaxf(a.x, d.x), fmaxf(a.y, d.y), fmaxf(a.z, d.z), fmaxf(a.w, d.w));
+                pooled[(b * T + t) * C4 + c] = v;
+            } else {
+                v = src[(b * Tsrc + t) * C4 + c];
+            }
+        }
+        const float sc = scale[b];
+        unsigned short hh[4], ll[4];
+        split2_c(v.x * sc, hh[0], ll[0]); split2_c(v.y * sc, hh[1], ll[1]);
+        split2_c(v.z * sc, hh[2], ll[2]); split2_c(v.w * sc, hh[3], ll[3]);
+        unsigned short* pp = planes + 4 * i;
+        *reinterpret_cast<uint2*>(pp) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+        *reinterpret_cast<uint2*>(pp + plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+    }
+}
+
+// zero the pad rows (first and last of every sequence) of a plane pair [B][T + 2][C] that a GEMM epilogue fills
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(unsigned short* __restrict__ planes, int64_t plane, int B, int T, int C8) {
+    const int64_t n = (int64_t)B * 2 * C8 * 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        int64_t r = i / C8;
+        const int pl = (int)(r & 1); r >>= 1;
+        const int which = (int)(r & 1);
+        const int64_t b = r >> 1;
+        const int64_t row = b * (T + 2) + (which ? T + 1 : 0);
+        *reinterpret_cast<uint4*>(planes + pl * plane + (row * C8 + c) * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// widths the fp16-split GEMM takes (K and N multiples of 16); anything else (test geometries) stays on the exact-fp32 MFMA
+static bool use_f16x3(int input_dim, int channels) {
+    static const bool off = [] { const char* e = getenv("RSAF_CNN_F32"); return e && e[0] == '1'; }();
+    return !off && input_dim % 16 == 0 && channels % 16 == 0;
+}
+
+struct F16Ws {          // float offsets into the workspace behind the fp32 buffers
+    int64_t xp, c1p, poolp, c3p, c4p, hp, wp[5], ws[5], wih_p[4], wih_s[4], stat, amax, scale, one, total;
+};
+constexpr int CNN_NSTAT = 5 + 5 + 4;     // weight matrices w1 wsc w2 w3 w4, their biases, wih[l]
+constexpr int CNN_NAMAX = 6, CNN_NSCALE = 6;
+
+static F16Ws make_f16_ws(const Dims& d, int B, int T) {
+    F16Ws w{};
+    int64_t o = 0;
+    auto take = [&](int64_t k) { int64_t s = o; o += pad4(k); return s; };
+    const int Tp = T / 2;
+    w.xp = take((int64_t)B * (T + 2) * d.D);
+    w.c1p = take((int64_t)B * (T + 2) * d.C);
+    w.poolp = take((int64_t)B * (Tp + 2) * d.C);
+    w.c3p = take((int64_t)B * (Tp + 2) * d.C);
+    w.c4p = take((int64_t)B * Tp * d.C);
+    w.hp = take((int64_t)B * Tp * 2 * d.H);
+    const int64_t wsz[5] = {(int64_t)d.C * 3 * d.D, (int64_t)d.C * d.D, (int64_t)d.C * 3 * d.C, (int64_t)d.C * 3 * d.C, (int64_t)d.C * 3 * d.C};
+    for (int i = 0; i < 5; ++i) { w.wp[i] = take(wsz[i]); w.ws[i] = take(d.C); }
+    for (int l = 0; l < d.L; ++l) { w.wih_p[l] = take((int64_t)8 * d.H * (l == 0 ? d.C : 2 * d.H)); w.wih_s[l] = take(8 * d.H); }
+    w.stat = take(2 * CNN_NSTAT);
+    w.amax = take((int64_t)CNN_NAMAX * B);
+    w.scale = take((int64_t)CNN_NSCALE * B);
+    w.one = take(4);
+    w.total = o;
+    return w;
+}
+
+static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layout& L, const float* W, float* ws, float* f16base,
+                         float* logits, float* res1_out, float* res2_out, float* lstm_out, float* pooled_out, hipStream_t s) {
+    int rc = RSAF_OK;
+    const int D = d.D, C = d.C, H = d.H, Tp = T / 2;
+    const int64_t conv = pad4((int64_t)B * T * C);
+    float* bufA = ws;
+    float* bufB = ws + conv;
+    float* bufC = ws + 2 * conv;
+    float* xproj = ws + 3 * conv;
+    float* seq0 = xproj + pad4((int64_t)B * Tp * 8 * H);
+    float* seq1 = seq0 + pad4((int64_t)B * Tp * 2 * H);
+    const F16Ws F = make_f16_ws(d, B, T);
+    auto planes = [&](int64_t off) { return reinterpret_cast<uint16_t*>(f16base + off); };
+    unsigned* stat = reinterpret_cast<unsigned*>(f16base + F.stat);          // [CNN_NSTAT][2]: {max row norm, max |element|}
+    unsigned* amax = reinterpret_cast<unsigned*>(f16base + F.amax);          // [6][B]: x, shortcut, conv1, conv2, conv3, (spare)
+    float* scale = f16base + F.scale;                                       // [6][B]: x, conv1, pooled, conv3, conv4, (spare)
+    float* one = f16base + F.one;
+    enum { AX = 0, ASC = 1, AC1 = 2, AC2 = 3, AC3 = 4 };
+    enum { SX = 0, SC1 = 1, SPOOL = 2, SC3 = 3, SC4 = 4 };
+    RSAF_CHECK_HIP(hipMemsetAsync(stat, 0, sizeof(unsigned) * 2 * CNN_NSTAT, s));
+    RSAF_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * CNN_NAMAX * B, s));
+    // weights -> plane pairs in k16 panels with their row scales; statistics: matrix i at slot i, its bias at slot 5 + i
+    const int64_t woff[5] = {L.w1, L.wsc, L.w2, L.w3, L.w4}, boff[5] = {L.b1, L.bsc, L.b2, L.b3, L.b4};
+    const int wk[5] = {3 * D, D, 3 * C, 3 * C, 3 * C};
+    for (int i = 0; i < 5; ++i) {
+        if (woff[i] < 0) continue;                                          // no 1x1 shortcut when D == C
+        if ((rc = launch_f16x2_row_scales(W + woff[i], C, wk[i], wk[i], f16base + F.ws[i], nullptr, stat + 2 * i, s))) return rc;
+        if ((rc = launch_split_f16x2(W + woff[i], C, wk[i], wk[i], f16base + F.ws[i], 1, planes(F.wp[i]), (int64_t)C * wk[i], 1, s))) return rc;
+        if ((rc = launch_f16x2_row_scales(W + boff[i], 1, C, C, one, nullptr, stat + 2 * (5 + i), s))) return rc;
+    }
+    for (int l = 0; l < d.L; ++l) {
+        const int in = l == 0 ? C : 2 * H;
+        if ((rc = launch_f16x2_row_scales(W + L.wih[l], 8 * H, in, in, f16base + F.wih_s[l], nullptr, stat + 2 * (10 + l), s))) return rc;
+        if ((rc = launch_split_f16x2(W + L.wih[l], 8 * H, in, in, f16base + F.wih_s[l], 1, planes(F.wih_p[l]), (int64_t)8 * H * in, 1, s))) return rc;
+    }
+    RSAF_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(one), 0x46800000, 1, s));   // 16384.0f: |h| < 1 for every LSTM output
+    auto cnn_scale = [&](int a_in, int a_res, int w_slot, int b_slot, float factor, int s_out) {
+        hipLaunchKernelGGL(cnn_scale_kernel, dim3((B + 255) / 256), dim3(256), 0, s, amax + (int64_t)a_in * B,
+                           a_res >= 0 ? amax + (int64_t)a_res * B : nullptr, w_slot >= 0 ? stat + 2 * w_slot : nullptr,
+                           b_slot >= 0 ? stat + 2 * b_slot : nullptr, factor, scale + (int64_t)s_out * B, B);
+    };
+    // one GEMM of the block: A = padded plane pair (row stride lda, Tr rows per sequence, first tap at a_row0), per-sequence scale
+    auto gemm = [&](const uint16_t* A, int64_t a_plane, int64_t a_seq_rows, int a_row0, int lda, int s_in, int widx, int M, int N, int K,
+                    float* Cf, uint16_t* Cp, int64_t c_plane, int64_t cp_seq_rows, int cp_row0, int s_out, const float* bias,
+                    const float* R, int act, int amax_slot, const char* tag) {
+        GemmH3Params p{};
+        p.A = A + (int64_t)a_row0 * lda; p.a_plane = a_plane; p.lda = lda; p.sA = a_seq_rows * lda;
+        p.a_scale = scale + (int64_t)s_in * B; p.a_scale_zs = 1; p.a_scale_ms = 0;
+        p.B = planes(F.wp[widx]); p.b_plane = (int64_t)N * K; p.ldb = 16; p.b_panel = 1; p.b_scale = f16base + F.ws[widx];
+        p.C = Cf; p.ldc = N; p.sC = (int64_t)M * N;
+        p.Cp = Cp ? Cp + (int64_t)cp_row0 * N : nullptr; p.c_plane = c_plane; p.ldcp = N; p.sCp = cp_seq_rows * N;
+        p.c_scale = s_out >= 0 ? scale + (int64_t)s_out * B : nullptr; p.c_scale_zs = 1; p.c_scale_ms = 0;
+        p.amax_out = amax_slot >= 0 ? amax + (int64_t)amax_slot * B : nullptr; p.amax_zs = 1;
+        p.bias = bias; p.R = R; p.ldr = N; p.sR = (int64_t)M * N;
+        p.M = M; p.N = N; p.K = K; p.nz = B; p.act = act; p.alpha = 1.0f;
+        return launch_gemm_f16x3(p, s, tag);
+    };
+    const int64_t pl_x = (int64_t)B * (T + 2) * D, pl_c = (int64_t)B * (T + 2) * C, pl_p = (int64_t)B * (Tp + 2) * C;
+    // x -> padded planes under the exact maximum of every sequence
+    {
+        ProfScope prof("cnn_split_input", s, 0.0, (double)B * T * D * 12.0);
+        const int64_t n4 = (int64_t)T * D / 4;
+        const int chunks = (int)std::min<int64_t>((n4 + 255) / 256, 64);
+        hipLaunchKernelGGL(seq_absmax_kernel, dim3(chunks, B), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4, chunks, amax + AX * B);
+        cnn_scale(AX, -1, -1, -1, 1.0f, SX);
+        const int64_t tot = (int64_t)B * (T + 2) * (D / 4);
+        hipLaunchKernelGGL(split_padded_kernel<false>, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 8192)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(x), B, T, T, D / 4, scale + SX * B, planes(F.xp), pl_x, nullptr);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    // res_block1 (src/models.py:64-76, :175): conv1 -> planes, shortcut -> fp32, conv2 (+ shortcut) -> fp32
+    cnn_scale(AX, -1, 0, 5, sqrtf((float)(3 * D)) * 1.00001f, SC1);
+    hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(64), dim3(256), 0, s, planes(F.c1p), pl_c, B, T, C / 8);
+    rc = gemm(planes(F.xp), pl_x, T + 2, 0, D, SX, 0, T, C, 3 * D, nullptr, planes(F.c1p), pl_c, T + 2, 1, SC1, W + L.b1, nullptr,
+              d.act, AC1, "cnn_conv_gemm");
+    if (rc) return rc;
+    const float* sc = x;
+    int sc_amax = AX;
+    if (D != C) {
+        rc = gemm(planes(F.xp), pl_x, T + 2, 1, D, SX, 1, T, C, D, bufB, nullptr, 0, 0, 0, -1, W + L.bsc, nullptr, ACT_NONE, ASC, "cnn_conv_gemm");
+        if (rc) return rc;
+        sc = bufB; sc_amax = ASC;
+    }
+    rc = gemm(planes(F.c1p), pl_c, T + 2, 0, C, SC1, 2, T, C, 3 * C, bufC, nullptr, 0, 0, 0, -1, W + L.b2, sc, d.act, AC2, "cnn_conv_gemm");
+    if (rc) return rc;
+    (void)sc_amax;
+    if ((rc = tap_copy(res1_out, bufC, (int64_t)B * T * C, s))) return rc;
+    // max_pool1d(2) (:177): pooled fp32 rows (the residual of res_block2) + padded planes; max |pooled| <= max |conv2 output|
+    cnn_scale(AC2, -1, -1, -1, 1.0f, SPOOL);
+    {
+        ProfScope prof("cnn_pool2", s, 0.0, (double)B * T * C * 4 * 2.0);
+        const int64_t tot = (int64_t)B * (Tp + 2) * (C / 4);
+        hipLaunchKernelGGL(split_padded_kernel<true>, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 8192)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(bufC), B, Tp, T, C / 4, scale + SPOOL * B, planes(F.poolp), pl_p,
+                           reinterpret_cast<float4*>(bufA));
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    // res_block2, identity shortcut (:178)
+    cnn_scale(AC2, -1, 3, 8, sqrtf((float)(3 * C)) * 1.00001f, SC3);
+    hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(64), dim3(256), 0, s, planes(F.c3p), pl_p, B, Tp, C / 8);
+    rc = gemm(planes(F.poolp), pl_p, Tp + 2, 0, C, SPOOL, 3, Tp, C, 3 * C, nullptr, planes(F.c3p), pl_p, Tp + 2, 1, SC3, W + L.b3, nullptr,
+              d.act, AC3, "cnn_conv_gemm");
+    if (rc) return rc;
+    cnn_scale(AC3, AC2, 4, 9, sqrtf((float)(3 * C)) * 1.00001f, SC4);      // + the residual (pooled: <= conv2's maximum)
+    rc = gemm(planes(F.c3p), pl_p, Tp + 2, 0, C, SC3, 4, Tp, C, 3 * C, bufC, planes(F.c4p), (int64_t)B * Tp * C, Tp, 0, SC4, W + L.b4, bufA,
+              d.act, -1, "cnn_conv_gemm");
+    if (rc) return rc;
+    if ((rc = tap_copy(res2_out, bufC, (int64_t)B * Tp * C, s))) return rc;
+    // LSTM (:184): input projections on the same GEMM; layer 0 reads conv4's planes (one scale per sequence), the layers
+    // behind it the plane pair of the previous layer's output under the fixed scale 2^14
+    const float* lin = bufC;
+    float* lout = seq0;
+    for (int l = 0; l < d.L; ++l) {
+        const int in = l == 0 ? C : 2 * H;
+        GemmH3Params p{};
+        p.B = planes(F.wih_p[l]); p.b_plane = (int64_t)8 * H * in; p.ldb = 16; p.b_panel = 1; p.b_scale = f16base + F.wih_s[l];
+        p.C = xproj; p.ldc = 8 * H; p.bias = W + L.bih[l]; p.N = 8 * H; p.K = in; p.act = ACT_NONE; p.alpha = 1.0f;
+        if (l == 0) {
+            p.A = planes(F.c4p); p.a_plane = (int64_t)B * Tp * C; p.lda = C; p.sA = (int64_t)Tp * C;
+            p.a_scale = scale + SC4 * B; p.a_scale_zs = 1; p.a_scale_ms = 0;
+            p.M = Tp; p.nz = B; p.sC = (int64_t)Tp * 8 * H;
+        } else {
+            const int64_t rows = (int64_t)B * Tp;
+            RSAF_CHECK_ARG(rows <= 0x7fffffffLL, "B*T too large");
+            if ((rc = launch_split_f16x2(lin, rows, in, in, one, 0, planes(F.hp), rows * in, 1, s))) return rc;
+            p.A = planes(F.hp); p.a_plane = rows * in; p.lda = 16; p.a_panel = 1;
+            p.a_scale = one; p.a_scale_zs = 0; p.a_scale_ms = 0;
+            p.M = (int)rows; p.nz = 1;
+        }
+        rc = launch_gemm_f16x3(p, s, "lstm_inproj_gemm");
+        if (rc) return rc;
+        rc = launch_lstm_rec(xproj, W + L.whh[l], lout, nullptr, nullptr, B, Tp, H, s);
+        if (rc) return rc;
+        lin = lout;
+        lout = (lout == seq0) ? seq1 : seq0;
+    }
+    if ((rc = tap_copy(lstm_out, lin, (int64_t)B * Tp * 2 * H, s))) return rc;
+    {
+        ProfScope prof("attnpool_fc", s, 0.0, (double)B * Tp * 2 * H * 4);
+        if (H == 128)
+            hipLaunchKernelGGL(attnpool_fc_kernel<4>, dim3(B), dim3(256), 0, s, lin, W + L.watt, W + L.batt,
+                               W + L.wfc, W + L.bfc, logits, pooled_out, Tp, d.NC);
+        else
+            hipLaunchKernelGGL(attnpool_fc_kernel<2>, dim3(B), dim3(256), 0, s, lin, W + L.watt, W + L.batt,
+                               W + L.wfc, W + L.bfc, logits, pooled_out, Tp, d.NC);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
+    return RSAF_OK;
+}
+
 }  // namespace cnnlstm
 }  // namespace rsaf
 
@@ -438,12 +715,12 @@ int64_t rsaf_cnnlstm_workspace_bytes(int B, int T, int input_dim, int channels, 
     const int64_t conv = pad4((int64_t)B * T * channels);
     const int64_t xp = pad4((int64_t)B * Tp * 8 * hidden);
     const int64_t sq = pad4((int64_t)B * Tp * 2 * hidden);
-    return (3 * conv + xp + 2 * sq) * (int64_t)sizeof(float);
-}
-
-static int tap_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
-    if (dst) RSAF_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return RSAF_OK;
+    int64_t f16 = 0;                                     // plane pairs, scales and statistics of the fp16-split GEMM path
+    if (use_f16x3(input_dim, channels)) {
+        Dims d{input_dim, channels, hidden, 2, lstm_layers, ACT_SILU};
+        f16 = make_f16_ws(d, B, T).total;
+    }
+    return (3 * conv + xp + 2 * sq + f16) * (int64_t)sizeof(float);
 }
 
 static int forward_impl(const float* x, int B, int T, int input_dim, int channels, int hidden, int num_classes,
@@ -474,6 +751,9 @@ static int forward_impl(const float* x, int B, int T, int input_dim, int channel
     float* seq0 = xproj + pad4((int64_t)B * Tp * 8 * H);
     float* seq1 = seq0 + pad4((int64_t)B * Tp * 2 * H);
     const float* W = weights;
+    if (use_f16x3(D, C))
+        return forward_f16x3(x, B, T, d, L, W, ws, seq1 + pad4((int64_t)B * Tp * 2 * H), logits, res1_out, res2_out, lstm_out,
+                             pooled_out, s);
 
     // res_block1 (src/models.py:64-76, :175)
     rc = conv3(x, W + L.w1, W + L.b1, nullptr, 0, 0, bufA, B, T, D, C, d.act, s);

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         if (tid < BM) {
             const int row = T.m0 + tid < T.Mz ? T.m0 + tid : T.Mz - 1;                      // clamped: rows past M are never stored
             e0 = p.a_scale[T.z1 * p.a_scale_zs + (int64_t)row * p.a_scale_ms];
-            e1 = OUT_PLANES ? p.c_scale[T.z1 * p.c_scale_zs + (int64_t)row * p.c_scale_ms] : 1.0f;
+            e1 = (OUT_PLANES && p.Cp) ? p.c_scale[T.z1 * p.c_scale_zs + (int64_t)row * p.c_scale_ms] : 1.0f;
         } else if (tid < BM + BN) {
             const int col = T.n0 + tid - BM;
             e0 = col < p.N ? p.b_scale[T.z2 * p.sBias2 + col] : 1.0f;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool ok = (tn + c4) < p.N && (tm + 8 * q + lr) < done.Mz;
-            r4[q] = ok ? *reinterpret_cast<const float4*>(Rt + (8 * q + lr) * (int)p.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r4[q] = (ok && p.R) ? *reinterpret_cast<const float4*>(Rt + (8 * q + lr) * (int)p.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (tid < BM + BN) { tab0[tid] = e0; tab1[tid] = e1; }
@@ -406,9 +406,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
                     for (int j = 0; j < CW; ++j) row_amax[q] = fmaxf(row_amax[q], fabsf(v[q][j]));
                 }
                 if (ok) {
-                    if (OUT_F32) *reinterpret_cast<float4*>(p.C + (done.coff >= 0 ? done.coff : z1 * p.sC) + z2 * p.sC2 + (int64_t)row * p.ldc + gc) =
+                    if (OUT_F32 && p.C) *reinterpret_cast<float4*>(p.C + (done.coff >= 0 ? done.coff : z1 * p.sC) + z2 * p.sC2 + (int64_t)row * p.ldc + gc) =
                         make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
-                    if (OUT_PLANES) {
+                    if (OUT_PLANES && p.Cp) {
                         const float cs = csc[q];
                         unsigned short hh[CW], ll[CW];
 #pragma unroll
@@ -578,12 +578,14 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     RSAF_CHECK_ARG(p.nz <= 65535, "at most 65535 batches per launch");
     RSAF_CHECK_ARG(!(p.a_panel || p.cp_panel) || p.nz == 1, "panel layouts are for unbatched operands");
     RSAF_CHECK_ARG(p.ldc < (1 << 24) && p.ldcp < (1 << 24) && p.ldr < (1 << 24), "leading dimensions must be below 2^24");
+    RSAF_CHECK_ARG(!p.R || p.C, "the residual comes with the fp32 output");
     RSAF_CHECK_ARG(p.nz2 <= 1 || (p.C && !p.Cp && !p.R && !p.a_panel && p.nz % p.nz2 == 0),
                    "two-level batches: fp32 output only, no residual, A row-major, nz a multiple of nz2");
     // algorithmic FLOPs of the contraction (2 M N K); the matrix pipe executes three fp16 products per term
     ProfScope prof(tag ? tag : "gemm_f16x3", stream, 2.0 * p.M * (double)p.N * p.K * p.nz, 0.0);
     using CfgA = H3Cfg<4, 2, 2, 4, 3, 1>;                // 256 x 256
     using CfgN = H3Cfg<2, 1, 4, 2, 3, 1>;                // 256 x 64: N <= 64 (the 48-wide groups of the positional convolution)
+    using CfgM = H3Cfg<4, 1, 2, 4, 3, 1>;                // 256 x 128: N <= 128 (the CNN-LSTM's 128 channels)
 #define H3_LAUNCH_CFG(CFG, ACT, F32, PL, HR)                                                                            \
     do {                                                                                                                \
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16x3_kernel<CFG, ACT, F32, PL, HR>,                        \
@@ -596,6 +598,13 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
 #define H3_LAUNCH(ACT, F32, PL, HR)                                                                                     \
     do {                                                                                                                \
         if (p.N <= 64) H3_LAUNCH_CFG(CfgN, ACT, F32, PL, HR);                                                            \
+        else H3_LAUNCH_CFG(CfgA, ACT, F32, PL, HR);                                                                      \
+    } while (0)
+    // the CNN-LSTM's shapes (N = 128 channels: the 256 x 128 tile) take three tile configurations
+#define H3_LAUNCH3(ACT, F32, PL, HR)                                                                                    \
+    do {                                                                                                                \
+        if (p.N <= 64) H3_LAUNCH_CFG(CfgN, ACT, F32, PL, HR);                                                            \
+        else if (p.N <= 128) H3_LAUNCH_CFG(CfgM, ACT, F32, PL, HR);                                                      \
         else H3_LAUNCH_CFG(CfgA, ACT, F32, PL, HR);                                                                      \
     } while (0)
     GemmH3Params pp = p;
@@ -611,19 +620,24 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     }
     const bool f32o = p.C != nullptr, plo = p.Cp != nullptr, hr = p.R != nullptr;
     // the combinations the Wav2Vec2 / CNN stages use (anything else is an argument error, not a silent fallback)
-    if (p.act == ACT_NONE && f32o && !plo && !hr) H3_LAUNCH(ACT_NONE, true, false, false);
+    if (p.act == ACT_NONE && f32o && !plo && !hr) H3_LAUNCH3(ACT_NONE, true, false, false);
     else if (p.act == ACT_NONE && f32o && !plo && hr) H3_LAUNCH(ACT_NONE, true, false, true);
     else if (p.act == ACT_GELU && !f32o && plo && !hr) H3_LAUNCH(ACT_GELU, false, true, false);
     else if (p.act == ACT_GELU && f32o && !plo && !hr) H3_LAUNCH(ACT_GELU, true, false, false);
     else if (p.act == ACT_SILU && f32o && !plo && !hr) H3_LAUNCH(ACT_SILU, true, false, false);
     else if (p.act == ACT_NONE && !f32o && plo && !hr) H3_LAUNCH(ACT_NONE, false, true, false);
     else if (p.act == ACT_NONE && f32o && plo && !hr) H3_LAUNCH(ACT_NONE, true, true, false);
+    // every other activation epilogue (residual and / or both outputs, SiLU -> planes: the CNN-LSTM's convolutions) runs on
+    // the all-outputs variant of its activation, whose fp32 / plane / residual pointers may each be NULL
+    else if (p.act == ACT_GELU) H3_LAUNCH3(ACT_GELU, true, true, true);
+    else if (p.act == ACT_SILU) H3_LAUNCH3(ACT_SILU, true, true, true);
     else {
         set_error("launch_gemm_f16x3: unsupported combination of activation / outputs / residual");
         return RSAF_ERR_ARG;
     }
 #undef H3_LAUNCH_CFG
 #undef H3_LAUNCH
+#undef H3_LAUNCH3
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -3376,6 +3376,11 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     {
         const char* e = getenv("RSAF_PITCH_FFT");
         const bool want = !(e && e[0] == 'w' && e[1] == 'g');
+#ifndef RSAF_TEST_KERNELS
+        // the workgroup-FFT kernels the one-wave kernels superseded (transforms of up to 2 048 points) are compiled only into
+        // a test build (RSAF_BUILD_TEST_KERNELS=1 python -m ...build), where they serve as an independent A/B check
+        RSAF_CHECK_ARG(want, "RSAF_PITCH_FFT=wg needs a library built with RSAF_BUILD_TEST_KERNELS=1");
+#endif
         // A shorter transform is zero-padded up to the smallest wave size: the correlation is linear as long as the lags stay
         // below (transform length - window), so a longer transform returns the same values (autocorrelation: 512 complex =
         // 1024 real points; cross-correlation: 1024 points, whose transform back has the 512 the wave kernel needs).
@@ -3385,8 +3390,12 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     if (wave_r && !P.is_cc) P.nfft = 128 * wave_r;                  // 2 S real points
     if (wave_r && P.is_cc) ncc = 64 * wave_r;
     if (!wave_r && lds_corr > 48 * 1024) {
+#ifdef RSAF_TEST_KERNELS
         const void* fn = (const void*)pitch_ac_kernel<11>;            // 4 096 points: 64 KB (the only AC instance above 48 KB)
         if (P.is_cc) fn = log2n == 11 ? (const void*)pitch_cc_kernel<11> : (const void*)pitch_cc_kernel<12>;   // 64 / 128 KB
+#else
+        const void* fn = (const void*)pitch_cc_kernel<12>;            // 4 096-point cross-correlation: the one transform above the wave sizes
+#endif
         RSAF_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_corr));
     }
     const double* twiddles = nullptr;
@@ -3468,7 +3477,10 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                            (double*)workspace, rstride, max_frames);                                                  \
         break;
                 switch (log2n) {
-                    RSAF_CC_CASE(6) RSAF_CC_CASE(7) RSAF_CC_CASE(8) RSAF_CC_CASE(9) RSAF_CC_CASE(10) RSAF_CC_CASE(11) RSAF_CC_CASE(12)
+#ifdef RSAF_TEST_KERNELS
+                    RSAF_CC_CASE(6) RSAF_CC_CASE(7) RSAF_CC_CASE(8) RSAF_CC_CASE(9) RSAF_CC_CASE(10) RSAF_CC_CASE(11)
+#endif
+                    RSAF_CC_CASE(12)
                     default: set_error("rsaf_mshds_pitch: unsupported FFT length"); return RSAF_ERR_ARG;
                 }
 #undef RSAF_CC_CASE
@@ -3481,8 +3493,10 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                            rstride, max_frames);                                                                      \
         break;
                 switch (log2m) {
+#ifdef RSAF_TEST_KERNELS
                     RSAF_AC_CASE(3) RSAF_AC_CASE(4) RSAF_AC_CASE(5) RSAF_AC_CASE(6) RSAF_AC_CASE(7) RSAF_AC_CASE(8)
                     RSAF_AC_CASE(9) RSAF_AC_CASE(10) RSAF_AC_CASE(11)
+#endif
                     default: set_error("rsaf_mshds_pitch: unsupported FFT length"); return RSAF_ERR_ARG;
                 }
 #undef RSAF_AC_CASE
