@@ -523,6 +523,35 @@ def main():
                                                    "through rsaf_w2v2_forward_ragged"}
             per_config["C3_ragged"]["relative_to_equal_length_C3"] = round(per_config["C3_ragged"]["value"] / per_config["C3"]["value"], 4)
             del wav_r
+        # The drop-in path a notebook gets: `src.*` on 16-bit WAV files with the default batch sizes (32 files per MSHDS batch,
+        # 64 files / 256 windows per Wav2Vec2 sub-batch), file read + decode + H2D + extraction + D2H of the sequences included
+        if pipe.w2v2 is not None and pipe.mshds is not None:
+            import tempfile
+            import wave
+            import pandas as pd
+            n_files = min(64, n_local)
+            with tempfile.TemporaryDirectory(prefix="rsaf_dropin_") as td:
+                paths = []
+                for k in range(n_files):
+                    pth = os.path.join(td, f"clip_{k:03d}.wav")
+                    with wave.open(pth, "wb") as wf:
+                        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+                        wf.writeframes(np.round(base[uniq[k % len(uniq)]] * 32767.0).astype(np.int16).tobytes())
+                    paths.append(pth)
+                df = pd.DataFrame({"filepath": paths})
+                os.environ.setdefault("RSAF_W2V2_RANDOM_SEED", "0")
+                from src.foundation_model_extractor import extract_wav2vec2_sequences
+                from src.mshds_extractor import extract_mshds_features
+
+                def dropin():
+                    f = extract_mshds_features(df, verbose=False)
+                    q = extract_wav2vec2_sequences(df, model_name="seeded-random-base", verbose=False)
+                    assert len(f) == n_files and len(q) == n_files
+                per_config["dropin_mshds_w2v2"] = {
+                    **timed(dropin, n_files * args.seconds),
+                    "workload": f"src.mshds_extractor.extract_mshds_features + src.foundation_model_extractor.extract_wav2vec2_sequences on "
+                                f"{n_files} x {args.seconds:g} s 16-bit WAV files (default batch sizes; file read, decode, H2D, D2H of the "
+                                f"{n_files} x 1842 x 768 float32 sequences included)"}
         per_config["note"] = "measured after the timed region in the same process (resident inputs, no CPU baseline); the headline value is the e2e line"
         log("per-config lines: " + ", ".join(f"{k} {v['value']}" for k, v in per_config.items() if k != "note"))
 

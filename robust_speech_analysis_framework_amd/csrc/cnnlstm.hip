@@ -478,6 +478,22 @@ __global__ __launch_bounds__(256) void split_padded_kernel(const float4* __restr
     }
 }
 
+// fp32 [B][n4 float4] -> plane pair of the same shape, times scale[b]
+__global__ __launch_bounds__(256) void split_rows_kernel(const float4* __restrict__ src, int B, int64_t n4_per_seq,
+                                                         const float* __restrict__ scale, unsigned short* __restrict__ planes, int64_t plane) {
+    const int64_t n = (int64_t)B * n4_per_seq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float4 v = src[i];
+        const float sc = scale[i / n4_per_seq];
+        unsigned short hh[4], ll[4];
+        split2_c(v.x * sc, hh[0], ll[0]); split2_c(v.y * sc, hh[1], ll[1]);
+        split2_c(v.z * sc, hh[2], ll[2]); split2_c(v.w * sc, hh[3], ll[3]);
+        unsigned short* pp = planes + 4 * i;
+        *reinterpret_cast<uint2*>(pp) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+        *reinterpret_cast<uint2*>(pp + plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+    }
+}
+
 // zero the pad rows (first and last of every sequence) of a plane pair [B][T + 2][C] that a GEMM epilogue fills
 __global__ __launch_bounds__(256) void zero_pad_rows_kernel(unsigned short* __restrict__ planes, int64_t plane, int B, int T, int C8) {
     const int64_t n = (int64_t)B * 2 * C8 * 2;
@@ -543,7 +559,7 @@ static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layo
     unsigned* amax = reinterpret_cast<unsigned*>(f16base + F.amax);          // [6][B]: x, shortcut, conv1, conv2, conv3, (spare)
     float* scale = f16base + F.scale;                                       // [6][B]: x, conv1, pooled, conv3, conv4, (spare)
     float* one = f16base + F.one;
-    enum { AX = 0, ASC = 1, AC1 = 2, AC2 = 3, AC3 = 4 };
+    enum { AX = 0, ASC = 1, AC1 = 2, AC2 = 3, AC3 = 4, AC4 = 5 };
     enum { SX = 0, SC1 = 1, SPOOL = 2, SC3 = 3, SC4 = 4 };
     RSAF_CHECK_HIP(hipMemsetAsync(stat, 0, sizeof(unsigned) * 2 * CNN_NSTAT, s));
     RSAF_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * CNN_NAMAX * B, s));
@@ -629,11 +645,17 @@ static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layo
     rc = gemm(planes(F.poolp), pl_p, Tp + 2, 0, C, SPOOL, 3, Tp, C, 3 * C, nullptr, planes(F.c3p), pl_p, Tp + 2, 1, SC3, W + L.b3, nullptr,
               d.act, AC3, "cnn_conv_gemm");
     if (rc) return rc;
-    cnn_scale(AC3, AC2, 4, 9, sqrtf((float)(3 * C)) * 1.00001f, SC4);      // + the residual (pooled: <= conv2's maximum)
-    rc = gemm(planes(F.c3p), pl_p, Tp + 2, 0, C, SC3, 4, Tp, C, 3 * C, bufC, planes(F.c4p), (int64_t)B * Tp * C, Tp, 0, SC4, W + L.b4, bufA,
-              d.act, -1, "cnn_conv_gemm");
+    rc = gemm(planes(F.c3p), pl_p, Tp + 2, 0, C, SC3, 4, Tp, C, 3 * C, bufC, nullptr, 0, 0, 0, -1, W + L.b4, bufA, d.act, AC4, "cnn_conv_gemm");
     if (rc) return rc;
     if ((rc = tap_copy(res2_out, bufC, (int64_t)B * Tp * C, s))) return rc;
+    // conv4's output as the plane pair of the first input projection, under the exact maximum of every sequence
+    cnn_scale(AC4, -1, -1, -1, 1.0f, SC4);
+    {
+        const int64_t tot = (int64_t)B * Tp * (C / 4);
+        hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 8192)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(bufC), B, (int64_t)Tp * (C / 4), scale + SC4 * B, planes(F.c4p), (int64_t)B * Tp * C);
+        RSAF_CHECK_HIP(hipGetLastError());
+    }
     // LSTM (:184): input projections on the same GEMM; layer 0 reads conv4's planes (one scale per sequence), the layers
     // behind it the plane pair of the previous layer's output under the fixed scale 2^14
     const float* lin = bufC;

@@ -57,8 +57,12 @@ struct H3Cfg {
     static constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;          // 1 KiB DMA wave-instructions per plane
     static constexpr int PATCH_BYTES = WM * WN * 32 * 36 * 4;           // wave-private transposition patches of the epilogue
     static constexpr int TAB_BYTES = 2 * (BM + BN) * 4;                 // the tile's row / column scales and biases (epilogue)
-    static constexpr int LDS_BYTES = NST * STAGE * 2 + PATCH_BYTES + TAB_BYTES;     // the patches do NOT alias the stages: the next tile's
-                                                                        // first k-tiles land while the epilogue runs
+    // The patches do not alias stages 0 and 1: the next tile's first two k-tiles land there while the epilogue runs.  Stage 2
+    // is free from the end of a tile's main loop until the next tile's first refill (issued inside that tile's main loop):
+    // the 512 x 128 configuration, whose three 40 KB stages leave no room beside them, keeps its patches there.
+    static constexpr bool PATCH_IN_STAGE2 = BM > 256;
+    static_assert(!PATCH_IN_STAGE2 || STAGE * 2 >= PATCH_BYTES, "stage 2 must hold the epilogue patches");
+    static constexpr int LDS_BYTES = NST * STAGE * 2 + (PATCH_IN_STAGE2 ? 0 : PATCH_BYTES) + TAB_BYTES;
 };
 
 // DMA source address = wave-uniform base (kept in an SGPR pair) + 32-bit per-lane byte offset: the instruction's
@@ -181,25 +185,30 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
     constexpr int NDMA = NPL * IPW;                          // DMA instructions of this wave per k-tile
     constexpr int HM = TM / 2;
     constexpr int PATCH_LD = 36;                             // floats per patch row (16-byte aligned rows, 2-way write conflicts)
-    float* patch = reinterpret_cast<float*>(smem3 + NST * STAGE) + wave * (32 * PATCH_LD);
+    float* patch = reinterpret_cast<float*>(smem3 + (CFG::PATCH_IN_STAGE2 ? 2 : NST) * STAGE) + wave * (32 * PATCH_LD);
 
     // The epilogue's per-row and per-column operands (scales of A and of the plane output; scales of B and bias) reach it
     // through LDS: thread t fetches row t's (t < BM) or column t - BM's pair when the tile STARTS, keeps it in two registers
     // through the main loop and files it behind the last k-tile.  (As global loads inside the epilogue they sat behind the
     // stores in the wave's in-order memory counter, or cost 30+ registers when all fetched up front.)
-    static_assert(CFG::THREADS >= BM + BN, "one thread per row and per column of the tile");
-    float* tab0 = reinterpret_cast<float*>(smem3 + NST * STAGE) + NW * (32 * PATCH_LD);   // [BM] a_scale | [BN] b_scale
+    constexpr int TPT = (BM + BN + CFG::THREADS - 1) / CFG::THREADS;     // table entries per thread (1; 2 for the 512 x 128 tile)
+    float* tab0 = reinterpret_cast<float*>(smem3 + NST * STAGE) + (CFG::PATCH_IN_STAGE2 ? 0 : NW * (32 * PATCH_LD));   // [BM] a_scale | [BN] b_scale
     float* tab1 = tab0 + (BM + BN);                                                        // [BM] c_scale | [BN] bias
-    float e0 = 1.0f, e1 = 0.0f;
+    float e0[TPT], e1[TPT];
     auto load_epi = [&](const Tile& T) {
-        if (tid < BM) {
-            const int row = T.m0 + tid < T.Mz ? T.m0 + tid : T.Mz - 1;                      // clamped: rows past M are never stored
-            e0 = p.a_scale[T.z1 * p.a_scale_zs + (int64_t)row * p.a_scale_ms];
-            e1 = (OUT_PLANES && p.Cp) ? p.c_scale[T.z1 * p.c_scale_zs + (int64_t)row * p.c_scale_ms] : 1.0f;
-        } else if (tid < BM + BN) {
-            const int col = T.n0 + tid - BM;
-            e0 = col < p.N ? p.b_scale[T.z2 * p.sBias2 + col] : 1.0f;
-            e1 = (p.bias && col < p.N) ? p.bias[T.z2 * p.sBias2 + col] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int i = tid + u * CFG::THREADS;
+            e0[u] = 1.0f; e1[u] = 0.0f;
+            if (i < BM) {
+                const int row = T.m0 + i < T.Mz ? T.m0 + i : T.Mz - 1;                      // clamped: rows past M are never stored
+                e0[u] = p.a_scale[T.z1 * p.a_scale_zs + (int64_t)row * p.a_scale_ms];
+                e1[u] = (OUT_PLANES && p.Cp) ? p.c_scale[T.z1 * p.c_scale_zs + (int64_t)row * p.c_scale_ms] : 1.0f;
+            } else if (i < BM + BN) {
+                const int col = T.n0 + i - BM;
+                e0[u] = col < p.N ? p.b_scale[T.z2 * p.sBias2 + col] : 1.0f;
+                e1[u] = (p.bias && col < p.N) ? p.bias[T.z2 * p.sBias2 + col] : 0.0f;
+            }
         }
     };
     Tile cur;
@@ -325,7 +334,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             r4[q] = (ok && p.R) ? *reinterpret_cast<const float4*>(Rt + (8 * q + lr) * (int)p.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    if (tid < BM + BN) { tab0[tid] = e0; tab1[tid] = e1; }
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+        const int i = tid + u * CFG::THREADS;
+        if (i < BM + BN) { tab0[i] = e0[u]; tab1[i] = e1[u]; }
+    }
     if (HAS_R) load_r(0, 0);
 
     // ---- next tile: its first two k-tiles travel while this tile's epilogue runs ----
@@ -585,7 +598,9 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     ProfScope prof(tag ? tag : "gemm_f16x3", stream, 2.0 * p.M * (double)p.N * p.K * p.nz, 0.0);
     using CfgA = H3Cfg<4, 2, 2, 4, 3, 1>;                // 256 x 256
     using CfgN = H3Cfg<2, 1, 4, 2, 3, 1>;                // 256 x 64: N <= 64 (the 48-wide groups of the positional convolution)
-    using CfgM = H3Cfg<4, 1, 2, 4, 3, 1>;                // 256 x 128: N <= 128 (the CNN-LSTM's 128 channels)
+    using CfgM = H3Cfg<4, 2, 4, 2, 3, 1>;                // 512 x 128: N <= 128 (the CNN-LSTM's 128 channels): the wave tile of the
+                                                         // 256 x 256 configuration (24 MFMAs per k-tile and wave; a 256 x 128 tile's 12
+                                                         // left the main loop bound by its barriers and DMA issue: 110 TFLOP/s-equivalent)
 #define H3_LAUNCH_CFG(CFG, ACT, F32, PL, HR)                                                                            \
     do {                                                                                                                \
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16x3_kernel<CFG, ACT, F32, PL, HR>,                        \
@@ -622,15 +637,14 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     // the combinations the Wav2Vec2 / CNN stages use (anything else is an argument error, not a silent fallback)
     if (p.act == ACT_NONE && f32o && !plo && !hr) H3_LAUNCH3(ACT_NONE, true, false, false);
     else if (p.act == ACT_NONE && f32o && !plo && hr) H3_LAUNCH(ACT_NONE, true, false, true);
-    else if (p.act == ACT_GELU && !f32o && plo && !hr) H3_LAUNCH(ACT_GELU, false, true, false);
+    else if (p.act == ACT_GELU && !f32o && plo && !hr) H3_LAUNCH3(ACT_GELU, false, true, false);
+    else if (p.act == ACT_SILU && !f32o && plo && !hr) H3_LAUNCH3(ACT_SILU, false, true, false);
     else if (p.act == ACT_GELU && f32o && !plo && !hr) H3_LAUNCH(ACT_GELU, true, false, false);
     else if (p.act == ACT_SILU && f32o && !plo && !hr) H3_LAUNCH(ACT_SILU, true, false, false);
+    else if (p.act == ACT_GELU && f32o && !plo && hr) H3_LAUNCH3(ACT_GELU, true, false, true);
+    else if (p.act == ACT_SILU && f32o && !plo && hr) H3_LAUNCH3(ACT_SILU, true, false, true);
     else if (p.act == ACT_NONE && !f32o && plo && !hr) H3_LAUNCH(ACT_NONE, false, true, false);
     else if (p.act == ACT_NONE && f32o && plo && !hr) H3_LAUNCH(ACT_NONE, true, true, false);
-    // every other activation epilogue (residual and / or both outputs, SiLU -> planes: the CNN-LSTM's convolutions) runs on
-    // the all-outputs variant of its activation, whose fp32 / plane / residual pointers may each be NULL
-    else if (p.act == ACT_GELU) H3_LAUNCH3(ACT_GELU, true, true, true);
-    else if (p.act == ACT_SILU) H3_LAUNCH3(ACT_SILU, true, true, true);
     else {
         set_error("launch_gemm_f16x3: unsupported combination of activation / outputs / residual");
         return RSAF_ERR_ARG;
