@@ -604,10 +604,12 @@ class MshdsEngine:
         return gp
 
     # ---- the reference's orchestration for a packed batch ----
-    def extract_packed(self, wav, sample_offs, lengths, stream=None, x1=None, xmax=None):
+    def extract_packed(self, wav, sample_offs, lengths, stream=None, x1=None, xmax=None, before_host_sync=None):
         """wav: 1-D float32 device tensor with the clips back to back -> (float64 [n, 25] device tensor,
         list of (floor, ceiling) per clip).  ``x1`` / ``xmax`` (per clip, seconds): time of the first sample and end of the
-        time domain of each sound as Praat carries them (``SoundDomain``); default = sounds read from 16 kHz files."""
+        time domain of each sound as Praat carries them (``SoundDomain``); default = sounds read from 16 kHz files.
+        ``before_host_sync``: called once, right before the host reads the speaker ranges back (the one point where the host
+        waits for the device): whatever it queues keeps the GPU busy while the host decides the ranges and queues the rest."""
         import torch
         n = len(lengths)
         out = torch.full((n, 25), float("nan"), dtype=torch.float64, device=self.device)
@@ -645,6 +647,8 @@ class MshdsEngine:
         sr = side(lambda: self.speechrate(wav, sample_offs, lengths, gpeak, stream, dom))           # :426
         # _pitch_values (:127-162): wide search, outlier-trimmed mean -> speaker range
         wide = self.pitch(wav, sample_offs, lengths, gpeak, time_step=0.005, floor=50.0, ceiling=600.0, stream=stream, dom=dom)
+        if before_host_sync is not None:
+            before_host_sync()
         st = wide["stats"].cpu().numpy()                       # one small D2H per batch
         join(sr)
         out[:, 0:5] = sr

@@ -107,10 +107,19 @@ class Pipeline:
         n_clips, n_samp = int(wav.shape[0]), int(wav.shape[1])
         main = torch.cuda.current_stream()
         mshds_cols = None
+        smile_cols = None
         if self.mshds is not None and not self.overlap:
             offs = np.arange(n_clips, dtype=np.int64) * n_samp
-            feats, _ = self.mshds.extract_packed(p.wav, offs, [n_samp] * n_clips)
+            # the openSMILE-style stage does not depend on MSHDS: queued at MSHDS' one host wait (the speaker ranges come back to
+            # the host there), it keeps the GPU busy while the host decides the ranges and queues the remaining analyses
+            hold = {}
+
+            def _smile_now():
+                if "smile" in self.stages:
+                    hold["cols"] = smile.smile_features(p).to(torch.float32)
+            feats, _ = self.mshds.extract_packed(p.wav, offs, [n_samp] * n_clips, before_host_sync=_smile_now)
             mshds_cols = feats.to(torch.float32)
+            smile_cols = hold.get("cols")
         fut = None
         if self.overlap:
             self._aux.wait_stream(main)
@@ -125,7 +134,7 @@ class Pipeline:
         if self.mshds is not None and not self.overlap:
             cols.append(mshds_cols)
         if "smile" in self.stages:
-            cols.append(smile.smile_features(p).to(torch.float32))
+            cols.append(smile_cols if smile_cols is not None else smile.smile_features(p).to(torch.float32))
         if self.w2v2 is not None:
             offs = np.arange(n_clips, dtype=np.int64) * n_samp
             seq, frame_off = self.w2v2.extract_packed(p.wav, offs, [n_samp] * n_clips)
