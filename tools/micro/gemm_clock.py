@@ -1,7 +1,7 @@
-"""In-kernel clock and matrix-pipe occupancy of the gemm_bf16x6 dispatches of a rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE
+"""In-kernel clock and matrix-pipe occupancy of the gemm_f16x3 dispatches of a rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE
 SQ_VALU_MFMA_BUSY_CYCLES run: clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch duration from the kernel trace.
 
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d DIR --output-format csv -- python3 tools/gemm6_bench.py
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d DIR --output-format csv -- python3 tools/gemm3_bench.py
   python tools/micro/gemm_clock.py DIR
 """
 import csv, glob, os, sys
@@ -18,11 +18,11 @@ cnt = defaultdict(dict)
 meta = {}
 for fn in cc:
     for r in csv.DictReader(open(fn, newline="")):
-        if "gemm_bf16x6" not in r["Kernel_Name"]:
+        if "gemm_f16x3" not in r["Kernel_Name"]:
             continue
         d = int(r["Dispatch_Id"])
         cnt[d][r["Counter_Name"]] = float(r["Counter_Value"])
-        meta[d] = (r["Kernel_Name"].split("G6Cfg")[1][:40], int(r["Grid_Size"]))
+        meta[d] = (r["Kernel_Name"].split("H3Cfg")[1][:48], int(r["Grid_Size"]))
 groups = defaultdict(list)
 for d, c in cnt.items():
     if d in dur and "GRBM_GUI_ACTIVE" in c:
