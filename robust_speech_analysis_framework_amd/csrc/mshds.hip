@@ -377,21 +377,32 @@ __device__ __forceinline__ double cheb_eval(const double* __restrict__ c, double
     const double t = 2.0 * frac - 1.0, t2 = 2.0 * t;
     double b1 = 0.0, b2 = 0.0;
 #pragma unroll
-    for (int j = NCH - 1; j >= 1; --j) { const double b0 = c[j] + t2 * b1 - b2; b2 = b1; b1 = b0; }
-    return c[0] + t * b1 - b2;
+    for (int j = NCH - 1; j >= 1; --j) { const double b0 = fma(t2, b1, c[j] - b2); b2 = b1; b1 = b0; }
+    return fma(t, b1, c[0] - b2);
 }
 
 // Praat NUMimproveMaximum (sinc) on the two cells around the 0-based integer position x0; P = [2][NCH] coefficients
 // (cell 0 = [x0-1, x0], cell 1 = [x0, x0+1]).  One lane per candidate; the loop runs while any lane is active.
+// The 2 x 16 coefficients of the lane's candidate stay in registers for the whole search: an evaluation is then a
+// per-coefficient select and ONE dependent multiply-add per Clenshaw step (the subtraction c_j - b_{j+2} does not wait
+// for b_{j+1}); reading the cell's row from LDS per evaluation put a memory round trip in front of every chain.
 __device__ void improve_max_cheb(const double* __restrict__ Pc, int x0, bool live, double& xm, double& ym) {
     const double SQRT_EPS = 1.4901161193847656e-08, TOL3 = 1e-10 / 3.0;
     const double ix1 = (double)x0 + 1.0;                    // 1-based like Praat
+    double c0[NCH], c1[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { c0[j] = Pc[j]; c1[j] = Pc[NCH + j]; }
     auto f = [&](double v1) {                               // v1: 1-based position in [ix1-1, ix1+1]
         double fl = floor(v1);
         double cell = fl - (ix1 - 1.0);
         cell = cell < 0.0 ? 0.0 : (cell > 1.0 ? 1.0 : cell);
         const double frac = v1 - (ix1 - 1.0 + cell);
-        return -cheb_eval(Pc + (int)cell * NCH, frac);
+        const bool hi = cell > 0.5;
+        const double t = 2.0 * frac - 1.0, t2 = 2.0 * t;
+        double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int j = NCH - 1; j >= 1; --j) { const double b0 = fma(t2, b1, (hi ? c1[j] : c0[j]) - b2); b2 = b1; b1 = b0; }
+        return -fma(t, b1, (hi ? c1[0] : c0[0]) - b2);
     };
     double a = ix1 - 1.0, b = ix1 + 1.0;
     double v = a + GOLD * (b - a);
@@ -1197,10 +1208,27 @@ __global__ __launch_bounds__(64, R == 32 ? 2 : 3) void pitch_cc_wave_kernel(cons
 // every kept candidate with Brent's method.  All phases are single-wave, so nothing waits at a workgroup barrier
 // and ~10 frames are resident per CU.
 constexpr int CT = 64;          // threads of the candidate kernel
+// Deferred refinement.  The Brent search of a frame keeps at most 15 of a wave's 64 lanes busy on a chain of dependent
+// float64 operations, and the coefficient build of a cell whose depth the array ends clip needs that cell's own table.
+// With `hdr` given the candidate kernel therefore stops at the candidate lists: it leaves a 128-byte record per frame
+// (flags, list lengths, the lists' lags) and - unless the cells' coefficients are built per cell by
+// pitch_cell_coef_kernel (`grouped`) - the Chebyshev coefficients of the candidates' cells in the workspace;
+// pitch_brent_kernel then refines one candidate per lane, four frames per wave.
+constexpr int HDR_INTS = 32;                    // [0] flags, [1] length of list A, [2] of list B, [4..11] lags of A (16 x u16),
+                                                // [12..19] lags of B, [20..23] for every slot of B: the slot of A with the same lag
+constexpr int PC_DOUBLES = MAXC * 2 * NCH;      // per frame and list: [slot][cell][coefficient]
+constexpr int HDR_A_DEFER = 1, HDR_B_DEFER = 2, HDR_B_COPY = 4;
+struct DeferArgs {
+    int* hdr;            // nullptr: everything in the candidate kernel (the form before round 4, kept as the A/B reference)
+    double* pc_a;        // coefficients of the list that is refined first (the lower voicing threshold of a dual pass)
+    double* pc_b;        // coefficients of the other list of a dual pass (only written when it holds a lag the first lacks)
+    int grouped;         // 1: pitch_cell_coef_kernel builds pc_a
+};
 __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restrict__ ci, const double* __restrict__ gpeak,
                                                         const PitchParams P, const double* __restrict__ rbuf, int rstride,
                                                         int max_frames, FrameOut* __restrict__ out,
-                                                        FrameOut* __restrict__ out2, const double* __restrict__ cheb) {
+                                                        FrameOut* __restrict__ out2, const double* __restrict__ cheb,
+                                                        const DeferArgs DA) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const ClipInfo c = ci[blockIdx.y];
     const int f = blockIdx.x;
@@ -1369,7 +1397,10 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     // is left unrefined (the depth-30 and refined strengths differ by far less than the margin).
     // Lanes per candidate follow the candidate count (uniform per frame): few candidates (the usual AC case)
     // get a whole wave each, a full list gets 16 lanes each, so one or two rounds cover every frame.
-    auto refine_list = [&](int nc, const int* place_lag, double* cf, double* cs) {
+    const int64_t wframe = (int64_t)blockIdx.y * max_frames + f;          // the frame's index in the workspace arrays
+    // returns true when the list's refinement is left to pitch_brent_kernel
+    auto refine_list = [&](int nc, const int* place_lag, double* cf, double* cs, double* pc_out) -> bool {
+        if (DA.hdr && DA.grouped) return true;                           // per-cell tables: nothing to build here
         // Depth of the sinc interpolation on a cell whose left sample is b (0-based): Praat clips it to the samples that
         // exist on either side, min(depth, b + 1, n - b - 1), for BOTH halves of the kernel.  A frame whose cells all
         // have the full depth takes the shared table on the matrix pipe; a clipped cell (cc passes: lags within `depth` of
@@ -1487,7 +1518,12 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
                 }
             }
             __syncthreads();
-            if (P.debug_stop == 6) return;
+            if (P.debug_stop == 6) return true;
+            if (DA.hdr) {                                            // the coefficients travel to pitch_brent_kernel
+                for (int i = 2 * NCH + tid; i < nc * 2 * NCH; i += CT) pc_out[i] = s_P[i];
+                __syncthreads();
+                return true;
+            }
             if (tid < 64) {                                          // nc <= 16: one lane per candidate
                 const int k = 1 + tid;
                 const bool live = k < nc;
@@ -1497,7 +1533,7 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
                 if (live) { cf[k] = 1.0 / DXS / (xm - RC); cs[k] = ym; }
             }
             __syncthreads();
-            return;
+            return false;
         }
         const int nref = nc - 1;
         const int span = P.refine_depth < 2 * L ? P.refine_depth : 2 * L;    // longest half kernel
@@ -1506,9 +1542,16 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
         else if (nref <= 8) { if (span >= 6 * 32) refine_candidates<32, true>(A, tid, CT); else refine_candidates<32, false>(A, tid, CT); }
         else { if (span >= 6 * 16) refine_candidates<16, true>(A, tid, CT); else refine_candidates<16, false>(A, tid, CT); }
         __syncthreads();
+        return false;
     };
+    int* hdr = DA.hdr ? DA.hdr + wframe * HDR_INTS : nullptr;
+    int flags = 0;
     if (!dual) {
-        refine_list(ncand, s_place, s_cf, s_cs);
+        if (refine_list(ncand, s_place, s_cf, s_cs, DA.pc_a ? DA.pc_a + wframe * PC_DOUBLES : nullptr)) flags = HDR_A_DEFER;
+        if (hdr) {
+            if (tid < MAXC) reinterpret_cast<unsigned short*>(hdr + 4)[tid] = (unsigned short)s_place[tid];
+            if (tid == 0) { hdr[0] = gp > 0.0 ? flags : 0; hdr[1] = ncand; hdr[2] = 0; }
+        }
     } else {
         // refine the lower-threshold list (normally a superset), copy the shared candidates by lag, and only
         // when a candidate of the primary list is missing from it (both lists overflowed) refine that list too
@@ -1517,16 +1560,17 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
         int* pl_a = low_is_second ? s_place2 : s_place;   double* cf_a = low_is_second ? s_cf2 : s_cf;   double* cs_a = low_is_second ? s_cs2 : s_cs;
         int* pl_b = low_is_second ? s_place : s_place2;   double* cf_b = low_is_second ? s_cf : s_cf2;   double* cs_b = low_is_second ? s_cs : s_cs2;
         const int nc_a = low_is_second ? ncand2 : ncand, nc_b = low_is_second ? ncand : ncand2;
-        refine_list(nc_a, pl_a, cf_a, cs_a);
+        const bool def_a = refine_list(nc_a, pl_a, cf_a, cs_a, DA.pc_a ? DA.pc_a + wframe * PC_DOUBLES : nullptr);
+        if (def_a) flags |= HDR_A_DEFER;
         if (tid == 0) s_cnt[3] = 0;
         __syncthreads();
+        int hit = 0;
         {
             const int pa_reg = tid < MAXC ? pl_a[tid] : 0;             // lane z holds the lag of candidate z of the refined list
             const int mine = (tid >= 1 && tid < nc_b) ? pl_b[tid] : -1;
-            int hit = 0;
             for (int z = 1; z < nc_a; ++z) if (__builtin_amdgcn_readlane(pa_reg, z) == mine) hit = z;   // v_readlane: no LDS round trip per z
             if (tid >= 1 && tid < nc_b) {
-                if (hit) { cf_b[tid] = cf_a[hit]; cs_b[tid] = cs_a[hit]; } else atomicAdd(&s_cnt[3], 1);
+                if (hit) { if (!def_a) { cf_b[tid] = cf_a[hit]; cs_b[tid] = cs_a[hit]; } } else atomicAdd(&s_cnt[3], 1);
             }
         }
         __syncthreads();
@@ -1536,7 +1580,17 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
                 for (int m = 0; m < nmax; ++m) if (s_maxlag[m] == pl_b[tid]) { cf_b[tid] = s_mfreq[m]; cs_b[tid] = s_mstr[m]; }
             }
             __syncthreads();
-            refine_list(nc_b, pl_b, cf_b, cs_b);
+            if (refine_list(nc_b, pl_b, cf_b, cs_b, DA.pc_b ? DA.pc_b + wframe * PC_DOUBLES : nullptr)) flags |= HDR_B_DEFER;
+        } else if (def_a) {
+            flags |= HDR_B_COPY;
+        }
+        if (hdr) {
+            if (tid < MAXC) {
+                reinterpret_cast<unsigned short*>(hdr + 4)[tid] = (unsigned short)pl_a[tid];
+                reinterpret_cast<unsigned short*>(hdr + 12)[tid] = (unsigned short)pl_b[tid];
+                reinterpret_cast<unsigned char*>(hdr + 20)[tid] = (unsigned char)hit;
+            }
+            if (tid == 0) { hdr[0] = gp > 0.0 ? flags : 0; hdr[1] = nc_a; hdr[2] = nc_b; }
         }
         if (tid == 0) {
             FrameOut* o2 = out2 + c.frame_off + f;
@@ -1558,6 +1612,186 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
         const bool on = tid < ncand && gp > 0.0;
         o->freq[tid] = on ? s_cf[tid] : 0.0;
         o->strength[tid] = on ? s_cs[tid] : 0.0;
+    }
+}
+
+// ---- deferred refinement, part 1: Chebyshev coefficients per CELL (analyses whose depth the array ends clip) ----------
+// A cell is the interval between two samples of Praat's symmetric correlation array (index b = its left sample); the
+// depth of the sinc interpolation on it is min(depth, b + 1, RN - b - 1) (NUM_interpolate_sinc), so in an analysis whose
+// array is shorter than lag + depth every cell has its own depth and with it its own weight table - which the frame-wise
+// kernel can only answer with the direct sum (a reciprocal and a cosine per tap and evaluation: 19.6 ms per 64 clips in the
+// harmonicity pass at a 100 Hz floor, against 7-9 ms where one table serves every cell).  The table depends on b alone,
+// only the taps that meet the non-zero lags |lag| <= L of r matter, and r[-lag] = r[lag] lets the table carry the sum of the
+// two taps that meet a lag; in those terms
+//     P_b[j][cell] = sum_m tab_b[m][j] * r_cell[m],        m = 0 .. L,
+// i.e. one GEMM per b over all the cells of the batch that sit on b: a workgroup owns (b, a chunk of frames), keeps tab_b
+// in LDS, scans the chunk's candidate lags for its two matches per frame (cell 0 of the candidate at lag b - RC + 1,
+// cell 1 of the one at lag b - RC), and runs 16 cells at a time through v_mfma_f64_16x16x4 (A = the table from LDS,
+// B = the cells' correlation rows from the workspace).  The host builds the tables (mshds.sinc_cell_tables).
+// Workgroup id -> (b, chunk): all b of a chunk run on ONE XCD (ids are dealt round-robin to the 8 XCDs), so the chunk's rows
+// - read 28 times over, by every cell of every candidate - stay in that XCD's L2.
+constexpr int CELL_Q = 192;          // queue slots per wave (at most 15 left over + 128 new per scan step)
+__global__ __launch_bounds__(256) void pitch_cell_coef_kernel(const ClipInfo* __restrict__ ci, int n_clips, int max_frames,
+                                                              const int* __restrict__ hdr, const double* __restrict__ rbuf,
+                                                              int rstride, int L, int RC, const double* __restrict__ tabs,
+                                                              int b_lo, int n_b, int ntap_pad, int chunk_frames, int n_chunks,
+                                                              double* __restrict__ pc) {
+    using namespace wfft;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tab = reinterpret_cast<double*>(smem_raw);                               // [ntap_pad][NCH]
+    unsigned* qall = reinterpret_cast<unsigned*>(tab + (size_t)ntap_pad * NCH);      // [4][CELL_Q]
+    const int64_t wid = blockIdx.x;
+    const int64_t q = wid >> 3;
+    const int bi = (int)(q % n_b);
+    const int64_t chunk = (q / n_b) * 8 + (wid & 7);
+    if (chunk >= n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned* qb = qall + wv * CELL_Q;
+    const int b = b_lo + bi;
+    const int lag0 = b - RC + 1, lag1 = b - RC;                // the lags whose cell 0 / cell 1 is this b
+    const int64_t total = (int64_t)n_clips * max_frames;
+    const int per_wave = chunk_frames / 4;
+    const int64_t g_begin = chunk * chunk_frames + (int64_t)wv * per_wave;
+    const int64_t g_end = g_begin + per_wave < total ? g_begin + per_wave : total;
+    const int nn = lane & 15, kq = lane >> 4;
+    // a lane's frame record: flags, list length, the 16 lags (zeros for a frame that does not exist or has nothing deferred)
+    struct Rec { int nc; int lw[8]; };
+    auto load_rec = [&](int64_t g) {
+        Rec r;
+        r.nc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.lw[i] = 0;
+        if (g < g_end) {
+            const int clip = (int)(g / max_frames), fr = (int)(g - (int64_t)clip * max_frames);
+            if (fr < ci[clip].n_frames) {
+                const int* h = hdr + g * HDR_INTS;
+                const int flags = h[0], nc = h[1];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r.lw[i] = h[4 + i];
+                r.nc = (flags & HDR_A_DEFER) ? nc : 0;
+            }
+        }
+        return r;
+    };
+    Rec rec = load_rec(g_begin + lane);                        // in flight while the table arrives
+    {
+        // the cell's table -> LDS, sixteen bytes per lane and load, eight loads in flight
+        const double2_t* src = reinterpret_cast<const double2_t*>(tabs + (int64_t)bi * ntap_pad * NCH);
+        double2_t* dst = reinterpret_cast<double2_t*>(tab);
+        const int n2 = ntap_pad * NCH / 2;
+        for (int i0 = tid; i0 < n2; i0 += 8 * 256) {
+            double2_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i0 + 256 * u < n2 ? i0 + 256 * u : n2 - 1];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + 256 * u < n2) dst[i0 + 256 * u] = v[u];
+        }
+    }
+    __syncthreads();
+    int count = 0;
+    // sixteen cells through the matrix pipe: eight tap groups per batch, the next batch's operands (rows from L2, table from
+    // LDS) are requested before the current batch's eight dependent MFMAs are issued
+    auto run_tile = [&](int off, int n) {                      // queue entries off .. off + n - 1 (n <= 16)
+        const unsigned e = qb[off + (nn < n ? nn : 0)];
+        const int64_t g = e >> 5;
+        const int k = (e >> 1) & 15, c = e & 1;
+        const double* rb = rbuf + g * rstride;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        double av[2][8], bv[2][8];
+        auto fetch = [&](int t0, double (&a8)[8], double (&b8)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 4 * u + kq;                 // the lag
+                const int tc = t < ntap_pad ? t : ntap_pad - 1;
+                b8[u] = rb[tc <= L ? tc : L];                  // lags beyond L only meet the zero rows that pad the table
+                a8[u] = t < ntap_pad ? tab[tc * NCH + nn] : 0.0;
+            }
+        };
+        fetch(0, av[0], bv[0]);
+        for (int t0 = 0; t0 < ntap_pad; t0 += 64) {
+            if (t0 + 32 < ntap_pad) fetch(t0 + 32, av[1], bv[1]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
+            if (t0 + 32 >= ntap_pad) break;
+            if (t0 + 64 < ntap_pad) fetch(t0 + 64, av[0], bv[0]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
+        }
+        if (nn < n) {                                          // D: lane (kq, nn), register v -> coefficient kq + 4 v of cell nn
+            double* dst = pc + (g * MAXC + k) * (2 * NCH) + c * NCH;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dst[kq + 4 * v] = acc[v];
+        }
+    };
+    for (int64_t g0 = g_begin; g0 < g_end; g0 += 64) {
+        const int64_t g = g0 + lane;
+        int m0 = 0, m1 = 0;
+#pragma unroll
+        for (int k = 1; k < MAXC; ++k) {                       // a list holds a lag once: at most one match per cell side
+            const int lg = (rec.lw[k >> 1] >> (16 * (k & 1))) & 0xffff;
+            if (k < rec.nc && lg == lag0) m0 = k;
+            if (k < rec.nc && lg == lag1) m1 = k;
+        }
+        rec = load_rec(g + 64);                                // the next step's records travel while this step's tiles run
+        const unsigned long long b0 = __ballot(m0 != 0), b1 = __ballot(m1 != 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (m0) qb[count + __popcll(b0 & below)] = ((unsigned)g << 5) | ((unsigned)m0 << 1);
+        count += __popcll(b0);
+        if (m1) qb[count + __popcll(b1 & below)] = ((unsigned)g << 5) | ((unsigned)m1 << 1) | 1u;
+        count += __popcll(b1);
+        wave_sync();
+        int done = 0;
+        for (; count - done >= 16; done += 16) run_tile(done, 16);
+        const int left = count - done;                         // < 16 entries move to the front
+        const unsigned rest = lane < left ? qb[done + lane] : 0u;
+        wave_sync();
+        if (lane < left) qb[lane] = rest;
+        count = left;
+        wave_sync();
+    }
+    if (count > 0) run_tile(0, count);
+}
+
+// ---- deferred refinement, part 2: Brent's search, one candidate per lane, four frames per wave ---------------------------
+__global__ __launch_bounds__(64) void pitch_brent_kernel(const ClipInfo* __restrict__ ci, const int* __restrict__ hdr,
+                                                         const double* __restrict__ pc_a, const double* __restrict__ pc_b,
+                                                         int max_frames, int RC, FrameOut* __restrict__ out_a,
+                                                         FrameOut* __restrict__ out_b) {
+    const ClipInfo c = ci[blockIdx.y];
+    const int f_first = blockIdx.x * 4;
+    if (f_first >= c.n_frames) return;
+    const int lane = threadIdx.x, slot = lane & 15;
+    const int f = f_first + (lane >> 4);
+    const bool valid = f < c.n_frames;
+    const int64_t g = (int64_t)blockIdx.y * max_frames + (valid ? f : f_first);
+    const int* h = hdr + g * HDR_INTS;
+    const int flags = valid ? h[0] : 0, nc_a = h[1], nc_b = h[2];
+    const int lag_a = reinterpret_cast<const unsigned short*>(h + 4)[slot];
+    const int64_t fo = c.frame_off + (valid ? f : f_first);
+    double fa = 0.0, sa = 0.0;
+    const bool live_a = (flags & HDR_A_DEFER) && slot >= 1 && slot < nc_a;
+    if (__any(live_a)) {
+        double xm, ym;
+        improve_max_cheb(pc_a + (g * MAXC + (live_a ? slot : 1)) * (2 * NCH), lag_a + RC, live_a, xm, ym);
+        if (ym > 1.0) ym = 1.0 / ym;
+        fa = 1.0 / DXS / (xm - RC);
+        sa = ym;
+        if (live_a) { out_a[fo].freq[slot] = fa; out_a[fo].strength[slot] = sa; }
+    }
+    if (out_b == nullptr) return;
+    if (__any((flags & HDR_B_COPY) != 0)) {
+        const int hit = reinterpret_cast<const unsigned char*>(h + 20)[slot];
+        const int src = (lane & 48) + hit;
+        const double fb = __shfl(fa, src, 64), sb = __shfl(sa, src, 64);
+        if ((flags & HDR_B_COPY) && slot >= 1 && slot < nc_b && hit) { out_b[fo].freq[slot] = fb; out_b[fo].strength[slot] = sb; }
+    }
+    const bool live_b = (flags & HDR_B_DEFER) && slot >= 1 && slot < nc_b;
+    if (__any(live_b)) {
+        const int lag_b = reinterpret_cast<const unsigned short*>(h + 12)[slot];
+        double xm, ym;
+        improve_max_cheb(pc_b + (g * MAXC + (live_b ? slot : 1)) * (2 * NCH), lag_b + RC, live_b, xm, ym);
+        if (ym > 1.0) ym = 1.0 / ym;
+        if (live_b) { out_b[fo].freq[slot] = 1.0 / DXS / (xm - RC); out_b[fo].strength[slot] = ym; }
     }
 }
 
@@ -3313,6 +3547,11 @@ static int fft_twiddles(int N, const double** out) {
 
 // second_*: optional outputs of the same analysis with another voicing threshold (h2_voicing_thr >= 0): the frame
 // kernel shares the correlation and the refinement, the path finder runs once per threshold
+// workspace per frame: the correlation row, the coefficient blocks of two candidate lists, the frame record
+static inline int64_t pitch_ws_bytes_per_frame(int rstride) {
+    return (int64_t)rstride * (int64_t)sizeof(double) + 2 * (int64_t)PC_DOUBLES * (int64_t)sizeof(double) + (int64_t)HDR_INTS * (int64_t)sizeof(int);
+}
+
 static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
                       const double* window, const double* window_r, const double* params_host, void* frame_out,
                       unsigned char* psi, int* end_state, double* sel_freq, double* sel_strength, double* stats_out,
@@ -3333,7 +3572,8 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     P.nsamp_window = (int)h[8]; P.nsamp_period = (int)h[9]; P.min_lag = (int)h[10]; P.max_lag = (int)h[11];
     P.brent_ixmax = (int)h[12]; P.max_cand = (int)h[13]; P.refine_depth = (int)h[14]; P.is_cc = (int)h[15];
     P.dt_window = h[16];
-    P.cheb_clipped = (int)h[17];
+    const int table_mode = (int)h[17];            // 0: shared table only, 1: + the tables of the clipped depths, 2: one table per cell
+    P.cheb_clipped = table_mode == 1 ? 1 : 0;
     P.voicing_thr2 = dual ? voicing_thr2 : -1.0;
     { const char* e = getenv("RSAF_PITCH_STOP"); P.debug_stop = e ? atoi(e) : 0; }
     P.refine_margin = 0.0;   // lazy refinement is off: it changed a few frames' selection (parity first)
@@ -3361,11 +3601,17 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     const size_t lds_cand = (size_t)(((r_hi_h - r_lo_h + 2) & ~1) + 3 * MAX_MAXIMA + 6 * MAXC + MAXC * 2 * NCH) * sizeof(double) +
                             (size_t)(MAX_MAXIMA + 2 * MAXC + 4) * sizeof(int);
     RSAF_CHECK_ARG(lds_corr <= 150 * 1024 && lds_cand <= 150 * 1024, "analysis window too long for LDS");
-    // the correlation rows of a group of clips live in the caller's workspace between the two kernels
-    const int64_t row_bytes_per_clip = (int64_t)max_frames * rstride * (int64_t)sizeof(double);
+    // the correlation rows of a group of clips live in the caller's workspace between the kernels, and behind them what the
+    // candidate kernel leaves for the refinement kernels: per frame the coefficient blocks of two lists and a 128-byte record
+    const int64_t row_bytes_per_clip = (int64_t)max_frames * pitch_ws_bytes_per_frame(rstride);
     RSAF_CHECK_ARG(max_frames == 0 || (workspace && workspace_bytes >= row_bytes_per_clip),
                    "workspace too small (rsaf_mshds_pitch_workspace_bytes)");
-    const int group = max_frames == 0 ? n_clips : (int)std::min<int64_t>(n_clips, workspace_bytes / std::max<int64_t>(row_bytes_per_clip, 1));
+    int group = max_frames == 0 ? n_clips : (int)std::min<int64_t>(n_clips, workspace_bytes / std::max<int64_t>(row_bytes_per_clip, 1));
+    if (max_frames > 0) group = (int)std::min<int64_t>(group, ((int64_t)1 << 26) / max_frames > 0 ? ((int64_t)1 << 26) / max_frames : 1);   // frame index in 27 bits (cell queue)
+    // in-kernel refinement (the form before the refinement kernels existed): the A/B reference of the tests
+    const bool defer = getenv("RSAF_PITCH_INKERNEL") == nullptr;
+    const bool grouped = defer && table_mode == 2 && !dual && P.is_cc && sinc_cheb != nullptr;
+    RSAF_CHECK_ARG(table_mode != 2 || (!dual && P.is_cc), "per-cell tables serve single-threshold cross-correlation analyses only");
     hipStream_t s = (hipStream_t)stream;
     int log2m = 0;
     while ((2 << log2m) < P.nfft) ++log2m;                           // nfft = 2 M = 2^(log2m + 1)
@@ -3413,16 +3659,27 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
         RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_cand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_cand));
     // the Chebyshev form needs the full depth on both sides of every cell a candidate can use
-    const double* cheb = sinc_cheb;
+    const double* cheb = table_mode == 2 ? nullptr : sinc_cheb;
+    const int cell_lag_lo = P.min_lag > 2 ? P.min_lag : 2;
+    const int cell_lag_hi = std::min(P.max_lag - 1, P.brent_ixmax - 1);
     {
-        const int lag_lo = P.min_lag > 2 ? P.min_lag : 2;
-        int lag_hi = P.max_lag - 1;
-        if (lag_hi > P.brent_ixmax - 1) lag_hi = P.brent_ixmax - 1;
+        const int lag_lo = cell_lag_lo, lag_hi = cell_lag_hi;
         const bool unclipped = P.brent_ixmax + lag_lo - 1 >= P.refine_depth && lag_hi + 2 + P.refine_depth <= P.brent_ixmax;
         P.cheb_all_full = unclipped ? 1 : 0;
         if (cheb == nullptr) P.cheb_clipped = 0;
         // clipped analyses keep the Chebyshev form only with the per-depth tables behind the shared one
         if ((!unclipped && !P.cheb_clipped) || getenv("RSAF_PITCH_NO_CHEB")) cheb = nullptr;
+    }
+    // per-cell tables (mshds.sinc_cell_tables): cells b_lo .. b_hi, the lags 0 .. L (r is symmetric: the two taps that meet
+    // a lag are summed in the table) padded to a multiple of four
+    const int cell_b_lo = P.brent_ixmax + cell_lag_lo - 1, cell_n_b = cell_lag_hi - cell_lag_lo + 2;
+    const int cell_ntap_pad = (Lr + 1 + 3) & ~3;
+    const size_t lds_cell = (size_t)cell_ntap_pad * NCH * sizeof(double) + 4 * CELL_Q * sizeof(unsigned);
+    if (grouped) {
+        RSAF_CHECK_ARG(cell_n_b >= 1 && lds_cell <= 150 * 1024, "per-cell tables: lag range too long for LDS");
+        if (lds_cell > 48 * 1024)
+            RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)pitch_cell_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds_cell));
     }
     if (max_frames > 0) {
         // algorithmic flops of the correlation kernels, counted for equal-length clips (an upper bound for ragged batches);
@@ -3509,13 +3766,43 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
             // v_mfma_f64_16x16x4_f64 (2 048 flops each).  The Brent iterations themselves (a dozen polynomial evaluations per
             // candidate) and the direct path's sinc sums are not counted.
             const double cand_rows = (double)max_frames * (double)nc;
-            ProfScope prof(cheb ? "mshds_pitch_cand_cheb" : "mshds_pitch_cand_direct", s,
+            // workspace of the group: rows | coefficients of list A | of list B | frame records
+            const int64_t gframes = (int64_t)nc * max_frames;
+            double* pc_a = (double*)workspace + gframes * rstride;
+            double* pc_b = pc_a + gframes * PC_DOUBLES;
+            int* hdr = reinterpret_cast<int*>(pc_b + gframes * PC_DOUBLES);
+            DeferArgs DA{defer ? hdr : nullptr, defer ? pc_a : nullptr, defer ? pc_b : nullptr, grouped ? 1 : 0};
+            {
+            ProfScope prof(grouped ? "mshds_pitch_cand_lists" : cheb ? "mshds_pitch_cand_cheb" : "mshds_pitch_cand_direct", s,
                            cheb ? cand_rows * 2048.0 * 2.0 * ceil(2.0 * P.refine_depth / 4.0) : 0.0,
                            cand_rows * (double)(Lr + 2) * 8.0);
             hipLaunchKernelGGL(pitch_cand_kernel, dim3(max_frames, nc), dim3(CT), lds_cand, s, cig, gpeak + c0, P,
                                (const double*)workspace, rstride, max_frames, (FrameOut*)frame_out,
-                               dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb);
+                               dual ? (FrameOut*)frame_out2 : (FrameOut*)nullptr, cheb, DA);
             RSAF_CHECK_HIP(hipGetLastError());
+            }
+            if (defer && P.debug_stop == 0) {
+                if (grouped) {
+                    // one table per cell on the fp64 matrix pipe: <= 28 cells per frame x (2 L + 1) taps x 16 coefficients
+                    static const int chunk_frames = [] { const char* e = getenv("RSAF_PITCH_CELL_CHUNK"); const int v = e ? atoi(e) : 4096; return v >= 256 && v % 256 == 0 ? v : 4096; }();
+                    const int64_t n_chunks = (gframes + chunk_frames - 1) / chunk_frames;
+                    const int64_t n_wg = 8 * (int64_t)cell_n_b * ((n_chunks + 7) / 8);
+                    RSAF_CHECK_ARG(n_wg <= 0x7fffffffLL, "per-cell tables: too many workgroups");
+                    ProfScope prof("mshds_pitch_cand_cells", s, cand_rows * 28.0 * 2.0 * cell_ntap_pad * NCH,   // <= 28 cells per frame
+                                   cand_rows * 28.0 * (double)(Lr + 1) * 8.0);
+                    hipLaunchKernelGGL(pitch_cell_coef_kernel, dim3((unsigned)n_wg), dim3(256), lds_cell, s, cig, nc, max_frames,
+                                       (const int*)hdr, (const double*)workspace, rstride, Lr, P.brent_ixmax, sinc_cheb,
+                                       cell_b_lo, cell_n_b, cell_ntap_pad, chunk_frames, (int)n_chunks, pc_a);
+                    RSAF_CHECK_HIP(hipGetLastError());
+                }
+                const bool low_is_second = dual && P.voicing_thr2 < P.voicing_thr;
+                FrameOut* oa = low_is_second ? (FrameOut*)frame_out2 : (FrameOut*)frame_out;
+                FrameOut* ob = !dual ? (FrameOut*)nullptr : low_is_second ? (FrameOut*)frame_out : (FrameOut*)frame_out2;
+                ProfScope prof("mshds_pitch_cand_brent", s, 0.0, cand_rows * 15.0 * 2.0 * NCH * 8.0);
+                hipLaunchKernelGGL(pitch_brent_kernel, dim3((max_frames + 3) / 4, nc), dim3(64), 0, s, cig, (const int*)hdr,
+                                   (const double*)pc_a, (const double*)pc_b, max_frames, P.brent_ixmax, oa, ob);
+                RSAF_CHECK_HIP(hipGetLastError());
+            }
         }
     }
     for (int pass = 0; pass < (dual ? 2 : 1); ++pass) {
@@ -3545,7 +3832,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
 int64_t rsaf_mshds_pitch_workspace_bytes_per_clip(int max_frames, const double* params_host /* 18 doubles */) {
     if (!params_host || max_frames < 0) return -1;
     const int Lr = (int)params_host[15] ? (int)params_host[11] : (int)params_host[12];
-    return (int64_t)max_frames * (Lr + 2) * (int64_t)sizeof(double);
+    return (int64_t)max_frames * pitch_ws_bytes_per_frame(Lr + 2);
 }
 
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,

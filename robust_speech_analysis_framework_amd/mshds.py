@@ -159,6 +159,47 @@ def sinc_cheb_tables(depth: int, with_clipped: bool):
     return np.concatenate(parts)
 
 
+CELL_TABLES_MAX_LDS = 96 * 1024
+
+
+def sinc_cell_tables(max_lag: int, brent_ixmax: int, min_lag: int, depth: int):
+    """Chebyshev tables per CELL for an analysis whose interpolation depth the array ends clip (``rsaf_mshds_pitch`` with
+    ``params[17] = 2``; ``csrc/mshds.hip: pitch_cell_coef_kernel``).  A cell is the interval right of sample b of Praat's
+    symmetric array r[0 .. 2 ixmax]; its depth is min(depth, b + 1, RN - b - 1) (NUM_interpolate_sinc).  Only the
+    samples |lag| <= L are non-zero and r[-lag] = r[lag], so cell b keeps, for every lag m = 0 .. L, the SUM of the two rows
+    of its depth's table that meet lag m (taps o = ixmax - b -+ m; one row for m = 0): the coefficients of a cell are
+    sum_m table[b][m][j] r[m].  Returns float64 [n_b, ntap_pad, 16] for b = ixmax + lag_lo - 1 .. ixmax + lag_hi
+    (lag_lo = max(min_lag, 2), lag_hi = min(max_lag, ixmax) - 1; ntap_pad = L + 1 rounded up to a multiple of 4, zero
+    rows behind), or None when a cell's depth falls below 3 (Praat switches to nearest / linear / cubic there) or the
+    table does not fit the kernel's LDS."""
+    L, RC = int(max_lag), int(brent_ixmax)
+    RN = 2 * RC + 1
+    lag_lo, lag_hi = max(int(min_lag), 2), min(L - 1, RC - 1)
+    if lag_hi < lag_lo:
+        return None
+    b_lo, b_hi = RC + lag_lo - 1, RC + lag_hi
+    ntap_pad = (L + 1 + 3) & ~3
+    if ntap_pad * 16 * 8 + 4 * 192 * 4 > CELL_TABLES_MAX_LDS:
+        return None
+    out = np.zeros((b_hi - b_lo + 1, ntap_pad, 16))
+    m = np.arange(L + 1)
+    by_depth = {}
+    for b in range(b_lo, b_hi + 1):
+        dc = min(int(depth), b + 1, RN - b - 1)
+        if dc < 3:
+            return None
+        if dc not in by_depth:
+            by_depth[dc] = sinc_cheb_table(dc)
+        tab = by_depth[dc]
+        for sign in (1, -1):
+            o = RC - b + sign * m                           # the tap that meets lag +m / -m
+            ok = (o >= -(dc - 1)) & (o <= dc)
+            if sign < 0:
+                ok &= m > 0
+            out[b - b_lo, m[ok]] += tab[o[ok] + dc - 1]
+    return out
+
+
 class _PitchGeom:
     """Window geometry of Sound: To Pitch (ac/cc) for one parameter set (Boersma 1993)."""
 
@@ -246,10 +287,19 @@ class MshdsEngine:
         # cross-correlation passes can have candidates whose interpolation depth the array ends clip: the per-depth tables
         # ride behind the shared one when they are small (depth 70: 618 KB; depth 700 would be 63 MB: direct evaluation)
         clipped_tables = bool(is_cc) and int(refine_depth) <= CHEB_CLIP_MAX_DEPTH
+        # deeper cross-correlation passes (the harmonicity pass: depth 700) get one table per cell instead: built once per
+        # geometry, 7-19 MB, and used by the per-cell coefficient kernel for clipped and unclipped cells alike
+        table_mode = 1 if clipped_tables else 0
+        cheb = None
+        if is_cc and not clipped_tables and voicing_threshold2 is None and g.half_window >= 2:
+            (cell,) = self._table(("sinc_cell", g.max_lag, g.brent_ixmax, g.min_lag, int(refine_depth)),
+                                  lambda: (sinc_cell_tables(g.max_lag, g.brent_ixmax, g.min_lag, int(refine_depth)),))
+            if cell is not None:
+                table_mode, cheb = 2, cell
         params = (C.c_double * 18)(g.dt, g.floor, g.ceiling, voicing_threshold, octave_cost, silence_threshold,
                                    octave_jump_cost, voiced_unvoiced_cost, g.nsamp_window, g.nsamp_period, g.min_lag,
                                    g.max_lag, g.brent_ixmax, max_candidates, refine_depth, 1 if is_cc else 0,
-                                   g.dt_window, 1 if clipped_tables else 0)
+                                   g.dt_window, table_mode)
         second = None
         if voicing_threshold2 is not None:
             second = {"geom": g, "ci": ci, "ci_dev": ci_d, "total_frames": total, "max_frames": mx,
@@ -261,8 +311,9 @@ class MshdsEngine:
                       "stats": torch.empty((max(n, 1), 8), dtype=torch.float64, device=dev)}
         wp = _lib.ptr(win) if win is not None else None
         wrp = _lib.ptr(wr) if wr is not None else None
-        (cheb,) = self._table(("sinc_cheb", int(refine_depth), clipped_tables),
-                              lambda: (sinc_cheb_tables(int(refine_depth), clipped_tables),))
+        if cheb is None:
+            (cheb,) = self._table(("sinc_cheb", int(refine_depth), clipped_tables),
+                                  lambda: (sinc_cheb_tables(int(refine_depth), clipped_tables),))
         chp = _lib.ptr(cheb)
         # correlation rows between the two pitch kernels: all clips at once if that stays below ~4 GB, else in groups
         per_clip = int(lib.rsaf_mshds_pitch_workspace_bytes_per_clip(mx, params)) if n else 0
@@ -520,7 +571,7 @@ class MshdsEngine:
         self._last_ltas = {"pitch": p, "pulses": pulses, "n_pulses": npul, "max_pulses": max_pulses}
         return out[:n]
 
-    pitch_ws_cap_bytes = 4.0e9   # cap of the correlation-row workspace between the two pitch kernels (clips run in groups)
+    pitch_ws_cap_bytes = 16.0e9  # cap of the workspace between the pitch kernels: correlation rows, coefficient blocks, frame records (clips run in groups)
     CPP_CHUNK = 48          # most clips per launch group (the cepstrogram workspace is ~68 MB per 30 s clip)
 
     def cpp(self, wav, sample_offs, lengths, gpeak, floor, ceiling, frame_shift=0.005, stream=None, pitch=None, dom=None):

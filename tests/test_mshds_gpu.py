@@ -545,6 +545,55 @@ def test_one_wave_pitch_kernels_agree_with_the_workgroup_kernels_on_30s_clips(en
     monkeypatch.delenv("RSAF_PITCH_FFT", raising=False)
 
 
+def test_refinement_kernels_agree_with_the_in_kernel_refinement(eng, monkeypatch):
+    """Candidate refinement exists twice: inside the candidate kernel (RSAF_PITCH_INKERNEL=1: one wave per frame, the form
+    before round 4; the harmonicity pass at a 100 Hz floor evaluates Praat's clipped sinc sums directly there) and as the
+    product's pipeline candidate kernel -> [per-cell coefficient GEMM] -> Brent kernel (one candidate per lane).  Every
+    candidate of every frame must come out the same: identical bits where both forms search the same polynomial (the AC
+    passes, both thresholds of the dual pass, the depth-70 pulse pass), within the Chebyshev fit (1e-10) where the
+    in-kernel form is the direct sum or accumulates the taps in another order (harmonicity passes)."""
+    import torch
+    clips = [synth.synth_clip(930 + k, 8.0) for k in range(3)] + [synth.synth_clip(77, 0.9), np.zeros(4000, np.float32)]
+    wav, offs, lens = _pack(clips)
+    gp = eng.clip_peaks(wav, offs, lens)
+    hnr = dict(max_candidates=15, silence_threshold=0.1, voicing_threshold=0.0, octave_cost=0.0, octave_jump_cost=0.0,
+               voiced_unvoiced_cost=0.0, periods=4.5, is_cc=True, refine_depth=700)
+    cfgs = [(dict(time_step=0.005, floor=50.0, ceiling=600.0), True),
+            (dict(time_step=0.005, floor=100.0, ceiling=500.0, voicing_threshold2=0.3), True),
+            (dict(time_step=0.005, floor=60.0, ceiling=250.0, voicing_threshold2=0.3), True),
+            (dict(time_step=0.005, floor=100.0, ceiling=500.0, voicing_threshold2=0.6), True),     # second threshold ABOVE the first
+            (dict(time_step=0.02, floor=30.0, ceiling=450.0, max_candidates=4, voicing_threshold=0.25, voiced_unvoiced_cost=0.25), True),
+            (dict(time_step=0.005, floor=100.0, ceiling=500.0, periods=1.0, is_cc=True, refine_depth=70), True),
+            (dict(time_step=0.005, floor=60.0, ceiling=8000.0, **hnr), False),
+            (dict(time_step=0.005, floor=75.0, ceiling=8000.0, **hnr), False),
+            (dict(time_step=0.005, floor=100.0, ceiling=8000.0, **hnr), False)]
+    fo = eng.fo_doubles
+    for kw, exact in cfgs:
+        monkeypatch.delenv("RSAF_PITCH_INKERNEL", raising=False)
+        a = eng.pitch(wav, offs, lens, gp, **kw)
+        torch.cuda.synchronize()
+        monkeypatch.setenv("RSAF_PITCH_INKERNEL", "1")
+        b = eng.pitch(wav, offs, lens, gp, **kw)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("RSAF_PITCH_INKERNEL", raising=False)
+        pairs = [(a, b)] + ([(a["second"], b["second"])] if "voicing_threshold2" in kw else [])
+        for ra, rb in pairs:
+            n = ra["total_frames"]
+            A = ra["frame_out"].cpu().numpy()[:n * fo].reshape(n, fo)
+            B = rb["frame_out"].cpu().numpy()[:n * fo].reshape(n, fo)
+            assert n > 1000 and np.array_equal(A[:, :2], B[:, :2])                   # intensity, candidate count
+            assert np.array_equal(A[:, 2:18] > 0, B[:, 2:18] > 0)                    # the same lists
+            if exact:
+                assert np.array_equal(A, B), kw
+            else:
+                assert np.abs(A[:, 18:] - B[:, 18:]).max() <= 1e-10, kw              # strengths
+                on = A[:, 2:18] > 0                                                  # positions: within Brent's own stopping
+                lag_a, lag_b = 16000.0 / A[:, 2:18][on], 16000.0 / B[:, 2:18][on]    # tolerance (2 sqrt(eps) x, x <= 2 500 samples)
+                assert np.abs(lag_a - lag_b).max() <= 1e-4, kw
+            sa, sb = ra["stats"].cpu().numpy(), rb["stats"].cpu().numpy()
+            assert np.allclose(sa, sb, rtol=1e-9, atol=0, equal_nan=True)
+
+
 def test_one_wave_cpps_kernels_agree_with_the_workgroup_kernels(eng, monkeypatch):
     """CPPS frames of full-window intervals run one wavefront per frame (register transforms, medians by rank selection).
     RSAF_CPP_WAVE=0 sends every frame through the workgroup kernels (bit-reversal FFT in LDS, bitonic sorts), =c only the

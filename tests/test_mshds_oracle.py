@@ -148,6 +148,45 @@ def test_sinc_cheb_table_reproduces_the_direct_interpolation():
         assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
 
 
+def test_sinc_cell_tables_reproduce_the_clipped_interpolation():
+    """The per-cell tables of the harmonicity pass (depth 700 on an array shorter than lag + depth: every cell has its
+    own depth, pitch_cell_coef_kernel) against the oracle's direct Praat formula: the geometry of the 100 Hz floor (every
+    cell clipped on the right), of the 60 Hz floor (none clipped) and a short array that clips on both sides."""
+    from numpy.polynomial import chebyshev as Ch
+    from robust_speech_analysis_framework_amd.mshds import sinc_cell_tables, sinc_cheb_table, _PitchGeom
+    rng = np.random.Generator(np.random.PCG64(10))
+    geoms = [_PitchGeom(0.005, 100.0, 8000.0, 4.5, True), _PitchGeom(0.005, 60.0, 8000.0, 4.5, True)]
+    cases = [(g.max_lag, g.brent_ixmax, g.min_lag, 700) for g in geoms] + [(40, 45, 2, 70)]
+    for L, RC, min_lag, depth in cases:
+        tabs = sinc_cell_tables(L, RC, min_lag, depth)
+        lag_lo, lag_hi = max(min_lag, 2), min(L - 1, RC - 1)
+        assert tabs.shape == (lag_hi - lag_lo + 2, (L + 1 + 3) & ~3, 16)
+        row = rng.standard_normal(L + 1)                               # what the kernel reads: the lags 0 .. L of a frame
+        y = np.zeros(2 * RC + 1)                                       # Praat's array: symmetric, zero beyond |lag| <= L
+        y[RC:RC + L + 1] = row
+        y[RC - L:RC] = row[:0:-1]
+        rvec = np.zeros(tabs.shape[1])
+        rvec[:L + 1] = row
+        worst = 0.0
+        for b in range(RC + lag_lo - 1, RC + lag_hi + 1):
+            coef = tabs[b - (RC + lag_lo - 1)].T @ rvec
+            frac = rng.uniform(1e-3, 1.0 - 1e-3, size=3)
+            ref = mo.interpolate_sinc(np.tile(y, (3, 1)), b + frac, depth)
+            got = Ch.chebval(2.0 * frac - 1.0, coef)
+            worst = max(worst, np.abs(got - ref).max())
+        assert worst < 2e-11 * max(1.0, np.abs(y).max()), (L, RC, worst)
+    # an unclipped cell's table is the shared table folded about lag 0
+    L, RC, min_lag, depth = cases[1]
+    tabs = sinc_cell_tables(L, RC, min_lag, depth)
+    b = RC + 100
+    shared = sinc_cheb_table(depth)
+    m = np.arange(1, L + 1)
+    fold = shared[(RC - b + m) + depth - 1] + shared[(RC - b - m) + depth - 1]
+    assert np.array_equal(tabs[b - (RC + max(min_lag, 2) - 1), 1:L + 1], fold)
+    assert np.array_equal(tabs[b - (RC + max(min_lag, 2) - 1), 0], shared[(RC - b) + depth - 1])
+    assert sinc_cell_tables(40, 45, 2, 700) is not None and sinc_cell_tables(800, 820, 2, 700) is None   # LDS bound
+
+
 def test_speechrate_harmonicity_call_cannot_change_the_result():
     """src/mshds_extractor.py:36-38: the HNR only selects mindip = 2 (both branches); a raise there (:123-124) needs a
     clip shorter than one cc frame (26.7 ms), for which the intensity call of :41 (128 ms window) raises as well."""

@@ -13,6 +13,8 @@ from robust_speech_analysis_framework_amd import _lib, synth
 from robust_speech_analysis_framework_amd.mshds import MshdsEngine
 
 clips = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+stops = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 3, 4, 5, 6, 0)
 dev = torch.device("cuda:0")
 wav = torch.from_numpy(synth.synth_batch(clips, 30.0, pool=8)).to(dev)
 n_s = wav.shape[1]
@@ -41,7 +43,9 @@ cfgs = {
 }
 res = {}
 for name, kw in cfgs.items():
-    for stop in (1, 2, 3, 4, 5, 6, 0):
+    if only and name not in only:
+        continue
+    for stop in stops:
         os.environ["RSAF_PITCH_STOP"] = str(stop)
         eng.pitch(flat, offs, lens, gpeak, **kw)           # warm
         torch.cuda.synchronize()
@@ -52,5 +56,7 @@ for name, kw in cfgs.items():
         ms = sum(v["ms"] for k, v in pr.items() if k.startswith("mshds_pitch_") and k != "mshds_pitch_path")
         res[f"{name}/stop{stop}"] = round(ms, 3)
         print(name, "stop", stop, "frame kernel ms", round(ms, 3), "path ms", round(pr.get("mshds_pitch_path", {}).get("ms", 0), 3), flush=True)
+        if stop == 0:
+            print("   ", {k[len("mshds_pitch_"):]: round(v["ms"], 3) for k, v in pr.items() if k.startswith("mshds_pitch_")}, flush=True)
 os.environ.pop("RSAF_PITCH_STOP", None)
 print(json.dumps(res))
