@@ -1213,7 +1213,7 @@ constexpr int CT = 64;          // threads of the candidate kernel
 // With `hdr` given the candidate kernel therefore stops at the candidate lists: it leaves a 128-byte record per frame
 // (flags, list lengths, the lists' lags) and - unless the cells' coefficients are built per cell by
 // pitch_cell_coef_kernel (`grouped`) - the Chebyshev coefficients of the candidates' cells in the workspace;
-// pitch_brent_kernel then refines one candidate per lane, four frames per wave.
+// pitch_brent_kernel then refines one candidate per lane (the candidates of sixteen frames packed into a wave).
 constexpr int HDR_INTS = 32;                    // [0] flags, [1] length of list A, [2] of list B, [4..11] lags of A (16 x u16),
                                                 // [12..19] lags of B, [20..23] for every slot of B: the slot of A with the same lag
 constexpr int PC_DOUBLES = MAXC * 2 * NCH;      // per frame and list: [slot][cell][coefficient]
@@ -1752,46 +1752,70 @@ __global__ __launch_bounds__(256) void pitch_cell_coef_kernel(const ClipInfo* __
     if (count > 0) run_tile(0, count);
 }
 
-// ---- deferred refinement, part 2: Brent's search, one candidate per lane, four frames per wave ---------------------------
+// ---- deferred refinement, part 2: Brent's search, one candidate per lane ----------------------------------------------
+// A wave takes BR_FRAMES consecutive frames of a clip and packs their deferred candidates (list A, then - where the second
+// list of a dual pass has to be refined on its own - list B) into its lanes: an autocorrelation pass keeps two or three
+// candidates per frame, so a frame-per-16-lanes mapping would leave four lanes in five idle through every iteration.
+// A candidate of list A also writes the slots of list B that hold the same lag (HDR_B_COPY: the second threshold's list).
+constexpr int BR_FRAMES = 16;
 __global__ __launch_bounds__(64) void pitch_brent_kernel(const ClipInfo* __restrict__ ci, const int* __restrict__ hdr,
                                                          const double* __restrict__ pc_a, const double* __restrict__ pc_b,
                                                          int max_frames, int RC, FrameOut* __restrict__ out_a,
                                                          FrameOut* __restrict__ out_b) {
     const ClipInfo c = ci[blockIdx.y];
-    const int f_first = blockIdx.x * 4;
-    if (f_first >= c.n_frames) return;
-    const int lane = threadIdx.x, slot = lane & 15;
-    const int f = f_first + (lane >> 4);
-    const bool valid = f < c.n_frames;
-    const int64_t g = (int64_t)blockIdx.y * max_frames + (valid ? f : f_first);
-    const int* h = hdr + g * HDR_INTS;
-    const int flags = valid ? h[0] : 0, nc_a = h[1], nc_b = h[2];
-    const int lag_a = reinterpret_cast<const unsigned short*>(h + 4)[slot];
-    const int64_t fo = c.frame_off + (valid ? f : f_first);
-    double fa = 0.0, sa = 0.0;
-    const bool live_a = (flags & HDR_A_DEFER) && slot >= 1 && slot < nc_a;
-    if (__any(live_a)) {
-        double xm, ym;
-        improve_max_cheb(pc_a + (g * MAXC + (live_a ? slot : 1)) * (2 * NCH), lag_a + RC, live_a, xm, ym);
-        if (ym > 1.0) ym = 1.0 / ym;
-        fa = 1.0 / DXS / (xm - RC);
-        sa = ym;
-        if (live_a) { out_a[fo].freq[slot] = fa; out_a[fo].strength[slot] = sa; }
+    const int f0 = blockIdx.x * BR_FRAMES;
+    if (f0 >= c.n_frames) return;
+    const int lane = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.y * max_frames + f0;
+    int cnt_a = 0, cnt_b = 0;
+    if (lane < BR_FRAMES && f0 + lane < c.n_frames) {
+        const int* h = hdr + (g0 + lane) * HDR_INTS;
+        const int flags = h[0];
+        if (flags & HDR_A_DEFER) cnt_a = h[1] > 1 ? h[1] - 1 : 0;
+        if (flags & HDR_B_DEFER) cnt_b = h[2] > 1 ? h[2] - 1 : 0;
     }
-    if (out_b == nullptr) return;
-    if (__any((flags & HDR_B_COPY) != 0)) {
-        const int hit = reinterpret_cast<const unsigned char*>(h + 20)[slot];
-        const int src = (lane & 48) + hit;
-        const double fb = __shfl(fa, src, 64), sb = __shfl(sa, src, 64);
-        if ((flags & HDR_B_COPY) && slot >= 1 && slot < nc_b && hit) { out_b[fo].freq[slot] = fb; out_b[fo].strength[slot] = sb; }
-    }
-    const bool live_b = (flags & HDR_B_DEFER) && slot >= 1 && slot < nc_b;
-    if (__any(live_b)) {
-        const int lag_b = reinterpret_cast<const unsigned short*>(h + 12)[slot];
+    const int tot = cnt_a + cnt_b;
+    int incl = tot;
+#pragma unroll
+    for (int o = 1; o < BR_FRAMES; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+    const int excl = incl - tot;
+    const int T = __builtin_amdgcn_readlane(incl, BR_FRAMES - 1);
+    for (int q0 = 0; q0 < T; q0 += 64) {
+        const int q = q0 + lane;
+        const bool live = q < T;
+        int j = 0;                                            // the last frame whose first candidate is at or before q
+#pragma unroll
+        for (int jj = 1; jj < BR_FRAMES; ++jj) if (__builtin_amdgcn_readlane(excl, jj) <= q) j = jj;
+        if (!live) j = 0;
+        const int r = q - __shfl(excl, j, 64), na = __shfl(cnt_a, j, 64);
+        const bool is_b = live && r >= na;
+        const int slot = live ? (is_b ? r - na : r) + 1 : 1;
+        const int64_t g = g0 + j;
+        const int* h = hdr + g * HDR_INTS;
+        const int lag = reinterpret_cast<const unsigned short*>(h + (is_b ? 12 : 4))[slot];
+        const double* Pc = (is_b ? pc_b : pc_a) + (g * MAXC + slot) * (2 * NCH);
         double xm, ym;
-        improve_max_cheb(pc_b + (g * MAXC + (live_b ? slot : 1)) * (2 * NCH), lag_b + RC, live_b, xm, ym);
+        improve_max_cheb(Pc, lag + RC, live, xm, ym);
         if (ym > 1.0) ym = 1.0 / ym;
-        if (live_b) { out_b[fo].freq[slot] = 1.0 / DXS / (xm - RC); out_b[fo].strength[slot] = ym; }
+        const double fq = 1.0 / DXS / (xm - RC);
+        if (live) {
+            FrameOut* o = (is_b ? out_b : out_a) + c.frame_off + f0 + j;
+            o->freq[slot] = fq;
+            o->strength[slot] = ym;
+            if (!is_b && out_b != nullptr && (h[0] & HDR_B_COPY)) {
+                const int nc_b = h[2];
+                FrameOut* o2 = out_b + c.frame_off + f0 + j;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned hw = (unsigned)h[20 + w];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = 4 * w + u;
+                        if (t >= 1 && t < nc_b && (int)((hw >> (8 * u)) & 0xff) == slot) { o2->freq[t] = fq; o2->strength[t] = ym; }
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -3799,7 +3823,7 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                 FrameOut* oa = low_is_second ? (FrameOut*)frame_out2 : (FrameOut*)frame_out;
                 FrameOut* ob = !dual ? (FrameOut*)nullptr : low_is_second ? (FrameOut*)frame_out : (FrameOut*)frame_out2;
                 ProfScope prof("mshds_pitch_cand_brent", s, 0.0, cand_rows * 15.0 * 2.0 * NCH * 8.0);
-                hipLaunchKernelGGL(pitch_brent_kernel, dim3((max_frames + 3) / 4, nc), dim3(64), 0, s, cig, (const int*)hdr,
+                hipLaunchKernelGGL(pitch_brent_kernel, dim3((max_frames + BR_FRAMES - 1) / BR_FRAMES, nc), dim3(64), 0, s, cig, (const int*)hdr,
                                    (const double*)pc_a, (const double*)pc_b, max_frames, P.brent_ixmax, oa, ob);
                 RSAF_CHECK_HIP(hipGetLastError());
             }
