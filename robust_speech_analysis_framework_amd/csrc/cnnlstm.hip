@@ -478,6 +478,50 @@ __global__ __launch_bounds__(256) void split_padded_kernel(const float4* __restr
     }
 }
 
+// fp32 [B][T][C] -> plane pair of the zero-padded sequences in k16 panels: [C / 16][B (T + 2)][16], times scale[z].  One
+// wave moves 16 rows x 64 channels: a lane reads 16 channels of a row (64 bytes) and writes 32 bytes per plane; the 16 rows
+// of a panel are 512 contiguous bytes.  The image is the A operand of BOTH the 3-tap convolution (a_tap_panels = C / 16:
+// tap k of output row t is image row t + k) and the 1x1 shortcut (the centre rows).
+__global__ __launch_bounds__(256) void split_padded_panels_kernel(const float4* __restrict__ src, int B, int T, int C,
+                                                                  const float* __restrict__ scale, unsigned short* __restrict__ planes,
+                                                                  int64_t plane) {
+    const int64_t R = (int64_t)B * (T + 2);
+    const int cgroups = C / 64;                                          // 64-channel groups per row (C % 64 == 0)
+    const int64_t tiles = ((R + 15) / 16) * cgroups;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+        const int cg = (int)(tile % cgroups);
+        const int64_t r = (tile / cgroups) * 16 + (lane >> 2);
+        if (r >= R) continue;
+        const int c0 = cg * 64 + (lane & 3) * 16;
+        const int64_t b = r / (T + 2);
+        const int tp = (int)(r - b * (T + 2));
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tp >= 1 && tp <= T) {
+            const float4* q = src + ((b * T + (tp - 1)) * C + c0) / 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = q[u];
+        }
+        const float sc = scale[b];
+        unsigned hw[8], lw[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned short hh[4], ll[4];
+            split2_c(v[u].x * sc, hh[0], ll[0]); split2_c(v[u].y * sc, hh[1], ll[1]);
+            split2_c(v[u].z * sc, hh[2], ll[2]); split2_c(v[u].w * sc, hh[3], ll[3]);
+            hw[2 * u] = hh[0] | ((unsigned)hh[1] << 16); hw[2 * u + 1] = hh[2] | ((unsigned)hh[3] << 16);
+            lw[2 * u] = ll[0] | ((unsigned)ll[1] << 16); lw[2 * u + 1] = ll[2] | ((unsigned)ll[3] << 16);
+        }
+        unsigned short* pp = planes + ((int64_t)(c0 / 16) * R + r) * 16;
+        *reinterpret_cast<uint4*>(pp) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *reinterpret_cast<uint4*>(pp + 8) = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+        *reinterpret_cast<uint4*>(pp + plane) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        *reinterpret_cast<uint4*>(pp + plane + 8) = make_uint4(lw[4], lw[5], lw[6], lw[7]);
+    }
+}
+
 // fp32 [B][n4 float4] -> plane pair of the same shape, times scale[b]
 __global__ __launch_bounds__(256) void split_rows_kernel(const float4* __restrict__ src, int B, int64_t n4_per_seq,
                                                          const float* __restrict__ scale, unsigned short* __restrict__ planes, int64_t plane) {
@@ -584,11 +628,18 @@ static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layo
                            b_slot >= 0 ? stat + 2 * b_slot : nullptr, factor, scale + (int64_t)s_out * B, B);
     };
     // one GEMM of the block: A = padded plane pair (row stride lda, Tr rows per sequence, first tap at a_row0), per-sequence scale
+    // (a_panels > 0: A is a panel image of a_panels channel panels over all B (T + 2) padded rows, see split_padded_panels_kernel)
+    int a_panels = 0;
     auto gemm = [&](const uint16_t* A, int64_t a_plane, int64_t a_seq_rows, int a_row0, int lda, int s_in, int widx, int M, int N, int K,
                     float* Cf, uint16_t* Cp, int64_t c_plane, int64_t cp_seq_rows, int cp_row0, int s_out, const float* bias,
                     const float* R, int act, int amax_slot, const char* tag) {
         GemmH3Params p{};
         p.A = A + (int64_t)a_row0 * lda; p.a_plane = a_plane; p.lda = lda; p.sA = a_seq_rows * lda;
+        if (a_panels > 0) {
+            p.A = A + (int64_t)a_row0 * 16; p.lda = 16; p.sA = a_seq_rows * 16;
+            p.a_panel = 1; p.a_panel_rows = (int)((int64_t)B * a_seq_rows);
+            p.a_tap_panels = K > a_panels * 16 ? a_panels : 0;
+        }
         p.a_scale = scale + (int64_t)s_in * B; p.a_scale_zs = 1; p.a_scale_ms = 0;
         p.B = planes(F.wp[widx]); p.b_plane = (int64_t)N * K; p.ldb = 16; p.b_panel = 1; p.b_scale = f16base + F.ws[widx];
         p.C = Cf; p.ldc = N; p.sC = (int64_t)M * N;
@@ -600,7 +651,11 @@ static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layo
         return launch_gemm_f16x3(p, s, tag);
     };
     const int64_t pl_x = (int64_t)B * (T + 2) * D, pl_c = (int64_t)B * (T + 2) * C, pl_p = (int64_t)B * (Tp + 2) * C;
-    // x -> padded planes under the exact maximum of every sequence
+    // x -> padded planes under the exact maximum of every sequence; in k16 panels when the width allows (D % 64 == 0, image
+    // rows below 2^27): row-major rows reach the DMA as 32-byte pieces of 512 different rows per k-tile, and with one column
+    // tile (N = 128) nothing hides that (RSAF_CNN_ROWMAJOR=1: the row-major image, the A/B reference)
+    static const bool no_panels = [] { const char* e = getenv("RSAF_CNN_ROWMAJOR"); return e && e[0] == '1'; }();
+    const bool x_panels = !no_panels && D % 64 == 0 && (int64_t)B * (T + 2) < ((int64_t)1 << 27);
     {
         ProfScope prof("cnn_split_input", s, 0.0, (double)B * T * D * 12.0);
         const int64_t n4 = (int64_t)T * D / 4;
@@ -608,13 +663,20 @@ static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layo
         hipLaunchKernelGGL(seq_absmax_kernel, dim3(chunks, B), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4, chunks, amax + AX * B);
         cnn_scale(AX, -1, -1, -1, 1.0f, SX);
         const int64_t tot = (int64_t)B * (T + 2) * (D / 4);
-        hipLaunchKernelGGL(split_padded_kernel<false>, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 8192)), dim3(256), 0, s,
-                           reinterpret_cast<const float4*>(x), B, T, T, D / 4, scale + SX * B, planes(F.xp), pl_x, nullptr);
+        if (x_panels) {
+            const int64_t tiles = (((int64_t)B * (T + 2) + 15) / 16) * (D / 64);
+            hipLaunchKernelGGL(split_padded_panels_kernel, dim3((unsigned)std::min<int64_t>((tiles + 3) / 4, 16384)), dim3(256), 0, s,
+                               reinterpret_cast<const float4*>(x), B, T, D, scale + SX * B, planes(F.xp), pl_x);
+        } else {
+            hipLaunchKernelGGL(split_padded_kernel<false>, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 8192)), dim3(256), 0, s,
+                               reinterpret_cast<const float4*>(x), B, T, T, D / 4, scale + SX * B, planes(F.xp), pl_x, nullptr);
+        }
         RSAF_CHECK_HIP(hipGetLastError());
     }
     // res_block1 (src/models.py:64-76, :175): conv1 -> planes, shortcut -> fp32, conv2 (+ shortcut) -> fp32
     cnn_scale(AX, -1, 0, 5, sqrtf((float)(3 * D)) * 1.00001f, SC1);
     hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(64), dim3(256), 0, s, planes(F.c1p), pl_c, B, T, C / 8);
+    a_panels = x_panels ? D / 16 : 0;
     rc = gemm(planes(F.xp), pl_x, T + 2, 0, D, SX, 0, T, C, 3 * D, nullptr, planes(F.c1p), pl_c, T + 2, 1, SC1, W + L.b1, nullptr,
               d.act, AC1, "cnn_conv_gemm");
     if (rc) return rc;
@@ -625,6 +687,7 @@ static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layo
         if (rc) return rc;
         sc = bufB; sc_amax = ASC;
     }
+    a_panels = 0;
     rc = gemm(planes(F.c1p), pl_c, T + 2, 0, C, SC1, 2, T, C, 3 * C, bufC, nullptr, 0, 0, 0, -1, W + L.b2, sc, d.act, AC2, "cnn_conv_gemm");
     if (rc) return rc;
     (void)sc_amax;

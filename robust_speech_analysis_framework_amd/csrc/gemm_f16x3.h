@@ -45,6 +45,10 @@ struct GemmH3Params {
     int nz2;
     int64_t sA2, sB2, sC2, sBias2;
     int b_panel_rows;
+    // A as a padded panel image shared by the taps of a convolution: a_panel with R = a_panel_rows rows per panel (batches
+    // allowed: sA = rows between the batches' first rows x 16), and, with a_tap_panels = P > 0, K = taps x P panels where
+    // k-tile kt reads panel kt % P one row further down per tap kt / P (a_tap_inv is filled in by the launcher)
+    int a_panel_rows, a_tap_panels, a_tap_inv;
 };
 
 int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         const bool isA = j < CFG::A_INSTR;
         const int jj = isA ? j : j - CFG::A_INSTR;
         pstride[i] = isA ? p.a_plane : p.b_plane;
-        kstride[i] = isA ? (p.a_panel ? (int64_t)p.M * 16 : 16) : (p.b_panel ? (int64_t)(p.b_panel_rows > 0 ? p.b_panel_rows : p.N) * 16 : 16);
+        kstride[i] = isA ? (p.a_panel ? (int64_t)(p.a_panel_rows > 0 ? p.a_panel_rows : p.M) * 16 : 16) : (p.b_panel ? (int64_t)(p.b_panel_rows > 0 ? p.b_panel_rows : p.N) * 16 : 16);
         ldsoff[i] = isA ? jj * 512 : NPL * A_PLANE + jj * 512;
     }
     auto set_tile = [&](const Tile& T) {                                  // DMA sources of a tile
@@ -167,6 +167,16 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
         }
     };
     const int nk = p.K / BK;
+    // element offset of k-tile KT of instruction i's operand.  A convolution over a padded panel image (a_tap_panels = P > 0:
+    // K = taps x P panels) walks the P channel panels of a tap and then moves ONE ROW down for the next tap: the rows of
+    // consecutive taps overlap, the image holds every activation once.  tap = KT / P by a host-checked reciprocal.
+    auto koff = [&](int i, int KT) -> int64_t {
+        if (p.a_tap_panels > 0 && (wave + NW * i) < CFG::A_INSTR) {
+            const int tap = (int)(((unsigned)KT * (unsigned)p.a_tap_inv) >> 16);
+            return (int64_t)(KT - tap * p.a_tap_panels) * kstride[i] + (int64_t)tap * 16;
+        }
+        return (int64_t)KT * kstride[i];
+    };
 
 #define H3_DMA(KT, ST)                                                                                          \
     do {                                                                                                        \
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
             if (live[i]) {                                                                                      \
                 const bool isA_ = (wave + NW * i) < CFG::A_INSTR;                                               \
                 _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                              \
-                    __builtin_amdgcn_global_load_lds(H3_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)(KT) * kstride[i]), voff[i]), \
+                    __builtin_amdgcn_global_load_lds(H3_ADDR(sbase[i] + (pl * pstride[i] + koff(i, (KT))), voff[i]), \
                         (lds_ptr3)(smem3 + (ST) * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0); \
             }                                                                                                   \
         }                                                                                                       \
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
                 if (live[i]) {
                     const bool isA_ = (wave + NW * i) < CFG::A_INSTR;
                     __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_global_load_lds(H3_ADDR(sbase[i] + (pl * pstride[i] + (int64_t)rkt * kstride[i]), voff[i]),
+                    __builtin_amdgcn_global_load_lds(H3_ADDR(sbase[i] + (pl * pstride[i] + koff(i, rkt)), voff[i]),
                         (lds_ptr3)(smem3 + rst * STAGE + ldsoff[i] + pl * (isA_ ? A_PLANE : B_PLANE)), 16, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -589,7 +599,10 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     RSAF_CHECK_ARG(!p.R || p.ldr > 0, "residual needs ldr");
     RSAF_CHECK_ARG(p.act >= 0 && p.act <= 2, "act must be 0 (none), 1 (gelu) or 2 (silu)");
     RSAF_CHECK_ARG(p.nz <= 65535, "at most 65535 batches per launch");
-    RSAF_CHECK_ARG(!(p.a_panel || p.cp_panel) || p.nz == 1, "panel layouts are for unbatched operands");
+    RSAF_CHECK_ARG(!p.cp_panel || p.nz == 1, "the panel layout of the plane output is for unbatched operands");
+    RSAF_CHECK_ARG(!p.a_panel || p.nz == 1 || p.a_panel_rows > 0, "a batched A in panels needs a_panel_rows");
+    RSAF_CHECK_ARG(p.a_tap_panels == 0 || (p.a_panel && p.a_panel_rows > 0 && p.a_tap_panels > 0 && (p.K / 16) % p.a_tap_panels == 0),
+                   "a_tap_panels: A in panels with a_panel_rows, K = taps x a_tap_panels x 16");
     RSAF_CHECK_ARG(p.ldc < (1 << 24) && p.ldcp < (1 << 24) && p.ldr < (1 << 24), "leading dimensions must be below 2^24");
     RSAF_CHECK_ARG(!p.R || p.C, "the residual comes with the fp32 output");
     RSAF_CHECK_ARG(p.nz2 <= 1 || (p.C && !p.Cp && !p.R && !p.a_panel && p.nz % p.nz2 == 0),
@@ -624,6 +637,11 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     } while (0)
     GemmH3Params pp = p;
     if (pp.group_m <= 0) pp.group_m = 2;
+    if (pp.a_tap_panels > 0) {                               // kt / P as (kt * inv) >> 16, checked for every k-tile of this launch
+        pp.a_tap_inv = 65536 / pp.a_tap_panels + 1;
+        for (int kt = 0; kt < pp.K / 16; ++kt)
+            RSAF_CHECK_ARG((int)(((unsigned)kt * (unsigned)pp.a_tap_inv) >> 16) == kt / pp.a_tap_panels, "a_tap_panels: K too long for the reciprocal");
+    }
     // persistent workgroups, one per CU (RSAF_GEMM_WGS overrides the count: a measurement knob)
     int persistent_wgs = 256;
     {
