@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __res
                                                              int64_t plane, int n, int Tmax, int Hd4, int G, int K,
                                                              const int* __restrict__ Tw, const int64_t* __restrict__ row0,
                                                              const unsigned* __restrict__ amax, float* __restrict__ win_scale) {
-    // destination [window][group][Tmax + K - 1][cg]: frame t of window w at tt = t + K / 2, zeros around its T_w frames
+    // destination per (window, group): Tmax + K - 1 rows of cg channels, frame t of window w at tt = t + K / 2, zeros around its T_w frames
     const int cg4 = Hd4 / G;
     const int TT = Tmax + K - 1;
     const int64_t total = (int64_t)n * G * TT * cg4;
@@ -792,10 +792,192 @@ __global__ __launch_bounds__(256) void regroup_planes_kernel(const float4* __res
         unsigned short hh[4], ll[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) split2_w(vv[k], hh[k], ll[k]);
-        unsigned short* pp = xg + 4 * i;
+        // k16 panels per (window, group): [cg / 16][TT][16] - tap k of output frame t is panel row t + k, so the GEMM's DMA
+        // moves 32 consecutive rows of a panel as one contiguous KiB (a_tap_panels = cg / 16)
+        unsigned short* pp = xg + ((((chunk * G + g) * (cg4 / 4) + (ci >> 2)) * TT + tt) * 16 + (ci & 3) * 4);
         *reinterpret_cast<uint2*>(pp) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
         *reinterpret_cast<uint2*>(pp + plane) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
     }
+}
+
+// ---- positional convolution: the window's panel image stays in LDS -----------------------------------------------------------
+// As a batched GEMM (gemm_f16x3, 256 x 64 tiles) every k-tile of the 128-tap convolution re-reads its A tile from L2 although
+// consecutive taps differ by ONE ROW: 6.3 MB of DMA per tile, 755 GB per 1 000 clips, 6.7 TB/s - the kernel sat on the L2 -> LDS
+// path at 125 TFLOP/s-equivalent whatever the tile shape.  Here a workgroup owns one (window, group): the group's cg channels of
+// the zero-padded window ([cg / 16 panels][T_w + PK - 1 rows][16], both fp16 planes: 120 KB at base geometry) are fetched ONCE,
+// tap k of output row t is LDS row t + k, and only the weights stream (6 KB per step of two k16 units, four stages).  Eight
+// waves x 64 rows; v_mfma_f32_16x16x32_f16 so that the 48 output channels are three full column tiles; the arithmetic is the
+// GEMM's (a_l b_h + a_h b_l + a_h b_h, fp32 accumulation, power-of-two scales undone in the epilogue, bias, GELU).
+// Rows and halves are stored with the GEMM's swizzle (16-byte half h of row r in slot h ^ ((r >> 3) & 1)): lanes r and r + 8 of a
+// fragment read then hit different banks for any tap offset.
+typedef _Float16 pc_f16x8 __attribute__((ext_vector_type(8)));
+typedef float pc_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* pc_lds_ptr;
+typedef const __attribute__((address_space(1))) void* pc_glb_ptr;
+constexpr int PC_ROWS = 512;                     // output rows per workgroup with SPLIT = 1 (8 waves x 4 row tiles of 16)
+
+// SPLIT = 2 (windows of at most 256 frames - the 5 s windows of the extractor give 249): 256 rows per workgroup, waves 0-3 take
+// the even steps and waves 4-7 the odd ones (split K; the halves meet through LDS in front of the epilogue), so that all eight
+// waves have rows to work on and each weight step is read from LDS by four waves instead of eight.
+template <int NT, int SPLIT>
+__global__ __launch_bounds__(512, 1) void posconv_f16x3_kernel(const unsigned short* __restrict__ xg, int64_t a_plane,
+                                                               const unsigned short* __restrict__ wp, int64_t b_plane, int Hd,
+                                                               const float* __restrict__ a_scale, const float* __restrict__ b_scale,
+                                                               const float* __restrict__ bias, const int* __restrict__ Tw,
+                                                               const int64_t* __restrict__ row0, float* __restrict__ y, int G, int TT,
+                                                               int PK, int rows_alloc) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned short pc_sm[];
+    constexpr int cg = 16 * NT, B_SEG = cg * 16, B_STAGE = 4 * B_SEG, B_INSTR = cg / 8, RGRPS = 8 / SPLIT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = blockIdx.x / G, g = blockIdx.x - w * G;
+    const int a_panel = rows_alloc * 16;                                   // elements per (plane, panel)
+    unsigned short* sA = pc_sm;
+    unsigned short* sB = pc_sm + 2 * NT * a_panel;
+    // the window's image -> LDS: instruction ii = (plane, panel, block of 32 rows), 1 KiB each
+    {
+        const int blocks = rows_alloc / 32, total = 2 * NT * blocks;
+        const int r_in = lane >> 1, slot = lane & 1;
+        for (int ii = wave; ii < total; ii += 8) {
+            const int pp = ii / blocks, rb = ii - pp * blocks;             // pp = plane * NT + panel
+            const int pl = pp / NT, panel = pp - pl * NT;
+            const int row = rb * 32 + r_in;
+            const int srow = row < TT ? row : TT - 1;
+            const int chunk = slot ^ ((row >> 3) & 1);
+            const unsigned short* src = xg + pl * a_plane + ((((int64_t)w * G + g) * NT + panel) * TT + srow) * 16 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((pc_glb_ptr)src, (pc_lds_ptr)(sA + pp * a_panel + rb * 512), 16, 0, 0);
+        }
+    }
+    // weights: step j = units 2 j, 2 j + 1 (a unit = 16 k of one tap); stage layout [unit in pair][plane][cg rows][16].
+    // Iteration i = steps SPLIT i .. SPLIT i + SPLIT - 1, ring of four iterations.
+    const int nit = PK * NT / 2 / SPLIT;
+    int64_t boff = 0;
+    if (wave < B_INSTR) {
+        const int c = wave * 64 + lane;                                    // 16-byte chunk of the stage
+        const int seg = c / (2 * cg), within = c - seg * (2 * cg);
+        const int row = within >> 1, slot = within & 1;
+        boff = (int64_t)(seg & 1) * b_plane + ((int64_t)(seg >> 1) * Hd + (g * cg + row)) * 16 + (slot ^ ((row >> 3) & 1)) * 8;
+    }
+    auto b_dma = [&](int i) {
+        if (wave < B_INSTR) {
+#pragma unroll
+            for (int kh = 0; kh < SPLIT; ++kh)
+                __builtin_amdgcn_global_load_lds((pc_glb_ptr)(wp + boff + (int64_t)(SPLIT * i + kh) * 2 * Hd * 16),
+                                                 (pc_lds_ptr)(sB + ((i & 3) * SPLIT + kh) * B_STAGE + wave * 512), 16, 0, 0);
+        }
+    };
+    b_dma(0);
+    if (nit > 1) b_dma(1);
+    if (nit > 2) b_dma(2);
+    pc_f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pc_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, q = lane >> 4, hlf = q & 1, upair = q >> 1;
+    const int khalf = wave / RGRPS, m_base = (wave - khalf * RGRPS) * 64;
+    // fragments of a step: B from its stage of the ring, A from the resident image at the step's tap
+    struct Frag { pc_f16x8 ah[4], al[4], bh[NT], bl[NT]; };
+    auto fetch = [&](int i, Frag& F) {
+        const int unit = 2 * (SPLIT * i + khalf) + upair;
+        const int tap = unit / NT, panel = unit - tap * NT;
+        const unsigned short* bst = sB + ((i & 3) * SPLIT + khalf) * B_STAGE + upair * 2 * B_SEG;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int brow = 16 * nt + r16;
+            const int off = brow * 16 + ((hlf ^ ((brow >> 3) & 1)) << 3);
+            F.bh[nt] = *reinterpret_cast<const pc_f16x8*>(bst + off);
+            F.bl[nt] = *reinterpret_cast<const pc_f16x8*>(bst + B_SEG + off);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = m_base + 16 * mt + r16 + tap;
+            const int off = panel * a_panel + row * 16 + ((hlf ^ ((row >> 3) & 1)) << 3);
+            F.ah[mt] = *reinterpret_cast<const pc_f16x8*>(sA + off);
+            F.al[mt] = *reinterpret_cast<const pc_f16x8*>(sA + NT * a_panel + off);
+        }
+    };
+    auto mfmas = [&](const Frag& F) {                                     // product by product: 4 NT independent accumulators
+#pragma unroll                                                             // between two instructions on the same one
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F.al[mt], F.bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F.ah[mt], F.bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F.ah[mt], F.bh[nt], acc[mt][nt], 0, 0, 0);
+    };
+    // Software pipeline: at the top of iteration i the fragments of iteration i are in registers; the wave waits for its share
+    // of iteration i + 1's weights (issued two iterations ago), the barrier publishes everybody's and frees the ring slot of
+    // iteration i + 3 (read as fragments during iteration i - 2), the DMA of iteration i + 3 goes out, the fragments of
+    // iteration i + 1 are requested and the 36 MFMAs of this iteration run while they arrive.
+    Frag F0, F1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the image and the first three weight iterations
+    __syncthreads();
+    fetch(0, F0);
+    auto step = [&](int i, const Frag& cur, Frag& nxt) {
+        if (i >= 1) {
+            if (i + 2 < nit) { if constexpr (SPLIT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (i + 3 < nit) b_dma(i + 3);
+        if (i + 1 < nit) fetch(i + 1, nxt);
+        mfmas(cur);
+    };
+    for (int i = 0; i < nit; i += 2) {                                     // nit is even (launcher)
+        step(i, F0, F1);
+        step(i + 1, F1, F0);
+    }
+    if constexpr (SPLIT == 2) {                                            // the odd steps' sums join the even steps' through LDS
+        __syncthreads();                                                   // (the image is dead)
+        float* red = reinterpret_cast<float*>(pc_sm) + (wave - khalf * RGRPS) * (4 * NT * 4 * 64);
+        if (khalf == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) red[((mt * NT + nt) * 4 + v) * 64 + lane] = acc[mt][nt][v];
+        }
+        __syncthreads();
+        if (khalf == 1) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[mt][nt][v] += red[((mt * NT + nt) * 4 + v) * 64 + lane];
+    }
+    // epilogue: D of the 16 x 16 tile: lane (q, r16), register v = row 4 q + v, column r16
+    const int Tv = Tw[w];
+    const int64_t r0 = row0[w];
+    const float sa_inv = pow2_inverse(a_scale[w]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = g * cg + 16 * nt + r16;
+        const float inv = sa_inv * pow2_inverse(b_scale[col]);
+        const float bs = bias[col];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int m = m_base + 16 * mt + 4 * q + v;
+                if (m < Tv) {
+                    float x = acc[mt][nt][v] * inv + bs;
+                    x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                    y[(r0 + m) * Hd + col] = x;
+                }
+            }
+    }
+}
+
+static int posconv_rows_alloc(int split, int PK) { return (PC_ROWS / split + PK - 1 + 31) & ~31; }
+static size_t posconv_lds_bytes(int cg, int PK, int split) {
+    return ((size_t)2 * (cg / 16) * posconv_rows_alloc(split, PK) * 16 + (size_t)4 * split * 4 * cg * 16) * sizeof(unsigned short);
 }
 
 static int ln(const float* x, const float* r, const float* g, const float* b, float* out, int64_t rows, int D,
@@ -1102,7 +1284,7 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
         const int64_t tot4 = (int64_t)n * TT * (Hd / 4);
         if (cg % 16 == 0) {
             // grouped conv as a two-level batched GEMM on the f16x3 kernel's 256 x 64 tile: batch (window, group), M = T_w rows
-            // (overlapping windows of the regrouped sequence: lda = cg), N = cg output channels, K = PK cg
+            // (the regrouped sequence as k16 panels of T_w + PK - 1 rows: tap k = one row down), N = cg output channels, K = PK cg
             const int64_t plane = (int64_t)n * TT * Hd;
             {
                 ProfScope prof("w2v2_regroup", s, 0.0, (double)tot4 * 32);
@@ -1111,8 +1293,39 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
                                    plane, n, Tt, Hd / 4, c.PG, c.PK, Tw + (int64_t)6 * n, row0, bits_at(W.fp_amax), ws + W.pos_scale);
                 RSAF_CHECK_HIP(hipGetLastError());
             }
+            static const bool pc_off = [] { const char* e = getenv("RSAF_W2V2_POSCONV_GEMM"); return e && e[0] == '1'; }();
+            const int split = Tt <= PC_ROWS / 2 ? 2 : 1;
+            const bool resident = !pc_off && cg <= 64 && Tt <= PC_ROWS && (c.PK * (cg / 16)) % (4 * split) == 0 &&
+                                  posconv_lds_bytes(cg, c.PK, split) <= 160 * 1024;
+            if (resident) {
+                // the window's image stays in LDS (posconv_f16x3_kernel); RSAF_W2V2_POSCONV_GEMM=1: the batched GEMM below (A/B)
+                const int rows_alloc = posconv_rows_alloc(split, c.PK);
+                const size_t lds = posconv_lds_bytes(cg, c.PK, split);
+                ProfScope prof("w2v2_posconv_gemm", s, 2.0 * (double)rows * cg * (double)c.PK * cg * c.PG, 0.0);
+#define RSAF_PC_LAUNCH(NT_, SP_)                                                                                               \
+    do {                                                                                                                       \
+        RSAF_CHECK_HIP(hipFuncSetAttribute((const void*)posconv_f16x3_kernel<NT_, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((posconv_f16x3_kernel<NT_, SP_>), dim3((unsigned)(n * c.PG)), dim3(512), lds, s,                    \
+                           reinterpret_cast<const unsigned short*>(planes_at(W.xg)), plane,                                    \
+                           reinterpret_cast<const unsigned short*>(planes_at(W.wp_pos)), (int64_t)Hd * c.PK * cg, Hd,          \
+                           ws + W.pos_scale, ws + W.ws_pos, Wt + L.posb, Tw + (int64_t)6 * n, row0, ws + W.y, c.PG, TT, c.PK,   \
+                           rows_alloc);                                                                                        \
+    } while (0)
+#define RSAF_PC_LAUNCH_NT(SP_)                                                                                                 \
+    switch (cg / 16) {                                                                                                         \
+        case 1: RSAF_PC_LAUNCH(1, SP_); break;                                                                                 \
+        case 2: RSAF_PC_LAUNCH(2, SP_); break;                                                                                 \
+        case 3: RSAF_PC_LAUNCH(3, SP_); break;                                                                                 \
+        default: RSAF_PC_LAUNCH(4, SP_); break;                                                                                \
+    }
+                if (split == 2) { RSAF_PC_LAUNCH_NT(2) } else { RSAF_PC_LAUNCH_NT(1) }
+#undef RSAF_PC_LAUNCH_NT
+#undef RSAF_PC_LAUNCH
+                RSAF_CHECK_HIP(hipGetLastError());
+            } else {
             GemmH3Params p{};
-            p.A = planes_at(W.xg); p.a_plane = plane; p.lda = cg; p.sA = (int64_t)c.PG * TT * cg; p.sA2 = (int64_t)TT * cg;
+            p.A = planes_at(W.xg); p.a_plane = plane; p.lda = 16; p.sA = (int64_t)c.PG * TT * cg; p.sA2 = (int64_t)TT * cg;
+            p.a_panel = 1; p.a_panel_rows = TT; p.a_tap_panels = cg / 16;
             p.a_scale = ws + W.pos_scale; p.a_scale_zs = 1; p.a_scale_ms = 0;
             p.B = planes_at(W.wp_pos); p.b_plane = (int64_t)Hd * c.PK * cg; p.ldb = 16; p.b_panel = 1; p.b_panel_rows = Hd; p.sB2 = (int64_t)cg * 16;
             p.b_scale = ws + W.ws_pos;
@@ -1121,6 +1334,7 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
             p.M = Tt; p.ztab = ztab + (int64_t)6 * n * 2; p.N = cg; p.K = c.PK * cg; p.nz = n * c.PG; p.nz2 = c.PG; p.act = ACT_GELU; p.alpha = 1.0f;
             rc = launch_gemm_f16x3(p, s, "w2v2_posconv_gemm");
             if (rc) return rc;
+            }
         } else {
             // group widths that are no multiple of 16 (test geometries): exact-fp32 GEMM, one launch per run of equal windows
             for (const auto& tg : R.tgroups) {
