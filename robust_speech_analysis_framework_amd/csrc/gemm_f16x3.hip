@@ -611,8 +611,6 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     ProfScope prof(tag ? tag : "gemm_f16x3", stream, 2.0 * p.M * (double)p.N * p.K * p.nz, 0.0);
     using CfgA = H3Cfg<4, 2, 2, 4, 3, 1>;                // 256 x 256
     using CfgN = H3Cfg<2, 1, 4, 2, 3, 1>;                // 256 x 64: N <= 64 (the 48-wide groups of the positional convolution)
-    using CfgT = H3Cfg<4, 1, 4, 2, 3, 1>;                // 512 x 64: N <= 64 and more than 256 rows per batch
-    static const bool narrow_short = [] { const char* e = getenv("RSAF_GEMM_TALL64"); return e && e[0] == '0'; }();
     using CfgM = H3Cfg<4, 2, 4, 2, 3, 1>;                // 512 x 128: N <= 128 (the CNN-LSTM's 128 channels): the wave tile of the
                                                          // 256 x 256 configuration (24 MFMAs per k-tile and wave; a 256 x 128 tile's 12
                                                          // left the main loop bound by its barriers and DMA issue: 110 TFLOP/s-equivalent)
@@ -628,14 +626,6 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
 #define H3_LAUNCH(ACT, F32, PL, HR)                                                                                     \
     do {                                                                                                                \
         if (p.N <= 64) H3_LAUNCH_CFG(CfgN, ACT, F32, PL, HR);                                                            \
-        else H3_LAUNCH_CFG(CfgA, ACT, F32, PL, HR);                                                                      \
-    } while (0)
-    // tall batches of narrow outputs (the positional convolution: 499 rows x 48 columns per window and group): 512 x 64 tiles,
-    // twelve MFMAs per wave between the k-tile's barriers where the 256 x 64 tile has six
-#define H3_LAUNCH_TALL(ACT, F32, PL, HR)                                                                                \
-    do {                                                                                                                \
-        if (p.N <= 64 && p.M > 256 && !narrow_short) H3_LAUNCH_CFG(CfgT, ACT, F32, PL, HR);                              \
-        else if (p.N <= 64) H3_LAUNCH_CFG(CfgN, ACT, F32, PL, HR);                                                       \
         else H3_LAUNCH_CFG(CfgA, ACT, F32, PL, HR);                                                                      \
     } while (0)
     // the CNN-LSTM's shapes (N = 128 channels: the 256 x 128 tile) take three tile configurations
@@ -667,7 +657,7 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
     else if (p.act == ACT_NONE && f32o && !plo && hr) H3_LAUNCH(ACT_NONE, true, false, true);
     else if (p.act == ACT_GELU && !f32o && plo && !hr) H3_LAUNCH3(ACT_GELU, false, true, false);
     else if (p.act == ACT_SILU && !f32o && plo && !hr) H3_LAUNCH3(ACT_SILU, false, true, false);
-    else if (p.act == ACT_GELU && f32o && !plo && !hr) H3_LAUNCH_TALL(ACT_GELU, true, false, false);
+    else if (p.act == ACT_GELU && f32o && !plo && !hr) H3_LAUNCH(ACT_GELU, true, false, false);
     else if (p.act == ACT_SILU && f32o && !plo && !hr) H3_LAUNCH(ACT_SILU, true, false, false);
     else if (p.act == ACT_GELU && f32o && !plo && hr) H3_LAUNCH3(ACT_GELU, true, false, true);
     else if (p.act == ACT_SILU && f32o && !plo && hr) H3_LAUNCH3(ACT_SILU, true, false, true);
@@ -680,7 +670,6 @@ int launch_gemm_f16x3(const GemmH3Params& p, hipStream_t stream, const char* tag
 #undef H3_LAUNCH_CFG
 #undef H3_LAUNCH
 #undef H3_LAUNCH3
-#undef H3_LAUNCH_TALL
     RSAF_CHECK_HIP(hipGetLastError());
     return RSAF_OK;
 }

@@ -205,7 +205,7 @@ def rooflines(prof, stages, clips, seconds, steps, hbm_peak_gbs, mfma_f32_peak_t
             continue
         if rec["flops"] > 0:
             fp64 = name.startswith("mshds_")
-            split3 = name in ("w2v2_gemm", "w2v2_posconv_gemm")      # both on gemm_f16x3 (base geometry)
+            split3 = name in ("w2v2_gemm", "w2v2_posconv_gemm")      # gemm_f16x3 / posconv_f16x3_kernel: the same three-product arithmetic
             peak = f64_peak_tflops if fp64 else (F16_MFMA_PEAK_TFLOPS if split3 else mfma_f32_peak_tflops)
             alg = rec["flops"] / (rec["ms"] * 1e-3) / 1e12
             # the f16x3 GEMM executes three fp16 MFMA products per algorithmic multiply-add (two-way fp16 splits of both

@@ -9,8 +9,8 @@ Wav2Vec2 GEMM kernel PER SHAPE beside the algorithmic bytes of that shape.
 
 Shapes: gemm_f16x3 runs persistent workgroups (one per CU), so the grid size no longer tells its shapes apart; every dispatch
 is labelled by its template variant (activation / outputs / residual, in the kernel name) and its position in the forward
-call: [conv1..5 (GELU -> planes), conv6 (GELU -> fp32)] per window group, feature projection, positional conv (the 256 x 64
-tile configuration: the only one), then per layer qkv (-> planes), out-projection (+R), ffn1 (GELU -> planes), ffn2 (+R).
+call: [conv1..5 (GELU -> planes), conv6 (GELU -> fp32)] per window group, feature projection, then per layer qkv (-> planes),
+out-projection (+R), ffn1 (GELU -> planes), ffn2 (+R).  The 512 x 128 tile configuration (the CNN-LSTM's GEMMs) is left out.
 The calls of a step and their window counts are replayed from the engine's own batching (w2v2.forward_windows).
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB;
@@ -44,7 +44,8 @@ def variant(name):
     if not m:
         return None
     tb = lambda v: v in ("true", "1")                                       # noqa: E731
-    return ("N" if m.group(2) == "1" else "A", int(m.group(7)), tb(m.group(8)), tb(m.group(9)), tb(m.group(10)))
+    cfg = "N" if m.group(2) == "1" else ("M" if m.group(3) == "4" else "A")  # 256 x 64 / 512 x 64 | 512 x 128 (CNN-LSTM) | 256 x 256
+    return (cfg, int(m.group(7)), tb(m.group(8)), tb(m.group(9)), tb(m.group(10)))
 
 
 def dispatches(root, counter):
@@ -57,6 +58,9 @@ def dispatches(root, counter):
         with open(fn, newline="") as f:
             for r in csv.DictReader(f):
                 if r.get("Counter_Name") == counter and "gemm_f16x3_kernel" in r["Kernel_Name"]:
+                    v = variant(r["Kernel_Name"])
+                    if v is not None and v[0] == "M":                      # the CNN-LSTM's convolutions / input projections
+                        continue
                     out.append((int(r.get("Dispatch_Id", 0) or 0), r["Kernel_Name"], float(r["Counter_Value"])))
     out.sort()
     return out
@@ -103,9 +107,7 @@ def call_sequence(lens, conv_group=512, C=512, H=768, inter=3072, layers=12, pos
             seq.append((f"conv{i} (K = {k * C})", ("A", 1, i == 6, i != 6, False), a + o + 4.0 * C * k * C))
     alg = lambda nn, kk, resid: 4.0 * (rows * kk + nn * kk) + rows * nn * (4.0 + 4.0 * resid)      # noqa: E731
     seq.append(("feature projection", ("A", 0, True, False, False), alg(H, C, 0)))
-    cg = H // pos_g
-    tt = sum(t[6] + pos_k - 1 for t in Tw)
-    seq.append(("positional conv (grouped)", ("N", 1, True, False, False), 4.0 * tt * H + 4.0 * H * pos_k * cg + 4.0 * rows * H))
+    # (the positional convolution is its own kernel since round 4: posconv_f16x3_kernel, listed under other_kernels)
     for _ in range(layers):
         seq.append(("qkv (-> planes)", ("A", 0, False, True, False), alg(3 * H, H, 0)))
         seq.append(("attention out-proj (+residual)", ("A", 0, True, False, True), alg(H, H, 1)))
@@ -125,7 +127,7 @@ def main():
     ap.add_argument("--windows", type=int, default=2048)            # --w2v2-chunks-per-call of the run (recorded; bench.py matches it)
     ap.add_argument("--kernel", default="w2v2_gemm")
     ap.add_argument("--command", default="")
-    ap.add_argument("--also", default="smile_lld_kernel,pitch_cand_kernel,lp_rows_kernel,layernorm_kernel,conv0_kernel,attn_f16x3_kernel",
+    ap.add_argument("--also", default="smile_lld_kernel,pitch_cand_kernel,pitch_cell_coef_kernel,pitch_brent_kernel,posconv_f16x3_kernel,lp_rows_kernel,layernorm_kernel,conv0_kernel,attn_f16x3_kernel",
                     help="other kernels (name substrings) whose FETCH / WRITE totals per launch are recorded beside the GEMM")
     a = ap.parse_args()
     fe, wr = dispatches(a.fetch_dir, "FETCH_SIZE"), dispatches(a.write_dir, "WRITE_SIZE")
