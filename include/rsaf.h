@@ -277,7 +277,7 @@ int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, i
                          double* db_out, double* stats_out, rsaf_stream_t stream);
 /* params_host[18] = {dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, octave_jump_cost,
  *   voiced_unvoiced_cost, nsamp_window, nsamp_period, min_lag, max_lag, brent_ixmax, max_candidates,
- *   refine_depth, is_cc, dt_window, cheb_has_clipped_depths}.  sel_freq / sel_strength: the path finder's choice per frame.
+ *   refine_depth, is_cc, dt_window, table_mode (0 | 1 | 2, see sinc_cheb)}.  sel_freq / sel_strength: the path finder's choice per frame.
  * stats_out[clip][8] = {n(f != 0), mean, population sd, mean after |z| <= 2, n voiced, mean Hz,
  *   sd in semitones (n-1), n after filter}.
  * sinc_cheb (may be NULL): [2 * refine_depth][16] Chebyshev coefficients on frac in [0, 1] of the sinc-interpolation
@@ -286,9 +286,18 @@ int rsaf_mshds_intensity(const float* wav, const void* clip_info, int n_clips, i
  *   params_host[17] = 1 the table is followed by the tables of the clipped depths e = 1 .. refine_depth - 1
  *   ([2 e][16] each, depth e at offset 2 * refine_depth * 16 + 16 e (e - 1) doubles): candidates whose depth the array
  *   ends clip to e >= 3 (cross-correlation passes) then take the polynomial form too (ABI 6).
- * workspace: the per-frame correlation rows between the correlation kernel (fp64 FFT auto- / cross-correlation, one
- *   workgroup per 16 frames) and the candidate kernel (one wave per frame); at least rsaf_mshds_pitch_workspace_bytes_per_clip bytes, the
- *   clips are processed in groups of floor(workspace_bytes / that). */
+ *   With params_host[17] = 2 (single-threshold cross-correlation analyses; the harmonicity pass: depth 700) sinc_cheb holds
+ *   ONE TABLE PER CELL instead (mshds.sinc_cell_tables): cells b = brent_ixmax + lag_lo - 1 .. brent_ixmax + lag_hi
+ *   (lag_lo = max(min_lag, 2), lag_hi = min(max_lag, brent_ixmax) - 1), each [ntap_pad][16] with ntap_pad = max_lag + 1
+ *   rounded up to a multiple of 4: row m = the sum of the rows of the cell's own depth min(depth, b + 1, RN - b - 1) that
+ *   meet lag +m and lag -m of the symmetric correlation array; the coefficients of every cell of the batch are then built
+ *   by a per-cell GEMM on the fp64 matrix pipe, clipped depths included (pitch_cell_coef_kernel).
+ * workspace: per frame the correlation row (between the correlation kernel - fp64 FFT auto- / cross-correlation, one wave
+ *   per frame - and the candidate kernel), the Chebyshev coefficient blocks of two candidate lists (2 x 4 KB) and a 128-byte
+ *   record (between the candidate kernel and the refinement kernels: the Brent search runs one candidate per lane in its own
+ *   kernel); at least rsaf_mshds_pitch_workspace_bytes_per_clip bytes, the clips are processed in groups of
+ *   floor(workspace_bytes / that).  Environment RSAF_PITCH_INKERNEL=1: refinement inside the candidate kernel (the form
+ *   before round 4; the tests' A/B reference). */
 int64_t rsaf_mshds_pitch_workspace_bytes_per_clip(int max_frames, const double* params_host);
 int rsaf_mshds_pitch(const float* wav, const void* clip_info, int n_clips, int max_frames, const double* gpeak,
                      const double* window, const double* window_r, const double* params_host,
