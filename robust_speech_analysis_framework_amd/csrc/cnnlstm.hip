@@ -654,7 +654,7 @@ static int forward_f16x3(const float* x, int B, int T, const Dims& d, const Layo
     // x -> padded planes under the exact maximum of every sequence; in k16 panels when the width allows (D % 64 == 0, image
     // rows below 2^27): row-major rows reach the DMA as 32-byte pieces of 512 different rows per k-tile, and with one column
     // tile (N = 128) nothing hides that (RSAF_CNN_ROWMAJOR=1: the row-major image, the A/B reference)
-    static const bool no_panels = [] { const char* e = getenv("RSAF_CNN_ROWMAJOR"); return e && e[0] == '1'; }();
+    const bool no_panels = [] { const char* e = getenv("RSAF_CNN_ROWMAJOR"); return e && e[0] == '1'; }();   // per call: the tests toggle it
     const bool x_panels = !no_panels && D % 64 == 0 && (int64_t)B * (T + 2) < ((int64_t)1 << 27);
     {
         ProfScope prof("cnn_split_input", s, 0.0, (double)B * T * D * 12.0);

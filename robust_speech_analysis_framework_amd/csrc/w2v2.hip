@@ -1293,7 +1293,7 @@ static int forward_impl(const float* wav, const int64_t* chunk_start, const int*
                                    plane, n, Tt, Hd / 4, c.PG, c.PK, Tw + (int64_t)6 * n, row0, bits_at(W.fp_amax), ws + W.pos_scale);
                 RSAF_CHECK_HIP(hipGetLastError());
             }
-            static const bool pc_off = [] { const char* e = getenv("RSAF_W2V2_POSCONV_GEMM"); return e && e[0] == '1'; }();
+            const bool pc_off = [] { const char* e = getenv("RSAF_W2V2_POSCONV_GEMM"); return e && e[0] == '1'; }();   // per call: the tests toggle it
             const int split = Tt <= PC_ROWS / 2 ? 2 : 1;
             const bool resident = !pc_off && cg <= 64 && Tt <= PC_ROWS && (c.PK * (cg / 16)) % (4 * split) == 0 &&
                                   posconv_lds_bytes(cg, c.PK, split) <= 160 * 1024;

@@ -98,6 +98,26 @@ def test_default_geometry_t1500(rsaf_lib):
     assert _rel(got.cpu().numpy(), co.forward_torch(sd, x, "silu")) < TOL
 
 
+def test_tap_shared_panel_image_matches_the_row_major_image(rsaf_lib, monkeypatch):
+    """conv1 and the 1x1 shortcut read the input's fp16 planes as ONE k16-panel image of the zero-padded rows (tap k of output
+    row t = image row t + k: csrc/cnnlstm.hip split_padded_panels_kernel, gemm_f16x3's a_tap_panels).  RSAF_CNN_ROWMAJOR=1 is
+    the row-major image it replaced: the same products in the same order, so the logits must agree to rounding - on a ragged
+    zero-padded batch whose sequence boundaries sit inside GEMM tiles, and both against the oracle."""
+    import torch
+    sd = synth_state_dict(768, 128, 128, 5151)
+    x = synth_input(5, 700, 768, 5152)
+    x[1, 333:] = 0.0
+    x[3, 17:] = 0.0
+    m = _model(768, 128, 128, "gelu", sd)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RSAF_CNN_ROWMAJOR", mode)
+        outs[mode] = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    monkeypatch.delenv("RSAF_CNN_ROWMAJOR", raising=False)
+    assert np.array_equal(outs["0"], outs["1"]) or _rel(outs["0"], outs["1"]) < 1e-6, _rel(outs["0"], outs["1"])
+    assert _rel(outs["0"], co.forward_torch(sd, x, "gelu")) < TOL
+
+
 def test_weights_repacked_after_update_and_errors(rsaf_lib):
     import torch
     from robust_speech_analysis_framework_amd import _lib

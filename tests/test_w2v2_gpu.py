@@ -209,3 +209,40 @@ def test_ragged_call_returns_the_bits_of_the_per_length_calls(rsaf_lib):
         eng.forward_windows(wav, [s0], [l], alone, [int(rows[k])])
     torch.cuda.synchronize()
     assert torch.equal(together, alone)
+
+
+def test_positional_conv_kernel_matches_the_gemm_form_and_the_oracle_on_10s_windows(rsaf_lib, monkeypatch):
+    """The positional convolution runs as its own kernel with the window's panel image resident in LDS
+    (csrc/w2v2.hip: posconv_f16x3_kernel; split K for windows of up to 256 frames, 512 rows per workgroup above).  Both
+    variants against the batched-GEMM form it replaced (RSAF_W2V2_POSCONV_GEMM=1: the same three-product arithmetic, another
+    summation order) on 5 s windows (249 frames), 10 s windows (499 frames) and a ragged mix, and the 10 s window - the
+    variant no other test reaches - against the numpy oracle."""
+    import torch
+    from robust_speech_analysis_framework_amd.w2v2 import W2V2Engine
+    cfg = W2V2Config()
+    sd = random_state_dict(cfg, seed=11)
+    eng = W2V2Engine(cfg, sd)
+    clip = synth.synth_clip(402, 21.0)
+    wav = torch.from_numpy(clip).cuda()
+    cases = [[(0, 80000), (64000, 80000), (128000, 80000)],
+             [(0, 160000), (100000, 160000)],
+             [(0, 160000), (3000, 100000), (50000, 80000), (7, 30000), (90000, 2000)]]
+    for spec in cases:
+        T = [cfg.frames(l) for _, l in spec]
+        rows = np.concatenate([[0], np.cumsum(T)])
+        outs = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("RSAF_W2V2_POSCONV_GEMM", mode)
+            out = torch.full((int(rows[-1]), cfg.hidden_size), float("nan"), dtype=torch.float32, device="cuda")
+            eng.forward_windows(wav, [s for s, _ in spec], [l for _, l in spec], out, rows[:-1])
+            torch.cuda.synchronize()
+            outs[mode] = out.cpu().numpy()
+        monkeypatch.delenv("RSAF_W2V2_POSCONV_GEMM", raising=False)
+        assert np.isfinite(outs["0"]).all()
+        scale = np.abs(outs["1"]).max()
+        print("positional conv A/B", [l for _, l in spec], np.abs(outs["0"] - outs["1"]).max() / scale)
+        assert np.abs(outs["0"] - outs["1"]).max() <= 1e-5 * scale, (spec, np.abs(outs["0"] - outs["1"]).max(), scale)
+    ref = wo.forward(sd, cfg, wo.hf_normalize(clip[:160000])[None])[0]
+    got = outs["0"][:cfg.frames(160000)]
+    assert got.shape == ref.shape == (499, cfg.hidden_size)
+    assert _rel(got, ref) < TOL, _rel(got, ref)
