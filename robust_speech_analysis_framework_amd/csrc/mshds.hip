@@ -1443,7 +1443,54 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
             const int d = P.refine_depth;
             const int kq = lane >> 4, nn = lane & 15;
             const int ncol = 2 * (nc - 1), tiles = (ncol + 15) >> 4;
-            if (nc > 1) {
+            if (nc > 1 && ncol <= 12 && n_clip_cols == 0) {
+                // Few candidates (the autocorrelation passes keep two or three): v_mfma_f64_4x4x4_4b instead - four independent
+                // 4 x 4 x 4 blocks in 16 cycles where the 16 x 16 x 4 instruction takes 64 with 4-12 of its 16 columns in use.
+                // Block = (lane % 16) / 4 holds coefficients 4 blk .. 4 blk + 3 (A[blk][i][k] in lane 16 k + 4 blk + i: the same table
+                // element as the wide instruction's A operand), every block gets the same B (B[blk][k][j] in lane 16 k + 4 blk + j:
+                // tap k of column j = lane % 4), D[blk][i][j] comes back in lane 16 i + 4 blk + j (tools/micro/mfma_f64_4x4_probe.hip).
+                const int bmin = row_min(cand_lane ? my_b0 : 0x7fffffff), bmax = -row_min(cand_lane ? -my_b0 : 0x7fffffff);
+                const int groups = (ncol + 3) >> 2;
+                int rb4[3];
+                bool cf4[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int n = 4 * g + (lane & 3), k = 1 + (n >> 1);
+                    rb4[g] = place_lag[k < nc ? k : 1] + RC - 1 + (n & 1);
+                    cf4[g] = n < ncol;                                   // (no clipped cell in this frame: they keep the wide path)
+                }
+                int o_lo = nz_lo - (bmax + 1), o_hi = nz_hi - bmin;
+                o_lo = o_lo < -(d - 1) ? -(d - 1) : o_lo;
+                o_hi = o_hi > d ? d : o_hi;
+                double a4[3] = {0.0, 0.0, 0.0};
+                const double* ctab = cheb + (int64_t)(d - 1) * NCH + nn;
+                int o = o_lo;
+                for (; o + 31 <= o_hi; o += 32) {
+                    double cw[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cw[u] = ctab[(int64_t)(o + 4 * u + kq) * NCH];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int oo = o + 4 * u + kq;
+                        a4[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(cw[u], cf4[0] ? r[rb4[0] + oo] : 0.0, a4[0], 0, 0, 0);
+                        if (groups > 1) a4[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(cw[u], cf4[1] ? r[rb4[1] + oo] : 0.0, a4[1], 0, 0, 0);
+                        if (groups > 2) a4[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(cw[u], cf4[2] ? r[rb4[2] + oo] : 0.0, a4[2], 0, 0, 0);
+                    }
+                }
+                for (; o <= o_hi; o += 4) {
+                    const int oo = o + kq, oc = oo <= o_hi ? oo : o_hi;          // taps past o_hi contribute zero
+                    const double cw = oo <= o_hi ? ctab[(int64_t)oc * NCH] : 0.0;
+                    a4[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(cw, cf4[0] ? r[rb4[0] + oc] : 0.0, a4[0], 0, 0, 0);
+                    if (groups > 1) a4[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(cw, cf4[1] ? r[rb4[1] + oc] : 0.0, a4[1], 0, 0, 0);
+                    if (groups > 2) a4[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(cw, cf4[2] ? r[rb4[2] + oc] : 0.0, a4[2], 0, 0, 0);
+                }
+                const int coef = (nn & 12) + kq;                             // 4 blk + i
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int n = 4 * g + (lane & 3), k = 1 + (n >> 1);
+                    if (g < groups && n < ncol) s_P[(k * 2 + (n & 1)) * NCH + coef] = a4[g];
+                }
+            } else if (nc > 1) {
                 const int bmin = row_min(cand_lane ? my_b0 : 0x7fffffff), bmax = -row_min(cand_lane ? -my_b0 : 0x7fffffff);
                 int rbase[2];
                 bool colfull[2];                                      // clipped cells are rebuilt below: their B operand is zero here
