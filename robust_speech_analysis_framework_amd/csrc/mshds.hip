@@ -1240,8 +1240,9 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     // r is Praat's symmetric array of 2 ixmax + 1 lags, but only |lag| <= L is non-zero and nothing reads beyond
     // the candidates' lags widened by the interpolation depth (and never past 2 L + 1): only that range is stored,
     // through a base pointer shifted so that the indices stay Praat's
+    // (with the per-cell coefficient kernel behind it, this kernel reads no further than its depth-30 first estimates)
     int r_lo, r_hi;
-    pitch_r_range(RC, L, P.min_lag, P.max_lag, P.refine_depth, &r_lo, &r_hi);
+    pitch_r_range(RC, L, P.min_lag, P.max_lag, (DA.hdr && DA.grouped) ? 30 : P.refine_depth, &r_lo, &r_hi);
     double* r_store = reinterpret_cast<double*>(smem_raw);
     double* r = r_store - (RC + r_lo);
     double* s_mfreq = r_store + ((r_hi - r_lo + 2) & ~1);   // [MAX_MAXIMA]
@@ -1273,18 +1274,18 @@ __global__ __launch_bounds__(64) void pitch_cand_kernel(const ClipInfo* __restri
     const double* rb = rbuf + ((int64_t)blockIdx.y * max_frames + f) * rstride;
     const double intensity = rb[L + 1];
     const double gp = gpeak[blockIdx.y];
-    // the row r[0..L] mirrored into Praat's symmetric array: eight loads in flight (unconditional, on clamped lags) before
+    // the row r[0..L] mirrored into Praat's symmetric array: ten loads in flight (unconditional, on clamped lags) before
     // the first store - one load per loop turn crossed the memory latency ten to fifteen times per frame
-    for (int j0 = RC + r_lo + tid; j0 <= RC + r_hi; j0 += 8 * CT) {
-        double v[8];
+    for (int j0 = RC + r_lo + tid; j0 <= RC + r_hi; j0 += 10 * CT) {
+        double v[10];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 10; ++u) {
             const int j = j0 + u * CT;
             const int l = j >= RC ? j - RC : RC - j;
             v[u] = rb[l <= L ? l : L];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 10; ++u) {
             const int j = j0 + u * CT;
             const int l = j >= RC ? j - RC : RC - j;
             if (j <= RC + r_hi) r[j] = l <= L ? v[u] : 0.0;
@@ -3667,8 +3668,11 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
     RSAF_CHECK_ARG(P.is_cc || P.nfft <= 4096, "autocorrelation window longer than 2 730 samples is not supported");
     const size_t lds_corr = P.is_cc ? (size_t)ncc * 2 * 2 * sizeof(double) + (size_t)(((Lr + 2) & ~1) + 32) * sizeof(double)   // two complex buffers + sumy2 + scratch
                                     : (size_t)(2 * P.nfft + 8) * sizeof(double);
-    int r_lo_h, r_hi_h;
-    pitch_r_range(P.brent_ixmax, Lr, P.min_lag, P.max_lag, P.refine_depth, &r_lo_h, &r_hi_h);
+    // in-kernel refinement (the form before the refinement kernels existed): the A/B reference of the tests
+    const bool defer = getenv("RSAF_PITCH_INKERNEL") == nullptr;
+    const bool grouped = defer && table_mode == 2 && !dual && P.is_cc && sinc_cheb != nullptr;
+    int r_lo_h, r_hi_h;                                            // (as in the kernel: the depth-30 estimates' reach in grouped mode)
+    pitch_r_range(P.brent_ixmax, Lr, P.min_lag, P.max_lag, grouped ? 30 : P.refine_depth, &r_lo_h, &r_hi_h);
     const size_t lds_cand = (size_t)(((r_hi_h - r_lo_h + 2) & ~1) + 3 * MAX_MAXIMA + 6 * MAXC + MAXC * 2 * NCH) * sizeof(double) +
                             (size_t)(MAX_MAXIMA + 2 * MAXC + 4) * sizeof(int);
     RSAF_CHECK_ARG(lds_corr <= 150 * 1024 && lds_cand <= 150 * 1024, "analysis window too long for LDS");
@@ -3679,9 +3683,6 @@ static int pitch_impl(const float* wav, const void* clip_info, int n_clips, int 
                    "workspace too small (rsaf_mshds_pitch_workspace_bytes)");
     int group = max_frames == 0 ? n_clips : (int)std::min<int64_t>(n_clips, workspace_bytes / std::max<int64_t>(row_bytes_per_clip, 1));
     if (max_frames > 0) group = (int)std::min<int64_t>(group, ((int64_t)1 << 26) / max_frames > 0 ? ((int64_t)1 << 26) / max_frames : 1);   // frame index in 27 bits (cell queue)
-    // in-kernel refinement (the form before the refinement kernels existed): the A/B reference of the tests
-    const bool defer = getenv("RSAF_PITCH_INKERNEL") == nullptr;
-    const bool grouped = defer && table_mode == 2 && !dual && P.is_cc && sinc_cheb != nullptr;
     RSAF_CHECK_ARG(table_mode != 2 || (!dual && P.is_cc), "per-cell tables serve single-threshold cross-correlation analyses only");
     hipStream_t s = (hipStream_t)stream;
     int log2m = 0;
