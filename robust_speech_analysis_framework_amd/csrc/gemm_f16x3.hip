@@ -413,9 +413,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WGS * CFG::THREADS / 256) void g
                 for (int j = 0; j < CW; ++j) {
                     float y = v[q][j] * (asi[q] * bsi[j]) + bias4[j];       // asi * bsi: a product of powers of two (and alpha)
                     if (HAS_R) y += rv[j % 4];
-                    if (ACT == ACT_GELU) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
                     if (ACT == ACT_SILU) y = y / (1.0f + expf(-y));
                     v[q][j] = y;
+                    if (ACT == ACT_GELU && (j & 1)) {                       // two elements per packed instruction (gemm_f16x3.h)
+                        const gelu_f32x2 g2 = gelu_pair(gelu_f32x2{v[q][j - 1], v[q][j]});
+                        v[q][j - 1] = g2.x; v[q][j] = g2.y;
+                    }
                     if (ACT != ACT_NONE && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four erf / exp chains at a time: registers
                 }
             }

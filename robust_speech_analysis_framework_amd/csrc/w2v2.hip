@@ -298,17 +298,29 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ xn
 #pragma unroll
         for (int j = 0; j < 10; ++j) xv[j] = x[5 * t + j];
         unsigned short hh[CPT], ll[CPT];
+        float gv[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             float y = 0.f;
 #pragma unroll
             for (int j = 0; j < 10; ++j) y = fmaf(wr[k][j], xv[j], y);
             if (APPLY) {
-                const float v = fmaf(y, a[k], b[k]);
-                const float gl = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                split2_w(gl * sc, hh[k], ll[k]);
+                gv[k] = fmaf(y, a[k], b[k]);
             } else {
                 s[k] += y; q[k] += y * y; mx[k] = fmaxf(mx[k], fabsf(y));
+            }
+        }
+        if (APPLY) {                                        // GELU two channels per packed instruction (gemm_f16x3.h)
+#pragma unroll
+            for (int k = 0; k < CPT; k += 2) {
+                if (k + 1 < CPT) {
+                    const gelu_f32x2 g2 = gelu_pair(gelu_f32x2{gv[k], gv[k + 1]});
+                    split2_w(g2.x * sc, hh[k], ll[k]);
+                    split2_w(g2.y * sc, hh[k + 1], ll[k + 1]);
+                } else {
+                    const gelu_f32x2 g2 = gelu_pair(gelu_f32x2{gv[k], gv[k]});
+                    split2_w(g2.x * sc, hh[k], ll[k]);
+                }
             }
         }
         if (APPLY) {
@@ -964,13 +976,11 @@ __global__ __launch_bounds__(512, 1) void posconv_f16x3_kernel(const unsigned sh
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < 4; v += 2) {
                 const int m = m_base + 16 * mt + 4 * q + v;
-                if (m < Tv) {
-                    float x = acc[mt][nt][v] * inv + bs;
-                    x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-                    y[(r0 + m) * Hd + col] = x;
-                }
+                const gelu_f32x2 g2 = gelu_pair(gelu_f32x2{acc[mt][nt][v] * inv + bs, acc[mt][nt][v + 1] * inv + bs});
+                if (m < Tv) y[(r0 + m) * Hd + col] = g2.x;
+                if (m + 1 < Tv) y[(r0 + m + 1) * Hd + col] = g2.y;
             }
     }
 }
