@@ -759,7 +759,7 @@ def get_engine(device="cuda"):
     return _ENGINE
 
 
-def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True, batch_files=32):
+def extract_mshds_features(input_df, audio_file_column="filepath", verbose=True, batch_files=64):
     """Drop-in for ``src/mshds_extractor.py:379-459``: one row per input row, in input order,
     columns ``filename`` + the 25 feature names; a file that cannot be processed gives a NaN row
     (``:450-457``).  Files at another sample rate are converted to 16 kHz on the device first."""
