@@ -54,7 +54,7 @@ constexpr double SHS_MINPITCH = 52.0, SHS_MAXPITCH = 620.0;
 constexpr double LN2 = 0.69314718055994530942;
 
 constexpr int RUNW = 16;                 // frames per wave
-constexpr int NSUM = 24;                 // doubles a frame leaves for the end-of-run pass
+constexpr int NSUM = 23;                 // doubles a frame leaves for the end-of-run pass (slots 0 .. 22)
 constexpr int RED_D = 8 * 65;            // doubles of the 8-sums-at-a-time reduction scratch
 
 template <int LOG2N>
@@ -69,8 +69,12 @@ struct Geo {
     // consumed, and the two magnitude arrays swap roles from frame to frame (this frame's magnitudes ARE the next frame's
     // "previous" ones: no copy; the smoothed and the summation spectrum go to the array the flux has finished with):
     // 15.6 -> 12.7 KB per wave at 16 kHz, i.e. 12 instead of 10 waves per CU.
-    static constexpr int Z_D = 2 * NC + 8;           // FFT buffer (c64[NC]); later the enhanced spectrum / spline moments | octave spectrum
-    static constexpr int ARR = NC + 8;               // one per-bin array
+    // The 2 048-point instance (44.1 / 48 kHz) is trimmed to the last double: 40 928 bytes per wave = FOUR waves per CU instead
+    // of three (its arrays need NC + 1 entries and the FFT buffer exactly 2 NC; the shorter instances keep the padding the
+    // reduction scratch in the FFT buffer relies on).
+    static constexpr bool TRIM = LOG2N >= 11;
+    static constexpr int Z_D = 2 * NC + (TRIM ? 0 : 8);   // FFT buffer (c64[NC]); later the enhanced spectrum / spline moments | octave spectrum
+    static constexpr int ARR = NC + (TRIM ? 2 : 8);       // one per-bin array (NB = NC + 1 entries)
     static constexpr int PAD_D = ((NC * 5) / 8 + 8 + 7) & ~7;   // zeros behind the octave spectrum: longer than the largest harmonic shift (< 0.62 NC)
     static constexpr int S_D = (Z_D - ARR) + PAD_D;  // the octave spectrum's room: NB bins + the pad
     static_assert(S_D >= NB + (NC * 5) / 8 + 1, "octave spectrum + pad must fit");
@@ -841,6 +845,7 @@ static int launch(const float* wav, const int64_t* clip_off, const int64_t* fram
     RSAF_CHECK_ARG(runs <= 0x7fffffffLL, "clip too long");
     constexpr size_t lds = (size_t)G::WAVE_D * sizeof(double);
     static_assert(lds <= 64 * 1024, "one wave's buffers must fit the default dynamic LDS limit");
+    static_assert(LOG2N < 11 || lds <= 40 * 1024, "the 2 048-point instance must leave room for four waves per CU");
     // algorithmic bytes: every sample read once (4 B) + the LLD rows written (38 * 8 B per frame)
     ProfScope prof("smile_lld", s, 0.0, 0.0);
     dim3 grid((unsigned)runs, (unsigned)n_clips);
